@@ -1,0 +1,298 @@
+/*
+ * oracle/oracle.c — CPU oracle (TEST INFRASTRUCTURE ONLY; see oracle.h for the rules and the parity pin).
+ *
+ * A from-scratch, sequential C restatement of the reference's per-contig algorithms.  The algorithmic
+ * STRUCTURE of the reference is kept on purpose (it doubles as the timed 1-core CPU baseline "port" in
+ * bench.py): two whole-contig search passes for telofind, a byte mark array + 5x re-read for telowin,
+ * the sequential sDUST recurrence with an explicit perfect-interval list, and O(n*w/inc) window sums.
+ * All file:line citations are relative to /root/reference/.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+void orc_free(void *p) { free(p); }
+
+/* ------------------------------------------------------------------------------------------------
+ * telofind — src/find_telomere.c
+ * ---------------------------------------------------------------------------------------------- */
+
+/* src/find_telomere.c:24-42 — reverse, complement A<->T C<->G, copy anything else */
+void orc_revcomp(const char *motif, char *out)
+{
+    size_t k = strlen(motif);
+    for (size_t i = 0; i < k; ++i) {
+        char c = motif[k - 1 - i];
+        out[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
+    }
+    out[k] = 0;
+}
+
+typedef struct { orc_hit_t *a; int64_t n, m; } hitvec_t;
+
+static void hv_push(hitvec_t *v, int64_t s, int64_t e, int strand)
+{
+    if (v->n == v->m) {
+        v->m = v->m ? v->m * 2 : 64;
+        v->a = (orc_hit_t *)realloc(v->a, (size_t)v->m * sizeof(orc_hit_t));
+    }
+    v->a[v->n].start = s; v->a[v->n].end = e; v->a[v->n].strand = strand; v->a[v->n].pad = 0;
+    v->n++;
+}
+
+/* One strand of src/find_telomere.c:49-58 (identical loop at :63-72): find the next occurrence at or
+ * after pos (strstr), extend while the next k bytes equal the pattern (strncmp), emit, resume at end+1. */
+static void one_strand(const char *q, int64_t len, const char *pat, int strand, hitvec_t *out)
+{
+    size_t k = strlen(pat);
+    int64_t pos = 0;
+    while (pos <= len) {
+        const char *hit = strstr(q + pos, pat);      /* q is NUL-terminated at q[len] */
+        if (!hit) break;
+        pos = hit - q;
+        int64_t start = pos;
+        while (strncmp(q + pos, pat, k) == 0) pos += (int64_t)k;
+        hv_push(out, start, pos, strand);
+        pos++;                                       /* src/find_telomere.c:57 */
+    }
+}
+
+int orc_telofind(const uint8_t *seq, int64_t len, const char *motif, orc_hit_t **hits, int64_t *n_hits)
+{
+    *hits = 0; *n_hits = 0;
+    size_t k = strlen(motif);
+    if (k == 0) return -1;                           /* the reference would never terminate */
+    char *q = (char *)malloc((size_t)len + 1);
+    if (!q) return -2;
+    /* src/find_telomere.c:76-81 — toupper() of the whole contig ("C" locale: a-z only) */
+    for (int64_t i = 0; i < len; ++i) {
+        uint8_t c = seq[i];
+        q[i] = (c >= 'a' && c <= 'z') ? (char)(c - 32) : (char)c;
+    }
+    q[len] = 0;
+    hitvec_t v = {0, 0, 0};
+    one_strand(q, len, motif, 0, &v);
+    char *rc = (char *)malloc(k + 1);
+    orc_revcomp(motif, rc);
+    one_strand(q, len, rc, 1, &v);
+    free(rc); free(q);
+    *hits = v.a; *n_hits = v.n;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * telowin — src/telomere_windows.c
+ * ---------------------------------------------------------------------------------------------- */
+
+double orc_telowin_threshold(double threshold, double identity_percent)
+{
+    double identity = identity_percent / 100;        /* src/telomere_windows.c:53 */
+    return threshold * pow(identity, 6);             /* :54 — always 6, whatever the motif length */
+}
+
+int orc_telowin(const orc_hit_t *hits, int64_t n_hits, int32_t contig_len, double thr_adj,
+                orc_win_t **wins, int64_t *n_wins)
+{
+    *wins = 0; *n_wins = 0;
+    uint8_t *b = (uint8_t *)calloc(contig_len > 0 ? (size_t)contig_len : 1, 1);   /* :72 */
+    if (!b) return -2;
+    for (int64_t h = 0; h < n_hits; ++h)             /* :75-79 */
+        for (int64_t i = hits[h].start; i < hits[h].end; ++i) b[i] = 1;
+    int64_t m = 0, n = 0; orc_win_t *w = 0;
+    const int WIN = 1000;                            /* :13 */
+    for (int i = 0; i <= contig_len; i += WIN / 5) { /* :31 */
+        int car = 0;
+        for (int j = i; j < i + WIN && j < contig_len; ++j) if (b[j]) car++;      /* :33-35 */
+        int den = (i + WIN < contig_len) ? WIN : contig_len - i;                   /* :36 */
+        if ((double)car / den >= thr_adj) {          /* :37 */
+            if (n == m) { m = m ? m * 2 : 64; w = (orc_win_t *)realloc(w, (size_t)m * sizeof(orc_win_t)); }
+            w[n].start = i; w[n].end = i + den; w[n].car = car; w[n].pad = 0; n++;
+        }
+        if (i + WIN >= contig_len) break;            /* :40 */
+    }
+    free(b);
+    *wins = w; *n_wins = n;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * sdust — src/sdust/sdust.c
+ * ---------------------------------------------------------------------------------------------- */
+
+#define NWORD 64   /* SD_WTOT = 4^3, src/sdust/sdust.c:9-10 */
+
+typedef struct { int start, finish, r, l; } pint_t;          /* :13-16 */
+
+typedef struct {
+    /* the sliding window of 3-mers (a FIFO of at most W-2 words), :42 kdq_t(int) *w */
+    int *ring; int cap, front, size;
+    int cw[NWORD], cv[NWORD];
+    int rw, rv, L;
+    pint_t *P; int nP, mP;                                   /* :43 */
+    uint64_t *res; int nres, mres;                           /* :44 */
+} sd_t;
+
+static int nt4(uint8_t c)                                    /* :23-40 seq_nt4_table */
+{
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default:
+        if (c < 4) return c;                                 /* table rows 0: bytes 0..3 map to themselves */
+        return 4;
+    }
+}
+
+static int ring_at(const sd_t *s, int i) { return s->ring[(s->front + i) % s->cap]; }
+
+/* :66-86 shift_window */
+static void sd_shift_window(sd_t *s, int t, int T, int W)
+{
+    if (s->size >= W - 3 + 1) {                              /* :69 */
+        int x = s->ring[s->front];
+        s->front = (s->front + 1) % s->cap; s->size--;
+        s->rw -= --s->cw[x];                                 /* :71 */
+        if (s->L > s->size) { --s->L; s->rv -= --s->cv[x]; } /* :72-73 */
+    }
+    s->ring[(s->front + s->size) % s->cap] = t; s->size++;   /* :75 */
+    ++s->L;
+    s->rw += s->cw[t]++;                                     /* :77 */
+    s->rv += s->cv[t]++;                                     /* :78 */
+    if (s->cv[t] * 10 > T << 1) {                            /* :79 */
+        int x;
+        do {
+            x = ring_at(s, s->size - s->L);                  /* :81 */
+            s->rv -= --s->cv[x];
+            --s->L;
+        } while (x != t);
+    }
+}
+
+/* :88-102 save_masked_regions */
+static void sd_save(sd_t *s, int start)
+{
+    if (s->nP == 0 || s->P[s->nP - 1].start >= start) return;        /* :92 */
+    pint_t *p = &s->P[s->nP - 1];
+    int saved = 0;
+    if (s->nres) {
+        int st = (int)(s->res[s->nres - 1] >> 32), f = (int)(uint32_t)s->res[s->nres - 1];
+        if (p->start <= f) {                                 /* :96 overlapping or adjacent */
+            saved = 1;
+            s->res[s->nres - 1] = (uint64_t)st << 32 | (uint32_t)(f > p->finish ? f : p->finish);
+        }
+    }
+    if (!saved) {                                            /* :99 */
+        if (s->nres == s->mres) { s->mres = s->mres ? s->mres * 2 : 64; s->res = (uint64_t *)realloc(s->res, (size_t)s->mres * 8); }
+        s->res[s->nres++] = (uint64_t)p->start << 32 | (uint32_t)p->finish;
+    }
+    int i;
+    for (i = s->nP - 1; i >= 0 && s->P[i].start < start; --i) {}      /* :100 */
+    s->nP = i + 1;
+}
+
+/* :104-128 find_perfect */
+static void sd_find_perfect(sd_t *s, int T, int start)
+{
+    int c[NWORD], r = s->rv, max_r = 0, max_l = 0;
+    memcpy(c, s->cv, sizeof(c));
+    for (int i = s->size - s->L - 1; i >= 0; --i) {          /* :108 */
+        int t = ring_at(s, i);
+        r += c[t]++;
+        int new_r = r, new_l = s->size - i - 1;              /* :111 */
+        if (new_r * 10 > T * new_l) {                        /* :112 */
+            int j;
+            for (j = 0; j < s->nP && s->P[j].start >= i + start; ++j) {          /* :113 */
+                pint_t *p = &s->P[j];
+                if (max_r == 0 || p->r * max_l > max_r * p->l) { max_r = p->r; max_l = p->l; }
+            }
+            if (max_r == 0 || new_r * max_l >= max_r * new_l) {                  /* :118 */
+                max_r = new_r; max_l = new_l;
+                if (s->nP == s->mP) { s->mP = s->mP ? s->mP * 2 : 64; s->P = (pint_t *)realloc(s->P, (size_t)s->mP * sizeof(pint_t)); }
+                memmove(&s->P[j + 1], &s->P[j], (size_t)(s->nP - j) * sizeof(pint_t));
+                ++s->nP;
+                s->P[j].start = i + start; s->P[j].finish = s->size + 2 + start;  /* :123 */
+                s->P[j].r = new_r; s->P[j].l = new_l;
+            }
+        }
+    }
+}
+
+uint64_t *orc_sdust(const uint8_t *seq, int32_t l_seq, int32_t T, int32_t W, int32_t *n)
+{
+    sd_t s; memset(&s, 0, sizeof(s));
+    s.cap = (W > 3 ? W : 3) + 2;
+    s.ring = (int *)malloc((size_t)s.cap * sizeof(int));
+    int l = 0; unsigned t = 0;
+    for (int i = 0; i <= l_seq; ++i) {                       /* :141 — note <= : sentinel at i == l_seq */
+        int b = i < l_seq ? nt4(seq[i]) : 4;
+        if (b < 4) {
+            ++l; t = (t << 2 | (unsigned)b) & (NWORD - 1);   /* :144 */
+            if (l >= 3) {
+                int start = (l - W > 0 ? l - W : 0) + (i + 1 - l);               /* :146 */
+                sd_save(&s, start);
+                sd_shift_window(&s, (int)t, T, W);
+                if (s.rw * 10 > s.L * T) sd_find_perfect(&s, T, start);           /* :149-150 */
+            }
+        } else {
+            int start = (l - W + 1 > 0 ? l - W + 1 : 0) + (i + 1 - l);           /* :152 */
+            while (s.nP) sd_save(&s, start++);               /* :153 */
+            l = 0; t = 0;                                    /* :154 — window and counters NOT reset */
+        }
+    }
+    free(s.ring); free(s.P);
+    *n = s.nres;
+    if (!s.res) s.res = (uint64_t *)malloc(8);
+    return s.res;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * (no)boringbits window stage — src/boringbits_main.c
+ * ---------------------------------------------------------------------------------------------- */
+
+int32_t orc_n_reg(int32_t length, int32_t window_size, int32_t window_inc)
+{
+    int32_t n = (length - window_size + window_inc - 1) / window_inc + 1;   /* :338, C truncation */
+    return n < 1 ? 1 : n;                                                    /* :339 */
+}
+
+void orc_get_regs(const uint16_t *depth, const uint16_t *mq_depth, int32_t length,
+                  int32_t window_size, int32_t window_inc, orc_reg_t *regs)
+{
+    int32_t n = orc_n_reg(length, window_size, window_inc);
+    for (int32_t j = 0; j < n; ++j) {                        /* :346 */
+        int32_t st = j * window_inc, end = st + window_size;
+        if (end > length) end = length;                      /* :349-351 */
+        /* int accumulators as in the reference (:354-359); unsigned here so that an (absurdly large
+         * -w) overflow wraps the way gcc -O2 makes the reference wrap instead of being undefined */
+        uint32_t d = 0, q = 0;
+        for (int32_t k = st; k < end; ++k) { d += depth[k]; q += mq_depth[k]; }
+        regs[j].st = st; regs[j].end = end;
+        regs[j].depth = (int32_t)d / (end - st);             /* :360 */
+        regs[j].mq_depth = (int32_t)q / (end - st);          /* :361 */
+    }
+}
+
+int32_t orc_mean_depth(double tot, double n) { return (int32_t)round(tot / n); }     /* :293-294 */
+
+int32_t orc_threshold(float factor, int32_t mean) { return (int32_t)round(factor * mean); }  /* :518-519 */
+
+int orc_is_fun(int32_t depth, int32_t mq_depth, int32_t lo, int32_t hi, float low_mq)
+{
+    return depth < lo || depth > hi || (mq_depth / (double)depth) < low_mq;      /* :439 */
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * bigenough — src/bigenough_main.c
+ * ---------------------------------------------------------------------------------------------- */
+
+int orc_bigenough_keep(int32_t covlen, int32_t start, int32_t end, int32_t threshold)
+{
+    /* :206  r->covlen > (r->end - r->start) * threshold / 100   with int operands: the product wraps
+     * (two's complement, as gcc -O2 compiles it) and the division truncates toward zero */
+    int32_t prod = (int32_t)((uint32_t)(end - start) * (uint32_t)threshold);
+    return covlen > prod / 100;
+}

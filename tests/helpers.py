@@ -1,0 +1,146 @@
+"""Shared test helpers: record readers with the reference reader's framing rules and text formatters that
+mirror the reference's printf formats, so oracle / GPU outputs can be diffed against golden stdout."""
+import gzip
+import os
+
+import numpy as np
+
+
+def _open(path):
+    with open(path, "rb") as f:
+        magic = f.read(2)
+    return gzip.open(path, "rb") if magic == b"\x1f\x8b" else open(path, "rb")
+
+
+def read_fastx(path):
+    """[(name, comment, seq, qual)] with klib kseq framing (src/kseq.h:184-224, :93-141): jump to the next
+    '>'/'@', name up to the first isspace() byte, comment = rest of that line, sequence lines until a line
+    that starts with '>', '@' or '+', a trailing CR dropped from each line once more than one byte is held,
+    '+' line skipped, quality read by length; a truncated quality string ends the stream."""
+    with _open(path) as f:
+        d = f.read()
+    n = len(d)
+    recs = []
+    pos = 0
+    SPACE = b" \t\n\v\f\r"
+
+    def getline(p, acc):
+        """append bytes up to the next LF to acc (kseq ks_getuntil2 KS_SEP_LINE, append=1)"""
+        e = d.find(b"\n", p)
+        if e < 0:
+            e = n
+        acc += d[p:e]
+        if len(acc) > 1 and acc[-1:] == b"\r":
+            del acc[-1]
+        return min(e + 1, n + 1)
+
+    last = 0
+    while True:
+        if last == 0:
+            while pos < n and d[pos] not in b">@":
+                pos += 1
+            if pos >= n:
+                break
+            pos += 1
+        if pos >= n:
+            break
+        e = pos
+        while e < n and d[e] not in SPACE:
+            e += 1
+        name = d[pos:e]
+        delim = d[e] if e < n else 0
+        pos = min(e + 1, n)
+        comment = bytearray()
+        if delim != 0x0A and e < n:
+            pos = getline(pos, comment)
+        seq = bytearray()
+        c = -1
+        while pos < n:
+            c = d[pos]
+            pos += 1
+            if c in b">+@":
+                break
+            if c == 0x0A:
+                c = -1
+                continue
+            seq.append(c)
+            pos = getline(pos, seq)
+            c = -1
+        last = c if c in (0x3E, 0x40) else 0
+        if c != 0x2B:
+            recs.append((name, bytes(comment), bytes(seq), None))
+            if pos >= n and last == 0:
+                break
+            continue
+        e = d.find(b"\n", pos)
+        if e < 0:
+            break
+        pos = e + 1
+        qual = bytearray()
+        while pos <= n and len(qual) < len(seq):
+            if pos >= n:
+                break
+            pos = getline(pos, qual)
+        last = 0
+        if len(qual) != len(seq):
+            break
+        recs.append((name, bytes(comment), bytes(seq), bytes(qual)))
+    return recs
+
+
+def read_bedgraph_pair(tot_path, mq_path):
+    """-> [(name, depth_u16, mq_u16)] with the reference reader's 65535 clamp (src/boringbits_main.c:261-268)"""
+    def load(p):
+        with _open(p) as f:
+            names, vals = [], []
+            for ln in f:
+                a = ln.split()
+                names.append(a[0])
+                vals.append(int(a[3]))
+        return names, np.minimum(np.array(vals, dtype=np.int64), 65535).astype(np.uint16)
+    n1, d = load(tot_path)
+    n2, q = load(mq_path)
+    assert n1 == n2
+    out = []
+    start = 0
+    for i in range(1, len(n1) + 1):
+        if i == len(n1) or n1[i] != n1[start]:
+            out.append((n1[start], d[start:i].copy(), q[start:i].copy()))
+            start = i
+    return out
+
+
+def fmt_telofind(name, length, hits):
+    """src/find_telomere.c:51,56"""
+    return b"".join(b"%s\t%d\t%d\t%d\t%d\t%d\n" % (name, length, h["strand"], h["start"], h["end"], h["end"] - h["start"])
+                    for h in hits)
+
+
+def fmt_g3(x):
+    """C's %.3g"""
+    return ("%.3g" % x).encode()
+
+
+def fmt_telowin(name, length, wins):
+    """src/telomere_windows.c:38"""
+    return b"".join(b"Window\t%s\t%d\t%d\t%d\t%s\n" % (name, length, w["start"], w["end"],
+                                                     fmt_g3(float(w["car"]) / float(w["end"] - w["start"])))
+                    for w in wins)
+
+
+def fmt_sdust(name, res):
+    """src/sdust/sdust.c:201 — both halves printed as (int)"""
+    out = []
+    for r in res:
+        r = int(r)
+        s = (r >> 32) & 0xFFFFFFFF
+        f = r & 0xFFFFFFFF
+        s = s - (1 << 32) if s >= 1 << 31 else s
+        f = f - (1 << 32) if f >= 1 << 31 else f
+        out.append(b"%s\t%d\t%d\n" % (name, s, f))
+    return b"".join(out)
+
+
+def golden(golden_dir, name):
+    with open(os.path.join(golden_dir, name), "rb") as f:
+        return f.read()

@@ -1,0 +1,146 @@
+"""ctypes bindings of the CPU oracle (oracle/liboracle.so) — TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by cornetto_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+
+
+class Hit(C.Structure):
+    _fields_ = [("start", C.c_int64), ("end", C.c_int64), ("strand", C.c_int32), ("pad", C.c_int32)]
+
+
+class Win(C.Structure):
+    _fields_ = [("start", C.c_int32), ("end", C.c_int32), ("car", C.c_int32), ("pad", C.c_int32)]
+
+
+class Reg(C.Structure):
+    _fields_ = [("st", C.c_int32), ("end", C.c_int32), ("depth", C.c_int32), ("mq_depth", C.c_int32)]
+
+
+HIT_DT = np.dtype([("start", "<i8"), ("end", "<i8"), ("strand", "<i4"), ("pad", "<i4")])
+WIN_DT = np.dtype([("start", "<i4"), ("end", "<i4"), ("car", "<i4"), ("pad", "<i4")])
+REG_DT = np.dtype([("st", "<i4"), ("end", "<i4"), ("depth", "<i4"), ("mq_depth", "<i4")])
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(ODIR, "liboracle.so")
+        src = os.path.join(ODIR, "oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", ODIR, "-s", "-B"])
+        L = C.CDLL(so)
+        L.orc_telofind.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.POINTER(C.POINTER(Hit)), C.POINTER(C.c_int64)]
+        L.orc_telofind.restype = C.c_int
+        L.orc_telowin_threshold.argtypes = [C.c_double, C.c_double]
+        L.orc_telowin_threshold.restype = C.c_double
+        L.orc_telowin.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.POINTER(C.POINTER(Win)), C.POINTER(C.c_int64)]
+        L.orc_telowin.restype = C.c_int
+        L.orc_sdust.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
+        L.orc_sdust.restype = C.POINTER(C.c_uint64)
+        L.orc_n_reg.argtypes = [C.c_int32] * 3
+        L.orc_n_reg.restype = C.c_int32
+        L.orc_get_regs.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        L.orc_get_regs.restype = None
+        L.orc_mean_depth.argtypes = [C.c_double, C.c_double]
+        L.orc_mean_depth.restype = C.c_int32
+        L.orc_threshold.argtypes = [C.c_float, C.c_int32]
+        L.orc_threshold.restype = C.c_int32
+        L.orc_is_fun.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float]
+        L.orc_is_fun.restype = C.c_int
+        L.orc_bigenough_keep.argtypes = [C.c_int32] * 4
+        L.orc_bigenough_keep.restype = C.c_int
+        L.orc_free.argtypes = [C.c_void_p]
+        L.orc_revcomp.argtypes = [C.c_char_p, C.c_char_p]
+        _lib = L
+    return _lib
+
+
+def _buf(seq):
+    """bytes / numpy uint8 -> (keepalive, pointer, length)"""
+    if isinstance(seq, (bytes, bytearray)):
+        a = np.frombuffer(bytes(seq), dtype=np.uint8)
+    else:
+        a = np.ascontiguousarray(seq, dtype=np.uint8)
+    return a, a.ctypes.data, a.size
+
+
+def telofind(seq, motif=b"TTAGGG"):
+    """-> structured array (start,end,strand): all strand-0 runs then all strand-1 runs"""
+    a, p, n = _buf(seq)
+    hp = C.POINTER(Hit)()
+    nh = C.c_int64()
+    rc = lib().orc_telofind(p, n, motif, C.byref(hp), C.byref(nh))
+    if rc != 0:
+        raise ValueError("orc_telofind rc=%d" % rc)
+    out = np.zeros(nh.value, dtype=HIT_DT)
+    if nh.value:
+        C.memmove(out.ctypes.data, hp, nh.value * C.sizeof(Hit))
+    lib().orc_free(hp)
+    return out
+
+
+def telowin(hits, contig_len, thr_adj):
+    hits = np.ascontiguousarray(hits, dtype=HIT_DT)
+    wp = C.POINTER(Win)()
+    nw = C.c_int64()
+    lib().orc_telowin(hits.ctypes.data, hits.size, contig_len, thr_adj, C.byref(wp), C.byref(nw))
+    out = np.zeros(nw.value, dtype=WIN_DT)
+    if nw.value:
+        C.memmove(out.ctypes.data, wp, nw.value * C.sizeof(Win))
+    lib().orc_free(wp)
+    return out
+
+
+def telowin_threshold(thr, identity):
+    return lib().orc_telowin_threshold(thr, identity)
+
+
+def sdust(seq, T=20, W=64):
+    """-> uint64 array of (start<<32|finish)"""
+    a, p, n = _buf(seq)
+    cnt = C.c_int32()
+    r = lib().orc_sdust(p, n, T, W, C.byref(cnt))
+    out = np.zeros(cnt.value, dtype=np.uint64)
+    if cnt.value:
+        C.memmove(out.ctypes.data, r, cnt.value * 8)
+    lib().orc_free(r)
+    return out
+
+
+def n_reg(length, w, inc):
+    return lib().orc_n_reg(length, w, inc)
+
+
+def get_regs(depth, mq, w, inc):
+    depth = np.ascontiguousarray(depth, dtype=np.uint16)
+    mq = np.ascontiguousarray(mq, dtype=np.uint16)
+    n = n_reg(depth.size, w, inc)
+    out = np.zeros(n, dtype=REG_DT)
+    lib().orc_get_regs(depth.ctypes.data, mq.ctypes.data, depth.size, w, inc, out.ctypes.data)
+    return out
+
+
+def mean_depth(tot, n):
+    return lib().orc_mean_depth(float(tot), float(n))
+
+
+def threshold(factor, mean):
+    return lib().orc_threshold(factor, mean)
+
+
+def is_fun(depth, mq, lo, hi, q):
+    return bool(lib().orc_is_fun(depth, mq, lo, hi, q))
+
+
+def bigenough_keep(covlen, start, end, T):
+    return bool(lib().orc_bigenough_keep(covlen, start, end, T))

@@ -1,0 +1,228 @@
+"""CPU: the oracle restatement (oracle/oracle.c) against golden stdout of the unmodified reference
+(tests/golden/*.exp, made by tests/golden/make_golden.py) and, where oracle/_ref is present, directly
+against the reference's own functions through ctypes.  This is the parity PIN of the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_bind as ob
+from helpers import (fmt_sdust, fmt_telofind, fmt_telowin, golden, read_bedgraph_pair, read_fastx)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _telofind_text(path, motif=b"TTAGGG"):
+    out = []
+    for name, _c, seq, _q in read_fastx(path):
+        out.append(fmt_telofind(name, len(seq), ob.telofind(seq, motif)))
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("fa,motif,exp", [
+    ("probe.fa", b"TTAGGG", "probe.telofind.exp"),
+    ("probe_selfoverlap.fa", b"AAAA", "probe_selfoverlap.AAAA.telofind.exp"),
+    ("probe_selfoverlap.fa", b"ACAC", "probe_selfoverlap.ACAC.telofind.exp"),
+    ("probe_selfoverlap.fa", b"ACACA", "probe_selfoverlap.ACACA.telofind.exp"),
+    ("mix.fa.gz", b"TTAGGG", "mix.telofind.exp"),
+    ("mix.fa.gz", b"ttaggg", "mix.lower_motif.telofind.exp"),
+    ("mix.fa.gz", b"TTAGGGTTAGGG", "mix.k12.telofind.exp"),
+    ("mix.fa.gz", b"AAAA", "mix.AAAA.telofind.exp"),
+    ("mix.fa.gz", b"GNG", "mix.GNG.telofind.exp"),
+])
+def test_telofind_golden(golden_dir, fa, motif, exp):
+    assert _telofind_text(os.path.join(golden_dir, fa), motif) == golden(golden_dir, exp)
+
+
+def _parse_telofind_tsv(data):
+    """group consecutive lines by contig name exactly as src/telomere_windows.c:69-74 does"""
+    groups = []
+    for ln in data.splitlines():
+        a = ln.split()
+        if not groups or groups[-1][0] != a[0]:
+            groups.append((a[0], int(a[1]), []))
+        groups[-1][2].append((int(a[3]), int(a[4]), int(a[2])))
+    return groups
+
+
+def _telowin_text(tsv, identity, thr):
+    t = ob.telowin_threshold(thr, identity)
+    out = []
+    for name, length, hs in _parse_telofind_tsv(tsv):
+        hits = np.zeros(len(hs), dtype=ob.HIT_DT)
+        for i, (s, e, st) in enumerate(hs):
+            hits[i] = (s, e, st, 0)
+        out.append(fmt_telowin(name, length, ob.telowin(hits, length, t)))
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("tsv,identity,thr,exp", [
+    ("probe.telomere", 99.9, 0.4, "probe.telowin.exp"),
+    ("probe.telomere", 100.0, 0.5, "probe.i100t05.telowin.exp"),
+    ("probe.telomere", 95.0, 0.4, "probe.i95.telowin.exp"),
+    ("mix.telofind.exp", 99.9, 0.4, "mix.telowin.exp"),
+    ("mix.telofind.exp", 99.9, 0.1, "mix.t01.telowin.exp"),
+])
+def test_telowin_golden(golden_dir, tsv, identity, thr, exp):
+    assert _telowin_text(golden(golden_dir, tsv), identity, thr) == golden(golden_dir, exp)
+
+
+def _sdust_text(path, T=20, W=64):
+    return b"".join(fmt_sdust(name, ob.sdust(seq, T, W)) for name, _c, seq, _q in read_fastx(path))
+
+
+@pytest.mark.parametrize("fa,T,W,exp", [
+    ("probe.fa", 20, 64, "probe.sdust.exp"),
+    ("probe_sdust.fa", 20, 64, "probe_sdust.sdust.exp"),
+    ("probe_sdust.fa", 10, 32, "probe_sdust.w32t10.sdust.exp"),
+    ("mix.fa.gz", 20, 64, "mix.sdust.exp"),
+    ("mix.fa.gz", 10, 32, "mix.w32t10.sdust.exp"),
+    ("mix.fa.gz", 25, 100, "mix.w100t25.sdust.exp"),
+    ("mix.fa.gz", 30, 16, "mix.w16t30.sdust.exp"),
+    ("mix.fa.gz", 5, 64, "mix.t5.sdust.exp"),
+    ("reads.fq", 20, 64, "reads.sdust.exp"),
+])
+def test_sdust_golden(golden_dir, fa, T, W, exp):
+    assert _sdust_text(os.path.join(golden_dir, fa), T, W) == golden(golden_dir, exp)
+
+
+def panel_text(ctgs, boring, w=2500, inc=50, L=0.4, H=2.5, Q=0.4, m=1000000, e=100000):
+    """the_boring_bits (src/boringbits_main.c:483-536) on oracle primitives"""
+    tot = sum(float(d.astype(np.float64).sum()) for _n, d, _q in ctgs)
+    totq = sum(float(q.astype(np.float64).sum()) for _n, _d, q in ctgs)
+    n = sum(d.size for _n, d, _q in ctgs)
+    mean = ob.mean_depth(tot, n)
+    _ = ob.mean_depth(totq, n)
+    lo, hi = ob.threshold(L, mean), ob.threshold(H, mean)
+    out = []
+    for name, d, q in ctgs:
+        regs = ob.get_regs(d, q, w, inc)
+        length = d.size
+        if boring:                                              # :463-481
+            if length > m:
+                for r in regs:
+                    if r["st"] > e and r["end"] < length - e and not ob.is_fun(r["depth"], r["mq_depth"], lo, hi, Q):
+                        out.append(b"%s\t%d\t%d\t%d\t%d\n" % (name, r["st"], r["end"], r["depth"], r["mq_depth"]))
+        else:                                                   # :425-445
+            if length < m:
+                out.append(b"%s\t%d\t%d\t.\t.\n" % (name, 0, m))
+            else:
+                out.append(b"%s\t%d\t%d\t.\t.\n" % (name, 0, e))
+                out.append(b"%s\t%d\t%d\t.\t.\n" % (name, length - e, length))
+                for r in regs:
+                    if ob.is_fun(r["depth"], r["mq_depth"], lo, hi, Q):
+                        out.append(b"%s\t%d\t%d\t%d\t%d\n" % (name, r["st"], r["end"], r["depth"], r["mq_depth"]))
+    return b"".join(out)
+
+
+PANEL_CASES = [
+    (True, dict(m=10000, e=1000, L=0.6, Q=0.6, H=1.6), "bg.boring_t1.exp"),
+    (False, dict(H=2.5, L=0.5, Q=0.5, m=10000, e=1000), "bg.fun_t2.exp"),
+    (False, dict(), "bg.fun_default.exp"),
+    (True, dict(), "bg.boring_default.exp"),
+    (False, dict(w=300, inc=7, L=0.33, H=1.45, Q=0.9, m=5000, e=500), "bg.fun_w300i7.exp"),
+    (True, dict(w=300, inc=7, L=0.33, H=1.45, Q=0.9, m=5000, e=500), "bg.boring_w300i7.exp"),
+    (False, dict(w=1000, inc=1000, m=2000, e=10000), "bg.fun_w1000i1000.exp"),
+]
+
+
+@pytest.fixture(scope="module")
+def bg_ctgs(golden_dir):
+    return read_bedgraph_pair(os.path.join(golden_dir, "cov-total.bg.gz"), os.path.join(golden_dir, "cov-mq20.bg.gz"))
+
+
+@pytest.mark.parametrize("boring,kw,exp", PANEL_CASES)
+def test_panel_golden(golden_dir, bg_ctgs, boring, kw, exp):
+    assert panel_text(bg_ctgs, boring, **kw) == golden(golden_dir, exp)
+
+
+def test_reference_exp_structure():
+    """the reference ships expected outputs whose inputs were stripped: pin the structural facts
+    they carry — 2500-wide windows, step 50, n_reg formula, edge lines first."""
+    assert ob.n_reg(100000, 2500, 50) == 1951
+    assert ob.n_reg(2551, 2500, 50) == 3
+    assert ob.n_reg(120, 2500, 50) == 1
+    assert ob.n_reg(2450, 2500, 50) == 1
+    assert ob.n_reg(2401, 2500, 50) == 1
+    # thresholds quoted in SURVEY appendix A-4 for mean 22
+    assert (ob.threshold(0.6, 22), ob.threshold(1.6, 22)) == (13, 35)
+    assert (ob.threshold(0.5, 22), ob.threshold(2.5, 22)) == (11, 55)
+
+
+def bigenough_text(chroms, bed, T=50):
+    """src/bigenough_main.c:229-296, :92-149, :152-227"""
+    regs = {}
+    for ln in chroms.splitlines():
+        a = ln.split()
+        regs[a[0]] = [int(a[1]), int(a[2]), 0]
+    lines = [ln.split() for ln in bed.splitlines()]
+    for a in lines:
+        r = regs[a[0]]
+        r[2] = int(np.int32(np.int64(r[2]) + np.int64(int(a[2]) - int(a[1]))))   # int covlen += int64
+    out, csv = [], []
+    for a in lines:
+        r = regs[a[0]]
+        if ob.bigenough_keep(r[2], r[0], r[1], T):
+            out.append(b"%s\t%s\t%s\n" % (a[0], a[1], a[2]))
+            csv.append(b"%s,%s,%s,+\n%s,%s,%s,-\n" % (a[0], a[1], a[2], a[0], a[1], a[2]))
+    return b"".join(out), b"".join(csv)
+
+
+@pytest.mark.parametrize("chroms,bed,T,exp_bed,exp_csv", [
+    ("chroms.bed", "in.boringbits.bed", 50, "out.boringbits.bed", "out.boringbits.csv"),
+    ("chroms.bed", "in_dip.boringbits.bed", 50, "out_dip.boringbits.bed", "out_dip.boringbits.csv"),
+    ("ovf_chroms.bed", "ovf_in.bed", 50, "ovf_T50.bed.exp", "ovf_T50.csv.exp"),
+    ("ovf_chroms.bed", "ovf_in.bed", 0, "ovf_T0.bed.exp", "ovf_T0.csv.exp"),
+    ("ovf_chroms.bed", "ovf_in.bed", 100, "ovf_T100.bed.exp", "ovf_T100.csv.exp"),
+    ("ovf_chroms.bed", "ovf_in.bed", 33, "ovf_T33.bed.exp", "ovf_T33.csv.exp"),
+])
+def test_bigenough_golden(golden_dir, chroms, bed, T, exp_bed, exp_csv):
+    d = os.path.join(golden_dir, "bigenough")
+    got_bed, got_csv = bigenough_text(golden(d, chroms), golden(d, bed), T)
+    assert got_bed == golden(d, exp_bed)
+    assert got_csv == golden(d, exp_csv)
+
+
+# ---------------------------------------------------------------------------------------------------
+# differential against the reference's own functions (only where oracle/_ref was built: this container)
+# ---------------------------------------------------------------------------------------------------
+REFSO = os.path.join(ROOT, "oracle", "_ref", "libcornetto_ref.so")
+
+
+@pytest.mark.skipif(not os.path.exists(REFSO), reason="oracle/_ref not built (no /root/reference here)")
+def test_sdust_vs_reference_function_random():
+    ref = C.CDLL(REFSO)
+    ref.sdust.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    ref.sdust.restype = C.POINTER(C.c_uint64)
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(7)
+    alpha = np.frombuffer(b"ACGTacgtNNRY", dtype=np.uint8)
+    for it in range(300):
+        n = int(rng.integers(0, 3000))
+        kind = it % 4
+        if kind == 0:
+            s = alpha[rng.integers(0, 4, size=n)]
+        elif kind == 1:
+            s = alpha[rng.integers(0, len(alpha), size=n)]
+        elif kind == 2:   # STR mosaic
+            parts = []
+            while sum(map(len, parts)) < n:
+                u = alpha[rng.integers(0, 4, size=int(rng.integers(1, 6)))]
+                parts.append(np.tile(u, int(rng.integers(1, 40))))
+                if rng.random() < 0.2:
+                    parts.append(np.frombuffer(b"N" * int(rng.integers(1, 5)), dtype=np.uint8))
+            s = np.concatenate(parts)[:n] if parts else np.zeros(0, np.uint8)
+        else:             # two-letter low complexity
+            s = alpha[rng.integers(0, 2, size=n)]
+        s = np.ascontiguousarray(s, dtype=np.uint8)
+        T = int(rng.choice([20, 20, 10, 5, 30]))
+        W = int(rng.choice([64, 64, 32, 16, 100, 8]))
+        cnt = C.c_int()
+        buf = s.tobytes() + b"\0"
+        r = ref.sdust(None, buf, len(s), T, W, C.byref(cnt))
+        exp = np.array([r[i] for i in range(cnt.value)], dtype=np.uint64)
+        libc.free(r)
+        got = ob.sdust(s, T, W)
+        assert np.array_equal(got, exp), (it, n, T, W)

@@ -1,0 +1,236 @@
+"""cornetto_amd — MI355X-native implementation of cornetto's panel-creation hot path.
+
+The product is native: ``libcornetto_hip.so`` (hand-written HIP kernels for gfx950 behind the C ABI of
+``include/cornetto_accel.h``) and the C host CLI ``cornetto`` (``cornetto_amd/cli``).  This module is a thin
+ctypes binding of that C ABI, used by the tests, ``bench.py`` and the multi-process drivers: plumbing, not
+a second implementation.  There is no Python or CPU fallback — if the shared library is missing, import
+of :func:`lib` fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+__all__ = ["lib", "Accel", "AccelError", "HIT_DT", "WIN_DT", "IVL_DT", "REG_DT", "REGREC_DT", "build",
+           "LIB_PATH", "CLI_PATH"]
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcornetto_hip.so")
+CLI_PATH = os.path.join(HERE, "cornetto")
+
+HIT_DT = np.dtype([("ctg", "<i4"), ("strand", "<i4"), ("start", "<i4"), ("end", "<i4")])
+WIN_DT = np.dtype([("ctg", "<i4"), ("start", "<i4"), ("end", "<i4"), ("car", "<i4")])
+IVL_DT = np.dtype([("ctg", "<i4"), ("start", "<i4"), ("finish", "<i4")])
+REG_DT = np.dtype([("st", "<i4"), ("end", "<i4"), ("depth", "<i4"), ("mq_depth", "<i4")])
+REGREC_DT = np.dtype([("ctg", "<i4"), ("st", "<i4"), ("end", "<i4"), ("depth", "<i4"), ("mq_depth", "<i4")])
+
+
+class AccelError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("cornetto_accel status %d: %s" % (status, msg))
+        self.status = status
+
+
+def build(verbose=False):
+    """compile libcornetto_hip.so and the CLI in-tree (hipcc --offload-arch=gfx950)"""
+    import subprocess
+    subprocess.check_call(["make", "-C", HERE] + ([] if verbose else ["-s"]))
+
+
+_lib = None
+
+
+def lib():
+    """the loaded C ABI; raises if the HIP library has not been built"""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `make -C cornetto_amd` (or __graft_entry__.build()); "
+                          "there is no fallback implementation" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, cp = C.c_void_p, C.c_int32, C.c_int64, C.c_char_p
+    pp = C.POINTER(vp)
+    sig = {
+        "cornetto_accel_device_count": (C.c_int, []),
+        "cornetto_accel_open": (C.c_int, [pp, C.c_int, vp]),
+        "cornetto_accel_close": (None, [vp]),
+        "cornetto_accel_last_error": (cp, [vp]),
+        "cornetto_accel_strerror": (cp, [C.c_int]),
+        "cornetto_free": (None, [vp]),
+        "cornetto_accel_last_timing": (C.c_int, [vp, C.POINTER(cp), C.POINTER(C.c_float), C.c_int]),
+        "cornetto_asm_upload": (C.c_int, [vp, vp, vp, i32, pp]),
+        "cornetto_asm_wrap": (C.c_int, [vp, vp, vp, vp, i32, pp]),
+        "cornetto_asm_free": (None, [vp, vp]),
+        "cornetto_telofind": (C.c_int, [vp, vp, cp, pp, C.POINTER(i64)]),
+        "cornetto_telowin_threshold": (C.c_double, [C.c_double, C.c_double]),
+        "cornetto_telowin": (C.c_int, [vp, vp, i64, vp, i32, C.c_double, pp, C.POINTER(i64)]),
+        "cornetto_telo_scan": (C.c_int, [vp, vp, cp, C.c_double, pp, C.POINTER(i64), pp, C.POINTER(i64)]),
+        "cornetto_sdust_asm": (C.c_int, [vp, vp, i32, i32, pp, C.POINTER(i64)]),
+        "cornetto_sdust": (C.POINTER(C.c_uint64), [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+        "cornetto_cov_upload": (C.c_int, [vp, vp, vp, vp, i32, pp]),
+        "cornetto_cov_wrap": (C.c_int, [vp, vp, vp, vp, vp, i32, pp]),
+        "cornetto_cov_free": (None, [vp, vp]),
+        "cornetto_n_reg": (i32, [i32, i32, i32]),
+        "cornetto_cov_prepare": (C.c_int, [vp, vp, i32, i32, C.POINTER(C.c_uint64)]),
+        "cornetto_cov_regs": (C.c_int, [vp, vp, i32, vp]),
+        "cornetto_cov_threshold": (i32, [C.c_float, i32]),
+        "cornetto_cov_select": (C.c_int, [vp, vp, i32, i32, C.c_float, i32, i32, C.c_int, pp, C.POINTER(i64)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    L._declared = sorted(sig)
+    _lib = L
+    return L
+
+
+def _take(ptr, n, dt):
+    """copy a library-owned result array into numpy and release it"""
+    out = np.zeros(n, dtype=dt)
+    if n:
+        C.memmove(out.ctypes.data, ptr, n * dt.itemsize)
+    lib().cornetto_free(ptr)
+    return out
+
+
+class _Resident:
+    def __init__(self, acc, ptr, free, lens):
+        self.acc, self.ptr, self._free, self.lens = acc, ptr, free, list(lens)
+
+    def close(self):
+        if self.ptr is not None:
+            self._free(self.acc.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Accel:
+    """one device + stream; mirrors the handle of include/cornetto_accel.h"""
+
+    def __init__(self, device=0, stream=None):
+        self.L = lib()
+        h = C.c_void_p()
+        rc = self.L.cornetto_accel_open(C.byref(h), device, stream)
+        if rc != 0:
+            raise AccelError(rc, self.L.cornetto_accel_strerror(rc).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cornetto_accel_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise AccelError(rc, self.L.cornetto_accel_last_error(self.h).decode() or
+                             self.L.cornetto_accel_strerror(rc).decode())
+
+    def last_timing(self):
+        """[(kernel name, ms)] of the most recent compute call (HIP events on the handle's stream)"""
+        names = (C.c_char_p * 64)()
+        ms = (C.c_float * 64)()
+        n = self.L.cornetto_accel_last_timing(self.h, names, ms, 64)
+        return [(names[i].decode(), float(ms[i])) for i in range(min(n, 64))]
+
+    # ---- sequences -------------------------------------------------------------------------------
+    def asm_upload(self, seqs):
+        """seqs: list of bytes / uint8 arrays -> resident assembly"""
+        arrs = [np.frombuffer(bytes(s), dtype=np.uint8) if isinstance(s, (bytes, bytearray)) else
+                np.ascontiguousarray(s, dtype=np.uint8) for s in seqs]
+        n = len(arrs)
+        ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in arrs])
+        lens = np.array([a.size for a in arrs], dtype=np.int64)
+        out = C.c_void_p()
+        self._chk(self.L.cornetto_asm_upload(self.h, ptrs, lens.ctypes.data, n, C.byref(out)))
+        return _Resident(self, out, self.L.cornetto_asm_free, lens)
+
+    def asm_wrap(self, dev_ptr, offsets, lens):
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        lens = np.ascontiguousarray(lens, dtype=np.int64)
+        out = C.c_void_p()
+        self._chk(self.L.cornetto_asm_wrap(self.h, dev_ptr, offsets.ctypes.data, lens.ctypes.data, len(lens), C.byref(out)))
+        return _Resident(self, out, self.L.cornetto_asm_free, lens)
+
+    # ---- telofind / telowin ----------------------------------------------------------------------
+    def telofind(self, asm, motif=b"TTAGGG"):
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self.L.cornetto_telofind(self.h, asm.ptr, motif, C.byref(p), C.byref(n)))
+        return _take(p, n.value, HIT_DT)
+
+    def telowin_threshold(self, thr, identity):
+        return self.L.cornetto_telowin_threshold(thr, identity)
+
+    def telowin(self, hits, ctg_len, thr_adj):
+        hits = np.ascontiguousarray(hits, dtype=HIT_DT)
+        ctg_len = np.ascontiguousarray(ctg_len, dtype=np.int32)
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self.L.cornetto_telowin(self.h, hits.ctypes.data, hits.size, ctg_len.ctypes.data, ctg_len.size,
+                                          thr_adj, C.byref(p), C.byref(n)))
+        return _take(p, n.value, WIN_DT)
+
+    def telo_scan(self, asm, motif, thr_adj, want_hits=True):
+        ph, nh, pw, nw = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+        self._chk(self.L.cornetto_telo_scan(self.h, asm.ptr, motif, thr_adj,
+                                            C.byref(ph) if want_hits else None, C.byref(nh) if want_hits else None,
+                                            C.byref(pw), C.byref(nw)))
+        hits = _take(ph, nh.value, HIT_DT) if want_hits else None
+        return hits, _take(pw, nw.value, WIN_DT)
+
+    # ---- sdust -----------------------------------------------------------------------------------
+    def sdust(self, asm, T=20, W=64):
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self.L.cornetto_sdust_asm(self.h, asm.ptr, T, W, C.byref(p), C.byref(n)))
+        return _take(p, n.value, IVL_DT)
+
+    # ---- coverage --------------------------------------------------------------------------------
+    def cov_upload(self, depths, mqs):
+        d = [np.ascontiguousarray(x, dtype=np.uint16) for x in depths]
+        q = [np.ascontiguousarray(x, dtype=np.uint16) for x in mqs]
+        n = len(d)
+        pd = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in d])
+        pq = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in q])
+        lens = np.array([a.size for a in d], dtype=np.int32)
+        out = C.c_void_p()
+        self._chk(self.L.cornetto_cov_upload(self.h, pd, pq, lens.ctypes.data, n, C.byref(out)))
+        return _Resident(self, out, self.L.cornetto_cov_free, lens)
+
+    def cov_wrap(self, d_depth, d_mq, offsets, lens):
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        out = C.c_void_p()
+        self._chk(self.L.cornetto_cov_wrap(self.h, d_depth, d_mq, offsets.ctypes.data, lens.ctypes.data, len(lens), C.byref(out)))
+        return _Resident(self, out, self.L.cornetto_cov_free, lens)
+
+    def cov_prepare(self, cov, w=2500, inc=50):
+        sums = (C.c_uint64 * 3)()
+        self._chk(self.L.cornetto_cov_prepare(self.h, cov.ptr, w, inc, sums))
+        cov.w, cov.inc = w, inc
+        return int(sums[0]), int(sums[1]), int(sums[2])
+
+    def cov_regs(self, cov, ctg):
+        n = self.L.cornetto_n_reg(int(cov.lens[ctg]), cov.w, cov.inc)
+        out = np.zeros(n, dtype=REG_DT)
+        self._chk(self.L.cornetto_cov_regs(self.h, cov.ptr, ctg, out.ctypes.data))
+        return out
+
+    def cov_threshold(self, factor, mean):
+        return self.L.cornetto_cov_threshold(factor, mean)
+
+    def cov_select(self, cov, lo, hi, low_mq, edge_len, min_ctg_len, boring):
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self.L.cornetto_cov_select(self.h, cov.ptr, lo, hi, low_mq, edge_len, min_ctg_len, int(boring),
+                                             C.byref(p), C.byref(n)))
+        return _take(p, n.value, REGREC_DT)

@@ -1,0 +1,164 @@
+// common.hpp — handle, error plumbing, event timing and device-buffer helpers shared by the HIP sources
+// of libcornetto_hip.so (gfx950 only).  Not part of the C ABI (include/cornetto_accel.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <utility>
+#include <vector>
+
+#include "../../include/cornetto_accel.h"
+
+struct cornetto_accel {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    char err[512] = {0};
+    // event timing of the kernels of the current / most recent compute call
+    struct Rec {
+        const char *name;
+        hipEvent_t a, b;
+    };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    std::vector<std::pair<const char *, float>> last;
+};
+
+static inline int cn_fail(cornetto_accel_t *h, int status, const char *fmt, ...)
+{
+    if (h) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(h->err, sizeof(h->err), fmt, ap);
+        va_end(ap);
+    }
+    return status;
+}
+
+#define CN_HIP(h, call)                                                                                      \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return cn_fail((h), CORNETTO_E_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #call,                \
+                           hipGetErrorString(e_));                                                           \
+    } while (0)
+
+#define CN_TRY(expr)                                                                                         \
+    do {                                                                                                     \
+        int rc_ = (expr);                                                                                    \
+        if (rc_ != CORNETTO_OK) return rc_;                                                                  \
+    } while (0)
+
+// ---- event timing ---------------------------------------------------------------------------------
+static inline hipEvent_t cn_event(cornetto_accel_t *h)
+{
+    if (!h->pool.empty()) {
+        hipEvent_t e = h->pool.back();
+        h->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+static inline void cn_timing_begin(cornetto_accel_t *h)
+{
+    for (auto &r : h->recs) {
+        h->pool.push_back(r.a);
+        h->pool.push_back(r.b);
+    }
+    h->recs.clear();
+    h->last.clear();
+}
+
+// resolve the recorded events into milliseconds; call after the stream has been synchronised
+static inline void cn_timing_end(cornetto_accel_t *h)
+{
+    h->last.clear();
+    for (auto &r : h->recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) ms = -1.f;
+        h->last.emplace_back(r.name, ms);
+        h->pool.push_back(r.a);
+        h->pool.push_back(r.b);
+    }
+    h->recs.clear();
+}
+
+// Launch `...` (a kernel<<<>>> expression on h->stream) bracketed by two events recorded under `name`.
+#define CN_LAUNCH(h, name, ...)                                                                              \
+    do {                                                                                                     \
+        cornetto_accel::Rec r_{(name), cn_event(h), cn_event(h)};                                            \
+        CN_HIP(h, hipEventRecord(r_.a, (h)->stream));                                                        \
+        __VA_ARGS__;                                                                                         \
+        CN_HIP(h, hipGetLastError());                                                                        \
+        CN_HIP(h, hipEventRecord(r_.b, (h)->stream));                                                        \
+        (h)->recs.push_back(r_);                                                                             \
+    } while (0)
+
+// ---- RAII device buffer ----------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t alloc(size_t n)
+    {
+        release();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    template <class T>
+    T *as() const
+    {
+        return reinterpret_cast<T *>(p);
+    }
+};
+
+// ---- resident data sets -----------------------------------------------------------------------------
+struct cornetto_asm {
+    const uint8_t *d_bases = nullptr;  // 1 B/base, every contig starts at a multiple of 64
+    void *owned = nullptr;             // hipMalloc'd storage when uploaded by us
+    int32_t n = 0;
+    std::vector<int64_t> off;          // byte offset of contig i
+    std::vector<int32_t> len;
+    int64_t total = 0;                 // sum of lens
+    // device copies of the contig table
+    int64_t *d_off = nullptr;
+    int32_t *d_len = nullptr;
+};
+
+struct cornetto_cov {
+    const uint16_t *d_depth = nullptr, *d_mq = nullptr;
+    void *owned_d = nullptr, *owned_q = nullptr;
+    int32_t n = 0;
+    std::vector<int64_t> off;          // element offset of contig i (multiple of 64)
+    std::vector<int32_t> len;
+    int64_t total = 0;
+    int64_t *d_off = nullptr;
+    int32_t *d_len = nullptr;
+    // stage-1 products (cornetto_cov_prepare)
+    int32_t w = 0, inc = 0;
+    std::vector<int64_t> blk_off;      // first block-sum slot of contig i
+    int64_t n_blk = 0;
+    uint32_t *d_blk = nullptr;         // [n_blk][4] = full depth, head depth, full mq, head mq
+    int64_t *d_blk_off = nullptr;
+    uint64_t sums[3] = {0, 0, 0};
+};
+
+static inline int64_t cn_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }

@@ -1,0 +1,463 @@
+// cov.hip — the (no)boringbits window stage for gfx950: replaces get_regs() (src/boringbits_main.c:322-378),
+// the mean-depth totals of get_depths() (:283-285,:293-294) and the selection loops of print_fun_bits /
+// print_boring_bits (:425-445, :463-481).
+//
+// The reference sums window_size (2500) positions for every window, step window_inc (50): each base is
+// read 50 times.  Here each base is read ONCE from HBM (4 B/base: u16 depth + u16 mq):
+//
+//  cov_blocks   a 256-thread workgroup owns 256 consecutive `inc`-sized blocks of one contig.  The raw
+//               u16 data of the tile is staged into LDS with coalesced 16-byte loads, then thread b sums
+//               block b out of LDS (odd dword stride for inc = 50: conflict free), also the first
+//               r = w % inc elements ("head").  A workgroup-wide inclusive scan (u32, wrapping like the
+//               reference's int accumulators) turns block sums into tile-local prefix sums; the tile total
+//               is kept exactly in u64 for the mean.
+//  cov_tilescan one workgroup: exclusive scan of tile totals (u32 offsets for the prefix, u64 grand totals).
+//  cov_windows  one thread per window j: sum = G[a+q-1] - G[a-1] + head[a+q] with G = local prefix +
+//               tile offset, q = w / inc; integer division by (end-st) truncating toward zero (:360-361);
+//               predicate depth<lo || depth>hi || mq/(double)depth < (double)low_mq (:439) in IEEE double;
+//               selected windows are compacted with one atomic reservation per tile and a (base,count)
+//               table, so the output order is the reference's print order whatever the dispatch order.
+#include <algorithm>
+#include <cmath>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int CB_THREADS = 256;
+constexpr int CB_MAX_INC_LDS = 128;   // inc <= this: LDS staging path (2 x 256 x inc x 2 B <= 128 KiB)
+
+struct CbArgs {
+    const uint16_t *depth, *mq;
+    const int64_t *ctg_off;    // element offsets
+    const int32_t *ctg_len;
+    const int2 *tiles;         // {ctg, first block of the tile within the contig}
+    int32_t inc, r;            // block size, head size (w % inc)
+    uint4 *blk;                // [tile*256 + b] = {local inclusive prefix depth, head depth, prefix mq, head mq}
+    uint2 *tile_tot32;         // wrapping tile totals {depth, mq}
+    ulonglong2 *tile_tot64;    // exact tile totals
+};
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+template <bool STAGE>
+__global__ __launch_bounds__(CB_THREADS) void cov_blocks(CbArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ uint32_t wsum[2][CB_THREADS / 64];
+    __shared__ unsigned long long wsum64[2][CB_THREADS / 64];
+
+    const int t = threadIdx.x;
+    const int2 tile = A.tiles[blockIdx.x];
+    const int len = A.ctg_len[tile.x];
+    const int64_t off = A.ctg_off[tile.x];
+    const int inc = A.inc, r = A.r;
+    const int64_t e0 = (int64_t)tile.y * inc;           // first element of the tile within the contig
+    const int64_t p0 = e0 + (int64_t)t * inc;           // first element of my block
+
+    uint32_t fd = 0, fq = 0, hd = 0, hq = 0;
+    unsigned long long xd = 0, xq = 0;                  // exact block sums
+    if (STAGE) {
+        uint16_t *sd = reinterpret_cast<uint16_t *>(smem);
+        uint16_t *sq = sd + CB_THREADS * inc;           // 256*inc*2 bytes: multiple of 16
+        const int nvec = CB_THREADS * inc / 8;          // 16-byte vectors per array
+        const uint4 *gd = reinterpret_cast<const uint4 *>(A.depth + off + e0);
+        const uint4 *gq = reinterpret_cast<const uint4 *>(A.mq + off + e0);
+        for (int v = t; v < nvec; v += CB_THREADS) {
+            uint4 a = make_uint4(0, 0, 0, 0), b = a;
+            if (e0 + 8LL * v < len) {                   // vectors at or past the contig end are zeros
+                a = gd[v];
+                b = gq[v];
+            }
+            reinterpret_cast<uint4 *>(sd)[v] = a;
+            reinterpret_cast<uint4 *>(sq)[v] = b;
+        }
+        __syncthreads();
+        const int base = t * inc;
+        const int nval = p0 >= len ? 0 : (int)(len - p0 < inc ? len - p0 : inc);   // elements of my block inside the contig
+        if (nval == inc && (inc & 1) == 0) {
+            const uint32_t *wd = reinterpret_cast<const uint32_t *>(sd + base);
+            const uint32_t *wq = reinterpret_cast<const uint32_t *>(sq + base);
+            for (int i = 0; i < inc / 2; ++i) {
+                const uint32_t a = wd[i], b = wq[i];
+                fd += (a & 0xFFFFu) + (a >> 16);
+                fq += (b & 0xFFFFu) + (b >> 16);
+            }
+        } else {
+            for (int i = 0; i < nval; ++i) {
+                fd += sd[base + i];
+                fq += sq[base + i];
+            }
+        }
+        const int nh = r < nval ? r : nval;
+        for (int i = 0; i < nh; ++i) {
+            hd += sd[base + i];
+            hq += sq[base + i];
+        }
+        xd = fd;
+        xq = fq;
+    } else {
+        // general path for large increments: direct loads (each thread walks its own block)
+        const uint16_t *d = A.depth + off, *q = A.mq + off;
+        for (int64_t p = p0; p < p0 + inc && p < len; ++p) {
+            const uint32_t a = d[p], b = q[p];
+            xd += a;
+            xq += b;
+            if (p - p0 < r) {
+                hd += a;
+                hq += b;
+            }
+        }
+        fd = (uint32_t)xd;
+        fq = (uint32_t)xq;
+    }
+
+    // workgroup inclusive scan of (fd, fq), wrapping; exact totals in u64
+    const int lane = t & 63, wv = t >> 6;
+    const uint32_t sdv = wave_incl_scan(fd, lane), sqv = wave_incl_scan(fq, lane);
+    unsigned long long td = xd, tq = xq;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        td += ((unsigned long long)__shfl_xor((unsigned)(td >> 32), d) << 32) | __shfl_xor((unsigned)td, d);
+        tq += ((unsigned long long)__shfl_xor((unsigned)(tq >> 32), d) << 32) | __shfl_xor((unsigned)tq, d);
+    }
+    if (lane == 63) {
+        wsum[0][wv] = sdv;
+        wsum[1][wv] = sqv;
+    }
+    if (lane == 0) {
+        wsum64[0][wv] = td;
+        wsum64[1][wv] = tq;
+    }
+    __syncthreads();
+    uint32_t pd = 0, pq = 0;
+#pragma unroll
+    for (int i = 0; i < CB_THREADS / 64; ++i)
+        if (i < wv) {
+            pd += wsum[0][i];
+            pq += wsum[1][i];
+        }
+    A.blk[(size_t)blockIdx.x * CB_THREADS + t] = make_uint4(sdv + pd, hd, sqv + pq, hq);
+    if (t == CB_THREADS - 1) {
+        A.tile_tot32[blockIdx.x] = make_uint2(sdv + pd, sqv + pq);
+        ulonglong2 x;
+        x.x = wsum64[0][0] + wsum64[0][1] + wsum64[0][2] + wsum64[0][3];
+        x.y = wsum64[1][0] + wsum64[1][1] + wsum64[1][2] + wsum64[1][3];
+        A.tile_tot64[blockIdx.x] = x;
+    }
+}
+
+// exclusive scan of the tile totals by ONE workgroup of 1024 threads (n_tiles is ~ bases / 12800)
+__global__ __launch_bounds__(1024) void cov_tilescan(const uint2 *tot32, const ulonglong2 *tot64, int64_t n, uint2 *toff,
+                                                     unsigned long long *grand /* [2] */)
+{
+    __shared__ uint32_t sa[1024], sb[1024];
+    __shared__ unsigned long long ga[1024], gb[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t lo = (int64_t)t * per, hi = lo + per < n ? lo + per : n;
+    uint32_t a = 0, b = 0;
+    unsigned long long xa = 0, xb = 0;
+    for (int64_t i = lo; i < hi; ++i) {
+        a += tot32[i].x;
+        b += tot32[i].y;
+        xa += tot64[i].x;
+        xb += tot64[i].y;
+    }
+    sa[t] = a; sb[t] = b; ga[t] = xa; gb[t] = xb;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {   // Hillis-Steele inclusive scan of the per-thread partials
+        uint32_t oa = 0, ob = 0;
+        unsigned long long ua = 0, ub = 0;
+        if (t >= d) { oa = sa[t - d]; ob = sb[t - d]; ua = ga[t - d]; ub = gb[t - d]; }
+        __syncthreads();
+        sa[t] += oa; sb[t] += ob; ga[t] += ua; gb[t] += ub;
+        __syncthreads();
+    }
+    uint32_t ra = sa[t] - a, rb = sb[t] - b;   // exclusive prefix of my segment
+    for (int64_t i = lo; i < hi; ++i) {
+        toff[i] = make_uint2(ra, rb);
+        ra += tot32[i].x;
+        rb += tot32[i].y;
+    }
+    if (t == 1023) {
+        grand[0] = ga[t];
+        grand[1] = gb[t];
+    }
+}
+
+struct CwArgs {
+    const uint4 *blk;
+    const uint2 *toff;
+    const int64_t *blk_off;    // first global block of each contig (multiple of 256)
+    const int32_t *ctg_len;
+    const int32_t *n_reg;      // windows per contig
+    const int2 *tiles;         // {ctg, first window}
+    int32_t w, inc, q, r;
+    // selection
+    int32_t mode;              // 0 = all windows of one contig into regs; 1 = fun; 2 = boring
+    int32_t lo, hi, edge, min_len;
+    double low_mq;
+    cornetto_reg_t *regs;
+    uint4 *sel;                // {ctg, window, depth, mq}
+    unsigned long long *counter;
+    uint32_t cap;
+    uint2 *tile_res;           // per tile {base, count}
+};
+
+__device__ __forceinline__ uint2 cw_prefix(const CwArgs &A, int64_t x)   // inclusive global prefix at block x
+{
+    const uint4 b = A.blk[x];
+    const uint2 o = A.toff[x >> 8];
+    return make_uint2(b.x + o.x, b.z + o.y);
+}
+
+__global__ __launch_bounds__(256) void cov_windows(CwArgs A)
+{
+    __shared__ uint32_t wcnt[4];
+    __shared__ unsigned long long sbase;
+    const int t = threadIdx.x;
+    const int2 tile = A.tiles[blockIdx.x];
+    const int ctg = tile.x;
+    const int len = A.ctg_len[ctg];
+    const int j = tile.y + t;
+    bool valid = j < A.n_reg[ctg];
+    int st = 0, end = 0, depth = 0, mq = 0;
+    bool sel = false;
+    if (valid) {
+        st = j * A.inc;                                  // :347
+        end = st + A.w;
+        if (end > len) end = len;                        // :349-351
+        const int64_t a = A.blk_off[ctg] + j;
+        const uint2 hi = cw_prefix(A, a + A.q - 1);   // q >= 1 always (inc <= w)
+        uint2 lo = make_uint2(0, 0);
+        if (a > 0) lo = cw_prefix(A, a - 1);
+        // blocks of a contig start at a multiple of 256 = a tile boundary of the prefix, and the global
+        // prefix is continuous across contigs, so G[a+q-1] - G[a-1] is the sum over exactly [a, a+q)
+        uint32_t sd = hi.x - lo.x, sq = hi.y - lo.y;
+        if (A.r) {
+            const uint4 hb = A.blk[a + A.q];
+            sd += hb.y;
+            sq += hb.w;
+        }
+        depth = (int32_t)sd / (end - st);                // :360  (positions >= len contributed zero)
+        mq = (int32_t)sq / (end - st);                   // :361
+        if (A.mode == 0) {
+            A.regs[j] = cornetto_reg_t{st, end, depth, mq};
+        } else {
+            const bool fun = depth < A.lo || depth > A.hi || ((double)mq / (double)depth) < A.low_mq;   // :439
+            if (A.mode == 1) sel = len >= A.min_len && fun;                                               // :428 else-branch
+            else sel = len > A.min_len && st > A.edge && end < len - A.edge && !fun;                      // :467,:473-474
+        }
+    }
+    if (A.mode == 0) return;
+    // ordered compaction inside the tile: ballot + popcount, one reservation per tile
+    const unsigned long long bal = __ballot(sel);
+    const int lane = t & 63, wv = t >> 6;
+    if (lane == 0) wcnt[wv] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < wv) pre += wcnt[i];
+        tot += wcnt[i];
+    }
+    if (t == 0) {
+        unsigned long long b = tot ? atomicAdd(A.counter, (unsigned long long)tot) : 0ull;
+        sbase = b;
+        A.tile_res[blockIdx.x] = make_uint2((uint32_t)b, tot);
+    }
+    __syncthreads();
+    if (sel) {
+        const unsigned long long idx = sbase + pre + __popcll(bal & ((1ull << lane) - 1ull));
+        if (idx < A.cap) A.sel[idx] = make_uint4((uint32_t)ctg, (uint32_t)j, (uint32_t)depth, (uint32_t)mq);
+    }
+}
+
+int32_t n_reg_host(int32_t length, int32_t w, int32_t inc)
+{
+    int32_t n = (length - w + inc - 1) / inc + 1;   // src/boringbits_main.c:338, C truncation
+    return n < 1 ? 1 : n;                           // :339
+}
+
+struct WinTiles {
+    std::vector<int2> tiles;
+    std::vector<int32_t> n_reg;
+};
+
+}  // namespace
+
+extern "C" {
+
+int32_t cornetto_n_reg(int32_t length, int32_t window_size, int32_t window_inc)
+{
+    if (window_inc <= 0) return 0;
+    return n_reg_host(length, window_size, window_inc);
+}
+
+int32_t cornetto_cov_threshold(float factor, int32_t mean)
+{
+    return (int32_t)round(factor * mean);   // float product promoted to double by round(): src/boringbits_main.c:518-519
+}
+
+int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int32_t inc, uint64_t sums[3])
+{
+    if (!h || !c || !sums) return cn_fail(h, CORNETTO_E_ARG, "cov_prepare: bad argument");
+    if (inc < 1 || w < inc) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "cov_prepare: needs 1 <= window_inc <= window_size (got -w %d -i %d; the reference aborts on its assert)", w, inc);
+    CN_HIP(h, hipSetDevice(h->device));
+    cn_timing_begin(h);
+    const int32_t q = w / inc, r = w % inc;
+    c->w = w;
+    c->inc = inc;
+    c->blk_off.assign(c->n + 1, 0);
+    std::vector<int2> tiles;
+    for (int32_t i = 0; i < c->n; ++i) {
+        if (c->len[i] < 1) return cn_fail(h, CORNETTO_E_ARG, "cov_prepare: contig %d is empty (a bedgraph cannot produce that)", i);
+        const int64_t nb = cn_align_up((int64_t)n_reg_host(c->len[i], w, inc) + q + 1, CB_THREADS);
+        c->blk_off[i + 1] = c->blk_off[i] + nb;
+        for (int64_t b = 0; b < nb; b += CB_THREADS) tiles.push_back(make_int2(i, (int)b));
+    }
+    c->n_blk = c->blk_off[c->n];
+    const size_t nt = tiles.size();
+    if (c->d_blk) { (void)hipFree(c->d_blk); c->d_blk = nullptr; }
+    if (c->d_blk_off) { (void)hipFree(c->d_blk_off); c->d_blk_off = nullptr; }
+    sums[0] = sums[1] = 0;
+    sums[2] = (uint64_t)c->total;
+    if (nt == 0) { cn_timing_end(h); return CORNETTO_OK; }
+    DevBuf d_tiles, d_t32, d_t64, d_grand;
+    // blk + tile offsets stay in the cov object: [n_blk] uint4, then [nt] uint2 offsets
+    if (hipMalloc((void **)&c->d_blk, (size_t)c->n_blk * sizeof(uint4) + nt * sizeof(uint2)) != hipSuccess ||
+        hipMalloc((void **)&c->d_blk_off, (size_t)(c->n + 1) * 8) != hipSuccess || d_tiles.alloc(nt * sizeof(int2)) != hipSuccess ||
+        d_t32.alloc(nt * sizeof(uint2)) != hipSuccess || d_t64.alloc(nt * sizeof(ulonglong2)) != hipSuccess || d_grand.alloc(16) != hipSuccess)
+        return cn_fail(h, CORNETTO_E_NOMEM, "cov_prepare: device allocation failed");
+    CN_HIP(h, hipMemcpyAsync(d_tiles.p, tiles.data(), nt * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    CN_HIP(h, hipMemcpyAsync(c->d_blk_off, c->blk_off.data(), (size_t)(c->n + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    uint4 *d_blk = reinterpret_cast<uint4 *>(c->d_blk);
+    uint2 *d_toff = reinterpret_cast<uint2 *>(d_blk + c->n_blk);
+    CbArgs A{c->d_depth, c->d_mq, c->d_off, c->d_len, d_tiles.as<int2>(), inc, r, d_blk, d_t32.as<uint2>(), d_t64.as<ulonglong2>()};
+    if (inc <= CB_MAX_INC_LDS) {
+        const size_t lds = (size_t)2 * CB_THREADS * inc * sizeof(uint16_t);
+        CN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&cov_blocks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CN_LAUNCH(h, "cov_blocks", cov_blocks<true><<<dim3((unsigned)nt), dim3(CB_THREADS), lds, h->stream>>>(A));
+    } else {
+        CN_LAUNCH(h, "cov_blocks", cov_blocks<false><<<dim3((unsigned)nt), dim3(CB_THREADS), 0, h->stream>>>(A));
+    }
+    CN_LAUNCH(h, "cov_tilescan", cov_tilescan<<<dim3(1), dim3(1024), 0, h->stream>>>(d_t32.as<uint2>(), d_t64.as<ulonglong2>(), (int64_t)nt, d_toff, d_grand.as<unsigned long long>()));
+    unsigned long long g[2] = {0, 0};
+    CN_HIP(h, hipMemcpyAsync(g, d_grand.p, 16, hipMemcpyDeviceToHost, h->stream));
+    CN_HIP(h, hipStreamSynchronize(h->stream));
+    cn_timing_end(h);
+    sums[0] = g[0];
+    sums[1] = g[1];
+    c->sums[0] = g[0]; c->sums[1] = g[1]; c->sums[2] = (uint64_t)c->total;
+    return CORNETTO_OK;
+}
+
+static int cov_run_windows(cornetto_accel_t *h, const cornetto_cov_t *c, int32_t only_ctg, int mode, int32_t lo, int32_t hi,
+                           float low_mq, int32_t edge, int32_t min_len, cornetto_reg_t *regs_host, std::vector<uint4> *sel_out)
+{
+    if (!c->d_blk) return cn_fail(h, CORNETTO_E_ARG, "cov: cornetto_cov_prepare() has not been called");
+    const int32_t w = c->w, inc = c->inc, q = w / inc, r = w % inc;
+    std::vector<int32_t> n_reg(c->n);
+    std::vector<int2> tiles;
+    for (int32_t i = 0; i < c->n; ++i) {
+        n_reg[i] = n_reg_host(c->len[i], w, inc);
+        if (only_ctg >= 0 && i != only_ctg) continue;
+        if (mode == 1 && !(c->len[i] >= min_len)) continue;   // short contigs print one '.' line and no windows
+        if (mode == 2 && !(c->len[i] > min_len)) continue;
+        for (int32_t j = 0; j < n_reg[i]; j += 256) tiles.push_back(make_int2(i, j));
+    }
+    const size_t nt = tiles.size();
+    if (nt == 0) return CORNETTO_OK;
+    DevBuf d_tiles, d_nreg, d_regs, d_sel, d_cnt, d_tres;
+    if (d_tiles.alloc(nt * sizeof(int2)) != hipSuccess || d_nreg.alloc((size_t)c->n * 4) != hipSuccess || d_cnt.alloc(8) != hipSuccess ||
+        d_tres.alloc(nt * sizeof(uint2)) != hipSuccess)
+        return cn_fail(h, CORNETTO_E_NOMEM, "cov: device allocation failed");
+    CN_HIP(h, hipMemcpyAsync(d_tiles.p, tiles.data(), nt * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    CN_HIP(h, hipMemcpyAsync(d_nreg.p, n_reg.data(), (size_t)c->n * 4, hipMemcpyHostToDevice, h->stream));
+    const uint4 *d_blk = reinterpret_cast<const uint4 *>(c->d_blk);
+    const uint2 *d_toff = reinterpret_cast<const uint2 *>(d_blk + c->n_blk);
+    CwArgs A{};
+    A.blk = d_blk; A.toff = d_toff; A.blk_off = c->d_blk_off; A.ctg_len = c->d_len; A.n_reg = d_nreg.as<int32_t>();
+    A.tiles = d_tiles.as<int2>(); A.w = w; A.inc = inc; A.q = q; A.r = r; A.mode = mode; A.lo = lo; A.hi = hi; A.edge = edge;
+    A.min_len = min_len; A.low_mq = (double)low_mq;   // float promoted exactly as in `x < low_mq_cov_thresh`
+    A.counter = d_cnt.as<unsigned long long>(); A.tile_res = d_tres.as<uint2>();
+    if (mode == 0) {
+        const size_t nr = (size_t)n_reg[only_ctg];
+        if (d_regs.alloc(nr * sizeof(cornetto_reg_t)) != hipSuccess) return cn_fail(h, CORNETTO_E_NOMEM, "cov: device allocation failed");
+        A.regs = d_regs.as<cornetto_reg_t>();
+        CN_LAUNCH(h, "cov_windows", cov_windows<<<dim3((unsigned)nt), dim3(256), 0, h->stream>>>(A));
+        CN_HIP(h, hipMemcpyAsync(regs_host, d_regs.p, nr * sizeof(cornetto_reg_t), hipMemcpyDeviceToHost, h->stream));
+        CN_HIP(h, hipStreamSynchronize(h->stream));
+        return CORNETTO_OK;
+    }
+    uint32_t cap = (uint32_t)std::min<size_t>(std::max<size_t>(1 << 16, nt * 256 / 8), 0x7fffffff);
+    unsigned long long cnt = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (d_sel.alloc((size_t)cap * sizeof(uint4)) != hipSuccess) return cn_fail(h, CORNETTO_E_NOMEM, "cov: device allocation failed");
+        A.sel = d_sel.as<uint4>();
+        A.cap = cap;
+        CN_HIP(h, hipMemsetAsync(d_cnt.p, 0, 8, h->stream));
+        CN_LAUNCH(h, "cov_windows", cov_windows<<<dim3((unsigned)nt), dim3(256), 0, h->stream>>>(A));
+        CN_HIP(h, hipMemcpyAsync(&cnt, d_cnt.p, 8, hipMemcpyDeviceToHost, h->stream));
+        CN_HIP(h, hipStreamSynchronize(h->stream));
+        if (cnt <= cap) break;
+        if (attempt == 1 || cnt > 0x7fffffffull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "cov: %llu selected windows", cnt);
+        cap = (uint32_t)cnt;   // exact rerun, never a truncated answer
+    }
+    std::vector<uint4> raw((size_t)cnt);
+    std::vector<uint2> tres(nt);
+    if (cnt) CN_HIP(h, hipMemcpy(raw.data(), d_sel.p, (size_t)cnt * sizeof(uint4), hipMemcpyDeviceToHost));
+    CN_HIP(h, hipMemcpy(tres.data(), d_tres.p, nt * sizeof(uint2), hipMemcpyDeviceToHost));
+    sel_out->clear();
+    sel_out->reserve((size_t)cnt);
+    for (size_t t = 0; t < nt; ++t)   // tiles are in (contig, window) order
+        for (uint32_t i = 0; i < tres[t].y; ++i) sel_out->push_back(raw[(size_t)tres[t].x + i]);
+    return CORNETTO_OK;
+}
+
+int cornetto_cov_regs(cornetto_accel_t *h, const cornetto_cov_t *c, int32_t ctg, cornetto_reg_t *regs)
+{
+    if (!h || !c || !regs || ctg < 0 || ctg >= c->n) return cn_fail(h, CORNETTO_E_ARG, "cov_regs: bad argument");
+    CN_HIP(h, hipSetDevice(h->device));
+    cn_timing_begin(h);
+    int rc = cov_run_windows(h, c, ctg, 0, 0, 0, 0.f, 0, 0, regs, nullptr);
+    cn_timing_end(h);
+    return rc;
+}
+
+int cornetto_cov_select(cornetto_accel_t *h, const cornetto_cov_t *c, int32_t lo, int32_t hi, float low_mq, int32_t edge_len,
+                        int32_t min_ctg_len, int boring, cornetto_regrec_t **recs, int64_t *n_recs)
+{
+    if (!h || !c || !recs || !n_recs) return cn_fail(h, CORNETTO_E_ARG, "cov_select: bad argument");
+    *recs = nullptr;
+    *n_recs = 0;
+    CN_HIP(h, hipSetDevice(h->device));
+    cn_timing_begin(h);
+    std::vector<uint4> sel;
+    int rc = cov_run_windows(h, c, -1, boring ? 2 : 1, lo, hi, low_mq, edge_len, min_ctg_len, nullptr, &sel);
+    cn_timing_end(h);
+    if (rc != CORNETTO_OK) return rc;
+    cornetto_regrec_t *o = (cornetto_regrec_t *)malloc((sel.size() ? sel.size() : 1) * sizeof(cornetto_regrec_t));
+    if (!o) return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: host allocation failed");
+    for (size_t i = 0; i < sel.size(); ++i) {
+        const int32_t ctg = (int32_t)sel[i].x, j = (int32_t)sel[i].y;
+        const int32_t st = j * c->inc;
+        int32_t end = st + c->w;
+        if (end > c->len[ctg]) end = c->len[ctg];
+        o[i] = cornetto_regrec_t{ctg, st, end, (int32_t)sel[i].z, (int32_t)sel[i].w};
+    }
+    *recs = o;
+    *n_recs = (int64_t)sel.size();
+    return CORNETTO_OK;
+}
+
+}  // extern "C"

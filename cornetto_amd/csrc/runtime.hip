@@ -1,0 +1,282 @@
+// runtime.hip — handle lifetime, resident data sets (bases / coverage in HBM) and small utilities of the
+// C ABI declared in include/cornetto_accel.h.
+#include "common.hpp"
+
+extern "C" {
+
+int cornetto_accel_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int cornetto_accel_open(cornetto_accel_t **out, int device, void *stream)
+{
+    if (!out) return CORNETTO_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return CORNETTO_E_NODEVICE;
+    if (hipSetDevice(device) != hipSuccess) return CORNETTO_E_NODEVICE;
+    cornetto_accel_t *h = new (std::nothrow) cornetto_accel;
+    if (!h) return CORNETTO_E_NOMEM;
+    h->device = device;
+    if (stream) {
+        h->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete h;
+            return CORNETTO_E_NODEVICE;
+        }
+        h->own_stream = true;
+    }
+    *out = h;
+    return CORNETTO_OK;
+}
+
+void cornetto_accel_close(cornetto_accel_t *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (auto &r : h->recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    for (auto e : h->pool) (void)hipEventDestroy(e);
+    if (h->own_stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char *cornetto_accel_last_error(const cornetto_accel_t *h) { return h ? h->err : "null handle"; }
+
+const char *cornetto_accel_strerror(int status)
+{
+    switch (status) {
+    case CORNETTO_OK: return "ok";
+    case CORNETTO_E_NODEVICE: return "no usable HIP device";
+    case CORNETTO_E_HIP: return "HIP runtime or kernel failure";
+    case CORNETTO_E_ARG: return "invalid argument";
+    case CORNETTO_E_NOMEM: return "out of memory";
+    case CORNETTO_E_UNSUPPORTED: return "parameter outside the supported range";
+    default: return "unknown status";
+    }
+}
+
+void cornetto_free(void *p) { free(p); }
+
+int cornetto_accel_last_timing(const cornetto_accel_t *h, const char **names, float *ms, int cap)
+{
+    if (!h) return 0;
+    int n = (int)h->last.size();
+    for (int i = 0; i < n && i < cap; ++i) {
+        if (names) names[i] = h->last[i].first;
+        if (ms) ms[i] = h->last[i].second;
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// sequences
+// ---------------------------------------------------------------------------------------------------
+static const int64_t SLACK = 256;  // readable bytes behind the last contig
+
+static int asm_finish_table(cornetto_accel_t *h, cornetto_asm_t *a)
+{
+    size_t n = (size_t)(a->n > 0 ? a->n : 1);
+    CN_HIP(h, hipMalloc((void **)&a->d_off, n * sizeof(int64_t)));
+    CN_HIP(h, hipMalloc((void **)&a->d_len, n * sizeof(int32_t)));
+    if (a->n) {
+        CN_HIP(h, hipMemcpyAsync(a->d_off, a->off.data(), a->n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+        CN_HIP(h, hipMemcpyAsync(a->d_len, a->len.data(), a->n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    }
+    CN_HIP(h, hipStreamSynchronize(h->stream));
+    return CORNETTO_OK;
+}
+
+void cornetto_asm_free(cornetto_accel_t *h, cornetto_asm_t *a)
+{
+    if (!a) return;
+    if (h) (void)hipSetDevice(h->device);
+    if (a->owned) (void)hipFree(a->owned);
+    if (a->d_off) (void)hipFree(a->d_off);
+    if (a->d_len) (void)hipFree(a->d_len);
+    delete a;
+}
+
+int cornetto_asm_upload(cornetto_accel_t *h, const uint8_t *const *seqs, const int64_t *lens, int32_t n,
+                        cornetto_asm_t **out)
+{
+    if (!h || !out || n < 0 || (n > 0 && (!seqs || !lens))) return cn_fail(h, CORNETTO_E_ARG, "asm_upload: bad argument");
+    *out = nullptr;
+    CN_HIP(h, hipSetDevice(h->device));
+    cornetto_asm_t *a = new (std::nothrow) cornetto_asm;
+    if (!a) return cn_fail(h, CORNETTO_E_NOMEM, "asm_upload: host allocation failed");
+    a->n = n;
+    int64_t pos = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        if (lens[i] < 0 || lens[i] > INT32_MAX) {
+            delete a;
+            return cn_fail(h, CORNETTO_E_ARG, "asm_upload: contig %d has length %lld (must be 0..2^31-1)", i, (long long)lens[i]);
+        }
+        a->off.push_back(pos);
+        a->len.push_back((int32_t)lens[i]);
+        a->total += lens[i];
+        pos = cn_align_up(pos + lens[i], 64);
+    }
+    int64_t bytes = pos + SLACK;
+    if (hipMalloc(&a->owned, (size_t)bytes) != hipSuccess) {
+        delete a;
+        return cn_fail(h, CORNETTO_E_NOMEM, "asm_upload: hipMalloc of %lld bytes failed", (long long)bytes);
+    }
+    a->d_bases = (const uint8_t *)a->owned;
+    int rc = CORNETTO_OK;
+    if (hipMemsetAsync(a->owned, 0, (size_t)bytes, h->stream) != hipSuccess) rc = CORNETTO_E_HIP;
+    for (int32_t i = 0; i < n && rc == CORNETTO_OK; ++i)
+        if (lens[i] > 0 && hipMemcpyAsync((uint8_t *)a->owned + a->off[i], seqs[i], (size_t)lens[i], hipMemcpyHostToDevice, h->stream) != hipSuccess)
+            rc = CORNETTO_E_HIP;
+    if (rc == CORNETTO_OK) rc = asm_finish_table(h, a);
+    if (rc != CORNETTO_OK) {
+        cornetto_asm_free(h, a);
+        return cn_fail(h, rc, "asm_upload: copy to device failed");
+    }
+    *out = a;
+    return CORNETTO_OK;
+}
+
+int cornetto_asm_wrap(cornetto_accel_t *h, const void *d_bases, const int64_t *offsets, const int64_t *lens,
+                      int32_t n, cornetto_asm_t **out)
+{
+    if (!h || !out || n < 0 || (n > 0 && (!d_bases || !offsets || !lens))) return cn_fail(h, CORNETTO_E_ARG, "asm_wrap: bad argument");
+    *out = nullptr;
+    if (((uintptr_t)d_bases & 63) != 0) return cn_fail(h, CORNETTO_E_ARG, "asm_wrap: device pointer must be 64-byte aligned");
+    CN_HIP(h, hipSetDevice(h->device));
+    cornetto_asm_t *a = new (std::nothrow) cornetto_asm;
+    if (!a) return cn_fail(h, CORNETTO_E_NOMEM, "asm_wrap: host allocation failed");
+    a->n = n;
+    a->d_bases = (const uint8_t *)d_bases;
+    for (int32_t i = 0; i < n; ++i) {
+        if (lens[i] < 0 || lens[i] > INT32_MAX || offsets[i] < 0 || (offsets[i] & 63)) {
+            delete a;
+            return cn_fail(h, CORNETTO_E_ARG, "asm_wrap: contig %d: offset %lld must be a non-negative multiple of 64, length %lld within 0..2^31-1",
+                           i, (long long)offsets[i], (long long)lens[i]);
+        }
+        a->off.push_back(offsets[i]);
+        a->len.push_back((int32_t)lens[i]);
+        a->total += lens[i];
+    }
+    int rc = asm_finish_table(h, a);
+    if (rc != CORNETTO_OK) {
+        cornetto_asm_free(h, a);
+        return rc;
+    }
+    *out = a;
+    return CORNETTO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// coverage
+// ---------------------------------------------------------------------------------------------------
+void cornetto_cov_free(cornetto_accel_t *h, cornetto_cov_t *c)
+{
+    if (!c) return;
+    if (h) (void)hipSetDevice(h->device);
+    if (c->owned_d) (void)hipFree(c->owned_d);
+    if (c->owned_q) (void)hipFree(c->owned_q);
+    if (c->d_off) (void)hipFree(c->d_off);
+    if (c->d_len) (void)hipFree(c->d_len);
+    if (c->d_blk) (void)hipFree(c->d_blk);
+    if (c->d_blk_off) (void)hipFree(c->d_blk_off);
+    delete c;
+}
+
+static int cov_finish_table(cornetto_accel_t *h, cornetto_cov_t *c)
+{
+    size_t n = (size_t)(c->n > 0 ? c->n : 1);
+    CN_HIP(h, hipMalloc((void **)&c->d_off, n * sizeof(int64_t)));
+    CN_HIP(h, hipMalloc((void **)&c->d_len, n * sizeof(int32_t)));
+    if (c->n) {
+        CN_HIP(h, hipMemcpyAsync(c->d_off, c->off.data(), c->n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+        CN_HIP(h, hipMemcpyAsync(c->d_len, c->len.data(), c->n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    }
+    CN_HIP(h, hipStreamSynchronize(h->stream));
+    return CORNETTO_OK;
+}
+
+int cornetto_cov_upload(cornetto_accel_t *h, const uint16_t *const *depth, const uint16_t *const *mq_depth,
+                        const int32_t *lens, int32_t n, cornetto_cov_t **out)
+{
+    if (!h || !out || n < 0 || (n > 0 && (!depth || !mq_depth || !lens))) return cn_fail(h, CORNETTO_E_ARG, "cov_upload: bad argument");
+    *out = nullptr;
+    CN_HIP(h, hipSetDevice(h->device));
+    cornetto_cov_t *c = new (std::nothrow) cornetto_cov;
+    if (!c) return cn_fail(h, CORNETTO_E_NOMEM, "cov_upload: host allocation failed");
+    c->n = n;
+    int64_t pos = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        if (lens[i] < 0) {
+            delete c;
+            return cn_fail(h, CORNETTO_E_ARG, "cov_upload: contig %d has negative length", i);
+        }
+        c->off.push_back(pos);
+        c->len.push_back(lens[i]);
+        c->total += lens[i];
+        pos = cn_align_up(pos + lens[i], 64);
+    }
+    size_t bytes = (size_t)(pos + SLACK) * sizeof(uint16_t);
+    if (hipMalloc(&c->owned_d, bytes) != hipSuccess || hipMalloc(&c->owned_q, bytes) != hipSuccess) {
+        cornetto_cov_free(h, c);
+        return cn_fail(h, CORNETTO_E_NOMEM, "cov_upload: hipMalloc of 2 x %zu bytes failed", bytes);
+    }
+    c->d_depth = (const uint16_t *)c->owned_d;
+    c->d_mq = (const uint16_t *)c->owned_q;
+    int rc = CORNETTO_OK;
+    if (hipMemsetAsync(c->owned_d, 0, bytes, h->stream) != hipSuccess || hipMemsetAsync(c->owned_q, 0, bytes, h->stream) != hipSuccess)
+        rc = CORNETTO_E_HIP;
+    for (int32_t i = 0; i < n && rc == CORNETTO_OK; ++i) {
+        if (lens[i] == 0) continue;
+        size_t nb = (size_t)lens[i] * sizeof(uint16_t);
+        if (hipMemcpyAsync((uint16_t *)c->owned_d + c->off[i], depth[i], nb, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipMemcpyAsync((uint16_t *)c->owned_q + c->off[i], mq_depth[i], nb, hipMemcpyHostToDevice, h->stream) != hipSuccess)
+            rc = CORNETTO_E_HIP;
+    }
+    if (rc == CORNETTO_OK) rc = cov_finish_table(h, c);
+    if (rc != CORNETTO_OK) {
+        cornetto_cov_free(h, c);
+        return cn_fail(h, rc, "cov_upload: copy to device failed");
+    }
+    *out = c;
+    return CORNETTO_OK;
+}
+
+int cornetto_cov_wrap(cornetto_accel_t *h, const void *d_depth, const void *d_mq_depth, const int64_t *offsets,
+                      const int32_t *lens, int32_t n, cornetto_cov_t **out)
+{
+    if (!h || !out || n < 0 || (n > 0 && (!d_depth || !d_mq_depth || !offsets || !lens))) return cn_fail(h, CORNETTO_E_ARG, "cov_wrap: bad argument");
+    *out = nullptr;
+    if (((uintptr_t)d_depth & 127) || ((uintptr_t)d_mq_depth & 127)) return cn_fail(h, CORNETTO_E_ARG, "cov_wrap: device pointers must be 128-byte aligned");
+    CN_HIP(h, hipSetDevice(h->device));
+    cornetto_cov_t *c = new (std::nothrow) cornetto_cov;
+    if (!c) return cn_fail(h, CORNETTO_E_NOMEM, "cov_wrap: host allocation failed");
+    c->n = n;
+    c->d_depth = (const uint16_t *)d_depth;
+    c->d_mq = (const uint16_t *)d_mq_depth;
+    for (int32_t i = 0; i < n; ++i) {
+        if (lens[i] < 0 || offsets[i] < 0 || (offsets[i] & 63)) {
+            delete c;
+            return cn_fail(h, CORNETTO_E_ARG, "cov_wrap: contig %d: element offset %lld must be a non-negative multiple of 64", i, (long long)offsets[i]);
+        }
+        c->off.push_back(offsets[i]);
+        c->len.push_back(lens[i]);
+        c->total += lens[i];
+    }
+    int rc = cov_finish_table(h, c);
+    if (rc != CORNETTO_OK) {
+        cornetto_cov_free(h, c);
+        return rc;
+    }
+    *out = c;
+    return CORNETTO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,622 @@
+// telo.hip — telofind (motif run finding, both strands) and telowin (1000/200 mark-density windows) for
+// gfx950.  Replaces find() src/find_telomere.c:44-74 and process_scaffold() src/telomere_windows.c:28-43
+// of the reference; see include/cornetto_accel.h for the boundary.
+//
+// tf_scan   one pass over the bases (1 B/base from HBM).  A 256-thread workgroup owns a tile of 254 x 64
+//           positions of one contig; every thread runs a shift-and automaton for the motif and for its
+//           reverse complement over its own 64 positions (+ halo) out of registers, yielding two 64-bit
+//           match masks.  Neighbouring masks are exchanged through LDS; for a motif without a proper
+//           border (TTAGGG, CCCTAA, every real telomere unit) matches cannot overlap, so the reference's
+//           greedy runs are exactly  head = m[p] & !m[p-k],  tail = m[p] & !m[p+k]  
+//           and the i-th head pairs with the i-th tail.  Heads/tails are compacted with a packed
+//           4-counter block scan and ONE atomic reservation per list per tile; a per-tile (base,count)
+//           table restores contig order afterwards, so output order never depends on dispatch order.
+//           The same pass writes the telowin mark bitmap (1 bit/base) = union of [p,p+k) over matches.
+// tf_greedy for motifs WITH a border (AAAA, ACACA ...) only: the sequential greedy rule of
+//           src/find_telomere.c:49-58 over the compacted match list, one thread per (contig,strand).
+// tw_fill   marks [start,end) of explicit hits in the bitmap (src/telomere_windows.c:75-79).
+// tw_scan   one thread per 200-bp window start: popcount of <=1000 bitmap bits, double-precision
+//           car/den >= threshold exactly as :36-37, passing windows appended.
+#include <algorithm>
+#include <cmath>
+#include <string>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int TF_THREADS = 256;
+constexpr int TF_SEG = 64;
+constexpr int TF_TILE = (TF_THREADS - 2) * TF_SEG;  // 16256 positions; threads 0 and 255 are halo only
+constexpr int MAX_MOTIF = 32;
+
+struct TfArgs {
+    const uint8_t *bases;
+    const int64_t *ctg_off;
+    const int32_t *ctg_len;
+    const int2 *tiles;   // {ctg, first position}
+    const uint2 *lut;    // [256] {fwd mask, rev mask}
+    int32_t k;
+    int32_t bordered;    // 0: heads/tails + bitmap; 1: all matches (lists 0 and 2)
+    unsigned long long *bitmap;
+    int32_t *list0, *list1, *list2, *list3;
+    unsigned long long *counters;  // [4]
+    uint32_t cap;
+    uint4 *tile_base, *tile_cnt;
+};
+
+__device__ __forceinline__ unsigned long long shfl_up64(unsigned long long v, int d)
+{
+    unsigned lo = __shfl_up((unsigned)v, d), hi = __shfl_up((unsigned)(v >> 32), d);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// union of [p, p+k) over set bits p of (prev:cur), restricted to cur's 64 positions
+__device__ __forceinline__ unsigned long long smear(unsigned long long cur, unsigned long long prev, int k)
+{
+    unsigned long long c = cur;
+    for (int j = 1; j < k; ++j) c |= (cur << j) | (prev >> (64 - j));
+    return c;
+}
+
+template <int H>  // halo bytes behind the 64 positions of a thread; motif length k <= H + 1
+__global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
+{
+    __shared__ uint2 lut[256];
+    __shared__ unsigned long long shF[TF_THREADS], shR[TF_THREADS];
+    __shared__ unsigned long long wtot[TF_THREADS / 64];
+    __shared__ unsigned long long sbase[4];
+
+    const int t = threadIdx.x;
+    lut[t] = A.lut[t];
+    const int2 tile = A.tiles[blockIdx.x];
+    const int ctg = tile.x;
+    const int len = A.ctg_len[ctg];
+    const int64_t off = A.ctg_off[ctg];
+    const int s0 = tile.y + (t - 1) * TF_SEG;
+    __syncthreads();
+
+    unsigned long long Mf = 0, Mr = 0;
+    if (s0 >= 0 && s0 < len) {
+        constexpr int NW = (TF_SEG + H + 3) / 4;      // dwords touched
+        constexpr int NV = (NW + 3) / 4;              // 16-byte loads
+        uint32_t w[NV * 4];
+        const uint4 *src = reinterpret_cast<const uint4 *>(A.bases + off + s0);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            uint4 v = src[i];
+            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        }
+        constexpr uint32_t INJ = 1u << (31 - H);
+        uint32_t Sf = 0, Sr = 0, Af = 0, Bf = 0, Ar = 0, Br = 0;
+#pragma unroll
+        for (int e = 0; e < TF_SEG + H; ++e) {
+            const uint32_t c = (w[e >> 2] >> (8 * (e & 3))) & 0xFFu;
+            const uint2 L = lut[c];
+            Sf = ((Sf << 1) | INJ) & L.x;
+            Sr = ((Sr << 1) | INJ) & L.y;
+            if (e >= H) {                             // bit 31 of S = "a match starts at e - H"
+                if (e - H < 32) {
+                    Af = __builtin_amdgcn_alignbit(Af, Sf, 31);
+                    Ar = __builtin_amdgcn_alignbit(Ar, Sr, 31);
+                } else {
+                    Bf = __builtin_amdgcn_alignbit(Bf, Sf, 31);
+                    Br = __builtin_amdgcn_alignbit(Br, Sr, 31);
+                }
+            }
+        }
+        Mf = (unsigned long long)__brev(Af) | ((unsigned long long)__brev(Bf) << 32);
+        Mr = (unsigned long long)__brev(Ar) | ((unsigned long long)__brev(Br) << 32);
+        const int nvalid = len - A.k + 1 - s0;        // start positions p with p + k <= len
+        if (nvalid < 64) {
+            const unsigned long long m = nvalid <= 0 ? 0ull : ((1ull << nvalid) - 1ull);
+            Mf &= m;
+            Mr &= m;
+        }
+    }
+    shF[t] = Mf;
+    shR[t] = Mr;
+    __syncthreads();
+
+    const bool inner = (t >= 1 && t <= TF_THREADS - 2);
+    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    if (inner) {
+        const unsigned long long pF = shF[t - 1], nF = shF[t + 1], pR = shR[t - 1], nR = shR[t + 1];
+        const int k = A.k;
+        if (A.bordered) {
+            q0 = Mf;
+            q2 = Mr;
+        } else {
+            q0 = Mf & ~((Mf << k) | (pF >> (64 - k)));
+            q1 = Mf & ~((Mf >> k) | (nF << (64 - k)));
+            q2 = Mr & ~((Mr << k) | (pR >> (64 - k)));
+            q3 = Mr & ~((Mr >> k) | (nR << (64 - k)));
+            if (A.bitmap && s0 >= 0 && s0 < len)
+                A.bitmap[(off + s0) >> 6] = smear(Mf, pF, k) | smear(Mr, pR, k);
+        }
+    }
+    // packed 4 x 16-bit exclusive scan over the workgroup (a tile holds < 2^15 heads per list)
+    unsigned long long pk = (unsigned long long)__popcll(q0) | ((unsigned long long)__popcll(q1) << 16) |
+                            ((unsigned long long)__popcll(q2) << 32) | ((unsigned long long)__popcll(q3) << 48);
+    unsigned long long inc = pk;
+    const int lane = t & 63, wv = t >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned long long o = shfl_up64(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wtot[wv] = inc;
+    __syncthreads();
+    unsigned long long wpre = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < TF_THREADS / 64; ++i) {
+        if (i < wv) wpre += wtot[i];
+        total += wtot[i];
+    }
+    const unsigned long long excl = wpre + inc - pk;
+    if (t == 0) {
+        uint32_t cnt[4], base[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            cnt[q] = (uint32_t)((total >> (16 * q)) & 0xFFFFu);
+            unsigned long long b = cnt[q] ? atomicAdd(&A.counters[q], (unsigned long long)cnt[q]) : 0ull;
+            sbase[q] = b;
+            base[q] = (uint32_t)b;
+        }
+        A.tile_base[blockIdx.x] = make_uint4(base[0], base[1], base[2], base[3]);
+        A.tile_cnt[blockIdx.x] = make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]);
+    }
+    __syncthreads();
+    if (!inner) return;
+    int32_t *lists[4] = {A.list0, A.list1, A.list2, A.list3};
+    unsigned long long qs[4] = {q0, q1, q2, q3};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned long long m = qs[q];
+        unsigned long long idx = sbase[q] + ((excl >> (16 * q)) & 0xFFFFu);
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (idx < A.cap) lists[q][idx] = s0 + b;
+            ++idx;
+        }
+    }
+}
+
+// The reference's sequential rule for one (contig, strand): src/find_telomere.c:49-58.
+// matches: ascending start positions of ALL occurrences, stored tile by tile (tile_base/tile_cnt, list q).
+struct GreedyArgs {
+    const int32_t *list0, *list2;
+    const uint4 *tile_base, *tile_cnt;
+    const int32_t *ctg_tile0;   // [n_ctg + 1] first tile of each contig
+    const int64_t *run_off;     // [2 * n_ctg] first output slot of (ctg, strand)
+    int32_t n_ctg, k;
+    int2 *runs;                 // {start, end}
+    int32_t *n_runs;            // [2 * n_ctg]
+};
+
+__global__ void tf_greedy(GreedyArgs G)
+{
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 2 * G.n_ctg) return;
+    const int ctg = id >> 1, strand = id & 1;
+    const int32_t *list = strand ? G.list2 : G.list0;
+    int2 *out = G.runs + G.run_off[id];
+    int n = 0;
+    long long pos = 0;          // next position the search may start from (:49 / :57)
+    bool in_run = false;
+    long long rs = 0, re = 0;   // current run [rs, re): re is also the only position that can extend it
+    for (int tl = G.ctg_tile0[ctg]; tl < G.ctg_tile0[ctg + 1]; ++tl) {
+        const uint4 b4 = G.tile_base[tl], c4 = G.tile_cnt[tl];
+        const uint32_t base = strand ? b4.z : b4.x, cnt = strand ? c4.z : c4.x;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const long long m = list[base + i];
+            if (in_run) {
+                if (m < re) continue;                    // inside the run, off phase: skipped by the reference
+                if (m == re) { re += G.k; continue; }    // strncmp at :52 succeeds
+                out[n++] = make_int2((int)rs, (int)re);  // run ended: strncmp failed at re
+                pos = re + 1;
+                in_run = false;
+            }
+            if (m >= pos) { in_run = true; rs = m; re = m + G.k; }
+        }
+    }
+    if (in_run) out[n++] = make_int2((int)rs, (int)re);
+    G.n_runs[id] = n;
+}
+
+// ---- telowin --------------------------------------------------------------------------------------
+__global__ void tw_fill(const int4 *hits /* {bit offset lo, bit offset hi, start, end} */, int64_t n,
+                        unsigned long long *bitmap)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 hv = hits[i];
+    const long long boff = ((long long)(uint32_t)hv.y << 32) | (uint32_t)hv.x;
+    long long a = boff + hv.z, b = boff + hv.w;    // [a, b) in bits
+    while (a < b) {
+        const long long wi = a >> 6;
+        const int lo = (int)(a & 63);
+        const long long wend = (wi + 1) << 6;
+        const int hi = (int)((b < wend ? b : wend) - (wi << 6));   // exclusive bit index within the word, 1..64
+        unsigned long long m = (hi == 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+        atomicOr(&bitmap[wi], m);
+        a = wend;
+    }
+}
+
+struct TwArgs {
+    const unsigned long long *bitmap;
+    const int64_t *bit_off;   // [n_ctg] first bit of contig (multiple of 64)
+    const int32_t *ctg_len;
+    const int2 *tiles;        // {ctg, first window index}
+    double thr;
+    int4 *out;                // {ctg, start, end, car}
+    unsigned long long *counter;
+    uint32_t cap;
+};
+
+__device__ __forceinline__ int popc_range(const unsigned long long *bm, long long a, long long b)
+{
+    int c = 0;
+    while (a < b) {
+        const long long wi = a >> 6;
+        const int lo = (int)(a & 63);
+        const long long wend = (wi + 1) << 6;
+        const int hi = (int)((b < wend ? b : wend) - (wi << 6));
+        const unsigned long long m = (hi == 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+        c += __popcll(bm[wi] & m);
+        a = wend;
+    }
+    return c;
+}
+
+__global__ __launch_bounds__(256) void tw_scan(TwArgs A)
+{
+    const int2 tile = A.tiles[blockIdx.x];
+    const int ctg = tile.x;
+    const int len = A.ctg_len[ctg];
+    const long long j = (long long)tile.y + threadIdx.x;
+    const long long i = j * 200;                                   // WINDOW_SIZE / 5, :31
+    // the loop of :31-41 visits i = 0, 200, ... up to and including the first i with i + 1000 >= len
+    if (i > len) return;
+    if (i > 0 && (i - 200) + 1000 >= len) return;
+    const long long end = (i + 1000 < len) ? i + 1000 : len;
+    const int den = (int)(end - i);                                // :36
+    const int car = popc_range(A.bitmap, A.bit_off[ctg] + i, A.bit_off[ctg] + end);
+    if ((double)car / den >= A.thr) {                              // :37 (0/0 -> NaN -> false, as in C)
+        const unsigned long long idx = atomicAdd(A.counter, 1ull);
+        if (idx < A.cap) A.out[idx] = make_int4(ctg, (int)i, (int)end, car);
+    }
+}
+
+// ---- host side --------------------------------------------------------------------------------------
+inline uint8_t c_toupper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
+
+std::string revcomp(const std::string &m)   // src/find_telomere.c:24-42
+{
+    std::string r(m.size(), 'N');
+    for (size_t i = 0; i < m.size(); ++i) {
+        char c = m[m.size() - 1 - i];
+        r[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
+    }
+    return r;
+}
+
+bool has_border(const std::string &m)
+{
+    for (size_t b = 1; b < m.size(); ++b)
+        if (m.compare(0, b, m, m.size() - b, b) == 0) return true;
+    return false;
+}
+
+struct TeloScan {
+    // ordered per-list positions with their contig, after the tile-order gather
+    std::vector<int32_t> pos[4];
+    std::vector<int32_t> ctg[4];
+};
+
+struct WinLayout {
+    std::vector<int64_t> bit_off;
+    std::vector<int2> tiles;
+    int64_t n_words = 0;
+};
+
+WinLayout win_layout_from_lengths(const int32_t *len, int32_t n, const int64_t *byte_off /* may be null */)
+{
+    WinLayout L;
+    int64_t bits = 0;
+    for (int32_t c = 0; c < n; ++c) {
+        int64_t bo = byte_off ? byte_off[c] : bits;
+        L.bit_off.push_back(bo);
+        bits = cn_align_up(bo + len[c], 64);
+        // windows j = 0..J, J = first j with 200 j + 1000 >= len
+        int64_t J = len[c] > 1000 ? (len[c] - 1000 + 199) / 200 : 0;
+        for (int64_t j0 = 0; j0 <= J; j0 += 256) L.tiles.push_back(make_int2(c, (int)j0));
+    }
+    L.n_words = bits / 64 + 4;
+    return L;
+}
+
+int run_tw_scan(cornetto_accel_t *h, const unsigned long long *d_bitmap, const WinLayout &L, const int32_t *d_len,
+                double thr, cornetto_win_t **wins, int64_t *n_wins)
+{
+    *wins = nullptr;
+    *n_wins = 0;
+    if (L.tiles.empty()) return CORNETTO_OK;
+    DevBuf d_boff, d_tiles, d_out, d_cnt;
+    if (d_boff.alloc(L.bit_off.size() * 8) != hipSuccess || d_tiles.alloc(L.tiles.size() * sizeof(int2)) != hipSuccess ||
+        d_cnt.alloc(8) != hipSuccess)
+        return cn_fail(h, CORNETTO_E_NOMEM, "telowin: device allocation failed");
+    CN_HIP(h, hipMemcpyAsync(d_boff.p, L.bit_off.data(), L.bit_off.size() * 8, hipMemcpyHostToDevice, h->stream));
+    CN_HIP(h, hipMemcpyAsync(d_tiles.p, L.tiles.data(), L.tiles.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    uint32_t cap = 1u << 16;
+    std::vector<int4> host;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (d_out.alloc((size_t)cap * sizeof(int4)) != hipSuccess) return cn_fail(h, CORNETTO_E_NOMEM, "telowin: device allocation failed");
+        CN_HIP(h, hipMemsetAsync(d_cnt.p, 0, 8, h->stream));
+        TwArgs A{d_bitmap, d_boff.as<int64_t>(), d_len, d_tiles.as<int2>(), thr, d_out.as<int4>(), d_cnt.as<unsigned long long>(), cap};
+        CN_LAUNCH(h, "tw_scan", tw_scan<<<dim3((unsigned)L.tiles.size()), dim3(256), 0, h->stream>>>(A));
+        unsigned long long cnt = 0;
+        CN_HIP(h, hipMemcpyAsync(&cnt, d_cnt.p, 8, hipMemcpyDeviceToHost, h->stream));
+        CN_HIP(h, hipStreamSynchronize(h->stream));
+        if (cnt > cap) {   // exact retry with the true size; never a truncated answer
+            cap = (uint32_t)cnt;
+            continue;
+        }
+        host.resize(cnt);
+        if (cnt) CN_HIP(h, hipMemcpy(host.data(), d_out.p, cnt * sizeof(int4), hipMemcpyDeviceToHost));
+        break;
+    }
+    std::sort(host.begin(), host.end(), [](const int4 &a, const int4 &b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
+    cornetto_win_t *w = (cornetto_win_t *)malloc((host.size() ? host.size() : 1) * sizeof(cornetto_win_t));
+    if (!w) return cn_fail(h, CORNETTO_E_NOMEM, "telowin: host allocation failed");
+    for (size_t i = 0; i < host.size(); ++i) {
+        w[i].ctg = host[i].x; w[i].start = host[i].y; w[i].end = host[i].z; w[i].car = host[i].w;
+    }
+    *wins = w;
+    *n_wins = (int64_t)host.size();
+    return CORNETTO_OK;
+}
+
+int telowin_from_hits(cornetto_accel_t *h, const cornetto_hit_t *hits, int64_t n_hits, const int32_t *ctg_len,
+                      int32_t n_ctg, double thr_adj, cornetto_win_t **wins, int64_t *n_wins)
+{
+    WinLayout L = win_layout_from_lengths(ctg_len, n_ctg, nullptr);
+    std::vector<int4> hv;
+    hv.reserve((size_t)n_hits);
+    for (int64_t i = 0; i < n_hits; ++i) {
+        const cornetto_hit_t &x = hits[i];
+        if (x.ctg < 0 || x.ctg >= n_ctg) return cn_fail(h, CORNETTO_E_ARG, "telowin: hit %lld names contig %d of %d", (long long)i, x.ctg, n_ctg);
+        if (x.start < 0 || x.end > ctg_len[x.ctg])
+            return cn_fail(h, CORNETTO_E_ARG, "telowin: hit %lld [%d,%d) lies outside contig %d of length %d", (long long)i, x.start, x.end, x.ctg, ctg_len[x.ctg]);
+        if (x.start >= x.end) continue;   // the reference's marking loop does nothing
+        const int64_t bo = L.bit_off[x.ctg];
+        hv.push_back(make_int4((int)(uint32_t)(bo & 0xFFFFFFFFll), (int)(uint32_t)(bo >> 32), x.start, x.end));
+    }
+    DevBuf d_bm, d_hits, d_len;
+    if (d_bm.alloc((size_t)L.n_words * 8) != hipSuccess || d_hits.alloc(hv.size() * sizeof(int4)) != hipSuccess ||
+        d_len.alloc((size_t)(n_ctg > 0 ? n_ctg : 1) * 4) != hipSuccess)
+        return cn_fail(h, CORNETTO_E_NOMEM, "telowin: device allocation failed");
+    CN_HIP(h, hipMemsetAsync(d_bm.p, 0, (size_t)L.n_words * 8, h->stream));
+    if (n_ctg) CN_HIP(h, hipMemcpyAsync(d_len.p, ctg_len, (size_t)n_ctg * 4, hipMemcpyHostToDevice, h->stream));
+    if (!hv.empty()) {
+        CN_HIP(h, hipMemcpyAsync(d_hits.p, hv.data(), hv.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+        const unsigned nb = (unsigned)((hv.size() + 255) / 256);
+        CN_LAUNCH(h, "tw_fill", tw_fill<<<dim3(nb), dim3(256), 0, h->stream>>>(d_hits.as<int4>(), (int64_t)hv.size(), d_bm.as<unsigned long long>()));
+    }
+    return run_tw_scan(h, d_bm.as<unsigned long long>(), L, d_len.as<int32_t>(), thr_adj, wins, n_wins);
+}
+
+// the whole telofind pass; optionally leaves the mark bitmap on the device (unbordered motifs)
+int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a, const char *motif_c, cornetto_hit_t **hits,
+                  int64_t *n_hits, DevBuf *bitmap_out, bool *bitmap_valid)
+{
+    if (!h || !a || !motif_c) return cn_fail(h, CORNETTO_E_ARG, "telofind: bad argument");
+    const std::string motif(motif_c);
+    const int k = (int)motif.size();
+    if (k < 1) return cn_fail(h, CORNETTO_E_ARG, "telofind: empty motif (the reference never terminates on it)");
+    if (k > MAX_MOTIF) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "telofind: motif of %d bytes; at most %d are supported", k, MAX_MOTIF);
+    CN_HIP(h, hipSetDevice(h->device));
+    if (hits) { *hits = nullptr; *n_hits = 0; }
+    if (bitmap_valid) *bitmap_valid = false;
+
+    const std::string rc = revcomp(motif);
+    const bool bordered = has_border(motif) || has_border(rc);
+    const int H = k <= 8 ? 7 : (k <= 16 ? 15 : 31);
+    // shift-and tables: motif position j -> bit (31 - H + j); positions k..H are wildcards
+    std::vector<uint2> lut(256);
+    for (int c = 0; c < 256; ++c) {
+        uint32_t f = 0, r = 0;
+        const uint8_t u = c_toupper((uint8_t)c);      // src/find_telomere.c:76-81: sequence upper-cased, motif not
+        for (int j = 0; j <= H; ++j) {
+            const uint32_t bit = 1u << (31 - H + j);
+            if (j >= k) { f |= bit; r |= bit; continue; }
+            if (u == (uint8_t)motif[j]) f |= bit;
+            if (u == (uint8_t)rc[j]) r |= bit;
+        }
+        lut[c] = make_uint2(f, r);
+    }
+    // tiles in contig order
+    std::vector<int2> tiles;
+    std::vector<int32_t> ctg_tile0(a->n + 1, 0);
+    for (int32_t c = 0; c < a->n; ++c) {
+        ctg_tile0[c] = (int32_t)tiles.size();
+        for (int64_t s = 0; s < a->len[c]; s += TF_TILE) tiles.push_back(make_int2(c, (int)s));
+    }
+    ctg_tile0[a->n] = (int32_t)tiles.size();
+    const size_t nt = tiles.size();
+
+    std::vector<cornetto_hit_t> out;
+    if (nt > 0) {
+        DevBuf d_tiles, d_lut, d_cnt, d_tb, d_tc, d_list[4];
+        if (d_tiles.alloc(nt * sizeof(int2)) != hipSuccess || d_lut.alloc(256 * sizeof(uint2)) != hipSuccess ||
+            d_cnt.alloc(32) != hipSuccess || d_tb.alloc(nt * sizeof(uint4)) != hipSuccess || d_tc.alloc(nt * sizeof(uint4)) != hipSuccess)
+            return cn_fail(h, CORNETTO_E_NOMEM, "telofind: device allocation failed");
+        CN_HIP(h, hipMemcpyAsync(d_tiles.p, tiles.data(), nt * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+        CN_HIP(h, hipMemcpyAsync(d_lut.p, lut.data(), 256 * sizeof(uint2), hipMemcpyHostToDevice, h->stream));
+        const bool want_bitmap = bitmap_out && !bordered;
+        if (want_bitmap) {
+            int64_t last_end = 0;
+            for (int32_t c = 0; c < a->n; ++c) last_end = std::max(last_end, a->off[c] + a->len[c]);
+            const size_t words = (size_t)(cn_align_up(last_end, 64) / 64 + 4);
+            if (bitmap_out->alloc(words * 8) != hipSuccess) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: bitmap allocation failed");
+            // every word of a contig is written by the kernel; zero only covers padding between contigs
+            CN_HIP(h, hipMemsetAsync(bitmap_out->p, 0, words * 8, h->stream));
+        }
+        uint32_t cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(1 << 16, a->total / 64), 0x7fffffff);
+        unsigned long long cnt[4] = {0, 0, 0, 0};
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            for (int q = 0; q < 4; ++q)
+                if (d_list[q].alloc((size_t)cap * 4) != hipSuccess) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: device allocation failed");
+            CN_HIP(h, hipMemsetAsync(d_cnt.p, 0, 32, h->stream));
+            TfArgs A{a->d_bases, a->d_off, a->d_len, d_tiles.as<int2>(), d_lut.as<uint2>(), k, bordered ? 1 : 0,
+                     want_bitmap ? bitmap_out->as<unsigned long long>() : nullptr,
+                     d_list[0].as<int32_t>(), d_list[1].as<int32_t>(), d_list[2].as<int32_t>(), d_list[3].as<int32_t>(),
+                     d_cnt.as<unsigned long long>(), cap, d_tb.as<uint4>(), d_tc.as<uint4>()};
+            if (H == 7) CN_LAUNCH(h, "tf_scan", tf_scan<7><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
+            else if (H == 15) CN_LAUNCH(h, "tf_scan", tf_scan<15><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
+            else CN_LAUNCH(h, "tf_scan", tf_scan<31><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
+            CN_HIP(h, hipMemcpyAsync(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost, h->stream));
+            CN_HIP(h, hipStreamSynchronize(h->stream));
+            const unsigned long long mx = std::max(std::max(cnt[0], cnt[1]), std::max(cnt[2], cnt[3]));
+            if (mx <= cap) break;
+            if (attempt == 1 || mx > 0x7fffffffull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "telofind: %llu list entries", mx);
+            cap = (uint32_t)mx;   // rerun with the exact size: results are never truncated
+        }
+        if (bitmap_valid) *bitmap_valid = want_bitmap;
+        if (hits) {
+            std::vector<uint4> tb(nt), tc(nt);
+            CN_HIP(h, hipMemcpy(tb.data(), d_tb.p, nt * sizeof(uint4), hipMemcpyDeviceToHost));
+            CN_HIP(h, hipMemcpy(tc.data(), d_tc.p, nt * sizeof(uint4), hipMemcpyDeviceToHost));
+            if (!bordered) {
+                std::vector<int32_t> raw[4];
+                for (int q = 0; q < 4; ++q) {
+                    raw[q].resize(cnt[q]);
+                    if (cnt[q]) CN_HIP(h, hipMemcpy(raw[q].data(), d_list[q].p, cnt[q] * 4, hipMemcpyDeviceToHost));
+                }
+                if (cnt[0] != cnt[1] || cnt[2] != cnt[3])
+                    return cn_fail(h, CORNETTO_E_HIP, "telofind: head/tail count mismatch (%llu/%llu, %llu/%llu)", cnt[0], cnt[1], cnt[2], cnt[3]);
+                // gather tile by tile -> contig order; per contig strand 0 then strand 1 (src/find_telomere.c:49-72)
+                for (int32_t c = 0; c < a->n; ++c) {
+                    for (int strand = 0; strand < 2; ++strand) {
+                        const int qh = strand * 2, qt = qh + 1;
+                        std::vector<int32_t> hd, tl;
+                        for (int32_t t = ctg_tile0[c]; t < ctg_tile0[c + 1]; ++t) {
+                            const uint32_t *b = &tb[t].x, *n = &tc[t].x;
+                            for (uint32_t i = 0; i < n[qh]; ++i) hd.push_back(raw[qh][b[qh] + i]);
+                            for (uint32_t i = 0; i < n[qt]; ++i) tl.push_back(raw[qt][b[qt] + i]);
+                        }
+                        if (hd.size() != tl.size())
+                            return cn_fail(h, CORNETTO_E_HIP, "telofind: contig %d strand %d: %zu heads, %zu tails", c, strand, hd.size(), tl.size());
+                        for (size_t i = 0; i < hd.size(); ++i) out.push_back(cornetto_hit_t{c, strand, hd[i], tl[i] + k});
+                    }
+                }
+            } else {
+                // sequential greedy rule on the device over the compacted matches
+                std::vector<int64_t> run_off(2 * (size_t)a->n + 1, 0);
+                for (int32_t c = 0; c < a->n; ++c) {
+                    int64_t mf = 0, mr = 0;
+                    for (int32_t t = ctg_tile0[c]; t < ctg_tile0[c + 1]; ++t) { mf += tc[t].x; mr += tc[t].z; }
+                    run_off[2 * c + 1] = run_off[2 * c] + mf;
+                    run_off[2 * c + 2] = run_off[2 * c + 1] + mr;
+                }
+                const int64_t tot = run_off[2 * (size_t)a->n];
+                DevBuf d_ct0, d_roff, d_runs, d_nruns;
+                if (d_ct0.alloc(ctg_tile0.size() * 4) != hipSuccess || d_roff.alloc(run_off.size() * 8) != hipSuccess ||
+                    d_runs.alloc((size_t)tot * sizeof(int2)) != hipSuccess || d_nruns.alloc(2 * (size_t)a->n * 4) != hipSuccess)
+                    return cn_fail(h, CORNETTO_E_NOMEM, "telofind: device allocation failed");
+                CN_HIP(h, hipMemcpyAsync(d_ct0.p, ctg_tile0.data(), ctg_tile0.size() * 4, hipMemcpyHostToDevice, h->stream));
+                CN_HIP(h, hipMemcpyAsync(d_roff.p, run_off.data(), run_off.size() * 8, hipMemcpyHostToDevice, h->stream));
+                GreedyArgs G{d_list[0].as<int32_t>(), d_list[2].as<int32_t>(), d_tb.as<uint4>(), d_tc.as<uint4>(), d_ct0.as<int32_t>(),
+                             d_roff.as<int64_t>(), a->n, k, d_runs.as<int2>(), d_nruns.as<int32_t>()};
+                const unsigned nb = (unsigned)((2 * a->n + 63) / 64);
+                CN_LAUNCH(h, "tf_greedy", tf_greedy<<<dim3(nb), dim3(64), 0, h->stream>>>(G));
+                std::vector<int2> runs((size_t)tot);
+                std::vector<int32_t> nr(2 * (size_t)a->n);
+                CN_HIP(h, hipStreamSynchronize(h->stream));
+                if (tot) CN_HIP(h, hipMemcpy(runs.data(), d_runs.p, (size_t)tot * sizeof(int2), hipMemcpyDeviceToHost));
+                CN_HIP(h, hipMemcpy(nr.data(), d_nruns.p, nr.size() * 4, hipMemcpyDeviceToHost));
+                for (int32_t c = 0; c < a->n; ++c)
+                    for (int strand = 0; strand < 2; ++strand)
+                        for (int32_t i = 0; i < nr[2 * c + strand]; ++i) {
+                            const int2 r = runs[run_off[2 * c + strand] + i];
+                            out.push_back(cornetto_hit_t{c, strand, r.x, r.y});
+                        }
+            }
+        }
+    }
+    if (hits) {
+        cornetto_hit_t *o = (cornetto_hit_t *)malloc((out.size() ? out.size() : 1) * sizeof(cornetto_hit_t));
+        if (!o) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: host allocation failed");
+        if (!out.empty()) memcpy(o, out.data(), out.size() * sizeof(cornetto_hit_t));
+        *hits = o;
+        *n_hits = (int64_t)out.size();
+    }
+    return CORNETTO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+double cornetto_telowin_threshold(double threshold, double identity_percent)
+{
+    const double identity = identity_percent / 100;   // src/telomere_windows.c:53
+    return threshold * pow(identity, 6);              // :54
+}
+
+int cornetto_telofind(cornetto_accel_t *h, const cornetto_asm_t *a, const char *motif, cornetto_hit_t **hits,
+                      int64_t *n_hits)
+{
+    if (!h || !hits || !n_hits) return cn_fail(h, CORNETTO_E_ARG, "telofind: bad argument");
+    cn_timing_begin(h);
+    int rc = telofind_impl(h, a, motif, hits, n_hits, nullptr, nullptr);
+    cn_timing_end(h);
+    return rc;
+}
+
+int cornetto_telowin(cornetto_accel_t *h, const cornetto_hit_t *hits, int64_t n_hits, const int32_t *ctg_len,
+                     int32_t n_ctg, double thr_adj, cornetto_win_t **wins, int64_t *n_wins)
+{
+    if (!h || !wins || !n_wins || n_hits < 0 || n_ctg < 0 || (n_hits > 0 && !hits) || (n_ctg > 0 && !ctg_len))
+        return cn_fail(h, CORNETTO_E_ARG, "telowin: bad argument");
+    CN_HIP(h, hipSetDevice(h->device));
+    cn_timing_begin(h);
+    int rc = telowin_from_hits(h, hits, n_hits, ctg_len, n_ctg, thr_adj, wins, n_wins);
+    cn_timing_end(h);
+    return rc;
+}
+
+int cornetto_telo_scan(cornetto_accel_t *h, const cornetto_asm_t *a, const char *motif, double thr_adj,
+                       cornetto_hit_t **hits, int64_t *n_hits, cornetto_win_t **wins, int64_t *n_wins)
+{
+    if (!h || !a || !wins || !n_wins || (hits && !n_hits)) return cn_fail(h, CORNETTO_E_ARG, "telo_scan: bad argument");
+    cn_timing_begin(h);
+    DevBuf bitmap;
+    bool valid = false;
+    cornetto_hit_t *hh = nullptr;
+    int64_t nh = 0;
+    // a bordered motif needs the runs themselves to build the marks, so the hits are always fetched then
+    const std::string m(motif ? motif : "");
+    const bool need_hits = hits || has_border(m) || has_border(revcomp(m));
+    int rc = telofind_impl(h, a, motif, need_hits ? &hh : nullptr, need_hits ? &nh : nullptr, &bitmap, &valid);
+    if (rc == CORNETTO_OK) {
+        if (valid) {
+            WinLayout L = win_layout_from_lengths(a->len.data(), a->n, a->off.data());
+            rc = run_tw_scan(h, bitmap.as<unsigned long long>(), L, a->d_len, thr_adj, wins, n_wins);
+        } else {
+            rc = telowin_from_hits(h, hh, nh, a->len.data(), a->n, thr_adj, wins, n_wins);
+        }
+    }
+    cn_timing_end(h);
+    if (rc != CORNETTO_OK || !hits) {
+        free(hh);
+    } else {
+        *hits = hh;
+        *n_hits = nh;
+    }
+    return rc;
+}
+
+}  // extern "C"

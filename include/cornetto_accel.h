@@ -1,0 +1,204 @@
+/*
+ * cornetto_accel.h — C ABI of libcornetto_hip.so: the MI355X (gfx950) implementation of cornetto's
+ * panel-creation hot path.  Plain C, plain pointers and sizes; HIP lives behind it.
+ *
+ * The reference (hasindu2008/cornetto v0.2.0, paths relative to its root) exposes no FFI: its boundary is
+ * the process CLI `cornetto <sub> ...` -> `int xxx_main(int argc, char *argv[])` (src/main.c:40-54,103-134)
+ * and, underneath, per-contig C functions.  Each entry point below names the reference unit it replaces.
+ * The host CLI in cornetto_amd/cli/ (C99) keeps the sub-command names, option letters, stdout bytes and
+ * exit codes and calls only what is declared here.  There is NO CPU fallback behind these symbols: every
+ * compute entry point runs HIP kernels and fails with CORNETTO_E_NODEVICE when no GPU is usable.
+ *
+ * Conventions
+ *   - every function returns 0 (CORNETTO_OK) or a negative CORNETTO_E_* status; nothing calls exit()
+ *     (the reference's ERROR()+exit(EXIT_FAILURE), src/error.h:97-103, is done by the CLI mains);
+ *   - result arrays are malloc'd by the library and released with cornetto_free();
+ *   - calls are synchronous; one cornetto_accel_t may be used by one host thread at a time;
+ *   - coordinates are 0-based, half-open, per contig, 32-bit (kseq_read returns int: src/kseq.h:185).
+ */
+#ifndef CORNETTO_ACCEL_H
+#define CORNETTO_ACCEL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CORNETTO_ACCEL_ABI 1
+
+enum {
+    CORNETTO_OK = 0,
+    CORNETTO_E_NODEVICE = -1, /* no usable HIP device / HIP runtime error at open */
+    CORNETTO_E_HIP = -2,      /* a HIP call or kernel failed; see cornetto_accel_last_error() */
+    CORNETTO_E_ARG = -3,      /* invalid argument (NULL, negative length, misaligned device offset, ...) */
+    CORNETTO_E_NOMEM = -4,    /* host or device allocation failed */
+    CORNETTO_E_UNSUPPORTED = -5 /* parameter outside the implemented range (motif > 32, W > 256, ...) */
+};
+
+typedef struct cornetto_accel cornetto_accel_t; /* device + stream + workspaces */
+typedef struct cornetto_asm cornetto_asm_t;     /* a set of contigs (or reads) resident in HBM, 1 B/base */
+typedef struct cornetto_cov cornetto_cov_t;     /* per-base depth + mq-depth (uint16) of a set of contigs in HBM */
+
+/* one telofind run; replaces one output line of find(): src/find_telomere.c:51,56 */
+typedef struct {
+    int32_t ctg;    /* index of the contig in the cornetto_asm_t */
+    int32_t strand; /* 0 = motif, 1 = reverse complement of the motif */
+    int32_t start, end;
+} cornetto_hit_t;
+
+/* one telowin window that met the threshold; replaces one printf of process_scaffold():
+ * src/telomere_windows.c:37-38.  ratio printed by the caller as (double)car/(end-start), "%.3g". */
+typedef struct {
+    int32_t ctg;
+    int32_t start, end; /* end = start + den */
+    int32_t car;        /* marked bases in the window */
+} cornetto_win_t;
+
+/* one masked interval of sdust for a set of contigs */
+typedef struct {
+    int32_t ctg;
+    int32_t start, finish;
+} cornetto_ivl_t;
+
+/* a coverage window; = reg_t of src/boringbits_main.c:133-138 */
+typedef struct {
+    int32_t st, end, depth, mq_depth;
+} cornetto_reg_t;
+
+/* a selected coverage window of a set of contigs (one stdout line of print_fun_bits / print_boring_bits) */
+typedef struct {
+    int32_t ctg;
+    int32_t st, end, depth, mq_depth;
+} cornetto_regrec_t;
+
+/* ---------------------------------------------------------------------------------------------------
+ * runtime
+ * ------------------------------------------------------------------------------------------------- */
+
+/* number of visible HIP devices (0 when there is none or the runtime is unusable) */
+int cornetto_accel_device_count(void);
+
+/* Open device `device` (ordinal among the visible devices).  `stream` is a hipStream_t to launch on, or
+ * NULL for a stream owned by the handle.  The seam the reference left for this is --accel=yes|no /
+ * CORNETTO_ACC: src/cornetto.h:47, src/boringbits_main.c:627-632. */
+int cornetto_accel_open(cornetto_accel_t **h, int device, void *stream);
+void cornetto_accel_close(cornetto_accel_t *h);
+
+/* message of the last failure on this handle ("" if none); valid until the next call on the handle */
+const char *cornetto_accel_last_error(const cornetto_accel_t *h);
+const char *cornetto_accel_strerror(int status);
+
+/* release a result array returned by this library */
+void cornetto_free(void *p);
+
+/* Device time of the kernels of the most recent compute call on this handle, measured with HIP events on
+ * the handle's stream.  Fills up to `cap` entries of names[]/ms[] (names are static strings) and returns
+ * the number of kernels recorded.  Used by bench.py for the live roofline figure. */
+int cornetto_accel_last_timing(const cornetto_accel_t *h, const char **names, float *ms, int cap);
+
+/* ---------------------------------------------------------------------------------------------------
+ * sequences in HBM
+ * ------------------------------------------------------------------------------------------------- */
+
+/* Copy n sequences (ASCII, any case, IUPAC allowed, need not be NUL-terminated) to the device.  Replaces
+ * the kseq_t.seq buffers the reference scans in place (src/find_telomere.c:101-105, src/sdust/sdust.c:196-199). */
+int cornetto_asm_upload(cornetto_accel_t *h, const uint8_t *const *seqs, const int64_t *lens, int32_t n,
+                        cornetto_asm_t **out);
+
+/* Wrap bases that already are in device memory: contig i occupies d_bases[offsets[i] .. offsets[i]+lens[i]).
+ * Every offset must be a multiple of 64 and the buffer must stay readable for 64 bytes past the last
+ * contig (padding content is ignored).  The buffer is borrowed, never freed. */
+int cornetto_asm_wrap(cornetto_accel_t *h, const void *d_bases, const int64_t *offsets, const int64_t *lens,
+                      int32_t n, cornetto_asm_t **out);
+void cornetto_asm_free(cornetto_accel_t *h, cornetto_asm_t *a);
+
+/* ---------------------------------------------------------------------------------------------------
+ * telofind / telowin
+ * ------------------------------------------------------------------------------------------------- */
+
+/* telofind over every contig of `a`: replaces disambiguate()+find() (src/find_telomere.c:76-81,44-74)
+ * called per record at :103-104.  motif: 1..32 bytes, compared as the reference does (sequence
+ * upper-cased, motif not).  hits come out in the reference's print order: by contig, all strand-0 runs by
+ * position, then all strand-1 runs. */
+int cornetto_telofind(cornetto_accel_t *h, const cornetto_asm_t *a, const char *motif,
+                      cornetto_hit_t **hits, int64_t *n_hits);
+
+/* adjusted threshold of telowin: threshold * pow(identity_percent/100, 6)  (src/telomere_windows.c:53-54) */
+double cornetto_telowin_threshold(double threshold, double identity_percent);
+
+/* telowin from explicit hits (what `cornetto telowin in.telomere ...` parses from the TSV): for each of the
+ * n_ctg contigs, mark [start,end) of its hits and scan 1000-bp windows, step 200.  Replaces the marking
+ * loop + process_scaffold() (src/telomere_windows.c:75-79,28-43).  hits[].ctg indexes ctg_len[]; hits with
+ * the same ctg need not be adjacent.  Windows are returned by contig, then by start. */
+int cornetto_telowin(cornetto_accel_t *h, const cornetto_hit_t *hits, int64_t n_hits, const int32_t *ctg_len,
+                     int32_t n_ctg, double thr_adj, cornetto_win_t **wins, int64_t *n_wins);
+
+/* fused telofind -> telowin on the device (no TSV round trip, the mark bitmap never leaves HBM).
+ * Equivalent to cornetto_telofind() followed by cornetto_telowin() on its hits.  hits/n_hits may be NULL. */
+int cornetto_telo_scan(cornetto_accel_t *h, const cornetto_asm_t *a, const char *motif, double thr_adj,
+                       cornetto_hit_t **hits, int64_t *n_hits, cornetto_win_t **wins, int64_t *n_wins);
+
+/* ---------------------------------------------------------------------------------------------------
+ * sdust
+ * ------------------------------------------------------------------------------------------------- */
+
+/* symmetric DUST over every contig of `a`; replaces sdust() called per record at src/sdust/sdust.c:199
+ * (sdust_core :130-160).  3 <= W <= 256, T >= 1.  Intervals by contig, then by start; per contig they are
+ * exactly the reference's (start<<32|finish) list, including intervals that run past the contig end
+ * after an N run. */
+int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a, int32_t T, int32_t W,
+                       cornetto_ivl_t **ivls, int64_t *n_ivls);
+
+/* Drop-in for `uint64_t *sdust(void *km, const uint8_t *seq, int l_seq, int T, int W, int *n)`
+ * (src/sdust/sdust.h:19): same arguments, same ownership (caller free()s), l_seq < 0 means strlen.
+ * km must be NULL.  Uses a process-wide handle on device $CORNETTO_DEVICE (default 0); returns NULL and
+ * sets *n = -1 when the device path is unavailable. */
+uint64_t *cornetto_sdust(void *km, const uint8_t *seq, int l_seq, int T, int W, int *n);
+
+/* ---------------------------------------------------------------------------------------------------
+ * (no)boringbits window stage
+ * ------------------------------------------------------------------------------------------------- */
+
+/* Copy per-base depth arrays of n contigs to the device; replaces ctg_depth_t.depth/.mq_depth filled by
+ * get_depths() (src/boringbits_main.c:116-122,279-281). */
+int cornetto_cov_upload(cornetto_accel_t *h, const uint16_t *const *depth, const uint16_t *const *mq_depth,
+                        const int32_t *lens, int32_t n, cornetto_cov_t **out);
+
+/* Wrap arrays already in device memory; offsets are in ELEMENTS and must be multiples of 64; both arrays
+ * must stay readable for 64 elements past the last contig. */
+int cornetto_cov_wrap(cornetto_accel_t *h, const void *d_depth, const void *d_mq_depth, const int64_t *offsets,
+                      const int32_t *lens, int32_t n, cornetto_cov_t **out);
+void cornetto_cov_free(cornetto_accel_t *h, cornetto_cov_t *c);
+
+/* number of windows of a contig: src/boringbits_main.c:338-339 */
+int32_t cornetto_n_reg(int32_t length, int32_t window_size, int32_t window_inc);
+
+/* Stage 1: per-`window_inc` block sums on the device plus the exact totals the mean needs.
+ * sums[0] = sum of depth, sums[1] = sum of mq_depth, sums[2] = number of positions; the caller forms
+ * mean = (int)round(sums[0]/sums[2]) (src/boringbits_main.c:283-285,293-294) — across ranks after an
+ * all-reduce of sums[].  Needs 1 <= window_inc <= window_size. */
+int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t window_size, int32_t window_inc,
+                         uint64_t sums[3]);
+
+/* get_regs() for one contig (src/boringbits_main.c:346-366): all cornetto_n_reg() windows, in order, into
+ * caller-provided regs[].  cornetto_cov_prepare() must have been called with the same sizes. */
+int cornetto_cov_regs(cornetto_accel_t *h, const cornetto_cov_t *c, int32_t ctg, cornetto_reg_t *regs);
+
+/* thresholds: (int)round(factor * mean) with the product formed in float (src/boringbits_main.c:518-519) */
+int32_t cornetto_cov_threshold(float factor, int32_t mean);
+
+/* Stage 2: classify every window and return the selected ones in print order (contig, then st).
+ *   boring == 0: print_fun_bits  (src/boringbits_main.c:425-445) — windows of contigs with
+ *                len >= min_ctg_len that satisfy depth<lo || depth>hi || mq/(double)depth < low_mq;
+ *                (the caller prints the '.' edge / short-contig lines, which need no data);
+ *   boring != 0: print_boring_bits (:463-481) — contigs with len > min_ctg_len, windows with
+ *                st > edge_len && end < len - edge_len that do NOT satisfy the predicate. */
+int cornetto_cov_select(cornetto_accel_t *h, const cornetto_cov_t *c, int32_t lo, int32_t hi, float low_mq,
+                        int32_t edge_len, int32_t min_ctg_len, int boring, cornetto_regrec_t **recs,
+                        int64_t *n_recs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CORNETTO_ACCEL_H */

@@ -1,0 +1,52 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/cornetto_accel.h declares; the
+no-GPU behaviour is a clean status, never a fallback computation."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "cornetto_accel.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(cornetto_[a-z0-9_]+)\s*\(", hdr)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import cornetto_amd
+    if not os.path.exists(cornetto_amd.LIB_PATH):
+        cornetto_amd.build()
+    return cornetto_amd.lib()
+
+
+def test_exports_every_declared_symbol(lib):
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(lib._declared) == names
+
+
+def test_no_device_is_a_status_not_a_fallback(lib):
+    import ctypes as C
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert lib.cornetto_accel_device_count() == 0
+    h = C.c_void_p()
+    assert lib.cornetto_accel_open(C.byref(h), 0, None) == -1       # CORNETTO_E_NODEVICE
+    n = C.c_int(0)
+    assert not lib.cornetto_sdust(None, C.c_char_p(b"ACGT"), 4, 20, 64, C.byref(n))
+    assert n.value == -1
+
+
+def test_pure_host_helpers(lib):
+    assert lib.cornetto_n_reg(2551, 2500, 50) == 3
+    assert lib.cornetto_n_reg(120, 2500, 50) == 1
+    assert lib.cornetto_cov_threshold(0.6, 22) == 13
+    assert lib.cornetto_cov_threshold(1.6, 22) == 35
+    assert abs(lib.cornetto_telowin_threshold(0.4, 99.9) - 0.397606) < 1e-6
+    assert lib.cornetto_accel_strerror(-5) == b"parameter outside the supported range"

@@ -1,0 +1,265 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes, include/cornetto_accel.h), against
+(a) the golden stdout of the unmodified reference and (b) the CPU oracle on seeded inputs.
+Bit-exact everywhere: integer / byte / index work."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_bind as ob
+from helpers import (fmt_sdust, fmt_telofind, fmt_telowin, golden, read_bedgraph_pair, read_fastx)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def acc():
+    import cornetto_amd
+    a = cornetto_amd.Accel(0)
+    yield a
+    a.close()
+
+
+def _records(golden_dir, fa):
+    return read_fastx(os.path.join(golden_dir, fa))
+
+
+def gpu_telofind_text(acc, recs, motif):
+    asm = acc.asm_upload([r[2] for r in recs])
+    hits = acc.telofind(asm, motif)
+    asm.close()
+    out = []
+    for h in hits:
+        name, ln = recs[h["ctg"]][0], len(recs[h["ctg"]][2])
+        out.append(b"%s\t%d\t%d\t%d\t%d\t%d\n" % (name, ln, h["strand"], h["start"], h["end"], h["end"] - h["start"]))
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("fa,motif,exp", [
+    ("probe.fa", b"TTAGGG", "probe.telofind.exp"),
+    ("probe_selfoverlap.fa", b"AAAA", "probe_selfoverlap.AAAA.telofind.exp"),
+    ("probe_selfoverlap.fa", b"ACAC", "probe_selfoverlap.ACAC.telofind.exp"),
+    ("probe_selfoverlap.fa", b"ACACA", "probe_selfoverlap.ACACA.telofind.exp"),
+    ("mix.fa.gz", b"TTAGGG", "mix.telofind.exp"),
+    ("mix.fa.gz", b"ttaggg", "mix.lower_motif.telofind.exp"),
+    ("mix.fa.gz", b"TTAGGGTTAGGG", "mix.k12.telofind.exp"),
+    ("mix.fa.gz", b"AAAA", "mix.AAAA.telofind.exp"),
+    ("mix.fa.gz", b"GNG", "mix.GNG.telofind.exp"),
+])
+def test_telofind_golden(acc, golden_dir, fa, motif, exp):
+    assert gpu_telofind_text(acc, _records(golden_dir, fa), motif) == golden(golden_dir, exp)
+
+
+def _parse_tsv(data):
+    names, lens, hits = [], [], []
+    for ln in data.splitlines():
+        a = ln.split()
+        if not names or names[-1] != a[0]:
+            names.append(a[0])
+            lens.append(int(a[1]))
+        hits.append((len(names) - 1, int(a[2]), int(a[3]), int(a[4])))
+    return names, lens, np.array(hits, dtype=[("ctg", "<i4"), ("strand", "<i4"), ("start", "<i4"), ("end", "<i4")])
+
+
+def _win_text(names, lens, wins):
+    return b"".join(b"Window\t%s\t%d\t%d\t%d\t%s\n" % (names[w["ctg"]], lens[w["ctg"]], w["start"], w["end"],
+                                                     ("%.3g" % (float(w["car"]) / float(w["end"] - w["start"]))).encode())
+                    for w in wins)
+
+
+@pytest.mark.parametrize("tsv,identity,thr,exp", [
+    ("probe.telomere", 99.9, 0.4, "probe.telowin.exp"),
+    ("probe.telomere", 100.0, 0.5, "probe.i100t05.telowin.exp"),
+    ("probe.telomere", 95.0, 0.4, "probe.i95.telowin.exp"),
+    ("mix.telofind.exp", 99.9, 0.4, "mix.telowin.exp"),
+    ("mix.telofind.exp", 99.9, 0.1, "mix.t01.telowin.exp"),
+])
+def test_telowin_golden(acc, golden_dir, tsv, identity, thr, exp):
+    names, lens, hits = _parse_tsv(golden(golden_dir, tsv))
+    wins = acc.telowin(hits, lens, acc.telowin_threshold(thr, identity))
+    assert _win_text(names, lens, wins) == golden(golden_dir, exp)
+
+
+@pytest.mark.parametrize("motif", [b"TTAGGG", b"AAAA", b"CCCTAA", b"ACACA"])
+def test_telo_scan_fused_vs_oracle(acc, golden_dir, motif):
+    recs = _records(golden_dir, "mix.fa.gz")
+    asm = acc.asm_upload([r[2] for r in recs])
+    thr = acc.telowin_threshold(0.4, 99.9)
+    hits, wins = acc.telo_scan(asm, motif, thr)
+    asm.close()
+    exp_h, exp_w = [], []
+    for ci, r in enumerate(recs):
+        oh = ob.telofind(r[2], motif)
+        exp_h += [(ci, int(h["strand"]), int(h["start"]), int(h["end"])) for h in oh]
+        exp_w += [(ci, int(w["start"]), int(w["end"]), int(w["car"])) for w in ob.telowin(oh, len(r[2]), thr)]
+    assert [tuple(map(int, h)) for h in hits] == exp_h
+    assert [tuple(map(int, w)) for w in wins] == exp_w
+
+
+def gpu_sdust_text(acc, recs, T, W):
+    asm = acc.asm_upload([r[2] for r in recs])
+    iv = acc.sdust(asm, T, W)
+    asm.close()
+    return b"".join(b"%s\t%d\t%d\n" % (recs[x["ctg"]][0], x["start"], x["finish"]) for x in iv)
+
+
+SDUST_CASES = [
+    ("probe.fa", 20, 64, "probe.sdust.exp"),
+    ("probe_sdust.fa", 20, 64, "probe_sdust.sdust.exp"),
+    ("probe_sdust.fa", 10, 32, "probe_sdust.w32t10.sdust.exp"),
+    ("mix.fa.gz", 20, 64, "mix.sdust.exp"),
+    ("mix.fa.gz", 10, 32, "mix.w32t10.sdust.exp"),
+    ("mix.fa.gz", 25, 100, "mix.w100t25.sdust.exp"),
+    ("mix.fa.gz", 30, 16, "mix.w16t30.sdust.exp"),
+    ("mix.fa.gz", 5, 64, "mix.t5.sdust.exp"),
+    ("reads.fq", 20, 64, "reads.sdust.exp"),
+]
+
+
+@pytest.mark.parametrize("chunk", ["0", "16", "100", "1000", "4096"])
+@pytest.mark.parametrize("fa,T,W,exp", SDUST_CASES)
+def test_sdust_golden(acc, golden_dir, monkeypatch, fa, T, W, exp, chunk):
+    """chunk = bases per lane (0 = default heuristic); tiny chunks stress the speculative warm-up"""
+    monkeypatch.setenv("CORNETTO_SDUST_CHUNK", chunk)
+    assert gpu_sdust_text(acc, _records(golden_dir, fa), T, W) == golden(golden_dir, exp)
+
+
+def test_sdust_dropin_signature(golden_dir):
+    """cornetto_sdust(): same arguments and ownership as sdust() of src/sdust/sdust.h:19"""
+    import ctypes as C
+    import cornetto_amd
+    L = cornetto_amd.lib()
+    recs = _records(golden_dir, "probe_sdust.fa")
+    out = []
+    for name, _c, seq, _q in recs:
+        n = C.c_int()
+        buf = C.create_string_buffer(seq, len(seq) + 1)
+        r = L.cornetto_sdust(None, C.cast(buf, C.c_void_p), -1, 20, 64, C.byref(n))
+        assert n.value >= 0
+        out.append(fmt_sdust(name, np.array([r[i] for i in range(n.value)], dtype=np.uint64)))
+        L.cornetto_free(r)
+    assert b"".join(out) == golden(golden_dir, "probe_sdust.sdust.exp")
+
+
+def _rand_seqs(rng, n_seq, kind):
+    alpha = np.frombuffer(b"ACGTacgtNNRY", dtype=np.uint8)
+    seqs = []
+    for it in range(n_seq):
+        n = int(rng.integers(0, 6000))
+        k = kind if kind >= 0 else it % 4
+        if k == 0:
+            s = alpha[rng.integers(0, 4, size=n)]
+        elif k == 1:
+            s = alpha[rng.integers(0, len(alpha), size=n)]
+        elif k == 2:
+            parts = []
+            while sum(map(len, parts)) < n:
+                u = alpha[rng.integers(0, 4, size=int(rng.integers(1, 6)))]
+                parts.append(np.tile(u, int(rng.integers(1, 40))))
+                if rng.random() < 0.2:
+                    parts.append(np.frombuffer(b"N" * int(rng.integers(1, 5)), dtype=np.uint8))
+            s = np.concatenate(parts)[:n] if parts else np.zeros(0, np.uint8)
+        else:
+            s = alpha[rng.integers(0, 2, size=n)]
+        seqs.append(np.ascontiguousarray(s, dtype=np.uint8))
+    return seqs
+
+
+@pytest.mark.parametrize("T,W,chunk", [(20, 64, "37"), (20, 64, "512"), (10, 32, "64"), (5, 64, "200"), (30, 16, "16"),
+                                       (25, 100, "300"), (20, 8, "50"), (20, 258, "700"), (1, 3, "40")])
+def test_sdust_random_vs_oracle(acc, monkeypatch, T, W, chunk):
+    monkeypatch.setenv("CORNETTO_SDUST_CHUNK", chunk)
+    rng = np.random.default_rng(1234 + T * 1000 + W)
+    seqs = _rand_seqs(rng, 120, -1)
+    asm = acc.asm_upload(seqs)
+    iv = acc.sdust(asm, T, W)
+    asm.close()
+    got = [(int(x["ctg"]), int(x["start"]), int(x["finish"])) for x in iv]
+    exp = []
+    for ci, s in enumerate(seqs):
+        for r in ob.sdust(s, T, W):
+            r = int(r)
+            exp.append((ci, r >> 32, r & 0xFFFFFFFF))
+    assert got == exp
+
+
+def test_telofind_random_vs_oracle(acc):
+    rng = np.random.default_rng(99)
+    for motif in (b"TTAGGG", b"CCCTAA", b"TTTAGGG", b"AC", b"A", b"ACGTACGTACGTACGTACGTACGTACGTACGT", b"TTAGGGTTAGGGTTAGG"):
+        seqs = []
+        for _ in range(40):
+            n = int(rng.integers(0, 40000))
+            s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].copy()
+            for _k in range(int(rng.integers(0, 6))):
+                if n > 200:
+                    p = int(rng.integers(0, n - 100))
+                    rep = np.frombuffer(motif * int(rng.integers(1, 60)), dtype=np.uint8)
+                    rep = rep[: n - p]
+                    s[p:p + len(rep)] = rep
+            if n > 10 and rng.random() < 0.5:
+                s[:: int(rng.integers(2, 50))] |= 0x20   # sprinkle lower case
+            seqs.append(s)
+        asm = acc.asm_upload(seqs)
+        hits = acc.telofind(asm, motif)
+        asm.close()
+        exp = []
+        for ci, s in enumerate(seqs):
+            exp += [(ci, int(h["strand"]), int(h["start"]), int(h["end"])) for h in ob.telofind(s, motif)]
+        assert [tuple(map(int, h)) for h in hits] == exp, motif
+
+
+# ---------------------------------------------------------------------------------------------------
+# coverage windows
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def bg_ctgs(golden_dir):
+    return read_bedgraph_pair(os.path.join(golden_dir, "cov-total.bg.gz"), os.path.join(golden_dir, "cov-mq20.bg.gz"))
+
+
+def gpu_panel_text(acc, ctgs, boring, w=2500, inc=50, L=0.4, H=2.5, Q=0.4, m=1000000, e=100000):
+    cov = acc.cov_upload([c[1] for c in ctgs], [c[2] for c in ctgs])
+    sd, sq, n = acc.cov_prepare(cov, w, inc)
+    assert sd == sum(int(c[1].astype(np.int64).sum()) for c in ctgs)
+    assert sq == sum(int(c[2].astype(np.int64).sum()) for c in ctgs)
+    mean = int(np.floor(sd / n + 0.5))          # round() of a non-negative double
+    lo, hi = acc.cov_threshold(L, mean), acc.cov_threshold(H, mean)
+    recs = acc.cov_select(cov, lo, hi, Q, e, m, boring)
+    cov.close()
+    by = {}
+    for r in recs:
+        by.setdefault(int(r["ctg"]), []).append(r)
+    out = []
+    for ci, (name, d, _q) in enumerate(ctgs):
+        if not boring:
+            if d.size < m:
+                out.append(b"%s\t%d\t%d\t.\t.\n" % (name, 0, m))
+                continue
+            out.append(b"%s\t%d\t%d\t.\t.\n" % (name, 0, e))
+            out.append(b"%s\t%d\t%d\t.\t.\n" % (name, d.size - e, d.size))
+        for r in by.get(ci, []):
+            out.append(b"%s\t%d\t%d\t%d\t%d\n" % (name, r["st"], r["end"], r["depth"], r["mq_depth"]))
+    return b"".join(out)
+
+
+from test_oracle_golden import PANEL_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("boring,kw,exp", PANEL_CASES)
+def test_panel_golden(acc, golden_dir, bg_ctgs, boring, kw, exp):
+    assert gpu_panel_text(acc, bg_ctgs, boring, **kw) == golden(golden_dir, exp)
+
+
+@pytest.mark.parametrize("w,inc", [(2500, 50), (300, 7), (1000, 1000), (2500, 49), (64, 1), (5000, 130), (777, 200), (50, 50)])
+def test_cov_regs_vs_oracle(acc, w, inc):
+    rng = np.random.default_rng(w * 131 + inc)
+    lens = [1, 2, 49, 50, 51, 120, 2449, 2450, 2451, 2500, 2501, 2551, 12800, 12801, 30000, 77777]
+    depths = [rng.integers(0, 65536, size=n).astype(np.uint16) for n in lens]
+    mqs = [rng.integers(0, 65536, size=n).astype(np.uint16) for n in lens]
+    cov = acc.cov_upload(depths, mqs)
+    sd, sq, n = acc.cov_prepare(cov, w, inc)
+    assert (sd, sq, n) == (sum(int(d.astype(np.int64).sum()) for d in depths), sum(int(q.astype(np.int64).sum()) for q in mqs), sum(lens))
+    for ci in range(len(lens)):
+        got = acc.cov_regs(cov, ci)
+        exp = ob.get_regs(depths[ci], mqs[ci], w, inc)
+        assert np.array_equal(got, exp.astype(got.dtype)), (w, inc, lens[ci])
+    cov.close()

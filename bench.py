@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""bench.py — Gbases/s scanned by the panel-creation hot path (telofind+telowin, sdust, (no)boringbits
+window stage) on a synthetic ~3 Gbp HG002-like assembly per GPU (BASELINE.json metric; SURVEY 8d inputs).
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  A "step" is one pass of the hot path over the rank's assembly, inputs resident in
+HBM (bases 1 B/base; depth + mq 2 x u16/base), results (telomere runs, telomere windows, sdust intervals,
+selected coverage windows) delivered to host memory of the rank, then gathered to rank 0 over RCCL.
+Weak scaling: every rank holds its own assembly (config 4 of BASELINE.json: N iteration assemblies);
+the only collectives are the 3 x u64 depth-total all-reduce and the result gather.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (sdust_kernel), from HIP events on the
+launch stream; `cpu_baseline` times the CPU oracle ("port": same algorithmic structure as the reference,
+1 core) on a bounded sample of the same workload (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def contig_lengths(total_target):
+    """hifiasm-like contig lengths: the reference's own HG002 assembly BED fixture (100 contigs, 3.16 Gb,
+    largest 242 Mb), data file of test/bigenough/hg002-cornetto-E_3 kept under tests/golden/."""
+    path = os.path.join(ROOT, "tests", "golden", "bigenough", "chroms.bed")
+    lens = [int(l.split()[2]) for l in open(path) if l.strip()]
+    if total_target and total_target < sum(lens):
+        scale = total_target / float(sum(lens))
+        lens = [max(1000, int(x * scale)) for x in lens]
+    return lens
+
+
+def make_assembly(torch, dev, lens, seed):
+    """bases (uint8 ASCII, contigs at 64-byte aligned offsets) with planted features — SURVEY 8d, C2"""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    offs, pos = [], 0
+    for n in lens:
+        offs.append(pos)
+        pos = (pos + n + 63) // 64 * 64
+    total = pos + 256
+    codes = torch.randint(0, 4, (total,), dtype=torch.uint8, device=dev, generator=g)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    bases = lut[codes.long()] if total < (1 << 28) else None
+    if bases is None:                                  # chunked lookup keeps the int64 index temporary small
+        bases = torch.empty_like(codes)
+        step = 1 << 28
+        for s in range(0, total, step):
+            bases[s:s + step] = lut[codes[s:s + step].long()]
+    del codes
+    rng = np.random.default_rng(seed)
+
+    def put(p, b):
+        bases[p:p + len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+
+    for off, n in zip(offs, lens):
+        if n < 50000:
+            continue
+        put(off, b"CCCTAA" * 2000)
+        put(off + n - 9000, b"TTAGGG" * 1500)
+        k = 0
+        for p in range(500000, n - 20000, 500000):
+            kind = k % 4
+            k += 1
+            if kind == 0:
+                put(off + p, b"TTAGGG" * int(rng.integers(3, 81)))
+            elif kind == 1:
+                put(off + p, bytes([b"ACGT"[int(rng.integers(0, 4))]]) * int(rng.integers(10, 301)))
+            elif kind == 2:
+                u = bytes(b"ACGT"[int(x)] for x in rng.integers(0, 4, size=2))
+                put(off + p, u * int(rng.integers(10, 201)))
+            else:
+                put(off + p, b"N" * int(rng.integers(1, 501)))
+        lo = off + n // 2
+        bases[lo:lo + 500] |= 0x20                     # one 500-bp lower-case stretch
+    return bases, np.array(offs, dtype=np.int64)
+
+
+def make_coverage(torch, dev, lens, offs, seed):
+    """per-base depth / mq-depth (u16 stored as int16 bit patterns) — SURVEY 8d, C3"""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed + 1)
+    total = int(offs[-1] + (lens[-1] + 63) // 64 * 64 + 256)
+    nk = (total + 999) // 1000
+    base = torch.poisson(torch.full((nk,), 30.0, device=dev), generator=g).to(torch.int16)
+    depth = base.repeat_interleave(1000)[:total].contiguous()
+    del base
+    step = 1 << 28
+    for s in range(0, total, step):
+        e = min(total, s + step)
+        depth[s:e] += torch.randint(-2, 3, (e - s,), dtype=torch.int16, device=dev, generator=g)
+    depth.clamp_(min=0)
+    mq = depth.clone()
+    rng = np.random.default_rng(seed + 1)
+    for off, n in zip(offs, lens):
+        k = 0
+        for p in range(400000, n - 70000, 400000):
+            L = int(rng.integers(2000, 60001))
+            s = int(off) + p
+            if k % 2 == 0:
+                depth[s:s + L] //= 5
+            else:
+                depth[s:s + L] *= 3
+            mq[s:s + L] = depth[s:s + L]
+            k += 1
+        for p in range(500000, n - 70000, 500000):
+            L = int(rng.integers(2000, 60001))
+            s = int(off) + p + 100000
+            mq[s:s + L] //= 4
+    return depth, mq
+
+
+def cpu_baseline(torch, bases, depth, mq, off0, n0, budget_bases):
+    """CPU oracle ("port" of the reference algorithms, oracle/oracle.c) on the first `budget_bases` of the
+    first contig of the same workload; single thread."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_bind as ob
+    n = int(min(budget_bases, n0))
+    seq = bases[off0:off0 + n].cpu().numpy()
+    d = depth[off0:off0 + n].cpu().numpy().view(np.uint16)
+    q = mq[off0:off0 + n].cpu().numpy().view(np.uint16)
+    ob.lib()
+    t0 = time.perf_counter()
+    hits = ob.telofind(seq, b"TTAGGG")
+    t1 = time.perf_counter()
+    ob.telowin(hits, n, ob.telowin_threshold(0.4, 99.9))
+    t2 = time.perf_counter()
+    ns = max(1, n // 2)
+    ob.sdust(seq[:ns], 20, 64)
+    t3 = time.perf_counter()
+    nr = max(1, n // 2)
+    ob.get_regs(d[:nr], q[:nr], 2500, 50)
+    t4 = time.perf_counter()
+    per_base = (t1 - t0) / n + (t2 - t1) / n + (t3 - t2) / ns + (t4 - t3) / nr
+    return {
+        "value": round(1e-9 / per_base, 6), "unit": "Gbases/s", "cores": 1, "kind": "port",
+        "sample": "first %d bases of contig 0 of the same synthetic assembly: telofind+telowin on all of it, "
+                  "sdust on %d, get_regs(2500,50) on %d; per-base times summed" % (n, ns, nr),
+        "stage_gbases_s": {"telofind": round(n / (t1 - t0) / 1e9, 4), "telowin": round(n / (t2 - t1) / 1e9, 4),
+                           "sdust": round(ns / (t3 - t2) / 1e9, 4), "get_regs": round(nr / (t4 - t3) / 1e9, 4)},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--gbases", type=float, default=0.0, help="assembly size per GPU in Gbases (0 = the full 3.16 Gbp fixture)")
+    ap.add_argument("--cpu-sample-mbases", type=float, default=200.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import cornetto_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    lens = contig_lengths(int(args.gbases * 1e9) if args.gbases > 0 else 0)
+    n_bases = int(sum(lens))
+    bases, offs = make_assembly(torch, dev, lens, 0xC0FFEE + rank)
+    depth, mq = make_coverage(torch, dev, lens, offs, 0xC0FFEE + rank)
+    torch.cuda.synchronize()
+
+    stream = torch.cuda.current_stream()
+    acc = cornetto_amd.Accel(local, stream.cuda_stream)
+    asm = acc.asm_wrap(bases.data_ptr(), offs, np.array(lens, dtype=np.int64))
+    cov = acc.cov_wrap(depth.data_ptr(), mq.data_ptr(), offs, np.array(lens, dtype=np.int32))
+    thr = acc.telowin_threshold(0.4, 99.9)
+    ktime = {}
+
+    def note():
+        for name, ms in acc.last_timing():
+            ktime.setdefault(name, []).append(ms)
+
+    def step(record):
+        hits, wins = acc.telo_scan(asm, b"TTAGGG", thr)
+        if record:
+            note()
+        ivls = acc.sdust(asm, 20, 64)
+        if record:
+            note()
+        sd, sq, n = acc.cov_prepare(cov, 2500, 50)
+        if record:
+            note()
+        tot = torch.tensor([sd, sq, n], dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.all_reduce(tot)                      # the one real exchange: assembly-wide mean depth
+        sd, sq, n = (int(x) for x in tot.tolist())
+        mean = int(np.floor(sd / n + 0.5))
+        lo, hi = acc.cov_threshold(0.4, mean), acc.cov_threshold(2.5, mean)
+        recs = acc.cov_select(cov, lo, hi, 0.4, 100000, 1000000, False)
+        if record:
+            note()
+        counts = torch.tensor([len(hits), len(wins), len(ivls), len(recs)], dtype=torch.int64, device=dev)
+        if world > 1:                                 # gather of the BED/TSV records to rank 0
+            allc = [torch.zeros_like(counts) for _ in range(world)]
+            dist.all_gather(allc, counts)
+            mx = torch.stack(allc).max(dim=0).values.tolist()
+            for arr, m in zip((hits, wins, ivls, recs), mx):
+                buf = torch.zeros(int(m) * arr.dtype.itemsize, dtype=torch.uint8, device=dev)
+                if len(arr):
+                    buf[: arr.nbytes] = torch.frombuffer(bytearray(arr.tobytes()), dtype=torch.uint8).to(dev)
+                out = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+                dist.gather(buf, out, dst=0)
+        return counts.tolist()
+
+    for _ in range(args.warmup):
+        step(False)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    counts = None
+    for _ in range(args.steps):
+        counts = step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n_bases * world / (elapsed / args.steps) / 1e9
+        kavg = {k: float(np.mean(v)) for k, v in ktime.items()}
+        # algorithmic bytes per launch: sdust_kernel and tf_scan read 1 B/base,
+        # cov_blocks reads 4 B/base (u16 depth + u16 mq)
+        alg = {"sdust_kernel": 1.0 * n_bases, "tf_scan": 1.0 * n_bases, "cov_blocks": 4.0 * n_bases}
+        kern = {}
+        for k, ms in sorted(kavg.items()):
+            kern[k] = {"ms": round(ms, 4)}
+            if k in alg and ms > 0:
+                kern[k]["algorithmic_GBps"] = round(alg[k] / (ms * 1e-3) / 1e9, 2)
+        dom = "sdust_kernel"
+        ach = alg[dom] / (kavg[dom] * 1e-3) / 1e9 if kavg.get(dom, 0) > 0 else 0.0
+        line = {
+            "metric": "Gbases/s scanned (telowin+sdust+boringbits)", "value": round(value, 4), "unit": "Gbases/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16 integer",
+            "data": "synthetic",
+            "config": {"workload": "telowin+sdust+noboringbits over one synthetic HG002-like hifiasm assembly per GPU "
+                                   "(%d contigs, %.3f Gbp, planted telomeres/STRs/N runs; per-base u16 depth+mq)" % (len(lens), n_bases / 1e9),
+                       "bases_per_gpu": n_bases, "contigs": len(lens), "motif": "TTAGGG", "sdust": "-w 64 -t 20",
+                       "windows": "-w 2500 -i 50", "parallelism": "contig-sharded, %d process(es), 1 GPU each" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                         "note": "sdust is an integer recurrence (LDS-latency/VALU bound), reported against HBM as the contract asks"},
+            "kernels": kern,
+            "results_per_rank": {"telomere_runs": counts[0], "telomere_windows": counts[1], "sdust_intervals": counts[2],
+                                 "selected_cov_windows": counts[3]},
+        }
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(torch, bases, depth, mq, int(offs[0]), lens[0], int(args.cpu_sample_mbases * 1e6))
+        print(json.dumps(line), flush=True)
+    asm.close()
+    cov.close()
+    acc.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,88 @@
+/* cli.h — shared declarations of the `cornetto` host CLI (C99) on top of the C ABI in
+ * include/cornetto_accel.h.  Drop-in for the reference's CLI on the panel-creation path: same
+ * sub-command names, option letters, stdout bytes and exit codes (reference: src/main.c:95-152). */
+#ifndef CORNETTO_CLI_H
+#define CORNETTO_CLI_H
+
+#include <stdint.h>
+#include <stdio.h>
+
+#include "cornetto_accel.h"
+
+#define CORNETTO_VERSION "0.2.0" /* src/cornetto.h:40 */
+
+/* ---- logging (format of src/error.h:54-103; stderr text is not part of parity, exit codes are) ---- */
+extern int cli_log_level; /* default 4 = LOG_VERB, src/error.c:33 */
+#define CLI_ERROR(...)                                                                                       \
+    do {                                                                                                     \
+        if (cli_log_level >= 1) {                                                                            \
+            fprintf(stderr, "[%s::ERROR]\033[1;31m ", __func__);                                             \
+            fprintf(stderr, __VA_ARGS__);                                                                    \
+            fprintf(stderr, "\033[0m\n At %s:%d\n", __FILE__, __LINE__ - 1);                                 \
+        }                                                                                                    \
+    } while (0)
+#define CLI_WARNING(...)                                                                                     \
+    do {                                                                                                     \
+        if (cli_log_level >= 2) {                                                                            \
+            fprintf(stderr, "[%s::WARNING]\033[1;33m ", __func__);                                           \
+            fprintf(stderr, __VA_ARGS__);                                                                    \
+            fprintf(stderr, "\033[0m\n At %s:%d\n", __FILE__, __LINE__ - 1);                                 \
+        }                                                                                                    \
+    } while (0)
+#define CLI_VERBOSE(...)                                                                                     \
+    do {                                                                                                     \
+        if (cli_log_level >= 4) {                                                                            \
+            fprintf(stderr, "[INFO] %s: ", __func__);                                                        \
+            fprintf(stderr, __VA_ARGS__);                                                                    \
+            fprintf(stderr, "\n");                                                                           \
+        }                                                                                                    \
+    } while (0)
+
+double cli_realtime(void);
+double cli_cputime(void);
+long cli_peakrss(void);
+void *cli_xmalloc(size_t n);
+void *cli_xrealloc(void *p, size_t n);
+char *cli_xstrdup(const char *s);
+
+/* Open the accelerator ($CORNETTO_DEVICE, default 0) or print the reason and exit(EXIT_FAILURE): this
+ * build has no CPU path. */
+cornetto_accel_t *cli_accel_open(void);
+/* print the handle's last error and exit(EXIT_FAILURE) if rc != 0 */
+void cli_accel_check(cornetto_accel_t *h, int rc, const char *what);
+
+/* ---- FASTA/FASTQ(+gz) records with the framing rules of klib kseq (src/kseq.h:184-224) ---- */
+typedef struct {
+    char *s;
+    size_t l, m;
+} cli_str_t;
+
+typedef struct cli_fastx cli_fastx_t;
+cli_fastx_t *cli_fastx_open(const char *path); /* "-" = stdin; NULL on failure */
+void cli_fastx_close(cli_fastx_t *f);
+/* >= 0: sequence length; -1 end of file; -2 truncated quality string */
+int64_t cli_fastx_read(cli_fastx_t *f, cli_str_t *name, cli_str_t *comment, cli_str_t *seq, cli_str_t *qual);
+
+/* a batch of records held in memory for one device pass */
+typedef struct {
+    char **names;
+    uint8_t **seqs;
+    int64_t *lens;
+    int32_t n, cap;
+    int64_t bases;
+} cli_batch_t;
+void cli_batch_push(cli_batch_t *b, const char *name, const char *seq, int64_t len);
+void cli_batch_clear(cli_batch_t *b);
+int64_t cli_batch_limit(void); /* $CORNETTO_BATCH_BASES, default 4e9 */
+
+/* ---- sub-commands: int xxx_main(int argc, char *argv[]) with argv[0] = sub-command (src/main.c:40-54) ---- */
+int depth_main(int argc, char *argv[]);
+int boringbits_main(int argc, char *argv[], int8_t boring);
+int bigenough_main(int argc, char *argv[]);
+int find_telomere_main(int argc, char *argv[]);
+int telomere_windows_main(int argc, char *argv[]);
+int sdust_main(int argc, char *argv[]);
+int assbed_main(int argc, char *argv[]);
+int seq_main(int argc, char *argv[]);
+
+#endif

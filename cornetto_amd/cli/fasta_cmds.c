@@ -1,0 +1,203 @@
+/* fasta_cmds.c — the FASTA/FASTQ driven sub-commands: telofind, sdust (device scans), fa2bed, seq (host
+ * only).  Reference: src/find_telomere.c:83-111, src/sdust/sdust.c:179-207, src/assbed.c:50-107,
+ * src/seq.c:53-138.  Records are read into a batch (whole assembly, or $CORNETTO_BATCH_BASES bases of
+ * reads at a time), scanned by ONE device pass per batch, and printed in input order. */
+#include <getopt.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "cli.h"
+
+typedef void (*batch_fn)(cornetto_accel_t *h, cli_batch_t *b, void *arg);
+
+static void for_each_batch(const char *path, int must_open, batch_fn fn, void *arg)
+{
+    cli_fastx_t *fx = cli_fastx_open(path);
+    if (!fx) {
+        if (must_open) {
+            CLI_ERROR("Failed to open %s : No such file or directory.", path);   /* F_CHK, src/error.h:114-119 */
+            exit(EXIT_FAILURE);
+        }
+        return; /* sdust: the reference has no NULL check (src/sdust/sdust.c:194) and crashes; we just stop */
+    }
+    cornetto_accel_t *h = NULL;
+    cli_str_t name = {0, 0, 0}, comment = {0, 0, 0}, seq = {0, 0, 0}, qual = {0, 0, 0};
+    cli_batch_t b;
+    memset(&b, 0, sizeof(b));
+    const int64_t limit = cli_batch_limit();
+    int64_t l;
+    while ((l = cli_fastx_read(fx, &name, &comment, &seq, &qual)) >= 0) {
+        if (l > 0x7fffffffLL) {
+            CLI_ERROR("record %s has %lld bases; the reference's reader is limited to 2^31-1 (src/kseq.h:185)", name.s, (long long)l);
+            exit(EXIT_FAILURE);
+        }
+        cli_batch_push(&b, name.s, seq.s, l);
+        if (b.bases >= limit) {
+            if (!h) h = cli_accel_open();
+            fn(h, &b, arg);
+            cli_batch_clear(&b);
+        }
+    }
+    if (b.n) {
+        if (!h) h = cli_accel_open();
+        fn(h, &b, arg);
+        cli_batch_clear(&b);
+    }
+    if (h) cornetto_accel_close(h);
+    free(b.names);
+    free(b.seqs);
+    free(b.lens);
+    free(name.s);
+    free(comment.s);
+    free(seq.s);
+    free(qual.s);
+    cli_fastx_close(fx);
+}
+
+/* ---------------------------------------------------------------- telofind */
+static void telofind_batch(cornetto_accel_t *h, cli_batch_t *b, void *arg)
+{
+    const char *motif = (const char *)arg;
+    cornetto_asm_t *a = NULL;
+    cli_accel_check(h, cornetto_asm_upload(h, (const uint8_t *const *)b->seqs, b->lens, b->n, &a), "copying sequences to the GPU");
+    cornetto_hit_t *hits = NULL;
+    int64_t n = 0;
+    cli_accel_check(h, cornetto_telofind(h, a, motif, &hits, &n), "telofind");
+    for (int64_t i = 0; i < n; ++i)   /* src/find_telomere.c:51,56 */
+        printf("%s\t%zu\t%d\t%zu\t%zu\t%zu\n", b->names[hits[i].ctg], (size_t)b->lens[hits[i].ctg], hits[i].strand,
+               (size_t)hits[i].start, (size_t)hits[i].end, (size_t)(hits[i].end - hits[i].start));
+    cornetto_free(hits);
+    cornetto_asm_free(h, a);
+}
+
+int find_telomere_main(int argc, char *argv[])
+{
+    if (argc < 2) { /* src/find_telomere.c:84-88 */
+        fprintf(stderr, "Error: invalid number of parameters\n");
+        fprintf(stderr, "Usage: find <input fasta> [optional sequence to search for, default is vertebrate TTAGGG]\n");
+        exit(EXIT_FAILURE);
+    }
+    const char *motif = argc >= 3 ? argv[2] : "TTAGGG";
+    if (motif[0] == 0) {
+        CLI_ERROR("%s", "empty search sequence");
+        exit(EXIT_FAILURE);
+    }
+    for_each_batch(argv[1], 1, telofind_batch, (void *)motif);
+    return EXIT_SUCCESS;
+}
+
+/* ---------------------------------------------------------------- sdust */
+typedef struct {
+    int W, T;
+} sdust_opt_t;
+
+static void sdust_batch(cornetto_accel_t *h, cli_batch_t *b, void *arg)
+{
+    const sdust_opt_t *o = (const sdust_opt_t *)arg;
+    cornetto_asm_t *a = NULL;
+    cli_accel_check(h, cornetto_asm_upload(h, (const uint8_t *const *)b->seqs, b->lens, b->n, &a), "copying sequences to the GPU");
+    cornetto_ivl_t *iv = NULL;
+    int64_t n = 0;
+    cli_accel_check(h, cornetto_sdust_asm(h, a, o->T, o->W, &iv, &n), "sdust");
+    for (int64_t i = 0; i < n; ++i) printf("%s\t%d\t%d\n", b->names[iv[i].ctg], iv[i].start, iv[i].finish);   /* :201 */
+    cornetto_free(iv);
+    cornetto_asm_free(h, a);
+}
+
+int sdust_main(int argc, char *argv[])
+{
+    sdust_opt_t o = {64, 20}; /* src/sdust/sdust.c:183 */
+    int c;
+    /* ketopt(..., permute=1, "w:t:") of the reference == POSIX getopt with GNU permutation */
+    optind = 1;
+    while ((c = getopt(argc, argv, "w:t:")) >= 0) {
+        if (c == 'w') o.W = atoi(optarg);
+        else if (c == 't') o.T = atoi(optarg);
+    }
+    if (optind == argc) {
+        fprintf(stderr, "Usage: sdust [-w %d] [-t %d] <in.fa>\n", o.W, o.T);
+        exit(1);
+    }
+    for_each_batch(argv[optind], 0, sdust_batch, &o);
+    return 0;
+}
+
+/* ---------------------------------------------------------------- fa2bed */
+static const struct option help_only[] = {{"verbose", required_argument, 0, 'v'}, {"help", no_argument, 0, 'h'}, {0, 0, 0, 0}};
+
+int assbed_main(int argc, char *argv[])
+{
+    FILE *fp_help = stderr;
+    int c, li = 0;
+    optind = 1;
+    while ((c = getopt_long(argc, argv, "h", help_only, &li)) >= 0)
+        if (c == 'h') fp_help = stdout;
+    if (argc - optind != 1 || fp_help == stdout) {
+        fprintf(fp_help, "Usage: cornetto asmbed <assembly.fasta> \n");
+        fprintf(fp_help, "   -h                         help\n");
+        exit(fp_help == stdout ? EXIT_SUCCESS : EXIT_FAILURE);
+    }
+    cli_fastx_t *fx = cli_fastx_open(argv[optind]);
+    if (!fx) {
+        CLI_ERROR("Failed to open %s : No such file or directory.", argv[optind]);
+        exit(EXIT_FAILURE);
+    }
+    cli_str_t name = {0, 0, 0}, comment = {0, 0, 0}, seq = {0, 0, 0}, qual = {0, 0, 0};
+    int64_t l;
+    while ((l = cli_fastx_read(fx, &name, &comment, &seq, &qual)) >= 0) fprintf(stdout, "%s\t%d\t%d\n", name.s, 0, (int)l);   /* src/assbed.c:99 */
+    cli_fastx_close(fx);
+    return 0;
+}
+
+/* ---------------------------------------------------------------- seq */
+int seq_main(int argc, char *argv[])
+{
+    static const struct option lo[] = {{"verbose", required_argument, 0, 'v'}, {"min-len", required_argument, 0, 'm'}, {"help", no_argument, 0, 'h'}, {0, 0, 0, 0}};
+    FILE *fp_help = stderr;
+    int min_len = 30000; /* src/seq.c:63 */
+    int c, li = 0;
+    optind = 1;
+    while ((c = getopt_long(argc, argv, "hm:", lo, &li)) >= 0) {
+        if (c == 'h') {
+            fp_help = stdout;
+        } else if (c == 'm') {
+            min_len = atoi(optarg);
+            if (min_len < 0) {
+                fprintf(stderr, "Error: min-len must be a positive integer\n");
+                exit(EXIT_FAILURE);
+            }
+        } else {
+            fprintf(stderr, "Unknown option: %s\n", argv[optind - 1]);
+            exit(EXIT_FAILURE);
+        }
+    }
+    if (argc - optind != 1 || fp_help == stdout) {
+        fprintf(fp_help, "Usage: cornetto seq <reads.fastq> \n");
+        fprintf(fp_help, "   -m INT                     min length [%d]\n", 30000);
+        fprintf(fp_help, "   -h                         help\n");
+        exit(fp_help == stdout ? EXIT_SUCCESS : EXIT_FAILURE);
+    }
+    cli_fastx_t *fx = cli_fastx_open(argv[optind]);
+    if (!fx) {
+        CLI_ERROR("Failed to open %s : No such file or directory.", argv[optind]);
+        exit(EXIT_FAILURE);
+    }
+    cli_str_t name = {0, 0, 0}, comment = {0, 0, 0}, seq = {0, 0, 0}, qual = {0, 0, 0};
+    uint64_t before = 0, after = 0, before_n = 0, after_n = 0;
+    int64_t l;
+    while ((l = cli_fastx_read(fx, &name, &comment, &seq, &qual)) >= 0) {
+        before += (uint64_t)l;
+        before_n++;
+        if (l >= min_len) { /* src/seq.c:120-129: name, TAB, comment */
+            after += (uint64_t)l;
+            after_n++;
+            printf("@%s", name.s);
+            if (comment.l) printf("\t%s", comment.s);
+            printf("\n%s\n+\n%s\n", seq.s, qual.s);
+        }
+    }
+    fprintf(stderr, "total reads: %lu\t%lu bases\t%.2f Gbases\n", (unsigned long)before_n, (unsigned long)before, before / 1e9);
+    fprintf(stderr, "reads >= %d: %lu\t%lu bases\t%.2f Gbases\n", min_len, (unsigned long)after_n, (unsigned long)after, after / 1e9);
+    cli_fastx_close(fx);
+    return 0;
+}

@@ -1,0 +1,112 @@
+/* util.c — timers, allocation helpers, accelerator open for the cornetto CLI */
+#include "cli.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <sys/resource.h>
+#include <sys/time.h>
+
+int cli_log_level = 4;
+
+double cli_realtime(void) /* src/misc.c:48-52 */
+{
+    struct timeval tp;
+    gettimeofday(&tp, NULL);
+    return tp.tv_sec + tp.tv_usec * 1e-6;
+}
+
+double cli_cputime(void) /* src/misc.c:54-59 */
+{
+    struct rusage r;
+    getrusage(RUSAGE_SELF, &r);
+    return r.ru_utime.tv_sec + r.ru_stime.tv_sec + 1e-6 * (r.ru_utime.tv_usec + r.ru_stime.tv_usec);
+}
+
+long cli_peakrss(void) /* src/misc.c:61-70 */
+{
+    struct rusage r;
+    getrusage(RUSAGE_SELF, &r);
+    return r.ru_maxrss * 1024;
+}
+
+void *cli_xmalloc(size_t n)
+{
+    void *p = malloc(n ? n : 1);
+    if (!p) {
+        CLI_ERROR("Failed to allocate %zu bytes", n);
+        exit(EXIT_FAILURE);
+    }
+    return p;
+}
+
+void *cli_xrealloc(void *p, size_t n)
+{
+    void *q = realloc(p, n ? n : 1);
+    if (!q) {
+        CLI_ERROR("Failed to allocate %zu bytes", n);
+        exit(EXIT_FAILURE);
+    }
+    return q;
+}
+
+char *cli_xstrdup(const char *s)
+{
+    size_t n = strlen(s) + 1;
+    char *d = (char *)cli_xmalloc(n);
+    memcpy(d, s, n);
+    return d;
+}
+
+cornetto_accel_t *cli_accel_open(void)
+{
+    const char *d = getenv("CORNETTO_DEVICE");
+    cornetto_accel_t *h = NULL;
+    int rc = cornetto_accel_open(&h, d ? atoi(d) : 0, NULL);
+    if (rc != CORNETTO_OK) {
+        CLI_ERROR("cannot open HIP device %d: %s. This build runs the scans on an AMD GPU only; there is no CPU path.",
+                  d ? atoi(d) : 0, cornetto_accel_strerror(rc));
+        exit(EXIT_FAILURE);
+    }
+    return h;
+}
+
+void cli_accel_check(cornetto_accel_t *h, int rc, const char *what)
+{
+    if (rc == CORNETTO_OK) return;
+    CLI_ERROR("%s failed: %s (%s)", what, cornetto_accel_last_error(h), cornetto_accel_strerror(rc));
+    exit(EXIT_FAILURE);
+}
+
+void cli_batch_push(cli_batch_t *b, const char *name, const char *seq, int64_t len)
+{
+    if (b->n == b->cap) {
+        b->cap = b->cap ? b->cap * 2 : 256;
+        b->names = (char **)cli_xrealloc(b->names, (size_t)b->cap * sizeof(char *));
+        b->seqs = (uint8_t **)cli_xrealloc(b->seqs, (size_t)b->cap * sizeof(uint8_t *));
+        b->lens = (int64_t *)cli_xrealloc(b->lens, (size_t)b->cap * sizeof(int64_t));
+    }
+    b->names[b->n] = cli_xstrdup(name);
+    b->seqs[b->n] = (uint8_t *)cli_xmalloc((size_t)len + 1);
+    memcpy(b->seqs[b->n], seq, (size_t)len);
+    b->seqs[b->n][len] = 0;
+    b->lens[b->n] = len;
+    b->bases += len;
+    b->n++;
+}
+
+void cli_batch_clear(cli_batch_t *b)
+{
+    for (int32_t i = 0; i < b->n; ++i) {
+        free(b->names[i]);
+        free(b->seqs[i]);
+    }
+    b->n = 0;
+    b->bases = 0;
+}
+
+int64_t cli_batch_limit(void)
+{
+    const char *s = getenv("CORNETTO_BATCH_BASES");
+    int64_t v = s ? atoll(s) : 0;
+    return v > 0 ? v : 4000000000LL;
+}

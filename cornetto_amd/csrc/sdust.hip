@@ -44,6 +44,7 @@ struct SdArgs {
     uint2 *out;        // [n_chunks][cap] (start, finish)
     uint32_t *out_n;   // [n_chunks] number of intervals the chunk produced (may exceed cap: overflow)
     uint32_t cap;
+    unsigned long long *stats;   // optional [4]: wave steps, cooperative find_perfect calls, cooperative trims, save/evicts
 };
 
 template <int RC>  // ring / slot capacity, power of two >= W - 2
@@ -260,6 +261,350 @@ __global__ __launch_bounds__(64) void sdust_kernel(SdArgs A)
 #undef SLOT
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// sdust_w64: the production kernel for W - 2 <= 64 (default W = 64).  Same recurrence, but every
+// data-dependent LOOP of the reference is replaced by wave-cooperative, loop-free code, because in a
+// 64-lane wave "rare per lane" is "every step per wave":
+//   * cv / rv are not maintained at all.  L (the longest suffix of the window in which no 3-mer occurs
+//     more than m = 2T/10 times, :79-85) is kept as the absolute index `vs` of the first word of that
+//     suffix; pushing word t can only move vs just past the (m+1)-th most recent occurrence of t, which is
+//     looked up — only when cw[t] > m — by ONE ballot over the owner's ring (lane j reads ring slot j).
+//   * find_perfect (:104-128): lane j takes window position j of the owning lane; suffix scores r_j
+//     come from 6 ballots (equal-word mask), a popcount and a suffix-sum scan; the running maximum over
+//     P entries / earlier candidates is a suffix-max scan with exact cross-multiplied ratio compares.
+//   * P occupancy is a 64-bit mask per lane (bit = start & 63), so save_masked_regions (:88-102) and the
+//     N flush (:153) are rotates / ctz instead of list walks.
+//   * for m <= 4 (T <= 24, the default) even that ballot is avoided: per 3-mer the low bytes of the
+//     positions of its last 4 pushes are kept in one LDS dword; they are trusted only when cw[t] >= m,
+//     which guarantees those pushes lie inside the <= 64-word window, so 8 bits identify them.
+// Chunks are dealt to lanes interleaved over groups of 64 waves, so that a long low-complexity array
+// (telomere, satellite) is spread over many waves instead of serialising inside one.
+// ---------------------------------------------------------------------------------------------------
+struct SdLds64 {
+    uint8_t ring[16][64][4];   // [slot >> 2][lane][slot & 3], slot = absolute word index & 63
+    uint32_t cwq[64][64];      // [3-mer][lane]: bits 6:0 = cw (copies in the window); bits 30:7 = (absolute index & 63)
+                               //   of its last 4 pushes, 6 bits each, newest lowest
+    uint32_t slot[64][65];     // [lane][start & 63] = r | l << 16; a row per lane: the cooperative pass reads one row
+                               //   conflict-free (the per-lane accesses are the rare ones); 65: odd row stride
+};
+
+// seq_nt4_table (src/sdust/sdust.c:23-40) without a table: A/a C/c G/g T/t -> 0..3, bytes 0..3 -> themselves, else 4
+__device__ __forceinline__ int nt4_code(uint32_t c)
+{
+    const uint32_t cl = c | 0x20u, idx = cl - 0x61u;                 // a=0 c=2 g=6 t=19
+    const bool acgt = idx < 20u && ((0x80045u >> idx) & 1u);
+    uint32_t code = (cl >> 1) & 3u;                                  // a0 c1 g3 t2
+    code ^= code >> 1;                                               // a0 c1 g2 t3
+    return acgt ? (int)code : (c < 4u ? (int)c : 4);
+}
+
+__device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ unsigned long long rdlane64(unsigned long long v, int l)
+{
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) |
+           (unsigned)__builtin_amdgcn_readlane((int)v, l);
+}
+__device__ __forceinline__ unsigned long long rotr64(unsigned long long x, int r)
+{
+    r &= 63;
+    return r ? (x >> r) | (x << (64 - r)) : x;
+}
+__device__ __forceinline__ unsigned long long rotl64(unsigned long long x, int r) { return rotr64(x, 64 - (r & 63)); }
+
+
+// ---- wave64 forward inclusive scans on DPP (no LDS traffic): row_shr 1,2,4,8 inside each row of 16 lanes,
+// then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3.
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+__device__ __forceinline__ int wave_scan_add(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, DPP_ROW_SHR(1), 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, DPP_ROW_SHR(2), 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, DPP_ROW_SHR(4), 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, DPP_ROW_SHR(8), 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, DPP_ROW_BCAST15, 0xA, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, DPP_ROW_BCAST31, 0xC, 0xF, false);
+    return x;
+}
+// running maximum of the ratio r/l (r == 0: no entry); exact, products < 2^24
+__device__ __forceinline__ void ratio_max_step(int &xr, int &xl, int pr, int pl)
+{
+    if (pr != 0 && (xr == 0 || __mul24(pr, xl) > __mul24(xr, pl))) { xr = pr; xl = pl; }
+}
+#define RATIO_SCAN_STEP(ctrl, rmask, bound)                                                   \
+    {                                                                                         \
+        const int pr = __builtin_amdgcn_update_dpp(0, xr, (ctrl), (rmask), 0xF, (bound));       \
+        const int pl = __builtin_amdgcn_update_dpp(0, xl, (ctrl), (rmask), 0xF, (bound));       \
+        ratio_max_step(xr, xl, pr, pl);                                                       \
+    }
+__device__ __forceinline__ void wave_scan_ratio_max(int &xr, int &xl)
+{
+    RATIO_SCAN_STEP(DPP_ROW_SHR(1), 0xF, true)
+    RATIO_SCAN_STEP(DPP_ROW_SHR(2), 0xF, true)
+    RATIO_SCAN_STEP(DPP_ROW_SHR(4), 0xF, true)
+    RATIO_SCAN_STEP(DPP_ROW_SHR(8), 0xF, true)
+    RATIO_SCAN_STEP(DPP_ROW_BCAST15, 0xA, false)
+    RATIO_SCAN_STEP(DPP_ROW_BCAST31, 0xC, false)
+}
+
+__global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
+{
+    __shared__ SdLds64 S;
+    const int lane = threadIdx.x;
+    for (int i = 0; i < 64; ++i) S.cwq[i][lane] = 0;
+    __syncthreads();
+
+    // chunk of this lane: interleaved inside groups of 64 waves (4096 consecutive chunks), so that
+    // neighbouring chunks (one low-complexity array spans many of them) land in different waves while a
+    // wave's 64 streams stay within a few MB (TLB / DRAM-page locality).  The grid is padded to whole groups.
+    const int cid = (((int)blockIdx.x >> 6) << 12) + lane * 64 + ((int)blockIdx.x & 63);
+    bool active = cid < A.n_chunks;
+
+    const int T = A.T, W = A.W, CAPW = W - 2;
+    const int m = (T << 1) / 10;                     // cv[t]*10 > T<<1  <=>  cv[t] > m   (:79)
+    SdChunk ch{0, 0, 0};
+    int len = 0;
+    const uint8_t *seq = A.bases;
+    if (active) {
+        ch = A.chunks[cid];
+        len = A.ctg_len[ch.ctg];
+        seq = A.bases + A.ctg_off[ch.ctg];
+    }
+#define RINGL(sl) S.ring[((sl) & 63) >> 2][lane][(sl) & 3]
+#define CWQ(t) S.cwq[(t)][lane]
+
+    // ---- warm-up start: W-2 word emissions before (chunk start - 2W) --------------------------------
+    int u = 0;
+    if (active && ch.start > 0) {
+        const int y = ch.start - 2 * W;
+        if (y > 2) {
+            int need = CAPW, run = 0, p = y - 1;
+            for (; p >= 0; --p) {
+                if (nt4_code(seq[p]) < 4) {
+                    if (++run >= 3 && --need == 0) break;
+                } else {
+                    run = 0;
+                }
+            }
+            u = p > 0 ? p : 0;
+        }
+    }
+
+    // ---- per-lane sequential state --------------------------------------------------------------------
+    int l = 0, size = 0, rw = 0;
+    int p = -1;                 // absolute index of the newest word in the window
+    int vs = 0;                 // absolute index of the first word of v (the suffix with all counts <= m)
+    unsigned t = 0, s_pref = 0;
+    unsigned long long occ = 0; // occupied P slots, bit = start & 63
+    int minstart = 0;
+    bool have_last = false;
+    uint32_t last_s = 0, last_f = 0, n_out = 0;
+    uint2 *out = A.out + (size_t)(active ? cid : 0) * A.cap;
+    const int rec_from = ch.start;
+    const int stop = (ch.end == len) ? len + 1 : ch.end;
+
+    auto emit = [&](int ps, int pf) {               // :93-99 on the lane-local list
+        if (have_last && ps <= (int)last_f) {
+            if (pf > (int)last_f) last_f = (uint32_t)pf;
+        } else {
+            if (have_last) {
+                if (n_out < A.cap) out[n_out] = make_uint2(last_s, last_f);
+                ++n_out;
+            }
+            have_last = true;
+            last_s = (uint32_t)ps;
+            last_f = (uint32_t)pf;
+        }
+    };
+    // save_masked_regions(start) when it does something: occ != 0 && minstart < start   (:88-102)
+    auto save_evict = [&](int start, int now) {
+        const uint32_t sl = S.slot[lane][minstart & 63];
+        if (now >= rec_from) emit(minstart, minstart + (int)(sl >> 16) + 3);
+        const int gone = start - minstart;           // starts minstart .. start-1 leave the window
+        if (gone >= 64) {
+            occ = 0;
+        } else {
+            unsigned long long r = rotr64(occ, minstart & 63);   // bit 0 <-> minstart
+            r &= ~0ull << gone;
+            occ = rotl64(r, minstart & 63);
+        }
+        if (occ) minstart = start + __builtin_ctzll(rotr64(occ, start & 63));
+    };
+
+    int i = u;
+    uint32_t word = 0, nextw = 0;
+    if (active && u < len) {
+        word = *reinterpret_cast<const uint32_t *>(seq + (u & ~3)) >> (8 * (u & 3));
+        if ((u & ~3) + 4 < len) nextw = *reinterpret_cast<const uint32_t *>(seq + (u & ~3) + 4);
+    }
+    active = active && i < stop;
+
+    unsigned st_steps = 0, st_fp = 0, st_trim = 0;
+    while (__any(active)) {
+        bool need_trim = false, need_fp = false;
+        int start = 0;
+        ++st_steps;
+        if (active) {
+            if ((i & 3) == 0 && i != u) {            // one dword per 4 steps, fetched 4 steps ahead
+                word = nextw;
+                if (i + 4 < len) nextw = *reinterpret_cast<const uint32_t *>(seq + i + 4);
+            }
+            const int b = i < len ? nt4_code(word & 0xFFu) : 4;
+            word >>= 8;
+            if (b < 4) {
+                ++l;
+                t = (t << 2 | (unsigned)b) & 63u;                            // :144
+                if (l >= 3) {
+                    start = (l - W > 0 ? l - W : 0) + (i + 1 - l);           // :146
+                    if (occ && minstart < start) save_evict(start, i);      // :147 (rare)
+                    // shift_window (:66-86) without cv / rv, straight-line: both table entries are read at
+                    // once (the oldest word was prefetched at the end of the previous word step)
+                    const uint32_t pop = size >= CAPW ? 1u : 0u;
+                    const unsigned s = s_pref;
+                    uint32_t es = CWQ(s);
+                    uint32_t et = CWQ(t);
+                    es -= pop;                               // --cw[s]   (:71)
+                    CWQ(s) = es;
+                    if (s == t) et = es;
+                    rw -= pop ? (int)(es & 127u) : 0;
+                    size -= (int)pop;
+                    ++p;
+                    RINGL(p) = (uint8_t)t;                   // :75
+                    ++size;
+                    const int c = (int)(et & 127u);
+                    rw += c;                                 // rw += cw[t]++   (:77)
+                    const uint32_t hist = et >> 7;           // last pushes of t, newest in the low 6 bits
+                    CWQ(t) = (uint32_t)(c + 1) | ((((hist << 6) | ((uint32_t)p & 63u)) & 0xFFFFFFu) << 7);
+                    if (m <= 4) {
+                        // v must not hold more than m copies of t: if the window held >= m before this push,
+                        // v now starts no earlier than just after the m-th most recent earlier push of t
+                        // (inside the <= 64-word window, so 6 bits identify it)
+                        if (m == 0) {
+                            vs = p + 1;
+                        } else if (c >= m) {
+                            const int o = p - (int)(((uint32_t)p - (hist >> (6 * (m - 1)))) & 63u);
+                            if (o + 1 > vs) vs = o + 1;
+                        }
+                    } else {
+                        need_trim = c + 1 > m;       // only then can the count inside v exceed m
+                    }
+                    s_pref = RINGL(p - size + 1);    // the word the next pop removes
+                    need_fp = true;                  // decided after the trim below
+                }
+            } else {
+                int st = (l - W + 1 > 0 ? l - W + 1 : 0) + (i + 1 - l);       // :152
+                while (occ) {                                                // :153
+                    if (minstart >= st) st = minstart + 1;
+                    save_evict(st, i);
+                    ++st;
+                }
+                l = 0;
+                t = 0;                                                       // :154
+            }
+        }
+        // ---- cooperative trim: vs moves just past the (m+1)-th most recent occurrence of t inside v ----
+        unsigned long long todo = __ballot(need_trim);
+        st_trim += (unsigned)__popcll(todo);
+        while (todo) {
+            const int o = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+            todo &= todo - 1;
+            const int o_p = rdlane(p, o), o_size = rdlane(size, o), o_vs = rdlane(vs, o);
+            const unsigned o_t = (unsigned)rdlane((int)t, o);
+            const unsigned mine = S.ring[lane >> 2][o][lane & 3];             // ring slot `lane` of the owner
+            const unsigned long long eq = __ballot(mine == o_t);
+            // chronological order: bit k <-> absolute word index o_p - 63 + k
+            const unsigned long long chron = rotr64(eq, (o_p + 1) & 63);
+            const int ws = o_p - o_size + 1;
+            const int first = o_vs > ws ? o_vs : ws;                           // first word of v before the trim
+            const int Lc = o_p - first + 1;                                    // 1..64
+            const unsigned long long inv = chron & (Lc >= 64 ? ~0ull : ~0ull << (64 - Lc));
+            if (__popcll(inv) > m) {
+                const int oldest = __builtin_ctzll(inv);                       // oldest occurrence of t inside v
+                if (lane == o) vs = o_p - 63 + oldest + 1;
+            }
+        }
+        if (need_fp) {
+            const int ws = p - size + 1;
+            const int first = vs > ws ? vs : ws;
+            const int L = p - first + 1;
+            need_fp = rw * 10 > L * T;                                         // :149
+        }
+        // ---- cooperative find_perfect (:104-128) ------------------------------------------------------
+        // lane <-> window position j = 63 - lane, so that "suffix of the window" = "prefix of the wave" and
+        // both scans are forward DPP scans (no LDS round trips).
+        todo = __ballot(need_fp);
+        st_fp += (unsigned)__popcll(todo);
+        while (todo) {
+            const int o = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+            todo &= todo - 1;
+            const int o_p = rdlane(p, o), o_size = rdlane(size, o), o_vs = rdlane(vs, o);
+            const int ws = o_p - o_size + 1;
+            const int first = o_vs > ws ? o_vs : ws;
+            const int i0 = first - ws - 1;                                     // = size - L - 1
+            const int j = 63 - lane;                                           // window position (0 = oldest)
+            const bool inwin = j < o_size;
+            const int rslot = (ws + j) & 63;
+            const unsigned wj = inwin ? S.ring[rslot >> 2][o][rslot & 3] : 0u;
+            unsigned long long eq = __ballot(inwin);
+#pragma unroll
+            for (int bb = 0; bb < 6; ++bb) {
+                const bool bit = (wj >> bb) & 1u;
+                const unsigned long long bal = __ballot(bit);
+                eq &= bit ? bal : ~bal;
+            }
+            // equal words at later window positions = lower lanes; suffix score r_j = inclusive prefix sum
+            const int r = wave_scan_add(inwin ? __popcll(eq & ((1ull << lane) - 1ull)) : 0);
+            const int new_l = o_size - j - 1;                                  // :111
+            const bool cand = inwin && j <= i0 && r * 10 > T * new_l;          // :112
+            const unsigned long long candmask = __ballot(cand);
+            if (candmask == 0) continue;                                       // nothing can be inserted
+            const int o_start = rdlane(start, o);
+            const unsigned long long o_occ = rdlane64(occ, o);
+            const int sidx = (o_start + j) & 63;
+            const bool has_e = inwin && ((o_occ >> sidx) & 1ull);
+            const uint32_t e = has_e ? S.slot[o][sidx] : 0u;
+            const int er = (int)(e & 0xFFFFu), el = (int)(e >> 16);
+            // X_j = better of (existing entry with this start, candidate j); inclusive maximum over positions >= j
+            int xr = er, xl = el;
+            if (cand && (er == 0 || __mul24(r, el) >= __mul24(er, new_l))) { xr = r; xl = new_l; }
+            wave_scan_ratio_max(xr, xl);
+            // maximum over positions > j = the scan value one lane down (wave_shr:1; lane 0 gets 0)
+            const int sr = __builtin_amdgcn_update_dpp(0, xr, 0x138, 0xF, 0xF, true);
+            const int sl2 = __builtin_amdgcn_update_dpp(0, xl, 0x138, 0xF, 0xF, true);
+            int mr = sr, ml = sl2;                                             // :113-117: entries with start >= i + start
+            if (er != 0 && (sr == 0 || __mul24(er, sl2) > __mul24(sr, el))) { mr = er; ml = el; }
+            const bool ins = cand && (mr == 0 || __mul24(r, ml) >= __mul24(mr, new_l));   // :118
+            if (ins) S.slot[o][sidx] = (uint32_t)r | ((uint32_t)new_l << 16);  // start = i + start, finish = start + l + 3
+            const unsigned long long insj = __brevll(__ballot(ins));           // bit j <-> window position j
+            if (insj && lane == o) {
+                const int lowest = o_start + __builtin_ctzll(insj);
+                if (occ == 0 || lowest < minstart) minstart = lowest;
+                occ |= rotl64(insj, o_start & 63);
+            }
+        }
+        if (active) {
+            ++i;
+            if (i >= stop) {
+                active = false;
+                if (have_last) {
+                    if (n_out < A.cap) out[n_out] = make_uint2(last_s, last_f);
+                    ++n_out;
+                }
+                A.out_n[cid] = n_out;
+            }
+        }
+    }
+    if (A.stats && lane == 0) {
+        atomicAdd(&A.stats[0], (unsigned long long)st_steps);
+        atomicAdd(&A.stats[1], (unsigned long long)st_fp);
+        atomicAdd(&A.stats[2], (unsigned long long)st_trim);
+    }
+#undef RINGL
+#undef CWQ
+}
+
 __global__ void sdust_gather(const uint2 *in, const uint32_t *cnt, const int64_t *dst_off, uint32_t cap,
                              int32_t n_chunks, uint2 *dst)
 {
@@ -320,12 +665,29 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a, int32_t T, 
         for (int attempt = 0; attempt < 2; ++attempt) {
             if (d_out.alloc(nc * (size_t)cap * sizeof(uint2)) != hipSuccess)
                 return cn_fail(h, CORNETTO_E_NOMEM, "sdust: device allocation of %zu bytes failed", nc * (size_t)cap * sizeof(uint2));
-            SdArgs A{a->d_bases, a->d_off, a->d_len, d_chunks.as<SdChunk>(), (int32_t)nc, T, W, d_out.as<uint2>(), d_cnt.as<uint32_t>(), cap};
-            const unsigned nb = (unsigned)((nc + 63) / 64);
-            if (W - 2 <= 64) CN_LAUNCH(h, "sdust_kernel", sdust_kernel<64><<<dim3(nb), dim3(64), 0, h->stream>>>(A));
+            DevBuf d_stats;
+            const bool want_stats = env_int("CORNETTO_SDUST_STATS", 0) != 0;
+            if (want_stats) {
+                if (d_stats.alloc(32) != hipSuccess) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: device allocation failed");
+                CN_HIP(h, hipMemsetAsync(d_stats.p, 0, 32, h->stream));
+            }
+            SdArgs A{a->d_bases, a->d_off, a->d_len, d_chunks.as<SdChunk>(), (int32_t)nc, T, W, d_out.as<uint2>(), d_cnt.as<uint32_t>(), cap,
+                     want_stats ? d_stats.as<unsigned long long>() : nullptr};
+            unsigned nb = (unsigned)((nc + 63) / 64);
+            const int variant = env_int("CORNETTO_SDUST_VARIANT", 0);   // 1 = force the per-lane reference-shaped kernel
+            if (W - 2 <= 64 && variant == 0) {
+                nb = (unsigned)((nc + 4095) / 4096) * 64;   // whole groups of 64 waves
+                CN_LAUNCH(h, "sdust_kernel", sdust_w64<<<dim3(nb), dim3(64), 0, h->stream>>>(A));
+            }
+            else if (W - 2 <= 64) CN_LAUNCH(h, "sdust_kernel", sdust_kernel<64><<<dim3(nb), dim3(64), 0, h->stream>>>(A));
             else CN_LAUNCH(h, "sdust_kernel", sdust_kernel<256><<<dim3(nb), dim3(64), 0, h->stream>>>(A));
             CN_HIP(h, hipMemcpyAsync(cnt.data(), d_cnt.p, nc * 4, hipMemcpyDeviceToHost, h->stream));
             CN_HIP(h, hipStreamSynchronize(h->stream));
+            if (want_stats) {
+                unsigned long long st[4] = {0, 0, 0, 0};
+                CN_HIP(h, hipMemcpy(st, d_stats.p, 32, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[sdust stats] chunks %zu waves %u wave-steps %llu find_perfect calls %llu trims %llu\n", nc, nb, st[0], st[1], st[2]);
+            }
             const uint32_t mx = *std::max_element(cnt.begin(), cnt.end());
             if (mx <= cap) break;
             if (attempt == 1) return cn_fail(h, CORNETTO_E_HIP, "sdust: chunk produced %u intervals after resizing to %u", mx, cap);

@@ -1,0 +1,120 @@
+"""GPU: the `cornetto` CLI end to end (host C -> C ABI -> HIP kernels) against golden stdout of the
+unmodified reference, byte for byte — the drop-in claim of the panel path."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+import cornetto_amd
+from helpers import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cli():
+    assert os.path.exists(cornetto_amd.CLI_PATH), "build the CLI first (make -C cornetto_amd)"
+    return cornetto_amd.CLI_PATH
+
+
+def run(cli, args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([cli] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+    return p.returncode, p.stdout, p.stderr
+
+
+@pytest.fixture(scope="module")
+def plain(golden_dir, tmp_path_factory):
+    """uncompressed copies of the gz fixtures (bedgraphs are read with fopen by the reference)"""
+    d = tmp_path_factory.mktemp("plain")
+    out = {}
+    for fn in ("cov-total.bg.gz", "cov-mq20.bg.gz", "mix.fa.gz"):
+        dst = d / fn[:-3]
+        dst.write_bytes(gzip.open(os.path.join(golden_dir, fn)).read())
+        out[fn[:-3]] = str(dst)
+    return out
+
+
+@pytest.mark.parametrize("args,exp", [
+    (["telofind", "probe.fa"], "probe.telofind.exp"),
+    (["telofind", "mix.fa.gz"], "mix.telofind.exp"),
+    (["telofind", "mix.fa.gz", "ttaggg"], "mix.lower_motif.telofind.exp"),
+    (["telofind", "mix.fa.gz", "TTAGGGTTAGGG"], "mix.k12.telofind.exp"),
+    (["telofind", "mix.fa.gz", "AAAA"], "mix.AAAA.telofind.exp"),
+    (["telofind", "mix.fa.gz", "GNG"], "mix.GNG.telofind.exp"),
+    (["telofind", "probe_selfoverlap.fa", "ACACA"], "probe_selfoverlap.ACACA.telofind.exp"),
+    (["sdust", "probe.fa"], "probe.sdust.exp"),
+    (["sdust", "probe_sdust.fa"], "probe_sdust.sdust.exp"),
+    (["sdust", "-w", "32", "-t", "10", "probe_sdust.fa"], "probe_sdust.w32t10.sdust.exp"),
+    (["sdust", "mix.fa.gz"], "mix.sdust.exp"),
+    (["sdust", "mix.fa.gz", "-w", "32", "-t", "10"], "mix.w32t10.sdust.exp"),
+    (["sdust", "-w", "100", "-t", "25", "mix.fa.gz"], "mix.w100t25.sdust.exp"),
+    (["sdust", "reads.fq"], "reads.sdust.exp"),
+    (["telowin", "probe.telomere", "99.9", "0.4"], "probe.telowin.exp"),
+    (["telowin", "probe.telomere", "100", "0.5"], "probe.i100t05.telowin.exp"),
+    (["telowin", "probe.telomere", "95"], "probe.i95.telowin.exp"),
+    (["telowin", "mix.telofind.exp", "99.9", "0.4"], "mix.telowin.exp"),
+    (["telowin", "mix.telofind.exp", "99.9", "0.1"], "mix.t01.telowin.exp"),
+])
+def test_fasta_side(cli, golden_dir, args, exp):
+    a = [os.path.join(golden_dir, x) if os.path.exists(os.path.join(golden_dir, x)) else x for x in args]
+    rc, out, err = run(cli, a)
+    assert rc == 0, err.decode()
+    assert out == golden(golden_dir, exp)
+
+
+def test_batched_reads_same_output(cli, golden_dir):
+    """tiny batches (one device pass per ~500 bases) must not change the output"""
+    for sub, exp in (("sdust", "reads.sdust.exp"), ("telofind", None)):
+        rc1, out1, _ = run(cli, [sub, os.path.join(golden_dir, "reads.fq")])
+        rc2, out2, _ = run(cli, [sub, os.path.join(golden_dir, "reads.fq")], env={"CORNETTO_BATCH_BASES": "500"})
+        assert rc1 == 0 and rc2 == 0 and out1 == out2
+        if exp:
+            assert out1 == golden(golden_dir, exp)
+
+
+def test_sdust_stdin(cli, golden_dir):
+    data = open(os.path.join(golden_dir, "probe_sdust.fa"), "rb").read()
+    p = subprocess.run([cli, "sdust", "-"], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0 and p.stdout == golden(golden_dir, "probe_sdust.sdust.exp")
+
+
+PANEL = [
+    (["boringbits", "T", "-q", "Q", "-m", "10000", "-e", "1000", "-L", "0.6", "-Q", "0.6", "-H", "1.6"], "bg.boring_t1.exp"),
+    (["noboringbits", "-H", "2.5", "-L", "0.5", "-Q", "0.5", "T", "-q", "Q", "-m", "10000", "-e", "1000"], "bg.fun_t2.exp"),
+    (["noboringbits", "T", "-q", "Q"], "bg.fun_default.exp"),
+    (["boringbits", "T", "-q", "Q"], "bg.boring_default.exp"),
+    (["noboringbits", "T", "-q", "Q", "-w", "300", "-i", "7", "-L", "0.33", "-H", "1.45", "-Q", "0.9", "-m", "5000", "-e", "500"], "bg.fun_w300i7.exp"),
+    (["boringbits", "T", "-q", "Q", "-w", "300", "-i", "7", "-L", "0.33", "-H", "1.45", "-Q", "0.9", "-m", "5000", "-e", "500"], "bg.boring_w300i7.exp"),
+    (["noboringbits", "T", "-q", "Q", "-w", "1000", "-i", "1000", "-m", "2000", "-e", "10000"], "bg.fun_w1000i1000.exp"),
+]
+
+
+@pytest.mark.parametrize("args,exp", PANEL)
+def test_panel(cli, golden_dir, plain, args, exp):
+    """the two option sets of the reference's own test/test.sh:25,29 plus defaults and odd window sizes"""
+    a = [plain["cov-total.bg"] if x == "T" else plain["cov-mq20.bg"] if x == "Q" else x for x in args]
+    rc, out, err = run(cli, a)
+    assert rc == 0, err.decode()
+    assert out == golden(golden_dir, exp)
+
+
+def test_panel_malformed_inputs_exit_1(cli, plain, tmp_path):
+    tot = open(plain["cov-total.bg"], "rb").read().splitlines(True)
+    mq = open(plain["cov-mq20.bg"], "rb").read().splitlines(True)
+
+    def attempt(t, q):
+        a, b = tmp_path / "t.bg", tmp_path / "q.bg"
+        a.write_bytes(b"".join(t))
+        b.write_bytes(b"".join(q))
+        return run(cli, ["noboringbits", str(a), "-q", str(b)])
+
+    assert attempt(tot[:50], mq[:50])[0] == 0
+    assert attempt([b"track type=bedGraph\n"] + tot[:50], [b"track type=bedGraph\n"] + mq[:50])[0] == 1   # 4 columns
+    assert attempt(tot[:50], mq[:49])[0] == 1                      # second file shorter
+    assert attempt(tot[:50], mq[:40] + mq[41:51])[0] == 1          # not in the same order
+    assert attempt(tot[:20] + tot[21:50], mq[:20] + mq[21:50])[0] == 1   # not incremental
+    rl = [b"ptg000001l\t0\t5\t30\n"]
+    assert attempt(rl, rl)[0] == 1                                 # run-length line: end != start+1

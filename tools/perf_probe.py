@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""perf probe (development aid, not a test): kernel times of one stage for a synthetic assembly.
+   python tools/perf_probe.py sdust --mbases 500 --features 0 --chunk 4096"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("stage", choices=["sdust", "telo", "cov", "all"])
+    ap.add_argument("--mbases", type=float, default=500)
+    ap.add_argument("--features", type=int, default=1)
+    ap.add_argument("--chunk", type=str, default="")
+    ap.add_argument("--reps", type=int, default=2)
+    a = ap.parse_args()
+    if a.chunk:
+        os.environ["CORNETTO_SDUST_CHUNK"] = a.chunk
+    import torch
+    import bench
+    import cornetto_amd
+    dev = torch.device("cuda", 0)
+    lens = bench.contig_lengths(int(a.mbases * 1e6))
+    if a.features:
+        bases, offs = bench.make_assembly(torch, dev, lens, 1)
+    else:
+        offs, pos = [], 0
+        for n in lens:
+            offs.append(pos)
+            pos = (pos + n + 63) // 64 * 64
+        offs = np.array(offs, dtype=np.int64)
+        lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+        bases = lut[torch.randint(0, 4, (pos + 256,), device=dev)]
+    torch.cuda.synchronize()
+    acc = cornetto_amd.Accel(0)
+    asm = acc.asm_wrap(bases.data_ptr(), offs, np.array(lens, dtype=np.int64))
+    n = sum(lens)
+    for rep in range(a.reps):
+        if a.stage in ("sdust", "all"):
+            iv = acc.sdust(asm, 20, 64)
+            print("sdust", a.mbases, "features", a.features, "chunk", a.chunk, [(k, round(v, 3)) for k, v in acc.last_timing()], "ivls", len(iv), flush=True)
+        if a.stage in ("telo", "all"):
+            h, w = acc.telo_scan(asm, b"TTAGGG", 0.3976)
+            print("telo", [(k, round(v, 3)) for k, v in acc.last_timing()], len(h), len(w), flush=True)
+        if a.stage in ("cov", "all"):
+            depth, mq = bench.make_coverage(torch, dev, lens, offs, 1)
+            torch.cuda.synchronize()
+            cov = acc.cov_wrap(depth.data_ptr(), mq.data_ptr(), offs, np.array(lens, dtype=np.int32))
+            s = acc.cov_prepare(cov, 2500, 50)
+            print("cov_prepare", [(k, round(v, 3)) for k, v in acc.last_timing()], flush=True)
+            r = acc.cov_select(cov, 12, 75, 0.4, 100000, 1000000, False)
+            print("cov_select", [(k, round(v, 3)) for k, v in acc.last_timing()], len(r), flush=True)
+
+
+if __name__ == "__main__":
+    main()

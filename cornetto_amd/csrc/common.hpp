@@ -26,6 +26,56 @@ struct cornetto_accel {
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
     std::vector<std::pair<const char *, float>> last;
+    // persistent workspaces (grown on demand, released at close): no hipMalloc/hipFree on the hot path
+    struct Ws {
+        void *p = nullptr;
+        size_t bytes = 0;
+    };
+    Ws dev[64];
+    Ws pin[32];
+};
+
+// device workspace slot `slot` with at least `bytes` bytes (contents undefined); nullptr on failure
+static inline void *cn_ws(cornetto_accel_t *h, int slot, size_t bytes)
+{
+    cornetto_accel::Ws &w = h->dev[slot];
+    if (bytes == 0) bytes = 16;
+    if (w.bytes >= bytes) return w.p;
+    if (w.p) (void)hipFree(w.p);
+    w.p = nullptr;
+    w.bytes = 0;
+    const size_t want = bytes + bytes / 8;     // a little head room so that slowly growing inputs do not re-allocate
+    if (hipMalloc(&w.p, want) == hipSuccess) w.bytes = want;
+    else if (hipMalloc(&w.p, bytes) == hipSuccess) w.bytes = bytes;
+    else w.p = nullptr;
+    return w.p;
+}
+
+// pinned host staging slot (for asynchronous device-to-host copies at full PCIe rate)
+static inline void *cn_pin(cornetto_accel_t *h, int slot, size_t bytes)
+{
+    cornetto_accel::Ws &w = h->pin[slot];
+    if (bytes == 0) bytes = 16;
+    if (w.bytes >= bytes) return w.p;
+    if (w.p) (void)hipHostFree(w.p);
+    w.p = nullptr;
+    w.bytes = 0;
+    const size_t want = bytes + bytes / 8;
+    if (hipHostMalloc(&w.p, want, hipHostMallocDefault) == hipSuccess) w.bytes = want;
+    else w.p = nullptr;
+    return w.p;
+}
+
+enum {   // device workspace slots
+    WS_TF_LUT, WS_TF_CNT, WS_TF_TB, WS_TF_TC, WS_TF_L0, WS_TF_L1, WS_TF_L2, WS_TF_L3, WS_TF_BITMAP,
+    WS_TF_ROFF, WS_TF_RUNS, WS_TF_NRUNS,
+    WS_TW_BOFF, WS_TW_TILES, WS_TW_OUT, WS_TW_CNT, WS_TW_HITS, WS_TW_LEN, WS_TW_BITMAP,
+    WS_SD_OUT, WS_SD_CNT, WS_SD_OFF, WS_SD_DST, WS_SD_STATS,
+    WS_CB_T32, WS_CB_T64, WS_CB_GRAND,
+    WS_CW_REGS, WS_CW_SEL, WS_CW_CNT, WS_CW_TRES
+};
+enum {   // pinned host slots
+    PIN_A, PIN_B, PIN_C, PIN_D, PIN_E, PIN_F, PIN_SMALL
 };
 
 static inline int cn_fail(cornetto_accel_t *h, int status, const char *fmt, ...)
@@ -141,6 +191,14 @@ struct cornetto_asm {
     // device copies of the contig table
     int64_t *d_off = nullptr;
     int32_t *d_len = nullptr;
+    // cached work decompositions (depend on the contig table only); device copies owned by the object
+    std::vector<int32_t> tf_ctg_tile0;   // telofind: first tile of each contig (+ total)
+    int2 *d_tf_tiles = nullptr;
+    int64_t tf_n_tiles = -1;
+    int64_t sd_chunk = -1;               // sdust: chunk size the cached chunk table was built for
+    std::vector<int32_t> sd_chunk_ctg;   // contig of every chunk
+    void *d_sd_chunks = nullptr;
+    int64_t sd_n_chunks = 0;
 };
 
 struct cornetto_cov {
@@ -159,6 +217,15 @@ struct cornetto_cov {
     uint32_t *d_blk = nullptr;         // [n_blk][4] = full depth, head depth, full mq, head mq
     int64_t *d_blk_off = nullptr;
     uint64_t sums[3] = {0, 0, 0};
+    // cached work decompositions
+    int2 *d_cb_tiles = nullptr;          // block tiles for (w, inc)
+    int64_t n_cb_tiles = 0;
+    std::vector<int32_t> n_reg;          // windows per contig for (w, inc)
+    int32_t *d_n_reg = nullptr;
+    int2 *d_cw_tiles = nullptr;          // window tiles of the last selection (mode, min_len)
+    std::vector<int2> cw_tiles;
+    int cw_mode = -1;
+    int32_t cw_min_len = 0, cw_only = -2;
 };
 
 static inline int64_t cn_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }

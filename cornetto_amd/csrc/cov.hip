@@ -21,6 +21,7 @@
 #include <cmath>
 
 #include "common.hpp"
+#include "scan.hpp"
 
 namespace {
 
@@ -155,48 +156,35 @@ __global__ __launch_bounds__(CB_THREADS) void cov_blocks(CbArgs A)
     }
 }
 
-// exclusive scan of the tile totals by ONE workgroup of 1024 threads (n_tiles is ~ bases / 12800)
-__global__ __launch_bounds__(1024) void cov_tilescan(const uint2 *tot32, const ulonglong2 *tot64, int64_t n, uint2 *toff,
-                                                     unsigned long long *grand /* [2] */)
+// exact grand totals of depth / mq for the mean: one 64-bit atomic pair per workgroup
+__global__ __launch_bounds__(256) void cov_total64(const ulonglong2 *tot64, int64_t n, unsigned long long *grand /* [2] */)
 {
-    __shared__ uint32_t sa[1024], sb[1024];
-    __shared__ unsigned long long ga[1024], gb[1024];
-    const int t = threadIdx.x;
-    const int64_t per = (n + 1023) / 1024;
-    const int64_t lo = (int64_t)t * per, hi = lo + per < n ? lo + per : n;
-    uint32_t a = 0, b = 0;
-    unsigned long long xa = 0, xb = 0;
-    for (int64_t i = lo; i < hi; ++i) {
-        a += tot32[i].x;
-        b += tot32[i].y;
-        xa += tot64[i].x;
-        xb += tot64[i].y;
+    __shared__ unsigned long long sa[4], sb[4];
+    unsigned long long a = 0, b = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const ulonglong2 v = tot64[i];
+        a += v.x;
+        b += v.y;
     }
-    sa[t] = a; sb[t] = b; ga[t] = xa; gb[t] = xb;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        a += ((unsigned long long)__shfl_xor((unsigned)(a >> 32), d) << 32) | __shfl_xor((unsigned)a, d);
+        b += ((unsigned long long)__shfl_xor((unsigned)(b >> 32), d) << 32) | __shfl_xor((unsigned)b, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sa[threadIdx.x >> 6] = a;
+        sb[threadIdx.x >> 6] = b;
+    }
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {   // Hillis-Steele inclusive scan of the per-thread partials
-        uint32_t oa = 0, ob = 0;
-        unsigned long long ua = 0, ub = 0;
-        if (t >= d) { oa = sa[t - d]; ob = sb[t - d]; ua = ga[t - d]; ub = gb[t - d]; }
-        __syncthreads();
-        sa[t] += oa; sb[t] += ob; ga[t] += ua; gb[t] += ub;
-        __syncthreads();
-    }
-    uint32_t ra = sa[t] - a, rb = sb[t] - b;   // exclusive prefix of my segment
-    for (int64_t i = lo; i < hi; ++i) {
-        toff[i] = make_uint2(ra, rb);
-        ra += tot32[i].x;
-        rb += tot32[i].y;
-    }
-    if (t == 1023) {
-        grand[0] = ga[t];
-        grand[1] = gb[t];
+    if (threadIdx.x == 0) {
+        atomicAdd(&grand[0], sa[0] + sa[1] + sa[2] + sa[3]);
+        atomicAdd(&grand[1], sb[0] + sb[1] + sb[2] + sb[3]);
     }
 }
 
 struct CwArgs {
     const uint4 *blk;
-    const uint2 *toff;
+    const uint32_t *toff_d, *toff_q;   // exclusive prefix of the tile totals (wrapping)
     const int64_t *blk_off;    // first global block of each contig (multiple of 256)
     const int32_t *ctg_len;
     const int32_t *n_reg;      // windows per contig
@@ -207,7 +195,7 @@ struct CwArgs {
     int32_t lo, hi, edge, min_len;
     double low_mq;
     cornetto_reg_t *regs;
-    uint4 *sel;                // {ctg, window, depth, mq}
+    cornetto_regrec_t *sel;    // selected windows, tile by tile (one reservation per tile)
     unsigned long long *counter;
     uint32_t cap;
     uint2 *tile_res;           // per tile {base, count}
@@ -216,8 +204,7 @@ struct CwArgs {
 __device__ __forceinline__ uint2 cw_prefix(const CwArgs &A, int64_t x)   // inclusive global prefix at block x
 {
     const uint4 b = A.blk[x];
-    const uint2 o = A.toff[x >> 8];
-    return make_uint2(b.x + o.x, b.z + o.y);
+    return make_uint2(b.x + A.toff_d[x >> 8], b.z + A.toff_q[x >> 8]);
 }
 
 __global__ __launch_bounds__(256) void cov_windows(CwArgs A)
@@ -278,8 +265,21 @@ __global__ __launch_bounds__(256) void cov_windows(CwArgs A)
     __syncthreads();
     if (sel) {
         const unsigned long long idx = sbase + pre + __popcll(bal & ((1ull << lane) - 1ull));
-        if (idx < A.cap) A.sel[idx] = make_uint4((uint32_t)ctg, (uint32_t)j, (uint32_t)depth, (uint32_t)mq);
+        if (idx < A.cap) A.sel[idx] = cornetto_regrec_t{ctg, st, end, depth, mq};
     }
+}
+
+// tile segments (reservation order) -> (contig, window) order: one wavefront per tile
+__global__ __launch_bounds__(256) void cov_order(const cornetto_regrec_t *raw, const uint2 *tres, const uint32_t *ooff, int64_t n_tiles,
+                                                 cornetto_regrec_t *dst)
+{
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tiles) return;
+    const uint2 r = tres[t];
+    const int32_t *src = reinterpret_cast<const int32_t *>(raw + r.x);
+    int32_t *d = reinterpret_cast<int32_t *>(dst + ooff[t]);
+    const uint32_t nint = r.y * 5u;
+    for (uint32_t i = threadIdx.x & 63; i < nint; i += 64) d[i] = src[i];
 }
 
 int32_t n_reg_host(int32_t length, int32_t w, int32_t inc)
@@ -287,11 +287,6 @@ int32_t n_reg_host(int32_t length, int32_t w, int32_t inc)
     int32_t n = (length - w + inc - 1) / inc + 1;   // src/boringbits_main.c:338, C truncation
     return n < 1 ? 1 : n;                           // :339
 }
-
-struct WinTiles {
-    std::vector<int2> tiles;
-    std::vector<int32_t> n_reg;
-};
 
 }  // namespace
 
@@ -315,34 +310,54 @@ int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int3
     CN_HIP(h, hipSetDevice(h->device));
     cn_timing_begin(h);
     const int32_t q = w / inc, r = w % inc;
-    c->w = w;
-    c->inc = inc;
-    c->blk_off.assign(c->n + 1, 0);
-    std::vector<int2> tiles;
-    for (int32_t i = 0; i < c->n; ++i) {
-        if (c->len[i] < 1) return cn_fail(h, CORNETTO_E_ARG, "cov_prepare: contig %d is empty (a bedgraph cannot produce that)", i);
-        const int64_t nb = cn_align_up((int64_t)n_reg_host(c->len[i], w, inc) + q + 1, CB_THREADS);
-        c->blk_off[i + 1] = c->blk_off[i] + nb;
-        for (int64_t b = 0; b < nb; b += CB_THREADS) tiles.push_back(make_int2(i, (int)b));
-    }
-    c->n_blk = c->blk_off[c->n];
-    const size_t nt = tiles.size();
-    if (c->d_blk) { (void)hipFree(c->d_blk); c->d_blk = nullptr; }
-    if (c->d_blk_off) { (void)hipFree(c->d_blk_off); c->d_blk_off = nullptr; }
     sums[0] = sums[1] = 0;
     sums[2] = (uint64_t)c->total;
+    if (c->w != w || c->inc != inc || !c->d_blk) {
+        // (re)build the decomposition for these window sizes; cached for later calls
+        c->w = w;
+        c->inc = inc;
+        c->cw_mode = -1;
+        c->blk_off.assign(c->n + 1, 0);
+        c->n_reg.assign(c->n, 0);
+        std::vector<int2> tiles;
+        for (int32_t i = 0; i < c->n; ++i) {
+            if (c->len[i] < 1) return cn_fail(h, CORNETTO_E_ARG, "cov_prepare: contig %d is empty (a bedgraph cannot produce that)", i);
+            c->n_reg[i] = n_reg_host(c->len[i], w, inc);
+            const int64_t nb = cn_align_up((int64_t)c->n_reg[i] + q + 1, CB_THREADS);
+            c->blk_off[i + 1] = c->blk_off[i] + nb;
+            for (int64_t b = 0; b < nb; b += CB_THREADS) tiles.push_back(make_int2(i, (int)b));
+        }
+        c->n_blk = c->blk_off[c->n];
+        c->n_cb_tiles = (int64_t)tiles.size();
+        if (c->d_blk) { (void)hipFree(c->d_blk); c->d_blk = nullptr; }
+        if (c->d_blk_off) { (void)hipFree(c->d_blk_off); c->d_blk_off = nullptr; }
+        if (c->d_cb_tiles) { (void)hipFree(c->d_cb_tiles); c->d_cb_tiles = nullptr; }
+        if (c->d_n_reg) { (void)hipFree(c->d_n_reg); c->d_n_reg = nullptr; }
+        const size_t nt = tiles.size();
+        if (nt == 0) { cn_timing_end(h); return CORNETTO_OK; }
+        // blk [n_blk] uint4, then two arrays of tile offsets [nt] u32 each
+        if (hipMalloc((void **)&c->d_blk, (size_t)c->n_blk * sizeof(uint4) + 2 * nt * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc((void **)&c->d_blk_off, (size_t)(c->n + 1) * 8) != hipSuccess ||
+            hipMalloc((void **)&c->d_cb_tiles, nt * sizeof(int2)) != hipSuccess ||
+            hipMalloc((void **)&c->d_n_reg, (size_t)c->n * 4) != hipSuccess)
+            return cn_fail(h, CORNETTO_E_NOMEM, "cov_prepare: device allocation failed");
+        CN_HIP(h, hipMemcpyAsync(c->d_cb_tiles, tiles.data(), nt * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+        CN_HIP(h, hipMemcpyAsync(c->d_blk_off, c->blk_off.data(), (size_t)(c->n + 1) * 8, hipMemcpyHostToDevice, h->stream));
+        CN_HIP(h, hipMemcpyAsync(c->d_n_reg, c->n_reg.data(), (size_t)c->n * 4, hipMemcpyHostToDevice, h->stream));
+        CN_HIP(h, hipStreamSynchronize(h->stream));   // `tiles` is a local
+    }
+    const size_t nt = (size_t)c->n_cb_tiles;
     if (nt == 0) { cn_timing_end(h); return CORNETTO_OK; }
-    DevBuf d_tiles, d_t32, d_t64, d_grand;
-    // blk + tile offsets stay in the cov object: [n_blk] uint4, then [nt] uint2 offsets
-    if (hipMalloc((void **)&c->d_blk, (size_t)c->n_blk * sizeof(uint4) + nt * sizeof(uint2)) != hipSuccess ||
-        hipMalloc((void **)&c->d_blk_off, (size_t)(c->n + 1) * 8) != hipSuccess || d_tiles.alloc(nt * sizeof(int2)) != hipSuccess ||
-        d_t32.alloc(nt * sizeof(uint2)) != hipSuccess || d_t64.alloc(nt * sizeof(ulonglong2)) != hipSuccess || d_grand.alloc(16) != hipSuccess)
-        return cn_fail(h, CORNETTO_E_NOMEM, "cov_prepare: device allocation failed");
-    CN_HIP(h, hipMemcpyAsync(d_tiles.p, tiles.data(), nt * sizeof(int2), hipMemcpyHostToDevice, h->stream));
-    CN_HIP(h, hipMemcpyAsync(c->d_blk_off, c->blk_off.data(), (size_t)(c->n + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    uint2 *d_t32 = (uint2 *)cn_ws(h, WS_CB_T32, nt * sizeof(uint2) + ((nt + 4095) / 4096 + 1) * 4 * 2);
+    ulonglong2 *d_t64 = (ulonglong2 *)cn_ws(h, WS_CB_T64, nt * sizeof(ulonglong2));
+    unsigned long long *d_grand = (unsigned long long *)cn_ws(h, WS_CB_GRAND, 16);
+    unsigned long long *p_grand = (unsigned long long *)cn_pin(h, PIN_SMALL, 64);
+    if (!d_t32 || !d_t64 || !d_grand || !p_grand) return cn_fail(h, CORNETTO_E_NOMEM, "cov_prepare: workspace allocation failed");
+    uint32_t *d_part = reinterpret_cast<uint32_t *>(d_t32 + nt);
     uint4 *d_blk = reinterpret_cast<uint4 *>(c->d_blk);
-    uint2 *d_toff = reinterpret_cast<uint2 *>(d_blk + c->n_blk);
-    CbArgs A{c->d_depth, c->d_mq, c->d_off, c->d_len, d_tiles.as<int2>(), inc, r, d_blk, d_t32.as<uint2>(), d_t64.as<ulonglong2>()};
+    uint32_t *d_toff_d = reinterpret_cast<uint32_t *>(d_blk + c->n_blk), *d_toff_q = d_toff_d + nt;
+    CN_HIP(h, hipMemsetAsync(d_grand, 0, 16, h->stream));
+    CbArgs A{c->d_depth, c->d_mq, c->d_off, c->d_len, c->d_cb_tiles, inc, r, d_blk, d_t32, d_t64};
     if (inc <= CB_MAX_INC_LDS) {
         const size_t lds = (size_t)2 * CB_THREADS * inc * sizeof(uint16_t);
         CN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&cov_blocks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -350,77 +365,111 @@ int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int3
     } else {
         CN_LAUNCH(h, "cov_blocks", cov_blocks<false><<<dim3((unsigned)nt), dim3(CB_THREADS), 0, h->stream>>>(A));
     }
-    CN_LAUNCH(h, "cov_tilescan", cov_tilescan<<<dim3(1), dim3(1024), 0, h->stream>>>(d_t32.as<uint2>(), d_t64.as<ulonglong2>(), (int64_t)nt, d_toff, d_grand.as<unsigned long long>()));
-    unsigned long long g[2] = {0, 0};
-    CN_HIP(h, hipMemcpyAsync(g, d_grand.p, 16, hipMemcpyDeviceToHost, h->stream));
+    CN_TRY(cnscan::exclusive_u32(h, "cov_tilescan", reinterpret_cast<const uint32_t *>(d_t32), (int64_t)nt, 2, d_toff_d, d_part, nullptr));
+    CN_TRY(cnscan::exclusive_u32(h, "cov_tilescan", reinterpret_cast<const uint32_t *>(d_t32) + 1, (int64_t)nt, 2, d_toff_q, d_part, nullptr));
+    const unsigned nb64 = (unsigned)std::min<size_t>(1024, (nt + 255) / 256);
+    CN_LAUNCH(h, "cov_total64", cov_total64<<<dim3(nb64), dim3(256), 0, h->stream>>>(d_t64, (int64_t)nt, d_grand));
+    CN_HIP(h, hipMemcpyAsync(p_grand, d_grand, 16, hipMemcpyDeviceToHost, h->stream));
     CN_HIP(h, hipStreamSynchronize(h->stream));
     cn_timing_end(h);
-    sums[0] = g[0];
-    sums[1] = g[1];
-    c->sums[0] = g[0]; c->sums[1] = g[1]; c->sums[2] = (uint64_t)c->total;
+    sums[0] = p_grand[0];
+    sums[1] = p_grand[1];
+    c->sums[0] = sums[0]; c->sums[1] = sums[1]; c->sums[2] = (uint64_t)c->total;
     return CORNETTO_OK;
 }
 
-static int cov_run_windows(cornetto_accel_t *h, const cornetto_cov_t *c, int32_t only_ctg, int mode, int32_t lo, int32_t hi,
-                           float low_mq, int32_t edge, int32_t min_len, cornetto_reg_t *regs_host, std::vector<uint4> *sel_out)
+// mode 0: all windows of contig only_ctg into regs_host; mode 1/2: selection into a malloc'd array
+static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_ctg, int mode, int32_t lo, int32_t hi,
+                           float low_mq, int32_t edge, int32_t min_len, cornetto_reg_t *regs_host, cornetto_regrec_t **recs,
+                           int64_t *n_recs)
 {
     if (!c->d_blk) return cn_fail(h, CORNETTO_E_ARG, "cov: cornetto_cov_prepare() has not been called");
     const int32_t w = c->w, inc = c->inc, q = w / inc, r = w % inc;
-    std::vector<int32_t> n_reg(c->n);
-    std::vector<int2> tiles;
-    for (int32_t i = 0; i < c->n; ++i) {
-        n_reg[i] = n_reg_host(c->len[i], w, inc);
-        if (only_ctg >= 0 && i != only_ctg) continue;
-        if (mode == 1 && !(c->len[i] >= min_len)) continue;   // short contigs print one '.' line and no windows
-        if (mode == 2 && !(c->len[i] > min_len)) continue;
-        for (int32_t j = 0; j < n_reg[i]; j += 256) tiles.push_back(make_int2(i, j));
+    if (c->cw_mode != mode || c->cw_min_len != min_len || c->cw_only != only_ctg) {   // window tiles, cached
+        c->cw_tiles.clear();
+        for (int32_t i = 0; i < c->n; ++i) {
+            if (only_ctg >= 0 && i != only_ctg) continue;
+            if (mode == 1 && !(c->len[i] >= min_len)) continue;   // short contigs print one '.' line and no windows
+            if (mode == 2 && !(c->len[i] > min_len)) continue;
+            for (int32_t j = 0; j < c->n_reg[i]; j += 256) c->cw_tiles.push_back(make_int2(i, j));
+        }
+        if (c->d_cw_tiles) { (void)hipFree(c->d_cw_tiles); c->d_cw_tiles = nullptr; }
+        if (!c->cw_tiles.empty()) {
+            if (hipMalloc((void **)&c->d_cw_tiles, c->cw_tiles.size() * sizeof(int2)) != hipSuccess)
+                return cn_fail(h, CORNETTO_E_NOMEM, "cov: device allocation failed");
+            CN_HIP(h, hipMemcpyAsync(c->d_cw_tiles, c->cw_tiles.data(), c->cw_tiles.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+        }
+        c->cw_mode = mode;
+        c->cw_min_len = min_len;
+        c->cw_only = only_ctg;
     }
-    const size_t nt = tiles.size();
+    const size_t nt = c->cw_tiles.size();
     if (nt == 0) return CORNETTO_OK;
-    DevBuf d_tiles, d_nreg, d_regs, d_sel, d_cnt, d_tres;
-    if (d_tiles.alloc(nt * sizeof(int2)) != hipSuccess || d_nreg.alloc((size_t)c->n * 4) != hipSuccess || d_cnt.alloc(8) != hipSuccess ||
-        d_tres.alloc(nt * sizeof(uint2)) != hipSuccess)
-        return cn_fail(h, CORNETTO_E_NOMEM, "cov: device allocation failed");
-    CN_HIP(h, hipMemcpyAsync(d_tiles.p, tiles.data(), nt * sizeof(int2), hipMemcpyHostToDevice, h->stream));
-    CN_HIP(h, hipMemcpyAsync(d_nreg.p, n_reg.data(), (size_t)c->n * 4, hipMemcpyHostToDevice, h->stream));
+    const size_t nt_blk = (size_t)c->n_cb_tiles;
     const uint4 *d_blk = reinterpret_cast<const uint4 *>(c->d_blk);
-    const uint2 *d_toff = reinterpret_cast<const uint2 *>(d_blk + c->n_blk);
+    const uint32_t *d_toff_d = reinterpret_cast<const uint32_t *>(d_blk + c->n_blk), *d_toff_q = d_toff_d + nt_blk;
+    unsigned long long *d_cnt = (unsigned long long *)cn_ws(h, WS_CW_CNT, 16);
+    // per tile: {base,count} (8 B) + ordered offset (4 B) + scan partials
+    uint2 *d_tres = (uint2 *)cn_ws(h, WS_CW_TRES, nt * 12 + ((nt + 4095) / 4096 + 1) * 4);
+    unsigned long long *p_cnt = (unsigned long long *)cn_pin(h, PIN_SMALL, 64);
+    if (!d_cnt || !d_tres || !p_cnt) return cn_fail(h, CORNETTO_E_NOMEM, "cov: workspace allocation failed");
+    uint32_t *d_ooff = reinterpret_cast<uint32_t *>(d_tres + nt), *d_part = d_ooff + nt;
     CwArgs A{};
-    A.blk = d_blk; A.toff = d_toff; A.blk_off = c->d_blk_off; A.ctg_len = c->d_len; A.n_reg = d_nreg.as<int32_t>();
-    A.tiles = d_tiles.as<int2>(); A.w = w; A.inc = inc; A.q = q; A.r = r; A.mode = mode; A.lo = lo; A.hi = hi; A.edge = edge;
+    A.blk = d_blk; A.toff_d = d_toff_d; A.toff_q = d_toff_q; A.blk_off = c->d_blk_off; A.ctg_len = c->d_len; A.n_reg = c->d_n_reg;
+    A.tiles = c->d_cw_tiles; A.w = w; A.inc = inc; A.q = q; A.r = r; A.mode = mode; A.lo = lo; A.hi = hi; A.edge = edge;
     A.min_len = min_len; A.low_mq = (double)low_mq;   // float promoted exactly as in `x < low_mq_cov_thresh`
-    A.counter = d_cnt.as<unsigned long long>(); A.tile_res = d_tres.as<uint2>();
+    A.counter = d_cnt; A.tile_res = d_tres;
     if (mode == 0) {
-        const size_t nr = (size_t)n_reg[only_ctg];
-        if (d_regs.alloc(nr * sizeof(cornetto_reg_t)) != hipSuccess) return cn_fail(h, CORNETTO_E_NOMEM, "cov: device allocation failed");
-        A.regs = d_regs.as<cornetto_reg_t>();
+        const size_t nr = (size_t)c->n_reg[only_ctg];
+        cornetto_reg_t *d_regs = (cornetto_reg_t *)cn_ws(h, WS_CW_REGS, nr * sizeof(cornetto_reg_t));
+        if (!d_regs) return cn_fail(h, CORNETTO_E_NOMEM, "cov: workspace allocation failed");
+        A.regs = d_regs;
         CN_LAUNCH(h, "cov_windows", cov_windows<<<dim3((unsigned)nt), dim3(256), 0, h->stream>>>(A));
-        CN_HIP(h, hipMemcpyAsync(regs_host, d_regs.p, nr * sizeof(cornetto_reg_t), hipMemcpyDeviceToHost, h->stream));
+        CN_HIP(h, hipMemcpyAsync(regs_host, d_regs, nr * sizeof(cornetto_reg_t), hipMemcpyDeviceToHost, h->stream));
         CN_HIP(h, hipStreamSynchronize(h->stream));
         return CORNETTO_OK;
     }
-    uint32_t cap = (uint32_t)std::min<size_t>(std::max<size_t>(1 << 16, nt * 256 / 8), 0x7fffffff);
+    // raw (reservation order) and ordered copies share one workspace: [cap] + [cap]
+    size_t cap = std::max<size_t>(1 << 16, nt * 256 / 8);
+    cap = std::max(cap, h->dev[WS_CW_SEL].bytes / (2 * sizeof(cornetto_regrec_t)));   // keep what an earlier call grew to
     unsigned long long cnt = 0;
+    cornetto_regrec_t *d_raw = nullptr, *d_dst = nullptr;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        if (d_sel.alloc((size_t)cap * sizeof(uint4)) != hipSuccess) return cn_fail(h, CORNETTO_E_NOMEM, "cov: device allocation failed");
-        A.sel = d_sel.as<uint4>();
-        A.cap = cap;
-        CN_HIP(h, hipMemsetAsync(d_cnt.p, 0, 8, h->stream));
+        cap = std::min<size_t>(cap, 0x7fffffff);
+        d_raw = (cornetto_regrec_t *)cn_ws(h, WS_CW_SEL, 2 * cap * sizeof(cornetto_regrec_t));
+        if (!d_raw) return cn_fail(h, CORNETTO_E_NOMEM, "cov: workspace allocation of %zu bytes failed", 2 * cap * sizeof(cornetto_regrec_t));
+        d_dst = d_raw + cap;
+        A.sel = d_raw;
+        A.cap = (uint32_t)cap;
+        CN_HIP(h, hipMemsetAsync(d_cnt, 0, 8, h->stream));
         CN_LAUNCH(h, "cov_windows", cov_windows<<<dim3((unsigned)nt), dim3(256), 0, h->stream>>>(A));
-        CN_HIP(h, hipMemcpyAsync(&cnt, d_cnt.p, 8, hipMemcpyDeviceToHost, h->stream));
+        CN_HIP(h, hipMemcpyAsync(p_cnt, d_cnt, 8, hipMemcpyDeviceToHost, h->stream));
         CN_HIP(h, hipStreamSynchronize(h->stream));
+        cnt = p_cnt[0];
         if (cnt <= cap) break;
         if (attempt == 1 || cnt > 0x7fffffffull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "cov: %llu selected windows", cnt);
-        cap = (uint32_t)cnt;   // exact rerun, never a truncated answer
+        cap = (size_t)cnt;   // exact rerun, never a truncated answer
     }
-    std::vector<uint4> raw((size_t)cnt);
-    std::vector<uint2> tres(nt);
-    if (cnt) CN_HIP(h, hipMemcpy(raw.data(), d_sel.p, (size_t)cnt * sizeof(uint4), hipMemcpyDeviceToHost));
-    CN_HIP(h, hipMemcpy(tres.data(), d_tres.p, nt * sizeof(uint2), hipMemcpyDeviceToHost));
-    sel_out->clear();
-    sel_out->reserve((size_t)cnt);
-    for (size_t t = 0; t < nt; ++t)   // tiles are in (contig, window) order
-        for (uint32_t i = 0; i < tres[t].y; ++i) sel_out->push_back(raw[(size_t)tres[t].x + i]);
+    cornetto_regrec_t *o = (cornetto_regrec_t *)malloc((cnt ? cnt : 1) * sizeof(cornetto_regrec_t));
+    if (!o) return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: host allocation failed");
+    if (cnt) {
+        // tiles are in (contig, window) order: exclusive scan of their counts = final position of each segment
+        int rc = cnscan::exclusive_u32(h, "cov_order", reinterpret_cast<const uint32_t *>(d_tres) + 1, (int64_t)nt, 2, d_ooff, d_part, nullptr);
+        if (rc != CORNETTO_OK) { free(o); return rc; }
+        const unsigned nb = (unsigned)((nt + 3) / 4);
+        hipEvent_t ea = cn_event(h), eb = cn_event(h);
+        (void)hipEventRecord(ea, h->stream);
+        cov_order<<<dim3(nb), dim3(256), 0, h->stream>>>(d_raw, d_tres, d_ooff, (int64_t)nt, d_dst);
+        (void)hipEventRecord(eb, h->stream);
+        h->recs.push_back(cornetto_accel::Rec{"cov_order", ea, eb});
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(o, d_dst, (size_t)cnt * sizeof(cornetto_regrec_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) {
+            free(o);
+            return cn_fail(h, CORNETTO_E_HIP, "cov_select: ordering / copy back failed");
+        }
+    }
+    *recs = o;
+    *n_recs = (int64_t)cnt;
     return CORNETTO_OK;
 }
 
@@ -429,7 +478,7 @@ int cornetto_cov_regs(cornetto_accel_t *h, const cornetto_cov_t *c, int32_t ctg,
     if (!h || !c || !regs || ctg < 0 || ctg >= c->n) return cn_fail(h, CORNETTO_E_ARG, "cov_regs: bad argument");
     CN_HIP(h, hipSetDevice(h->device));
     cn_timing_begin(h);
-    int rc = cov_run_windows(h, c, ctg, 0, 0, 0, 0.f, 0, 0, regs, nullptr);
+    int rc = cov_run_windows(h, const_cast<cornetto_cov_t *>(c), ctg, 0, 0, 0, 0.f, 0, 0, regs, nullptr, nullptr);
     cn_timing_end(h);
     return rc;
 }
@@ -442,22 +491,13 @@ int cornetto_cov_select(cornetto_accel_t *h, const cornetto_cov_t *c, int32_t lo
     *n_recs = 0;
     CN_HIP(h, hipSetDevice(h->device));
     cn_timing_begin(h);
-    std::vector<uint4> sel;
-    int rc = cov_run_windows(h, c, -1, boring ? 2 : 1, lo, hi, low_mq, edge_len, min_ctg_len, nullptr, &sel);
+    int rc = cov_run_windows(h, const_cast<cornetto_cov_t *>(c), -1, boring ? 2 : 1, lo, hi, low_mq, edge_len, min_ctg_len, nullptr, recs, n_recs);
     cn_timing_end(h);
-    if (rc != CORNETTO_OK) return rc;
-    cornetto_regrec_t *o = (cornetto_regrec_t *)malloc((sel.size() ? sel.size() : 1) * sizeof(cornetto_regrec_t));
-    if (!o) return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: host allocation failed");
-    for (size_t i = 0; i < sel.size(); ++i) {
-        const int32_t ctg = (int32_t)sel[i].x, j = (int32_t)sel[i].y;
-        const int32_t st = j * c->inc;
-        int32_t end = st + c->w;
-        if (end > c->len[ctg]) end = c->len[ctg];
-        o[i] = cornetto_regrec_t{ctg, st, end, (int32_t)sel[i].z, (int32_t)sel[i].w};
+    if (rc == CORNETTO_OK && !*recs) {   // nothing to scan (no contig qualifies): an empty, freeable result
+        *recs = (cornetto_regrec_t *)malloc(sizeof(cornetto_regrec_t));
+        if (!*recs) return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: host allocation failed");
     }
-    *recs = o;
-    *n_recs = (int64_t)sel.size();
-    return CORNETTO_OK;
+    return rc;
 }
 
 }  // extern "C"

@@ -44,6 +44,10 @@ void cornetto_accel_close(cornetto_accel_t *h)
         (void)hipEventDestroy(r.b);
     }
     for (auto e : h->pool) (void)hipEventDestroy(e);
+    for (auto &w : h->dev)
+        if (w.p) (void)hipFree(w.p);
+    for (auto &w : h->pin)
+        if (w.p) (void)hipHostFree(w.p);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -101,6 +105,8 @@ void cornetto_asm_free(cornetto_accel_t *h, cornetto_asm_t *a)
     if (a->owned) (void)hipFree(a->owned);
     if (a->d_off) (void)hipFree(a->d_off);
     if (a->d_len) (void)hipFree(a->d_len);
+    if (a->d_tf_tiles) (void)hipFree(a->d_tf_tiles);
+    if (a->d_sd_chunks) (void)hipFree(a->d_sd_chunks);
     delete a;
 }
 
@@ -187,6 +193,9 @@ void cornetto_cov_free(cornetto_accel_t *h, cornetto_cov_t *c)
     if (c->d_len) (void)hipFree(c->d_len);
     if (c->d_blk) (void)hipFree(c->d_blk);
     if (c->d_blk_off) (void)hipFree(c->d_blk_off);
+    if (c->d_cb_tiles) (void)hipFree(c->d_cb_tiles);
+    if (c->d_n_reg) (void)hipFree(c->d_n_reg);
+    if (c->d_cw_tiles) (void)hipFree(c->d_cw_tiles);
     delete c;
 }
 

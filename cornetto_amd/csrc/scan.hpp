@@ -1,0 +1,103 @@
+// scan.hpp — device-wide exclusive prefix sum of 32-bit counters (strided input), used to turn per-tile /
+// per-chunk counts into ordered output offsets without a host round trip.  Three small launches:
+// tile-local scan (4096 items per workgroup) + scan of the tile totals by one workgroup + offset add.
+#pragma once
+#include "common.hpp"
+
+namespace cnscan {
+namespace {   // internal linkage: every translation unit that includes this gets its own copy
+
+constexpr int SC_THREADS = 256;
+constexpr int SC_ITEMS = 16;                       // per thread
+constexpr int SC_TILE = SC_THREADS * SC_ITEMS;     // 4096
+
+__device__ __forceinline__ uint32_t wave_incl(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// out[i] = sum_{k < i, same tile} in[k * stride]; partial[tile] = tile total
+__global__ __launch_bounds__(SC_THREADS) void scan_local(const uint32_t *in, int64_t n, int stride, uint32_t *out, uint32_t *partial)
+{
+    __shared__ uint32_t wtot[SC_THREADS / 64];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int64_t base = (int64_t)blockIdx.x * SC_TILE + (int64_t)t * SC_ITEMS;
+    uint32_t v[SC_ITEMS], s = 0;
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; ++k) {
+        const int64_t i = base + k;
+        v[k] = i < n ? in[i * stride] : 0u;
+        s += v[k];
+    }
+    const uint32_t inc = wave_incl(s, lane);
+    if (lane == 63) wtot[wv] = inc;
+    __syncthreads();
+    uint32_t pre = inc - s;
+#pragma unroll
+    for (int w = 0; w < SC_THREADS / 64; ++w)
+        if (w < wv) pre += wtot[w];
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; ++k) {
+        const int64_t i = base + k;
+        if (i < n) out[i] = pre;
+        pre += v[k];
+    }
+    if (t == SC_THREADS - 1) partial[blockIdx.x] = pre;
+}
+
+// exclusive scan of up to 1024 * per partials by one workgroup, in place; total -> *total
+__global__ __launch_bounds__(1024) void scan_partials(uint32_t *partial, int64_t np, unsigned long long *total)
+{
+    __shared__ uint32_t sh[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (np + 1023) / 1024;
+    const int64_t lo = (int64_t)t * per, hi = lo + per < np ? lo + per : np;
+    uint32_t s = 0;
+    for (int64_t i = lo; i < hi; ++i) s += partial[i];
+    sh[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t o = t >= d ? sh[t - d] : 0u;
+        __syncthreads();
+        sh[t] += o;
+        __syncthreads();
+    }
+    uint32_t run = sh[t] - s;
+    for (int64_t i = lo; i < hi; ++i) {
+        const uint32_t x = partial[i];
+        partial[i] = run;
+        run += x;
+    }
+    if (t == 1023 && total) *total = sh[t];
+}
+
+__global__ __launch_bounds__(SC_THREADS) void scan_add(uint32_t *out, int64_t n, const uint32_t *partial)
+{
+    const uint32_t add = partial[blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * SC_TILE;
+    for (int k = threadIdx.x; k < SC_TILE; k += SC_THREADS) {
+        const int64_t i = base + k;
+        if (i < n) out[i] += add;
+    }
+}
+
+// out[i] (u32) = exclusive prefix of in[i*stride]; d_total (optional, device u64) = grand total.
+// `partial` must hold ceil(n / 4096) u32.
+static inline int exclusive_u32(cornetto_accel_t *h, const char *name, const uint32_t *in, int64_t n, int stride, uint32_t *out,
+                                uint32_t *partial, unsigned long long *d_total)
+{
+    if (n <= 0) return CORNETTO_OK;
+    const int64_t np = (n + SC_TILE - 1) / SC_TILE;
+    CN_LAUNCH(h, name, scan_local<<<dim3((unsigned)np), dim3(SC_THREADS), 0, h->stream>>>(in, n, stride, out, partial));
+    CN_LAUNCH(h, name, scan_partials<<<dim3(1), dim3(1024), 0, h->stream>>>(partial, np, d_total));
+    CN_LAUNCH(h, name, scan_add<<<dim3((unsigned)np), dim3(SC_THREADS), 0, h->stream>>>(out, n, partial));
+    return CORNETTO_OK;
+}
+
+}  // namespace
+}  // namespace cnscan

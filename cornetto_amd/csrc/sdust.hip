@@ -27,6 +27,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "scan.hpp"
 
 namespace {
 
@@ -45,6 +46,7 @@ struct SdArgs {
     uint32_t *out_n;   // [n_chunks] number of intervals the chunk produced (may exceed cap: overflow)
     uint32_t cap;
     unsigned long long *stats;   // optional [4]: wave steps, cooperative find_perfect calls, cooperative trims, save/evicts
+    uint32_t *ovf;               // max over chunks of (intervals produced) when that exceeds cap, else untouched
 };
 
 template <int RC>  // ring / slot capacity, power of two >= W - 2
@@ -255,6 +257,7 @@ __global__ __launch_bounds__(64) void sdust_kernel(SdArgs A)
         ++n_out;
     }
     A.out_n[cid] = n_out;
+    if (n_out > A.cap) atomicMax(A.ovf, n_out);
 #undef RING
 #undef CW
 #undef CV
@@ -593,6 +596,7 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
                     ++n_out;
                 }
                 A.out_n[cid] = n_out;
+                if (n_out > A.cap) atomicMax(A.ovf, n_out);
             }
         }
     }
@@ -605,16 +609,17 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
 #undef CWQ
 }
 
-__global__ void sdust_gather(const uint2 *in, const uint32_t *cnt, const int64_t *dst_off, uint32_t cap,
-                             int32_t n_chunks, uint2 *dst)
+// chunk rows (fixed capacity) -> one dense list in chunk order, tagged with the contig: one wavefront per chunk
+__global__ void sdust_gather(const uint2 *in, const uint32_t *cnt, const uint32_t *dst_off, uint32_t cap, const SdChunk *chunks,
+                             int32_t n_chunks, cornetto_ivl_t *dst)
 {
-    // one wavefront per chunk row
     const int cid = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     if (cid >= n_chunks) return;
     const uint32_t n = cnt[cid];
+    const int32_t ctg = chunks[cid].ctg;
     const uint2 *src = in + (size_t)cid * cap;
-    uint2 *d = dst + dst_off[cid];
-    for (uint32_t i = threadIdx.x & 63; i < n; i += 64) d[i] = src[i];
+    cornetto_ivl_t *d = dst + dst_off[cid];
+    for (uint32_t i = threadIdx.x & 63; i < n; i += 64) d[i] = cornetto_ivl_t{ctg, (int32_t)src[i].x, (int32_t)src[i].y};
 }
 
 int env_int(const char *name, int dflt)
@@ -627,10 +632,11 @@ int env_int(const char *name, int dflt)
 
 extern "C" {
 
-int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a, int32_t T, int32_t W, cornetto_ivl_t **ivls,
+int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, int32_t W, cornetto_ivl_t **ivls,
                        int64_t *n_ivls)
 {
-    if (!h || !a || !ivls || !n_ivls) return cn_fail(h, CORNETTO_E_ARG, "sdust: bad argument");
+    if (!h || !a_in || !ivls || !n_ivls) return cn_fail(h, CORNETTO_E_ARG, "sdust: bad argument");
+    cornetto_asm_t *a = const_cast<cornetto_asm_t *>(a_in);   // only the cached chunk table is touched
     *ivls = nullptr;
     *n_ivls = 0;
     if (W < 3 || W > 258) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "sdust: -w %d outside 3..258 (the reference crashes below 3)", W);
@@ -638,96 +644,112 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a, int32_t T, 
     CN_HIP(h, hipSetDevice(h->device));
     cn_timing_begin(h);
 
-    // chunking: enough lanes to fill the chip a few times over; CORNETTO_SDUST_CHUNK overrides (tests use
-    // tiny chunks to stress the speculative start)
+    // chunk = bases per lane.  Small enough that a long low-complexity array is shared by many waves, large
+    // enough that the ~3W-base speculative warm-up stays a few percent.  CORNETTO_SDUST_CHUNK overrides
+    // (tests use tiny chunks to stress the speculative start).
     int64_t chunk = env_int("CORNETTO_SDUST_CHUNK", 0);
-    if (chunk <= 0) {
-        const int64_t target_lanes = 256LL * 8 * 64 * 4;
-        chunk = a->total / target_lanes;
-        chunk = std::max<int64_t>(1024, std::min<int64_t>(16384, chunk));
-    }
+    if (chunk <= 0) chunk = 2048;
     chunk = std::max<int64_t>(16, chunk);
-    std::vector<SdChunk> chunks;
-    for (int32_t c = 0; c < a->n; ++c)
-        for (int64_t s = 0; s < a->len[c]; s += chunk)
-            chunks.push_back(SdChunk{c, (int32_t)s, (int32_t)std::min<int64_t>(a->len[c], s + chunk)});
-    const size_t nc = chunks.size();
-    std::vector<cornetto_ivl_t> res;
+    if (a->sd_chunk != chunk) {
+        std::vector<SdChunk> chunks;
+        for (int32_t c = 0; c < a->n; ++c)
+            for (int64_t s = 0; s < a->len[c]; s += chunk)
+                chunks.push_back(SdChunk{c, (int32_t)s, (int32_t)std::min<int64_t>(a->len[c], s + chunk)});
+        if (chunks.size() > 0x7fffffffull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "sdust: too many chunks");
+        if (a->d_sd_chunks) { (void)hipFree(a->d_sd_chunks); a->d_sd_chunks = nullptr; }
+        if (!chunks.empty()) {
+            if (hipMalloc(&a->d_sd_chunks, chunks.size() * sizeof(SdChunk)) != hipSuccess)
+                return cn_fail(h, CORNETTO_E_NOMEM, "sdust: device allocation failed");
+            CN_HIP(h, hipMemcpyAsync(a->d_sd_chunks, chunks.data(), chunks.size() * sizeof(SdChunk), hipMemcpyHostToDevice, h->stream));
+            CN_HIP(h, hipStreamSynchronize(h->stream));
+        }
+        a->sd_chunk = chunk;
+        a->sd_n_chunks = (int64_t)chunks.size();
+    }
+    const size_t nc = (size_t)a->sd_n_chunks;
+    cornetto_ivl_t *o = nullptr;
+    int64_t n_out = 0;
     if (nc > 0) {
-        if (nc > 0x7fffffffull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "sdust: too many chunks");
-        DevBuf d_chunks, d_out, d_cnt, d_off, d_dst;
-        if (d_chunks.alloc(nc * sizeof(SdChunk)) != hipSuccess || d_cnt.alloc(nc * 4) != hipSuccess)
-            return cn_fail(h, CORNETTO_E_NOMEM, "sdust: device allocation failed");
-        CN_HIP(h, hipMemcpyAsync(d_chunks.p, chunks.data(), nc * sizeof(SdChunk), hipMemcpyHostToDevice, h->stream));
-        uint32_t cap = (uint32_t)std::max<int64_t>(16, chunk / 32);
-        cap = (uint32_t)env_int("CORNETTO_SDUST_CAP", (int)cap);
-        std::vector<uint32_t> cnt(nc);
+        const SdChunk *d_chunks = reinterpret_cast<const SdChunk *>(a->d_sd_chunks);
+        // per chunk: count (4 B) + ordered offset (4 B) + scan partials; then {total u64, ovf u32}
+        uint32_t *d_cnt = (uint32_t *)cn_ws(h, WS_SD_CNT, nc * 8 + ((nc + 4095) / 4096 + 1) * 4);
+        unsigned long long *d_tot = (unsigned long long *)cn_ws(h, WS_SD_STATS, 64);
+        unsigned long long *p_tot = (unsigned long long *)cn_pin(h, PIN_SMALL, 64);
+        if (!d_cnt || !d_tot || !p_tot) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
+        uint32_t *d_off = d_cnt + nc, *d_part = d_off + nc;
+        const bool want_stats = env_int("CORNETTO_SDUST_STATS", 0) != 0;
+        size_t cap = (size_t)std::max<int64_t>(16, chunk / 32);
+        cap = (size_t)env_int("CORNETTO_SDUST_CAP", (int)cap);
+        if (h->dev[WS_SD_OUT].bytes / (nc * sizeof(uint2)) > cap) cap = h->dev[WS_SD_OUT].bytes / (nc * sizeof(uint2));
+        unsigned long long tot = 0;
+        uint2 *d_out = nullptr;
         for (int attempt = 0; attempt < 2; ++attempt) {
-            if (d_out.alloc(nc * (size_t)cap * sizeof(uint2)) != hipSuccess)
-                return cn_fail(h, CORNETTO_E_NOMEM, "sdust: device allocation of %zu bytes failed", nc * (size_t)cap * sizeof(uint2));
-            DevBuf d_stats;
-            const bool want_stats = env_int("CORNETTO_SDUST_STATS", 0) != 0;
-            if (want_stats) {
-                if (d_stats.alloc(32) != hipSuccess) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: device allocation failed");
-                CN_HIP(h, hipMemsetAsync(d_stats.p, 0, 32, h->stream));
-            }
-            SdArgs A{a->d_bases, a->d_off, a->d_len, d_chunks.as<SdChunk>(), (int32_t)nc, T, W, d_out.as<uint2>(), d_cnt.as<uint32_t>(), cap,
-                     want_stats ? d_stats.as<unsigned long long>() : nullptr};
+            d_out = (uint2 *)cn_ws(h, WS_SD_OUT, nc * cap * sizeof(uint2));
+            if (!d_out) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation of %zu bytes failed", nc * cap * sizeof(uint2));
+            CN_HIP(h, hipMemsetAsync(d_tot, 0, 64, h->stream));
+            SdArgs A{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, d_out, d_cnt, (uint32_t)cap,
+                     want_stats ? d_tot + 2 : nullptr, reinterpret_cast<uint32_t *>(d_tot + 1)};
             unsigned nb = (unsigned)((nc + 63) / 64);
             const int variant = env_int("CORNETTO_SDUST_VARIANT", 0);   // 1 = force the per-lane reference-shaped kernel
             if (W - 2 <= 64 && variant == 0) {
                 nb = (unsigned)((nc + 4095) / 4096) * 64;   // whole groups of 64 waves
                 CN_LAUNCH(h, "sdust_kernel", sdust_w64<<<dim3(nb), dim3(64), 0, h->stream>>>(A));
+            } else if (W - 2 <= 64) {
+                CN_LAUNCH(h, "sdust_kernel", sdust_kernel<64><<<dim3(nb), dim3(64), 0, h->stream>>>(A));
+            } else {
+                CN_LAUNCH(h, "sdust_kernel", sdust_kernel<256><<<dim3(nb), dim3(64), 0, h->stream>>>(A));
             }
-            else if (W - 2 <= 64) CN_LAUNCH(h, "sdust_kernel", sdust_kernel<64><<<dim3(nb), dim3(64), 0, h->stream>>>(A));
-            else CN_LAUNCH(h, "sdust_kernel", sdust_kernel<256><<<dim3(nb), dim3(64), 0, h->stream>>>(A));
-            CN_HIP(h, hipMemcpyAsync(cnt.data(), d_cnt.p, nc * 4, hipMemcpyDeviceToHost, h->stream));
+            // ordered position of every chunk's intervals (chunks are in contig order) + grand total
+            CN_TRY(cnscan::exclusive_u32(h, "sdust_scan", d_cnt, (int64_t)nc, 1, d_off, d_part, d_tot));
+            CN_HIP(h, hipMemcpyAsync(p_tot, d_tot, 64, hipMemcpyDeviceToHost, h->stream));
             CN_HIP(h, hipStreamSynchronize(h->stream));
-            if (want_stats) {
-                unsigned long long st[4] = {0, 0, 0, 0};
-                CN_HIP(h, hipMemcpy(st, d_stats.p, 32, hipMemcpyDeviceToHost));
-                fprintf(stderr, "[sdust stats] chunks %zu waves %u wave-steps %llu find_perfect calls %llu trims %llu\n", nc, nb, st[0], st[1], st[2]);
+            if (want_stats)
+                fprintf(stderr, "[sdust stats] chunks %zu waves %u wave-steps %llu find_perfect calls %llu trims %llu\n", nc, nb, p_tot[2], p_tot[3], p_tot[4]);
+            const uint32_t ovf = (uint32_t)(p_tot[1] & 0xFFFFFFFFull);
+            if (ovf <= cap) {
+                tot = p_tot[0];
+                break;
             }
-            const uint32_t mx = *std::max_element(cnt.begin(), cnt.end());
-            if (mx <= cap) break;
-            if (attempt == 1) return cn_fail(h, CORNETTO_E_HIP, "sdust: chunk produced %u intervals after resizing to %u", mx, cap);
-            cap = mx;   // rerun with room for the densest chunk: results are never truncated
+            if (attempt == 1) return cn_fail(h, CORNETTO_E_HIP, "sdust: a chunk produced %u intervals after resizing to %zu", ovf, cap);
+            cap = ovf;   // rerun with room for the densest chunk: results are never truncated
         }
-        std::vector<int64_t> off(nc + 1, 0);
-        for (size_t i = 0; i < nc; ++i) off[i + 1] = off[i] + cnt[i];
-        const int64_t tot = off[nc];
-        std::vector<uint2> flat((size_t)tot);
+        if (tot > 0x7fffffffull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "sdust: %llu intervals", tot);
+        o = (cornetto_ivl_t *)malloc((tot ? tot : 1) * sizeof(cornetto_ivl_t));
+        if (!o) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: host allocation failed");
         if (tot > 0) {
-            if (d_off.alloc(nc * 8) != hipSuccess || d_dst.alloc((size_t)tot * sizeof(uint2)) != hipSuccess)
-                return cn_fail(h, CORNETTO_E_NOMEM, "sdust: device allocation failed");
-            CN_HIP(h, hipMemcpyAsync(d_off.p, off.data(), nc * 8, hipMemcpyHostToDevice, h->stream));
-            const unsigned nb = (unsigned)((nc + 3) / 4);
-            CN_LAUNCH(h, "sdust_gather", sdust_gather<<<dim3(nb), dim3(256), 0, h->stream>>>(d_out.as<uint2>(), d_cnt.as<uint32_t>(), d_off.as<int64_t>(), cap, (int32_t)nc, d_dst.as<uint2>()));
-            CN_HIP(h, hipMemcpyAsync(flat.data(), d_dst.p, (size_t)tot * sizeof(uint2), hipMemcpyDeviceToHost, h->stream));
-            CN_HIP(h, hipStreamSynchronize(h->stream));
-        }
-        // stitch chunk lists in order with the reference's merge rule (src/sdust/sdust.c:94-98)
-        res.reserve((size_t)tot);
-        int32_t cur_ctg = -1;
-        for (size_t ci = 0; ci < nc; ++ci) {
-            const int32_t ctg = chunks[ci].ctg;
-            for (int64_t j = off[ci]; j < off[ci + 1]; ++j) {
-                const int32_t s = (int32_t)flat[j].x, f = (int32_t)flat[j].y;
-                if (ctg == cur_ctg && !res.empty() && s <= res.back().finish) {
-                    if (f > res.back().finish) res.back().finish = f;
+            cornetto_ivl_t *d_dst = (cornetto_ivl_t *)cn_ws(h, WS_SD_DST, (size_t)tot * sizeof(cornetto_ivl_t));
+            cornetto_ivl_t *p_dst = (cornetto_ivl_t *)cn_pin(h, PIN_A, (size_t)tot * sizeof(cornetto_ivl_t));
+            if (!d_dst || !p_dst) { free(o); return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed"); }
+            const unsigned nbg = (unsigned)((nc + 3) / 4);
+            hipEvent_t ea = cn_event(h), eb = cn_event(h);
+            (void)hipEventRecord(ea, h->stream);
+            sdust_gather<<<dim3(nbg), dim3(256), 0, h->stream>>>(d_out, d_cnt, d_off, (uint32_t)cap, d_chunks, (int32_t)nc, d_dst);
+            (void)hipEventRecord(eb, h->stream);
+            h->recs.push_back(cornetto_accel::Rec{"sdust_gather", ea, eb});
+            if (hipGetLastError() != hipSuccess ||
+                hipMemcpyAsync(p_dst, d_dst, (size_t)tot * sizeof(cornetto_ivl_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                hipStreamSynchronize(h->stream) != hipSuccess) {
+                free(o);
+                return cn_fail(h, CORNETTO_E_HIP, "sdust: gather / copy back failed");
+            }
+            // stitch chunk lists in order with the reference's merge rule (src/sdust/sdust.c:94-98)
+            for (unsigned long long j = 0; j < tot; ++j) {
+                const cornetto_ivl_t v = p_dst[j];
+                if (n_out > 0 && o[n_out - 1].ctg == v.ctg && v.start <= o[n_out - 1].finish) {
+                    if (v.finish > o[n_out - 1].finish) o[n_out - 1].finish = v.finish;
                 } else {
-                    res.push_back(cornetto_ivl_t{ctg, s, f});
-                    cur_ctg = ctg;
+                    o[n_out++] = v;
                 }
             }
         }
     }
     cn_timing_end(h);
-    cornetto_ivl_t *o = (cornetto_ivl_t *)malloc((res.size() ? res.size() : 1) * sizeof(cornetto_ivl_t));
-    if (!o) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: host allocation failed");
-    if (!res.empty()) memcpy(o, res.data(), res.size() * sizeof(cornetto_ivl_t));
+    if (!o) {
+        o = (cornetto_ivl_t *)malloc(sizeof(cornetto_ivl_t));
+        if (!o) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: host allocation failed");
+    }
     *ivls = o;
-    *n_ivls = (int64_t)res.size();
+    *n_ivls = n_out;
     return CORNETTO_OK;
 }
 

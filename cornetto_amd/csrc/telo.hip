@@ -310,12 +310,6 @@ bool has_border(const std::string &m)
     return false;
 }
 
-struct TeloScan {
-    // ordered per-list positions with their contig, after the tile-order gather
-    std::vector<int32_t> pos[4];
-    std::vector<int32_t> ctg[4];
-};
-
 struct WinLayout {
     std::vector<int64_t> bit_off;
     std::vector<int2> tiles;
@@ -343,30 +337,34 @@ int run_tw_scan(cornetto_accel_t *h, const unsigned long long *d_bitmap, const W
 {
     *wins = nullptr;
     *n_wins = 0;
-    if (L.tiles.empty()) return CORNETTO_OK;
-    DevBuf d_boff, d_tiles, d_out, d_cnt;
-    if (d_boff.alloc(L.bit_off.size() * 8) != hipSuccess || d_tiles.alloc(L.tiles.size() * sizeof(int2)) != hipSuccess ||
-        d_cnt.alloc(8) != hipSuccess)
-        return cn_fail(h, CORNETTO_E_NOMEM, "telowin: device allocation failed");
-    CN_HIP(h, hipMemcpyAsync(d_boff.p, L.bit_off.data(), L.bit_off.size() * 8, hipMemcpyHostToDevice, h->stream));
-    CN_HIP(h, hipMemcpyAsync(d_tiles.p, L.tiles.data(), L.tiles.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
-    uint32_t cap = 1u << 16;
     std::vector<int4> host;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        if (d_out.alloc((size_t)cap * sizeof(int4)) != hipSuccess) return cn_fail(h, CORNETTO_E_NOMEM, "telowin: device allocation failed");
-        CN_HIP(h, hipMemsetAsync(d_cnt.p, 0, 8, h->stream));
-        TwArgs A{d_bitmap, d_boff.as<int64_t>(), d_len, d_tiles.as<int2>(), thr, d_out.as<int4>(), d_cnt.as<unsigned long long>(), cap};
-        CN_LAUNCH(h, "tw_scan", tw_scan<<<dim3((unsigned)L.tiles.size()), dim3(256), 0, h->stream>>>(A));
-        unsigned long long cnt = 0;
-        CN_HIP(h, hipMemcpyAsync(&cnt, d_cnt.p, 8, hipMemcpyDeviceToHost, h->stream));
-        CN_HIP(h, hipStreamSynchronize(h->stream));
-        if (cnt > cap) {   // exact retry with the true size; never a truncated answer
-            cap = (uint32_t)cnt;
-            continue;
+    if (!L.tiles.empty()) {
+        int64_t *d_boff = (int64_t *)cn_ws(h, WS_TW_BOFF, L.bit_off.size() * 8);
+        int2 *d_tiles = (int2 *)cn_ws(h, WS_TW_TILES, L.tiles.size() * sizeof(int2));
+        unsigned long long *d_cnt = (unsigned long long *)cn_ws(h, WS_TW_CNT, 16);
+        unsigned long long *p_cnt = (unsigned long long *)cn_pin(h, PIN_SMALL, 64);
+        if (!d_boff || !d_tiles || !d_cnt || !p_cnt) return cn_fail(h, CORNETTO_E_NOMEM, "telowin: workspace allocation failed");
+        CN_HIP(h, hipMemcpyAsync(d_boff, L.bit_off.data(), L.bit_off.size() * 8, hipMemcpyHostToDevice, h->stream));
+        CN_HIP(h, hipMemcpyAsync(d_tiles, L.tiles.data(), L.tiles.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+        size_t cap = std::max<size_t>(1u << 16, h->dev[WS_TW_OUT].bytes / sizeof(int4));
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            int4 *d_out = (int4 *)cn_ws(h, WS_TW_OUT, cap * sizeof(int4));
+            if (!d_out) return cn_fail(h, CORNETTO_E_NOMEM, "telowin: workspace allocation failed");
+            CN_HIP(h, hipMemsetAsync(d_cnt, 0, 8, h->stream));
+            TwArgs A{d_bitmap, d_boff, d_len, d_tiles, thr, d_out, d_cnt, (uint32_t)std::min<size_t>(cap, 0x7fffffff)};
+            CN_LAUNCH(h, "tw_scan", tw_scan<<<dim3((unsigned)L.tiles.size()), dim3(256), 0, h->stream>>>(A));
+            CN_HIP(h, hipMemcpyAsync(p_cnt, d_cnt, 8, hipMemcpyDeviceToHost, h->stream));
+            CN_HIP(h, hipStreamSynchronize(h->stream));
+            const unsigned long long cnt = p_cnt[0];
+            if (cnt > cap) {   // exact retry with the true size; never a truncated answer
+                if (attempt == 1) return cn_fail(h, CORNETTO_E_HIP, "telowin: %llu windows after resizing", cnt);
+                cap = (size_t)cnt;
+                continue;
+            }
+            host.resize(cnt);
+            if (cnt) CN_HIP(h, hipMemcpy(host.data(), d_out, cnt * sizeof(int4), hipMemcpyDeviceToHost));
+            break;
         }
-        host.resize(cnt);
-        if (cnt) CN_HIP(h, hipMemcpy(host.data(), d_out.p, cnt * sizeof(int4), hipMemcpyDeviceToHost));
-        break;
     }
     std::sort(host.begin(), host.end(), [](const int4 &a, const int4 &b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
     cornetto_win_t *w = (cornetto_win_t *)malloc((host.size() ? host.size() : 1) * sizeof(cornetto_win_t));
@@ -394,25 +392,28 @@ int telowin_from_hits(cornetto_accel_t *h, const cornetto_hit_t *hits, int64_t n
         const int64_t bo = L.bit_off[x.ctg];
         hv.push_back(make_int4((int)(uint32_t)(bo & 0xFFFFFFFFll), (int)(uint32_t)(bo >> 32), x.start, x.end));
     }
-    DevBuf d_bm, d_hits, d_len;
-    if (d_bm.alloc((size_t)L.n_words * 8) != hipSuccess || d_hits.alloc(hv.size() * sizeof(int4)) != hipSuccess ||
-        d_len.alloc((size_t)(n_ctg > 0 ? n_ctg : 1) * 4) != hipSuccess)
-        return cn_fail(h, CORNETTO_E_NOMEM, "telowin: device allocation failed");
-    CN_HIP(h, hipMemsetAsync(d_bm.p, 0, (size_t)L.n_words * 8, h->stream));
-    if (n_ctg) CN_HIP(h, hipMemcpyAsync(d_len.p, ctg_len, (size_t)n_ctg * 4, hipMemcpyHostToDevice, h->stream));
+    unsigned long long *d_bm = (unsigned long long *)cn_ws(h, WS_TW_BITMAP, (size_t)L.n_words * 8);
+    int4 *d_hits = (int4 *)cn_ws(h, WS_TW_HITS, hv.size() * sizeof(int4));
+    int32_t *d_len = (int32_t *)cn_ws(h, WS_TW_LEN, (size_t)(n_ctg > 0 ? n_ctg : 1) * 4);
+    if (!d_bm || !d_hits || !d_len) return cn_fail(h, CORNETTO_E_NOMEM, "telowin: workspace allocation failed");
+    CN_HIP(h, hipMemsetAsync(d_bm, 0, (size_t)L.n_words * 8, h->stream));
+    if (n_ctg) CN_HIP(h, hipMemcpyAsync(d_len, ctg_len, (size_t)n_ctg * 4, hipMemcpyHostToDevice, h->stream));
     if (!hv.empty()) {
-        CN_HIP(h, hipMemcpyAsync(d_hits.p, hv.data(), hv.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+        CN_HIP(h, hipMemcpyAsync(d_hits, hv.data(), hv.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
         const unsigned nb = (unsigned)((hv.size() + 255) / 256);
-        CN_LAUNCH(h, "tw_fill", tw_fill<<<dim3(nb), dim3(256), 0, h->stream>>>(d_hits.as<int4>(), (int64_t)hv.size(), d_bm.as<unsigned long long>()));
+        CN_LAUNCH(h, "tw_fill", tw_fill<<<dim3(nb), dim3(256), 0, h->stream>>>(d_hits, (int64_t)hv.size(), d_bm));
     }
-    return run_tw_scan(h, d_bm.as<unsigned long long>(), L, d_len.as<int32_t>(), thr_adj, wins, n_wins);
+    int rc = run_tw_scan(h, d_bm, L, d_len, thr_adj, wins, n_wins);
+    if (hipStreamSynchronize(h->stream) != hipSuccess && rc == CORNETTO_OK) rc = CORNETTO_E_HIP;   // hv / ctg_len are caller memory
+    return rc;
 }
 
 // the whole telofind pass; optionally leaves the mark bitmap on the device (unbordered motifs)
-int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a, const char *motif_c, cornetto_hit_t **hits,
-                  int64_t *n_hits, DevBuf *bitmap_out, bool *bitmap_valid)
+int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *motif_c, cornetto_hit_t **hits,
+                  int64_t *n_hits, bool want_bitmap_req, unsigned long long **bitmap_out, bool *bitmap_valid)
 {
-    if (!h || !a || !motif_c) return cn_fail(h, CORNETTO_E_ARG, "telofind: bad argument");
+    if (!h || !a_in || !motif_c) return cn_fail(h, CORNETTO_E_ARG, "telofind: bad argument");
+    cornetto_asm_t *a = const_cast<cornetto_asm_t *>(a_in);   // only the cached tile table is touched
     const std::string motif(motif_c);
     const int k = (int)motif.size();
     if (k < 1) return cn_fail(h, CORNETTO_E_ARG, "telofind: empty motif (the reference never terminates on it)");
@@ -437,83 +438,116 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a, const char *moti
         }
         lut[c] = make_uint2(f, r);
     }
-    // tiles in contig order
-    std::vector<int2> tiles;
-    std::vector<int32_t> ctg_tile0(a->n + 1, 0);
-    for (int32_t c = 0; c < a->n; ++c) {
-        ctg_tile0[c] = (int32_t)tiles.size();
-        for (int64_t s = 0; s < a->len[c]; s += TF_TILE) tiles.push_back(make_int2(c, (int)s));
+    // tiles in contig order (cached with the assembly)
+    if (a->tf_n_tiles < 0) {
+        std::vector<int2> tiles;
+        a->tf_ctg_tile0.assign(a->n + 1, 0);
+        for (int32_t c = 0; c < a->n; ++c) {
+            a->tf_ctg_tile0[c] = (int32_t)tiles.size();
+            for (int64_t s = 0; s < a->len[c]; s += TF_TILE) tiles.push_back(make_int2(c, (int)s));
+        }
+        a->tf_ctg_tile0[a->n] = (int32_t)tiles.size();
+        if (!tiles.empty()) {
+            if (hipMalloc((void **)&a->d_tf_tiles, tiles.size() * sizeof(int2)) != hipSuccess)
+                return cn_fail(h, CORNETTO_E_NOMEM, "telofind: device allocation failed");
+            CN_HIP(h, hipMemcpyAsync(a->d_tf_tiles, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+            CN_HIP(h, hipStreamSynchronize(h->stream));
+        }
+        a->tf_n_tiles = (int64_t)tiles.size();
     }
-    ctg_tile0[a->n] = (int32_t)tiles.size();
-    const size_t nt = tiles.size();
+    const std::vector<int32_t> &ctg_tile0 = a->tf_ctg_tile0;
+    const size_t nt = (size_t)a->tf_n_tiles;
 
-    std::vector<cornetto_hit_t> out;
+    cornetto_hit_t *out = nullptr;
+    int64_t n_out = 0;
     if (nt > 0) {
-        DevBuf d_tiles, d_lut, d_cnt, d_tb, d_tc, d_list[4];
-        if (d_tiles.alloc(nt * sizeof(int2)) != hipSuccess || d_lut.alloc(256 * sizeof(uint2)) != hipSuccess ||
-            d_cnt.alloc(32) != hipSuccess || d_tb.alloc(nt * sizeof(uint4)) != hipSuccess || d_tc.alloc(nt * sizeof(uint4)) != hipSuccess)
-            return cn_fail(h, CORNETTO_E_NOMEM, "telofind: device allocation failed");
-        CN_HIP(h, hipMemcpyAsync(d_tiles.p, tiles.data(), nt * sizeof(int2), hipMemcpyHostToDevice, h->stream));
-        CN_HIP(h, hipMemcpyAsync(d_lut.p, lut.data(), 256 * sizeof(uint2), hipMemcpyHostToDevice, h->stream));
-        const bool want_bitmap = bitmap_out && !bordered;
+        uint2 *d_lut = (uint2 *)cn_ws(h, WS_TF_LUT, 256 * sizeof(uint2));
+        unsigned long long *d_cnt = (unsigned long long *)cn_ws(h, WS_TF_CNT, 32);
+        uint4 *d_tb = (uint4 *)cn_ws(h, WS_TF_TB, nt * sizeof(uint4));
+        uint4 *d_tc = (uint4 *)cn_ws(h, WS_TF_TC, nt * sizeof(uint4));
+        unsigned long long *p_cnt = (unsigned long long *)cn_pin(h, PIN_SMALL, 64);
+        if (!d_lut || !d_cnt || !d_tb || !d_tc || !p_cnt) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: workspace allocation failed");
+        CN_HIP(h, hipMemcpyAsync(d_lut, lut.data(), 256 * sizeof(uint2), hipMemcpyHostToDevice, h->stream));
+        const bool want_bitmap = want_bitmap_req && !bordered;
+        unsigned long long *d_bitmap = nullptr;
         if (want_bitmap) {
             int64_t last_end = 0;
             for (int32_t c = 0; c < a->n; ++c) last_end = std::max(last_end, a->off[c] + a->len[c]);
             const size_t words = (size_t)(cn_align_up(last_end, 64) / 64 + 4);
-            if (bitmap_out->alloc(words * 8) != hipSuccess) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: bitmap allocation failed");
-            // every word of a contig is written by the kernel; zero only covers padding between contigs
-            CN_HIP(h, hipMemsetAsync(bitmap_out->p, 0, words * 8, h->stream));
+            d_bitmap = (unsigned long long *)cn_ws(h, WS_TF_BITMAP, words * 8);
+            if (!d_bitmap) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: bitmap allocation failed");
+            // every word of a contig is written by the kernel; the memset only covers padding between contigs
+            CN_HIP(h, hipMemsetAsync(d_bitmap, 0, words * 8, h->stream));
+            if (bitmap_out) *bitmap_out = d_bitmap;
         }
-        uint32_t cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(1 << 16, a->total / 64), 0x7fffffff);
+        size_t cap = (size_t)std::min<int64_t>(std::max<int64_t>(1 << 16, a->total / 256), 0x7fffffff);
+        cap = std::max(cap, h->dev[WS_TF_L0].bytes / 4);   // keep what an earlier call grew to
         unsigned long long cnt[4] = {0, 0, 0, 0};
+        int32_t *d_list[4] = {nullptr, nullptr, nullptr, nullptr};
         for (int attempt = 0; attempt < 2; ++attempt) {
-            for (int q = 0; q < 4; ++q)
-                if (d_list[q].alloc((size_t)cap * 4) != hipSuccess) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: device allocation failed");
-            CN_HIP(h, hipMemsetAsync(d_cnt.p, 0, 32, h->stream));
-            TfArgs A{a->d_bases, a->d_off, a->d_len, d_tiles.as<int2>(), d_lut.as<uint2>(), k, bordered ? 1 : 0,
-                     want_bitmap ? bitmap_out->as<unsigned long long>() : nullptr,
-                     d_list[0].as<int32_t>(), d_list[1].as<int32_t>(), d_list[2].as<int32_t>(), d_list[3].as<int32_t>(),
-                     d_cnt.as<unsigned long long>(), cap, d_tb.as<uint4>(), d_tc.as<uint4>()};
+            for (int q = 0; q < 4; ++q) {
+                d_list[q] = (int32_t *)cn_ws(h, WS_TF_L0 + q, cap * 4);
+                if (!d_list[q]) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: workspace allocation failed");
+            }
+            CN_HIP(h, hipMemsetAsync(d_cnt, 0, 32, h->stream));
+            TfArgs A{a->d_bases, a->d_off, a->d_len, a->d_tf_tiles, d_lut, k, bordered ? 1 : 0, want_bitmap ? d_bitmap : nullptr,
+                     d_list[0], d_list[1], d_list[2], d_list[3], d_cnt, (uint32_t)cap, d_tb, d_tc};
             if (H == 7) CN_LAUNCH(h, "tf_scan", tf_scan<7><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
             else if (H == 15) CN_LAUNCH(h, "tf_scan", tf_scan<15><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
             else CN_LAUNCH(h, "tf_scan", tf_scan<31><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
-            CN_HIP(h, hipMemcpyAsync(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost, h->stream));
-            CN_HIP(h, hipStreamSynchronize(h->stream));
+            CN_HIP(h, hipMemcpyAsync(p_cnt, d_cnt, 32, hipMemcpyDeviceToHost, h->stream));
+            CN_HIP(h, hipStreamSynchronize(h->stream));   // also covers the `lut` upload
+            for (int q = 0; q < 4; ++q) cnt[q] = p_cnt[q];
             const unsigned long long mx = std::max(std::max(cnt[0], cnt[1]), std::max(cnt[2], cnt[3]));
             if (mx <= cap) break;
             if (attempt == 1 || mx > 0x7fffffffull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "telofind: %llu list entries", mx);
-            cap = (uint32_t)mx;   // rerun with the exact size: results are never truncated
+            cap = (size_t)mx;   // rerun with the exact size: results are never truncated
         }
         if (bitmap_valid) *bitmap_valid = want_bitmap;
         if (hits) {
-            std::vector<uint4> tb(nt), tc(nt);
-            CN_HIP(h, hipMemcpy(tb.data(), d_tb.p, nt * sizeof(uint4), hipMemcpyDeviceToHost));
-            CN_HIP(h, hipMemcpy(tc.data(), d_tc.p, nt * sizeof(uint4), hipMemcpyDeviceToHost));
+            // tile tables and lists -> pinned host memory
+            uint4 *tb = (uint4 *)cn_pin(h, PIN_A, nt * sizeof(uint4));
+            uint4 *tc = (uint4 *)cn_pin(h, PIN_B, nt * sizeof(uint4));
+            int32_t *raw[4];
+            for (int q = 0; q < 4; ++q) raw[q] = (int32_t *)cn_pin(h, PIN_C + q, (size_t)cnt[q] * 4);
+            if (!tb || !tc || !raw[0] || !raw[1] || !raw[2] || !raw[3]) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: pinned allocation failed");
+            CN_HIP(h, hipMemcpyAsync(tb, d_tb, nt * sizeof(uint4), hipMemcpyDeviceToHost, h->stream));
+            CN_HIP(h, hipMemcpyAsync(tc, d_tc, nt * sizeof(uint4), hipMemcpyDeviceToHost, h->stream));
+            for (int q = 0; q < 4; ++q)
+                if (cnt[q]) CN_HIP(h, hipMemcpyAsync(raw[q], d_list[q], (size_t)cnt[q] * 4, hipMemcpyDeviceToHost, h->stream));
             if (!bordered) {
-                std::vector<int32_t> raw[4];
-                for (int q = 0; q < 4; ++q) {
-                    raw[q].resize(cnt[q]);
-                    if (cnt[q]) CN_HIP(h, hipMemcpy(raw[q].data(), d_list[q].p, cnt[q] * 4, hipMemcpyDeviceToHost));
-                }
+                CN_HIP(h, hipStreamSynchronize(h->stream));
                 if (cnt[0] != cnt[1] || cnt[2] != cnt[3])
                     return cn_fail(h, CORNETTO_E_HIP, "telofind: head/tail count mismatch (%llu/%llu, %llu/%llu)", cnt[0], cnt[1], cnt[2], cnt[3]);
-                // gather tile by tile -> contig order; per contig strand 0 then strand 1 (src/find_telomere.c:49-72)
+                out = (cornetto_hit_t *)malloc((size_t)(cnt[0] + cnt[2] + 1) * sizeof(cornetto_hit_t));
+                if (!out) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: host allocation failed");
+                // per contig: strand 0 runs then strand 1 runs (src/find_telomere.c:49-72); inside a contig the
+                // tiles are in position order, and the i-th head of a (contig, strand) pairs with its i-th tail
                 for (int32_t c = 0; c < a->n; ++c) {
                     for (int strand = 0; strand < 2; ++strand) {
                         const int qh = strand * 2, qt = qh + 1;
-                        std::vector<int32_t> hd, tl;
-                        for (int32_t t = ctg_tile0[c]; t < ctg_tile0[c + 1]; ++t) {
-                            const uint32_t *b = &tb[t].x, *n = &tc[t].x;
-                            for (uint32_t i = 0; i < n[qh]; ++i) hd.push_back(raw[qh][b[qh] + i]);
-                            for (uint32_t i = 0; i < n[qt]; ++i) tl.push_back(raw[qt][b[qt] + i]);
+                        int32_t th = ctg_tile0[c], tt = ctg_tile0[c];   // tile cursors of the head / tail lists
+                        uint32_t ih = 0, it = 0;
+                        const int32_t tend = ctg_tile0[c + 1];
+                        for (;;) {
+                            while (th < tend && ih >= (&tc[th].x)[qh]) { ++th; ih = 0; }
+                            while (tt < tend && it >= (&tc[tt].x)[qt]) { ++tt; it = 0; }
+                            if (th >= tend || tt >= tend) {
+                                if (th < tend || tt < tend) {
+                                    free(out);
+                                    return cn_fail(h, CORNETTO_E_HIP, "telofind: contig %d strand %d: unpaired run head/tail", c, strand);
+                                }
+                                break;
+                            }
+                            const int32_t hd = raw[qh][(&tb[th].x)[qh] + ih++];
+                            const int32_t tl = raw[qt][(&tb[tt].x)[qt] + it++];
+                            out[n_out++] = cornetto_hit_t{c, strand, hd, tl + k};
                         }
-                        if (hd.size() != tl.size())
-                            return cn_fail(h, CORNETTO_E_HIP, "telofind: contig %d strand %d: %zu heads, %zu tails", c, strand, hd.size(), tl.size());
-                        for (size_t i = 0; i < hd.size(); ++i) out.push_back(cornetto_hit_t{c, strand, hd[i], tl[i] + k});
                     }
                 }
             } else {
                 // sequential greedy rule on the device over the compacted matches
+                CN_HIP(h, hipStreamSynchronize(h->stream));
                 std::vector<int64_t> run_off(2 * (size_t)a->n + 1, 0);
                 for (int32_t c = 0; c < a->n; ++c) {
                     int64_t mf = 0, mr = 0;
@@ -522,36 +556,42 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a, const char *moti
                     run_off[2 * c + 2] = run_off[2 * c + 1] + mr;
                 }
                 const int64_t tot = run_off[2 * (size_t)a->n];
-                DevBuf d_ct0, d_roff, d_runs, d_nruns;
-                if (d_ct0.alloc(ctg_tile0.size() * 4) != hipSuccess || d_roff.alloc(run_off.size() * 8) != hipSuccess ||
-                    d_runs.alloc((size_t)tot * sizeof(int2)) != hipSuccess || d_nruns.alloc(2 * (size_t)a->n * 4) != hipSuccess)
+                DevBuf d_ct0;
+                int64_t *d_roff = (int64_t *)cn_ws(h, WS_TF_ROFF, run_off.size() * 8);
+                int2 *d_runs = (int2 *)cn_ws(h, WS_TF_RUNS, (size_t)tot * sizeof(int2));
+                int32_t *d_nruns = (int32_t *)cn_ws(h, WS_TF_NRUNS, 2 * (size_t)a->n * 4);
+                if (d_ct0.alloc(ctg_tile0.size() * 4) != hipSuccess || !d_roff || !d_runs || !d_nruns)
                     return cn_fail(h, CORNETTO_E_NOMEM, "telofind: device allocation failed");
                 CN_HIP(h, hipMemcpyAsync(d_ct0.p, ctg_tile0.data(), ctg_tile0.size() * 4, hipMemcpyHostToDevice, h->stream));
-                CN_HIP(h, hipMemcpyAsync(d_roff.p, run_off.data(), run_off.size() * 8, hipMemcpyHostToDevice, h->stream));
-                GreedyArgs G{d_list[0].as<int32_t>(), d_list[2].as<int32_t>(), d_tb.as<uint4>(), d_tc.as<uint4>(), d_ct0.as<int32_t>(),
-                             d_roff.as<int64_t>(), a->n, k, d_runs.as<int2>(), d_nruns.as<int32_t>()};
+                CN_HIP(h, hipMemcpyAsync(d_roff, run_off.data(), run_off.size() * 8, hipMemcpyHostToDevice, h->stream));
+                GreedyArgs G{d_list[0], d_list[2], d_tb, d_tc, d_ct0.as<int32_t>(), d_roff, a->n, k, d_runs, d_nruns};
                 const unsigned nb = (unsigned)((2 * a->n + 63) / 64);
                 CN_LAUNCH(h, "tf_greedy", tf_greedy<<<dim3(nb), dim3(64), 0, h->stream>>>(G));
                 std::vector<int2> runs((size_t)tot);
                 std::vector<int32_t> nr(2 * (size_t)a->n);
                 CN_HIP(h, hipStreamSynchronize(h->stream));
-                if (tot) CN_HIP(h, hipMemcpy(runs.data(), d_runs.p, (size_t)tot * sizeof(int2), hipMemcpyDeviceToHost));
-                CN_HIP(h, hipMemcpy(nr.data(), d_nruns.p, nr.size() * 4, hipMemcpyDeviceToHost));
+                if (tot) CN_HIP(h, hipMemcpy(runs.data(), d_runs, (size_t)tot * sizeof(int2), hipMemcpyDeviceToHost));
+                CN_HIP(h, hipMemcpy(nr.data(), d_nruns, nr.size() * 4, hipMemcpyDeviceToHost));
+                int64_t total_runs = 0;
+                for (int32_t v : nr) total_runs += v;
+                out = (cornetto_hit_t *)malloc((size_t)(total_runs + 1) * sizeof(cornetto_hit_t));
+                if (!out) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: host allocation failed");
                 for (int32_t c = 0; c < a->n; ++c)
                     for (int strand = 0; strand < 2; ++strand)
                         for (int32_t i = 0; i < nr[2 * c + strand]; ++i) {
                             const int2 r = runs[run_off[2 * c + strand] + i];
-                            out.push_back(cornetto_hit_t{c, strand, r.x, r.y});
+                            out[n_out++] = cornetto_hit_t{c, strand, r.x, r.y};
                         }
             }
         }
     }
     if (hits) {
-        cornetto_hit_t *o = (cornetto_hit_t *)malloc((out.size() ? out.size() : 1) * sizeof(cornetto_hit_t));
-        if (!o) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: host allocation failed");
-        if (!out.empty()) memcpy(o, out.data(), out.size() * sizeof(cornetto_hit_t));
-        *hits = o;
-        *n_hits = (int64_t)out.size();
+        if (!out) {
+            out = (cornetto_hit_t *)malloc(sizeof(cornetto_hit_t));
+            if (!out) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: host allocation failed");
+        }
+        *hits = out;
+        *n_hits = n_out;
     }
     return CORNETTO_OK;
 }
@@ -571,7 +611,7 @@ int cornetto_telofind(cornetto_accel_t *h, const cornetto_asm_t *a, const char *
 {
     if (!h || !hits || !n_hits) return cn_fail(h, CORNETTO_E_ARG, "telofind: bad argument");
     cn_timing_begin(h);
-    int rc = telofind_impl(h, a, motif, hits, n_hits, nullptr, nullptr);
+    int rc = telofind_impl(h, a, motif, hits, n_hits, false, nullptr, nullptr);
     cn_timing_end(h);
     return rc;
 }
@@ -593,18 +633,18 @@ int cornetto_telo_scan(cornetto_accel_t *h, const cornetto_asm_t *a, const char 
 {
     if (!h || !a || !wins || !n_wins || (hits && !n_hits)) return cn_fail(h, CORNETTO_E_ARG, "telo_scan: bad argument");
     cn_timing_begin(h);
-    DevBuf bitmap;
+    unsigned long long *d_bitmap = nullptr;
     bool valid = false;
     cornetto_hit_t *hh = nullptr;
     int64_t nh = 0;
     // a bordered motif needs the runs themselves to build the marks, so the hits are always fetched then
     const std::string m(motif ? motif : "");
     const bool need_hits = hits || has_border(m) || has_border(revcomp(m));
-    int rc = telofind_impl(h, a, motif, need_hits ? &hh : nullptr, need_hits ? &nh : nullptr, &bitmap, &valid);
+    int rc = telofind_impl(h, a, motif, need_hits ? &hh : nullptr, need_hits ? &nh : nullptr, true, &d_bitmap, &valid);
     if (rc == CORNETTO_OK) {
         if (valid) {
             WinLayout L = win_layout_from_lengths(a->len.data(), a->n, a->off.data());
-            rc = run_tw_scan(h, bitmap.as<unsigned long long>(), L, a->d_len, thr_adj, wins, n_wins);
+            rc = run_tw_scan(h, d_bitmap, L, a->d_len, thr_adj, wins, n_wins);
         } else {
             rc = telowin_from_hits(h, hh, nh, a->len.data(), a->n, thr_adj, wins, n_wins);
         }

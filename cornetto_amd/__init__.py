@@ -86,13 +86,30 @@ def lib():
     return L
 
 
+class _Owner:
+    """keeps a library-owned result buffer alive for the numpy view over it; released with cornetto_free()"""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().cornetto_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
 def _take(ptr, n, dt):
-    """copy a library-owned result array into numpy and release it"""
-    out = np.zeros(n, dtype=dt)
-    if n:
-        C.memmove(out.ctypes.data, ptr, n * dt.itemsize)
-    lib().cornetto_free(ptr)
-    return out
+    """zero-copy numpy view of a library-owned result array (freed when the array is garbage collected)"""
+    if not n:
+        lib().cornetto_free(ptr)
+        return np.zeros(0, dtype=dt)
+    addr = ptr.value if isinstance(ptr, C.c_void_p) else int(ptr)
+    buf = (C.c_char * (n * dt.itemsize)).from_address(addr)
+    buf._owner = _Owner(addr)          # the ctypes array is the numpy base; the owner dies with it
+    return np.frombuffer(buf, dtype=dt)
 
 
 class _Resident:

@@ -72,7 +72,8 @@ enum {   // device workspace slots
     WS_TW_BOFF, WS_TW_TILES, WS_TW_OUT, WS_TW_CNT, WS_TW_HITS, WS_TW_LEN, WS_TW_BITMAP,
     WS_SD_OUT, WS_SD_CNT, WS_SD_OFF, WS_SD_DST, WS_SD_STATS,
     WS_CB_T32, WS_CB_T64, WS_CB_GRAND,
-    WS_CW_REGS, WS_CW_SEL, WS_CW_CNT, WS_CW_TRES
+    WS_CW_REGS, WS_CW_SEL, WS_CW_CNT, WS_CW_TRES,
+    WS_TF_HITS
 };
 enum {   // pinned host slots
     PIN_A, PIN_B, PIN_C, PIN_D, PIN_E, PIN_F, PIN_SMALL

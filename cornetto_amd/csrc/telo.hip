@@ -9,9 +9,12 @@
 //           border (TTAGGG, CCCTAA, every real telomere unit) matches cannot overlap, so the reference's
 //           greedy runs are exactly  head = m[p] & !m[p-k],  tail = m[p] & !m[p+k]  
 //           and the i-th head pairs with the i-th tail.  Heads/tails are compacted with a packed
-//           4-counter block scan and ONE atomic reservation per list per tile; a per-tile (base,count)
-//           table restores contig order afterwards, so output order never depends on dispatch order.
-//           The same pass writes the telowin mark bitmap (1 bit/base) = union of [p,p+k) over matches.
+//           4-counter block scan into a small fixed row per tile (no atomics: a returning atomic per tile
+//           on one counter line costs ~12 ns and was 95 % of the kernel); device scans of the per-tile
+//           counts then give every tile its place in the dense, contig-ordered lists (tf_gather), and
+//           tf_pair writes the final records in the reference's print order.  A tile that overflows its row
+//           (never for real telomere motifs) triggers a second pass that writes straight to the scanned
+//           offsets.  The same pass writes the telowin mark bitmap (1 bit/base) = union of [p,p+k) over matches.
 // tf_greedy for motifs WITH a border (AAAA, ACACA ...) only: the sequential greedy rule of
 //           src/find_telomere.c:49-58 over the compacted match list, one thread per (contig,strand).
 // tw_fill   marks [start,end) of explicit hits in the bitmap (src/telomere_windows.c:75-79).
@@ -22,6 +25,7 @@
 #include <string>
 
 #include "common.hpp"
+#include "scan.hpp"
 
 namespace {
 
@@ -29,6 +33,7 @@ constexpr int TF_THREADS = 256;
 constexpr int TF_SEG = 64;
 constexpr int TF_TILE = (TF_THREADS - 2) * TF_SEG;  // 16256 positions; threads 0 and 255 are halo only
 constexpr int MAX_MOTIF = 32;
+constexpr int TF_ROW = 32;   // list entries a tile can hold in its fixed row (single-pass mode)
 
 struct TfArgs {
     const uint8_t *bases;
@@ -38,11 +43,12 @@ struct TfArgs {
     const uint2 *lut;    // [256] {fwd mask, rev mask}
     int32_t k;
     int32_t bordered;    // 0: heads/tails + bitmap; 1: all matches (lists 0 and 2)
+    int32_t mode;        // 0: count only; 1: write at tile_off (dense lists); 2: write into fixed rows of TF_ROW
     unsigned long long *bitmap;
-    int32_t *list0, *list1, *list2, *list3;
-    unsigned long long *counters;  // [4]
-    uint32_t cap;
-    uint4 *tile_base, *tile_cnt;
+    int32_t *list0, *list1, *list2, *list3;   // mode 1: dense lists; mode 2: [tile][TF_ROW] rows
+    const uint32_t *off0, *off1, *off2, *off3;   // mode 1: exclusive scan of the per-tile counts
+    uint4 *tile_cnt;
+    uint32_t *ovf;       // mode 2: max per-tile count when it exceeds TF_ROW
 };
 
 __device__ __forceinline__ unsigned long long shfl_up64(unsigned long long v, int d)
@@ -65,7 +71,6 @@ __global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
     __shared__ uint2 lut[256];
     __shared__ unsigned long long shF[TF_THREADS], shR[TF_THREADS];
     __shared__ unsigned long long wtot[TF_THREADS / 64];
-    __shared__ unsigned long long sbase[4];
 
     const int t = threadIdx.x;
     lut[t] = A.lut[t];
@@ -155,39 +160,102 @@ __global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
     }
     const unsigned long long excl = wpre + inc - pk;
     if (t == 0) {
-        uint32_t cnt[4], base[4];
+        uint32_t cnt[4], mx = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             cnt[q] = (uint32_t)((total >> (16 * q)) & 0xFFFFu);
-            unsigned long long b = cnt[q] ? atomicAdd(&A.counters[q], (unsigned long long)cnt[q]) : 0ull;
-            sbase[q] = b;
-            base[q] = (uint32_t)b;
+            mx = cnt[q] > mx ? cnt[q] : mx;
         }
-        A.tile_base[blockIdx.x] = make_uint4(base[0], base[1], base[2], base[3]);
-        A.tile_cnt[blockIdx.x] = make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]);
+        if (A.mode != 1) A.tile_cnt[blockIdx.x] = make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]);
+        if (A.mode == 2 && mx > TF_ROW) atomicMax(A.ovf, mx);   // rare: second pass will write densely
     }
-    __syncthreads();
-    if (!inner) return;
+    if (!inner || A.mode == 0) return;
     int32_t *lists[4] = {A.list0, A.list1, A.list2, A.list3};
+    const uint32_t *offs[4] = {A.off0, A.off1, A.off2, A.off3};
     unsigned long long qs[4] = {q0, q1, q2, q3};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         unsigned long long m = qs[q];
-        unsigned long long idx = sbase[q] + ((excl >> (16 * q)) & 0xFFFFu);
-        while (m) {
-            const int b = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            if (idx < A.cap) lists[q][idx] = s0 + b;
-            ++idx;
+        if (!m) continue;
+        uint32_t idx = (uint32_t)((excl >> (16 * q)) & 0xFFFFu);
+        if (A.mode == 1) {
+            int32_t *dst = lists[q] + offs[q][blockIdx.x];
+            while (m) {
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                dst[idx++] = s0 + b;
+            }
+        } else {
+            int32_t *dst = lists[q] + (size_t)blockIdx.x * TF_ROW;
+            while (m) {
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if (idx < TF_ROW) dst[idx] = s0 + b;
+                ++idx;
+            }
         }
     }
 }
 
+// fixed rows -> dense lists in tile (= contig, position) order; wave q of a workgroup copies list q of one tile
+__global__ __launch_bounds__(256) void tf_gather(const int32_t *r0, const int32_t *r1, const int32_t *r2, const int32_t *r3,
+                                                 const uint4 *tile_cnt, const uint32_t *o0, const uint32_t *o1, const uint32_t *o2,
+                                                 const uint32_t *o3, int32_t *d0, int32_t *d1, int32_t *d2, int32_t *d3)
+{
+    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t tile = blockIdx.x;
+    const uint4 c4 = tile_cnt[tile];
+    const uint32_t cnt = q == 0 ? c4.x : q == 1 ? c4.y : q == 2 ? c4.z : c4.w;
+    const int32_t *src = (q == 0 ? r0 : q == 1 ? r1 : q == 2 ? r2 : r3) + tile * TF_ROW;
+    const uint32_t *off = q == 0 ? o0 : q == 1 ? o1 : q == 2 ? o2 : o3;
+    int32_t *dst = (q == 0 ? d0 : q == 1 ? d1 : q == 2 ? d2 : d3) + off[tile];
+    if ((uint32_t)lane < cnt && lane < TF_ROW) dst[lane] = src[lane];
+}
+
+// list offsets at contig boundaries: ctg_off[q][c] = number of entries of list q before contig c (c = n: total)
+__global__ void tf_ctgoff(const int32_t *ctg_tile0, int32_t n_ctg, int64_t n_tiles, const uint32_t *o0, const uint32_t *o1,
+                          const uint32_t *o2, const uint32_t *o3, const unsigned long long *totals, uint32_t *ctg_off /* [4][n+1] */,
+                          uint32_t *err)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_ctg) return;
+    const int64_t t = ctg_tile0[c];
+    uint32_t v[4];
+    if (t < n_tiles) { v[0] = o0[t]; v[1] = o1[t]; v[2] = o2[t]; v[3] = o3[t]; }
+    else { v[0] = (uint32_t)totals[0]; v[1] = (uint32_t)totals[1]; v[2] = (uint32_t)totals[2]; v[3] = (uint32_t)totals[3]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ctg_off[(size_t)q * (n_ctg + 1) + c] = v[q];
+    if (v[0] != v[1] || v[2] != v[3]) atomicOr(err, 1u);   // every run has one head and one tail inside its contig
+}
+
+// the i-th head of a (contig, strand) pairs with its i-th tail; records go out in the reference's print
+// order: by contig, strand 0 then strand 1, by position (src/find_telomere.c:49-72)
+__global__ void tf_pair(const int32_t *hf, const int32_t *tf, const int32_t *hr, const int32_t *tr, const uint32_t *ctg_off,
+                        int32_t n_ctg, uint32_t n_f, uint32_t n_r, int32_t k, cornetto_hit_t *out)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_f + n_r) return;
+    const int strand = g >= n_f;
+    const uint32_t i = strand ? g - n_f : g;
+    const uint32_t *cf = ctg_off, *cr = ctg_off + 2 * (size_t)(n_ctg + 1);   // head offsets of strand 0 / strand 1
+    const uint32_t *mine = strand ? cr : cf;
+    int lo = 0, hi = n_ctg;                      // largest c with mine[c] <= i
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (mine[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    const int c = lo;
+    const uint32_t pos = strand ? cf[c + 1] + cr[c] + (i - cr[c]) : cf[c] + cr[c] + (i - cf[c]);
+    const int32_t st = strand ? hr[i] : hf[i], en = (strand ? tr[i] : tf[i]) + k;
+    out[pos] = cornetto_hit_t{c, strand, st, en};
+}
+
 // The reference's sequential rule for one (contig, strand): src/find_telomere.c:49-58.
-// matches: ascending start positions of ALL occurrences, stored tile by tile (tile_base/tile_cnt, list q).
+// matches: ascending start positions of ALL occurrences, in dense lists; tile tl holds cnt entries from off[tl].
 struct GreedyArgs {
     const int32_t *list0, *list2;
-    const uint4 *tile_base, *tile_cnt;
+    const uint32_t *off0, *off2;   // per-tile offsets into the dense match lists
+    const uint4 *tile_cnt;
     const int32_t *ctg_tile0;   // [n_ctg + 1] first tile of each contig
     const int64_t *run_off;     // [2 * n_ctg] first output slot of (ctg, strand)
     int32_t n_ctg, k;
@@ -207,8 +275,8 @@ __global__ void tf_greedy(GreedyArgs G)
     bool in_run = false;
     long long rs = 0, re = 0;   // current run [rs, re): re is also the only position that can extend it
     for (int tl = G.ctg_tile0[ctg]; tl < G.ctg_tile0[ctg + 1]; ++tl) {
-        const uint4 b4 = G.tile_base[tl], c4 = G.tile_cnt[tl];
-        const uint32_t base = strand ? b4.z : b4.x, cnt = strand ? c4.z : c4.x;
+        const uint4 c4 = G.tile_cnt[tl];
+        const uint32_t base = strand ? G.off2[tl] : G.off0[tl], cnt = strand ? c4.z : c4.x;
         for (uint32_t i = 0; i < cnt; ++i) {
             const long long m = list[base + i];
             if (in_run) {
@@ -461,13 +529,19 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
     cornetto_hit_t *out = nullptr;
     int64_t n_out = 0;
     if (nt > 0) {
+        const size_t np = (nt + 4095) / 4096 + 1;
         uint2 *d_lut = (uint2 *)cn_ws(h, WS_TF_LUT, 256 * sizeof(uint2));
-        unsigned long long *d_cnt = (unsigned long long *)cn_ws(h, WS_TF_CNT, 32);
-        uint4 *d_tb = (uint4 *)cn_ws(h, WS_TF_TB, nt * sizeof(uint4));
+        // small device block: totals[4] u64, ovf u32, err u32
+        unsigned long long *d_cnt = (unsigned long long *)cn_ws(h, WS_TF_CNT, 64);
         uint4 *d_tc = (uint4 *)cn_ws(h, WS_TF_TC, nt * sizeof(uint4));
+        // 4 scanned offset arrays + scan partials
+        uint32_t *d_off = (uint32_t *)cn_ws(h, WS_TF_TB, (4 * nt + np) * sizeof(uint32_t));
         unsigned long long *p_cnt = (unsigned long long *)cn_pin(h, PIN_SMALL, 64);
-        if (!d_lut || !d_cnt || !d_tb || !d_tc || !p_cnt) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: workspace allocation failed");
+        if (!d_lut || !d_cnt || !d_tc || !d_off || !p_cnt) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: workspace allocation failed");
+        uint32_t *d_offq[4] = {d_off, d_off + nt, d_off + 2 * nt, d_off + 3 * nt}, *d_part = d_off + 4 * nt;
+        uint32_t *d_ovf = reinterpret_cast<uint32_t *>(d_cnt + 4), *d_err = d_ovf + 1;
         CN_HIP(h, hipMemcpyAsync(d_lut, lut.data(), 256 * sizeof(uint2), hipMemcpyHostToDevice, h->stream));
+        CN_HIP(h, hipMemsetAsync(d_cnt, 0, 64, h->stream));
         const bool want_bitmap = want_bitmap_req && !bordered;
         unsigned long long *d_bitmap = nullptr;
         if (want_bitmap) {
@@ -480,73 +554,95 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
             CN_HIP(h, hipMemsetAsync(d_bitmap, 0, words * 8, h->stream));
             if (bitmap_out) *bitmap_out = d_bitmap;
         }
-        size_t cap = (size_t)std::min<int64_t>(std::max<int64_t>(1 << 16, a->total / 256), 0x7fffffff);
-        cap = std::max(cap, h->dev[WS_TF_L0].bytes / 4);   // keep what an earlier call grew to
-        unsigned long long cnt[4] = {0, 0, 0, 0};
-        int32_t *d_list[4] = {nullptr, nullptr, nullptr, nullptr};
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            for (int q = 0; q < 4; ++q) {
-                d_list[q] = (int32_t *)cn_ws(h, WS_TF_L0 + q, cap * 4);
-                if (!d_list[q]) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: workspace allocation failed");
-            }
-            CN_HIP(h, hipMemsetAsync(d_cnt, 0, 32, h->stream));
-            TfArgs A{a->d_bases, a->d_off, a->d_len, a->d_tf_tiles, d_lut, k, bordered ? 1 : 0, want_bitmap ? d_bitmap : nullptr,
-                     d_list[0], d_list[1], d_list[2], d_list[3], d_cnt, (uint32_t)cap, d_tb, d_tc};
+        auto launch = [&](const TfArgs &A) -> int {
             if (H == 7) CN_LAUNCH(h, "tf_scan", tf_scan<7><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
             else if (H == 15) CN_LAUNCH(h, "tf_scan", tf_scan<15><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
             else CN_LAUNCH(h, "tf_scan", tf_scan<31><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
-            CN_HIP(h, hipMemcpyAsync(p_cnt, d_cnt, 32, hipMemcpyDeviceToHost, h->stream));
-            CN_HIP(h, hipStreamSynchronize(h->stream));   // also covers the `lut` upload
-            for (int q = 0; q < 4; ++q) cnt[q] = p_cnt[q];
-            const unsigned long long mx = std::max(std::max(cnt[0], cnt[1]), std::max(cnt[2], cnt[3]));
-            if (mx <= cap) break;
-            if (attempt == 1 || mx > 0x7fffffffull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "telofind: %llu list entries", mx);
-            cap = (size_t)mx;   // rerun with the exact size: results are never truncated
+            return CORNETTO_OK;
+        };
+        TfArgs A{};
+        A.bases = a->d_bases; A.ctg_off = a->d_off; A.ctg_len = a->d_len; A.tiles = a->d_tf_tiles; A.lut = d_lut; A.k = k;
+        A.bordered = bordered ? 1 : 0; A.bitmap = want_bitmap ? d_bitmap : nullptr; A.tile_cnt = d_tc; A.ovf = d_ovf;
+        // pass 1: single pass into fixed rows (unbordered motif, hits wanted), or counts only
+        const bool rows_mode = hits && !bordered;
+        int32_t *d_rows[4] = {nullptr, nullptr, nullptr, nullptr};
+        if (rows_mode) {
+            for (int q = 0; q < 4; ++q) {
+                d_rows[q] = (int32_t *)cn_ws(h, WS_TF_L0 + q, nt * TF_ROW * sizeof(int32_t));
+                if (!d_rows[q]) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: workspace allocation failed");
+            }
+            A.mode = 2;
+            A.list0 = d_rows[0]; A.list1 = d_rows[1]; A.list2 = d_rows[2]; A.list3 = d_rows[3];
+        } else {
+            A.mode = 0;
         }
+        CN_TRY(launch(A));
         if (bitmap_valid) *bitmap_valid = want_bitmap;
         if (hits) {
-            // tile tables and lists -> pinned host memory
-            uint4 *tb = (uint4 *)cn_pin(h, PIN_A, nt * sizeof(uint4));
-            uint4 *tc = (uint4 *)cn_pin(h, PIN_B, nt * sizeof(uint4));
-            int32_t *raw[4];
-            for (int q = 0; q < 4; ++q) raw[q] = (int32_t *)cn_pin(h, PIN_C + q, (size_t)cnt[q] * 4);
-            if (!tb || !tc || !raw[0] || !raw[1] || !raw[2] || !raw[3]) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: pinned allocation failed");
-            CN_HIP(h, hipMemcpyAsync(tb, d_tb, nt * sizeof(uint4), hipMemcpyDeviceToHost, h->stream));
-            CN_HIP(h, hipMemcpyAsync(tc, d_tc, nt * sizeof(uint4), hipMemcpyDeviceToHost, h->stream));
+            // place of every tile in the dense, contig-ordered lists + list totals
             for (int q = 0; q < 4; ++q)
-                if (cnt[q]) CN_HIP(h, hipMemcpyAsync(raw[q], d_list[q], (size_t)cnt[q] * 4, hipMemcpyDeviceToHost, h->stream));
+                CN_TRY(cnscan::exclusive_u32(h, "tf_order", reinterpret_cast<const uint32_t *>(d_tc) + q, (int64_t)nt, 4, d_offq[q], d_part, d_cnt + q));
+            CN_HIP(h, hipMemcpyAsync(p_cnt, d_cnt, 64, hipMemcpyDeviceToHost, h->stream));
+            CN_HIP(h, hipStreamSynchronize(h->stream));   // also covers the `lut` upload
+            unsigned long long cnt[4] = {p_cnt[0], p_cnt[1], p_cnt[2], p_cnt[3]};
+            const uint32_t ovf = (uint32_t)(p_cnt[4] & 0xFFFFFFFFull);
+            for (int q = 0; q < 4; ++q)
+                if (cnt[q] > 0x7fffffffull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "telofind: %llu list entries", cnt[q]);
+            // dense lists: one workspace, 4 segments
+            const size_t seg[4] = {(size_t)cnt[0], (size_t)cnt[1], (size_t)cnt[2], (size_t)cnt[3]};
+            int32_t *d_dense = (int32_t *)cn_ws(h, WS_TF_RUNS, (seg[0] + seg[1] + seg[2] + seg[3] + 4) * sizeof(int32_t));
+            if (!d_dense) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: workspace allocation failed");
+            int32_t *d_list[4] = {d_dense, d_dense + seg[0], d_dense + seg[0] + seg[1], d_dense + seg[0] + seg[1] + seg[2]};
+            if (rows_mode && ovf <= TF_ROW) {
+                hipEvent_t ea = cn_event(h), eb = cn_event(h);
+                (void)hipEventRecord(ea, h->stream);
+                tf_gather<<<dim3((unsigned)nt), dim3(256), 0, h->stream>>>(d_rows[0], d_rows[1], d_rows[2], d_rows[3], d_tc, d_offq[0], d_offq[1],
+                                                                           d_offq[2], d_offq[3], d_list[0], d_list[1], d_list[2], d_list[3]);
+                (void)hipEventRecord(eb, h->stream);
+                h->recs.push_back(cornetto_accel::Rec{"tf_gather", ea, eb});
+                CN_HIP(h, hipGetLastError());
+            } else {
+                // second pass writes straight to the scanned offsets (bordered motif, or a tile overflowed its row)
+                A.mode = 1;
+                A.bitmap = nullptr;
+                A.list0 = d_list[0]; A.list1 = d_list[1]; A.list2 = d_list[2]; A.list3 = d_list[3];
+                A.off0 = d_offq[0]; A.off1 = d_offq[1]; A.off2 = d_offq[2]; A.off3 = d_offq[3];
+                CN_TRY(launch(A));
+            }
+            int32_t *d_ct0 = (int32_t *)cn_ws(h, WS_TF_NRUNS, ((size_t)a->n + 1) * 4 + 2 * (size_t)a->n * 4 + 16);
+            if (!d_ct0) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: workspace allocation failed");
+            CN_HIP(h, hipMemcpyAsync(d_ct0, ctg_tile0.data(), ((size_t)a->n + 1) * 4, hipMemcpyHostToDevice, h->stream));
             if (!bordered) {
-                CN_HIP(h, hipStreamSynchronize(h->stream));
                 if (cnt[0] != cnt[1] || cnt[2] != cnt[3])
                     return cn_fail(h, CORNETTO_E_HIP, "telofind: head/tail count mismatch (%llu/%llu, %llu/%llu)", cnt[0], cnt[1], cnt[2], cnt[3]);
-                out = (cornetto_hit_t *)malloc((size_t)(cnt[0] + cnt[2] + 1) * sizeof(cornetto_hit_t));
+                const size_t tot = (size_t)(cnt[0] + cnt[2]);
+                uint32_t *d_coff = (uint32_t *)cn_ws(h, WS_TF_ROFF, 4 * ((size_t)a->n + 1) * 4);
+                cornetto_hit_t *d_hits = (cornetto_hit_t *)cn_ws(h, WS_TF_HITS, tot * sizeof(cornetto_hit_t));
+                if (!d_coff || !d_hits) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: workspace allocation failed");
+                out = (cornetto_hit_t *)malloc((tot ? tot : 1) * sizeof(cornetto_hit_t));
                 if (!out) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: host allocation failed");
-                // per contig: strand 0 runs then strand 1 runs (src/find_telomere.c:49-72); inside a contig the
-                // tiles are in position order, and the i-th head of a (contig, strand) pairs with its i-th tail
-                for (int32_t c = 0; c < a->n; ++c) {
-                    for (int strand = 0; strand < 2; ++strand) {
-                        const int qh = strand * 2, qt = qh + 1;
-                        int32_t th = ctg_tile0[c], tt = ctg_tile0[c];   // tile cursors of the head / tail lists
-                        uint32_t ih = 0, it = 0;
-                        const int32_t tend = ctg_tile0[c + 1];
-                        for (;;) {
-                            while (th < tend && ih >= (&tc[th].x)[qh]) { ++th; ih = 0; }
-                            while (tt < tend && it >= (&tc[tt].x)[qt]) { ++tt; it = 0; }
-                            if (th >= tend || tt >= tend) {
-                                if (th < tend || tt < tend) {
-                                    free(out);
-                                    return cn_fail(h, CORNETTO_E_HIP, "telofind: contig %d strand %d: unpaired run head/tail", c, strand);
-                                }
-                                break;
-                            }
-                            const int32_t hd = raw[qh][(&tb[th].x)[qh] + ih++];
-                            const int32_t tl = raw[qt][(&tb[tt].x)[qt] + it++];
-                            out[n_out++] = cornetto_hit_t{c, strand, hd, tl + k};
-                        }
-                    }
+                hipEvent_t ea = cn_event(h), eb = cn_event(h);
+                (void)hipEventRecord(ea, h->stream);
+                tf_ctgoff<<<dim3((unsigned)((a->n + 256) / 256)), dim3(256), 0, h->stream>>>(d_ct0, a->n, (int64_t)nt, d_offq[0], d_offq[1], d_offq[2],
+                                                                                           d_offq[3], d_cnt, d_coff, d_err);
+                if (tot)
+                    tf_pair<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream>>>(d_list[0], d_list[1], d_list[2], d_list[3], d_coff, a->n,
+                                                                                             (uint32_t)cnt[0], (uint32_t)cnt[2], k, d_hits);
+                (void)hipEventRecord(eb, h->stream);
+                h->recs.push_back(cornetto_accel::Rec{"tf_pair", ea, eb});
+                bool ok = hipGetLastError() == hipSuccess;
+                ok = ok && hipMemcpyAsync(p_cnt, d_cnt, 64, hipMemcpyDeviceToHost, h->stream) == hipSuccess;
+                if (tot) ok = ok && hipMemcpyAsync(out, d_hits, tot * sizeof(cornetto_hit_t), hipMemcpyDeviceToHost, h->stream) == hipSuccess;
+                ok = ok && hipStreamSynchronize(h->stream) == hipSuccess;
+                if (!ok || (p_cnt[4] >> 32) != 0) {
+                    free(out);
+                    return cn_fail(h, CORNETTO_E_HIP, "telofind: pairing run heads with tails failed%s", ok ? " (a contig has unequal heads and tails)" : "");
                 }
+                n_out = (int64_t)tot;
             } else {
-                // sequential greedy rule on the device over the compacted matches
+                // sequential greedy rule on the device over the dense match lists
+                std::vector<uint4> tc(nt);
+                CN_HIP(h, hipMemcpyAsync(tc.data(), d_tc, nt * sizeof(uint4), hipMemcpyDeviceToHost, h->stream));
                 CN_HIP(h, hipStreamSynchronize(h->stream));
                 std::vector<int64_t> run_off(2 * (size_t)a->n + 1, 0);
                 for (int32_t c = 0; c < a->n; ++c) {
@@ -556,15 +652,12 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
                     run_off[2 * c + 2] = run_off[2 * c + 1] + mr;
                 }
                 const int64_t tot = run_off[2 * (size_t)a->n];
-                DevBuf d_ct0;
                 int64_t *d_roff = (int64_t *)cn_ws(h, WS_TF_ROFF, run_off.size() * 8);
-                int2 *d_runs = (int2 *)cn_ws(h, WS_TF_RUNS, (size_t)tot * sizeof(int2));
-                int32_t *d_nruns = (int32_t *)cn_ws(h, WS_TF_NRUNS, 2 * (size_t)a->n * 4);
-                if (d_ct0.alloc(ctg_tile0.size() * 4) != hipSuccess || !d_roff || !d_runs || !d_nruns)
-                    return cn_fail(h, CORNETTO_E_NOMEM, "telofind: device allocation failed");
-                CN_HIP(h, hipMemcpyAsync(d_ct0.p, ctg_tile0.data(), ctg_tile0.size() * 4, hipMemcpyHostToDevice, h->stream));
+                int2 *d_runs = (int2 *)cn_ws(h, WS_TF_L1, (size_t)tot * sizeof(int2));
+                int32_t *d_nruns = d_ct0 + (a->n + 1);
+                if (!d_roff || !d_runs) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: device allocation failed");
                 CN_HIP(h, hipMemcpyAsync(d_roff, run_off.data(), run_off.size() * 8, hipMemcpyHostToDevice, h->stream));
-                GreedyArgs G{d_list[0], d_list[2], d_tb, d_tc, d_ct0.as<int32_t>(), d_roff, a->n, k, d_runs, d_nruns};
+                GreedyArgs G{d_list[0], d_list[2], d_offq[0], d_offq[2], d_tc, d_ct0, d_roff, a->n, k, d_runs, d_nruns};
                 const unsigned nb = (unsigned)((2 * a->n + 63) / 64);
                 CN_LAUNCH(h, "tf_greedy", tf_greedy<<<dim3(nb), dim3(64), 0, h->stream>>>(G));
                 std::vector<int2> runs((size_t)tot);
@@ -583,6 +676,8 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
                             out[n_out++] = cornetto_hit_t{c, strand, r.x, r.y};
                         }
             }
+        } else {
+            CN_HIP(h, hipStreamSynchronize(h->stream));   // `lut` is a local
         }
     }
     if (hits) {

@@ -47,6 +47,8 @@ struct SdArgs {
     uint32_t cap;
     unsigned long long *stats;   // optional [4]: wave steps, cooperative find_perfect calls, cooperative trims, save/evicts
     uint32_t *ovf;               // max over chunks of (intervals produced) when that exceeds cap, else untouched
+    uint32_t *slots;             // sdust_w64: [n_chunks][64] P slots (start & 63 -> r | l << 16), global memory
+    int32_t map_stride;          // chunk -> lane mapping (0: 64-wave groups, 1: strided over the grid)
 };
 
 template <int RC>  // ring / slot capacity, power of two >= W - 2
@@ -281,15 +283,13 @@ __global__ __launch_bounds__(64) void sdust_kernel(SdArgs A)
 //   * for m <= 4 (T <= 24, the default) even that ballot is avoided: per 3-mer the low bytes of the
 //     positions of its last 4 pushes are kept in one LDS dword; they are trusted only when cw[t] >= m,
 //     which guarantees those pushes lie inside the <= 64-word window, so 8 bits identify them.
-// Chunks are dealt to lanes interleaved over groups of 64 waves, so that a long low-complexity array
-// (telomere, satellite) is spread over many waves instead of serialising inside one.
+// Chunks are dealt to lanes strided over the whole grid, so that a long low-complexity array (telomere,
+// satellite) is spread over many waves instead of serialising inside one.
 // ---------------------------------------------------------------------------------------------------
 struct SdLds64 {
     uint8_t ring[16][64][4];   // [slot >> 2][lane][slot & 3], slot = absolute word index & 63
     uint32_t cwq[64][64];      // [3-mer][lane]: bits 6:0 = cw (copies in the window); bits 30:7 = (absolute index & 63)
                                //   of its last 4 pushes, 6 bits each, newest lowest
-    uint32_t slot[64][65];     // [lane][start & 63] = r | l << 16; a row per lane: the cooperative pass reads one row
-                               //   conflict-free (the per-lane accesses are the rare ones); 65: odd row stride
 };
 
 // seq_nt4_table (src/sdust/sdust.c:23-40) without a table: A/a C/c G/g T/t -> 0..3, bytes 0..3 -> themselves, else 4
@@ -359,10 +359,14 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
     for (int i = 0; i < 64; ++i) S.cwq[i][lane] = 0;
     __syncthreads();
 
-    // chunk of this lane: interleaved inside groups of 64 waves (4096 consecutive chunks), so that
-    // neighbouring chunks (one low-complexity array spans many of them) land in different waves while a
-    // wave's 64 streams stay within a few MB (TLB / DRAM-page locality).  The grid is padded to whole groups.
-    const int cid = (((int)blockIdx.x >> 6) << 12) + lane * 64 + ((int)blockIdx.x & 63);
+    // chunk of this lane: strided over the whole grid (lane l of wave w owns chunk l * waves + w).  A wave's 64
+    // lanes then sample 64 far-apart places of the input, so the share of low-complexity lanes in a wave is the
+    // global average instead of the local one (a telomere array or a satellite-rich small contig no longer
+    // serialises inside one wave: 50 -> 28 ms on the 3.16 Gbp assembly), while the waves resident at any time
+    // still advance through 64 compact regions (no measurable memory penalty).  map_stride = 0 keeps the
+    // older 64-wave group interleave for comparison.
+    int cid = lane * (int)gridDim.x + (int)blockIdx.x;
+    if (!A.map_stride) cid = (((int)blockIdx.x >> 6) << 12) + lane * 64 + ((int)blockIdx.x & 63);
     bool active = cid < A.n_chunks;
 
     const int T = A.T, W = A.W, CAPW = W - 2;
@@ -375,6 +379,9 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
         len = A.ctg_len[ch.ctg];
         seq = A.bases + A.ctg_off[ch.ctg];
     }
+    // P slots of this lane: one 256-byte row in global memory (L2 resident; touched only around
+    // find_perfect / save_masked_regions), which keeps the per-wave LDS at 20 KB = 8 waves per CU
+    uint32_t *myslots = A.slots + (size_t)(active ? cid : 0) * 64;
 #define RINGL(sl) S.ring[((sl) & 63) >> 2][lane][(sl) & 3]
 #define CWQ(t) S.cwq[(t)][lane]
 
@@ -394,6 +401,7 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
             u = p > 0 ? p : 0;
         }
     }
+    u &= ~3;   // starting a little earlier is still exact, and keeps every lane on the same 4-byte phase
 
     // ---- per-lane sequential state --------------------------------------------------------------------
     int l = 0, size = 0, rw = 0;
@@ -423,7 +431,7 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
     };
     // save_masked_regions(start) when it does something: occ != 0 && minstart < start   (:88-102)
     auto save_evict = [&](int start, int now) {
-        const uint32_t sl = S.slot[lane][minstart & 63];
+        const uint32_t sl = __hip_atomic_load(&myslots[minstart & 63], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (now >= rec_from) emit(minstart, minstart + (int)(sl >> 16) + 3);
         const int gone = start - minstart;           // starts minstart .. start-1 leave the window
         if (gone >= 64) {
@@ -439,100 +447,109 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
     int i = u;
     uint32_t word = 0, nextw = 0;
     if (active && u < len) {
-        word = *reinterpret_cast<const uint32_t *>(seq + (u & ~3)) >> (8 * (u & 3));
-        if ((u & ~3) + 4 < len) nextw = *reinterpret_cast<const uint32_t *>(seq + (u & ~3) + 4);
+        word = *reinterpret_cast<const uint32_t *>(seq + u);
+        if (u + 4 < len) nextw = *reinterpret_cast<const uint32_t *>(seq + u + 4);
     }
     active = active && i < stop;
+    const bool small_t = T <= 100000;   // L*T < 2^24: 24-bit multiplies are exact
 
     unsigned st_steps = 0, st_fp = 0, st_trim = 0;
-    while (__any(active)) {
+    for (unsigned k = 0; __any(active); ++k) {
+        ++st_steps;
+        if ((k & 3) == 0 && k != 0) {                // wave-uniform: one dword per 4 steps, fetched 4 steps ahead
+            word = nextw;
+            if (active && i + 4 < len) nextw = *reinterpret_cast<const uint32_t *>(seq + i + 4);
+        }
+        const int b = (active && i < len) ? nt4_code(word & 0xFFu) : 4;
+        word >>= 8;
+        const bool isbase = b < 4;
+        const int l_old = l;
+        l = isbase ? l + 1 : 0;
+        t = isbase ? ((t << 2 | (unsigned)b) & 63u) : 0u;                     // :144 / :154
+        const bool isword = active && isbase && l >= 3;
         bool need_trim = false, need_fp = false;
         int start = 0;
-        ++st_steps;
-        if (active) {
-            if ((i & 3) == 0 && i != u) {            // one dword per 4 steps, fetched 4 steps ahead
-                word = nextw;
-                if (i + 4 < len) nextw = *reinterpret_cast<const uint32_t *>(seq + i + 4);
-            }
-            const int b = i < len ? nt4_code(word & 0xFFu) : 4;
-            word >>= 8;
-            if (b < 4) {
-                ++l;
-                t = (t << 2 | (unsigned)b) & 63u;                            // :144
-                if (l >= 3) {
-                    start = (l - W > 0 ? l - W : 0) + (i + 1 - l);           // :146
-                    if (occ && minstart < start) save_evict(start, i);      // :147 (rare)
-                    // shift_window (:66-86) without cv / rv, straight-line: both table entries are read at
-                    // once (the oldest word was prefetched at the end of the previous word step)
-                    const uint32_t pop = size >= CAPW ? 1u : 0u;
-                    const unsigned s = s_pref;
-                    uint32_t es = CWQ(s);
-                    uint32_t et = CWQ(t);
-                    es -= pop;                               // --cw[s]   (:71)
-                    CWQ(s) = es;
-                    if (s == t) et = es;
-                    rw -= pop ? (int)(es & 127u) : 0;
-                    size -= (int)pop;
-                    ++p;
-                    RINGL(p) = (uint8_t)t;                   // :75
-                    ++size;
-                    const int c = (int)(et & 127u);
-                    rw += c;                                 // rw += cw[t]++   (:77)
-                    const uint32_t hist = et >> 7;           // last pushes of t, newest in the low 6 bits
-                    CWQ(t) = (uint32_t)(c + 1) | ((((hist << 6) | ((uint32_t)p & 63u)) & 0xFFFFFFu) << 7);
-                    if (m <= 4) {
-                        // v must not hold more than m copies of t: if the window held >= m before this push,
-                        // v now starts no earlier than just after the m-th most recent earlier push of t
-                        // (inside the <= 64-word window, so 6 bits identify it)
-                        if (m == 0) {
-                            vs = p + 1;
-                        } else if (c >= m) {
-                            const int o = p - (int)(((uint32_t)p - (hist >> (6 * (m - 1)))) & 63u);
-                            if (o + 1 > vs) vs = o + 1;
-                        }
-                    } else {
-                        need_trim = c + 1 > m;       // only then can the count inside v exceed m
-                    }
-                    s_pref = RINGL(p - size + 1);    // the word the next pop removes
-                    need_fp = true;                  // decided after the trim below
-                }
-            } else {
-                int st = (l - W + 1 > 0 ? l - W + 1 : 0) + (i + 1 - l);       // :152
-                while (occ) {                                                // :153
+
+        // ---- N or end of sequence with a non-empty P: flush (:152-153).  Rare: one wave-uniform test.
+        if (__any(active && !isbase && occ != 0)) {
+            if (active && !isbase) {
+                int st = (l_old - W + 1 > 0 ? l_old - W + 1 : 0) + (i + 1 - l_old);
+                while (occ) {
                     if (minstart >= st) st = minstart + 1;
                     save_evict(st, i);
                     ++st;
                 }
-                l = 0;
-                t = 0;                                                       // :154
             }
         }
-        // ---- cooperative trim: vs moves just past the (m+1)-th most recent occurrence of t inside v ----
-        unsigned long long todo = __ballot(need_trim);
-        st_trim += (unsigned)__popcll(todo);
-        while (todo) {
-            const int o = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
-            todo &= todo - 1;
-            const int o_p = rdlane(p, o), o_size = rdlane(size, o), o_vs = rdlane(vs, o);
-            const unsigned o_t = (unsigned)rdlane((int)t, o);
-            const unsigned mine = S.ring[lane >> 2][o][lane & 3];             // ring slot `lane` of the owner
-            const unsigned long long eq = __ballot(mine == o_t);
-            // chronological order: bit k <-> absolute word index o_p - 63 + k
-            const unsigned long long chron = rotr64(eq, (o_p + 1) & 63);
-            const int ws = o_p - o_size + 1;
-            const int first = o_vs > ws ? o_vs : ws;                           // first word of v before the trim
-            const int Lc = o_p - first + 1;                                    // 1..64
-            const unsigned long long inv = chron & (Lc >= 64 ? ~0ull : ~0ull << (64 - Lc));
-            if (__popcll(inv) > m) {
-                const int oldest = __builtin_ctzll(inv);                       // oldest occurrence of t inside v
-                if (lane == o) vs = o_p - 63 + oldest + 1;
+        if (isword) {
+            start = (l - W > 0 ? l - W : 0) + (i + 1 - l);                  // :146
+        }
+        // ---- save_masked_regions (:147).  Rare as well.
+        if (__any(isword && occ != 0 && minstart < start)) {
+            if (isword && occ != 0 && minstart < start) save_evict(start, i);
+        }
+        if (isword) {
+            // shift_window (:66-86) without cv / rv, straight-line: both table entries are read at once
+            // (the oldest word was prefetched at the end of the previous word step)
+            const uint32_t pop = size >= CAPW ? 1u : 0u;
+            const unsigned s = s_pref;
+            uint32_t es = CWQ(s);
+            uint32_t et = CWQ(t);
+            es -= pop;                               // --cw[s]   (:71)
+            CWQ(s) = es;
+            if (s == t) et = es;
+            rw -= pop ? (int)(es & 127u) : 0;
+            size += 1 - (int)pop;
+            ++p;
+            RINGL(p) = (uint8_t)t;                   // :75
+            const int c = (int)(et & 127u);
+            rw += c;                                 // rw += cw[t]++   (:77)
+            const uint32_t hist = et >> 7;           // last pushes of t, newest in the low 6 bits
+            CWQ(t) = (uint32_t)(c + 1) | ((((hist << 6) | ((uint32_t)p & 63u)) & 0xFFFFFFu) << 7);
+            if (m <= 4) {
+                // v must not hold more than m copies of t: if the window held >= m before this push, v now
+                // starts no earlier than just after the m-th most recent earlier push of t (inside the
+                // <= 64-word window, so 6 bits identify it)
+                if (m == 0) {
+                    vs = p + 1;
+                } else if (c >= m) {
+                    const int o = p - (int)(((uint32_t)p - (hist >> (6 * (m - 1)))) & 63u);
+                    vs = o + 1 > vs ? o + 1 : vs;
+                }
+            } else {
+                need_trim = c + 1 > m;               // only then can the count inside v exceed m
+            }
+            s_pref = RINGL(p - size + 1);            // the word the next pop removes
+        }
+        // ---- cooperative trim for m > 4: vs moves just past the (m+1)-th most recent occurrence of t in v ----
+        unsigned long long todo = 0;
+        if (m > 4) {
+            todo = __ballot(need_trim);
+            st_trim += (unsigned)__popcll(todo);
+            while (todo) {
+                const int o = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+                todo &= todo - 1;
+                const int o_p = rdlane(p, o), o_size = rdlane(size, o), o_vs = rdlane(vs, o);
+                const unsigned o_t = (unsigned)rdlane((int)t, o);
+                const unsigned mine = S.ring[lane >> 2][o][lane & 3];             // ring slot `lane` of the owner
+                const unsigned long long eq = __ballot(mine == o_t);
+                // chronological order: bit k <-> absolute word index o_p - 63 + k
+                const unsigned long long chron = rotr64(eq, (o_p + 1) & 63);
+                const int ws = o_p - o_size + 1;
+                const int first = o_vs > ws ? o_vs : ws;                           // first word of v before the trim
+                const int Lc = o_p - first + 1;                                    // 1..64
+                const unsigned long long inv = chron & (Lc >= 64 ? ~0ull : ~0ull << (64 - Lc));
+                if (__popcll(inv) > m) {
+                    const int oldest = __builtin_ctzll(inv);                       // oldest occurrence of t inside v
+                    if (lane == o) vs = o_p - 63 + oldest + 1;
+                }
             }
         }
-        if (need_fp) {
+        if (isword) {
             const int ws = p - size + 1;
             const int first = vs > ws ? vs : ws;
             const int L = p - first + 1;
-            need_fp = rw * 10 > L * T;                                         // :149
+            need_fp = small_t ? (rw * 10 > __mul24(L, T)) : (rw * 10 > L * T);     // :149
         }
         // ---- cooperative find_perfect (:104-128) ------------------------------------------------------
         // lane <-> window position j = 63 - lane, so that "suffix of the window" = "prefix of the wave" and
@@ -560,14 +577,16 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
             // equal words at later window positions = lower lanes; suffix score r_j = inclusive prefix sum
             const int r = wave_scan_add(inwin ? __popcll(eq & ((1ull << lane) - 1ull)) : 0);
             const int new_l = o_size - j - 1;                                  // :111
-            const bool cand = inwin && j <= i0 && r * 10 > T * new_l;          // :112
+            const bool cand = inwin && j <= i0 && r * 10 > __mul24(T, new_l);  // :112 (new_l < 64, T < 2^21)
             const unsigned long long candmask = __ballot(cand);
             if (candmask == 0) continue;                                       // nothing can be inserted
             const int o_start = rdlane(start, o);
             const unsigned long long o_occ = rdlane64(occ, o);
+            const int o_cid = rdlane(cid, o);
+            uint32_t *orow = A.slots + (size_t)o_cid * 64;
             const int sidx = (o_start + j) & 63;
             const bool has_e = inwin && ((o_occ >> sidx) & 1ull);
-            const uint32_t e = has_e ? S.slot[o][sidx] : 0u;
+            const uint32_t e = has_e ? __hip_atomic_load(&orow[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             const int er = (int)(e & 0xFFFFu), el = (int)(e >> 16);
             // X_j = better of (existing entry with this start, candidate j); inclusive maximum over positions >= j
             int xr = er, xl = el;
@@ -579,7 +598,7 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
             int mr = sr, ml = sl2;                                             // :113-117: entries with start >= i + start
             if (er != 0 && (sr == 0 || __mul24(er, sl2) > __mul24(sr, el))) { mr = er; ml = el; }
             const bool ins = cand && (mr == 0 || __mul24(r, ml) >= __mul24(mr, new_l));   // :118
-            if (ins) S.slot[o][sidx] = (uint32_t)r | ((uint32_t)new_l << 16);  // start = i + start, finish = start + l + 3
+            if (ins) orow[sidx] = (uint32_t)r | ((uint32_t)new_l << 16);       // start = i + start, finish = start + l + 3
             const unsigned long long insj = __brevll(__ballot(ins));           // bit j <-> window position j
             if (insj && lane == o) {
                 const int lowest = o_start + __builtin_ctzll(insj);
@@ -687,12 +706,14 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             d_out = (uint2 *)cn_ws(h, WS_SD_OUT, nc * cap * sizeof(uint2));
             if (!d_out) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation of %zu bytes failed", nc * cap * sizeof(uint2));
             CN_HIP(h, hipMemsetAsync(d_tot, 0, 64, h->stream));
+            uint32_t *d_slots = (uint32_t *)cn_ws(h, WS_SD_OFF, nc * 64 * sizeof(uint32_t));
+            if (!d_slots) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
             SdArgs A{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, d_out, d_cnt, (uint32_t)cap,
-                     want_stats ? d_tot + 2 : nullptr, reinterpret_cast<uint32_t *>(d_tot + 1)};
+                     want_stats ? d_tot + 2 : nullptr, reinterpret_cast<uint32_t *>(d_tot + 1), d_slots, env_int("CORNETTO_SDUST_MAP", 1)};
             unsigned nb = (unsigned)((nc + 63) / 64);
             const int variant = env_int("CORNETTO_SDUST_VARIANT", 0);   // 1 = force the per-lane reference-shaped kernel
             if (W - 2 <= 64 && variant == 0) {
-                nb = (unsigned)((nc + 4095) / 4096) * 64;   // whole groups of 64 waves
+                if (env_int("CORNETTO_SDUST_MAP", 1) == 0) nb = (unsigned)((nc + 4095) / 4096) * 64;   // whole groups of 64 waves
                 CN_LAUNCH(h, "sdust_kernel", sdust_w64<<<dim3(nb), dim3(64), 0, h->stream>>>(A));
             } else if (W - 2 <= 64) {
                 CN_LAUNCH(h, "sdust_kernel", sdust_kernel<64><<<dim3(nb), dim3(64), 0, h->stream>>>(A));

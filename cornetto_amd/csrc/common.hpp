@@ -230,3 +230,8 @@ struct cornetto_cov {
 };
 
 static inline int64_t cn_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// Result arrays handed to the caller.  Small ones are malloc'd; large ones (>= 1 MiB) come from a process-wide
+// pool of pinned host buffers, so the device-to-host copy runs at full PCIe rate and never page-faults on
+// fresh memory.  Either kind is released with cornetto_free() (runtime.hip).
+void *cn_result_alloc(size_t bytes);

@@ -450,12 +450,12 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
         if (attempt == 1 || cnt > 0x7fffffffull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "cov: %llu selected windows", cnt);
         cap = (size_t)cnt;   // exact rerun, never a truncated answer
     }
-    cornetto_regrec_t *o = (cornetto_regrec_t *)malloc((cnt ? cnt : 1) * sizeof(cornetto_regrec_t));
+    cornetto_regrec_t *o = (cornetto_regrec_t *)cn_result_alloc((cnt ? cnt : 1) * sizeof(cornetto_regrec_t));
     if (!o) return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: host allocation failed");
     if (cnt) {
         // tiles are in (contig, window) order: exclusive scan of their counts = final position of each segment
         int rc = cnscan::exclusive_u32(h, "cov_order", reinterpret_cast<const uint32_t *>(d_tres) + 1, (int64_t)nt, 2, d_ooff, d_part, nullptr);
-        if (rc != CORNETTO_OK) { free(o); return rc; }
+        if (rc != CORNETTO_OK) { cornetto_free(o); return rc; }
         const unsigned nb = (unsigned)((nt + 3) / 4);
         hipEvent_t ea = cn_event(h), eb = cn_event(h);
         (void)hipEventRecord(ea, h->stream);
@@ -464,7 +464,7 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
         h->recs.push_back(cornetto_accel::Rec{"cov_order", ea, eb});
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(o, d_dst, (size_t)cnt * sizeof(cornetto_regrec_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess) {
-            free(o);
+            cornetto_free(o);
             return cn_fail(h, CORNETTO_E_HIP, "cov_select: ordering / copy back failed");
         }
     }

@@ -2,6 +2,41 @@
 // C ABI declared in include/cornetto_accel.h.
 #include "common.hpp"
 
+#include <map>
+#include <mutex>
+#include <unordered_map>
+
+// ---- pinned result pool ------------------------------------------------------------------------------
+namespace {
+std::mutex g_pool_mu;
+std::unordered_map<void *, size_t> g_pool_live;      // pinned buffers currently owned by callers
+std::multimap<size_t, void *> g_pool_free;           // pinned buffers ready for reuse, by capacity
+constexpr size_t POOL_MIN = 1u << 20;                // below this, plain malloc
+constexpr size_t POOL_KEEP = 8;                      // free buffers kept before releasing to the driver
+}  // namespace
+
+void *cn_result_alloc(size_t bytes)
+{
+    if (bytes < POOL_MIN) return malloc(bytes ? bytes : 1);
+    size_t cap = POOL_MIN;
+    while (cap < bytes) cap <<= 1;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_pool_free.lower_bound(cap);
+        if (it != g_pool_free.end() && it->first <= 2 * cap) {
+            void *p = it->second;
+            g_pool_live[p] = it->first;
+            g_pool_free.erase(it);
+            return p;
+        }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess || !p) return malloc(bytes);
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_live[p] = cap;
+    return p;
+}
+
 extern "C" {
 
 int cornetto_accel_device_count(void)
@@ -67,7 +102,28 @@ const char *cornetto_accel_strerror(int status)
     }
 }
 
-void cornetto_free(void *p) { free(p); }
+void cornetto_free(void *p)
+{
+    if (!p) return;
+    void *drop = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_pool_live.find(p);
+        if (it == g_pool_live.end()) {
+            drop = nullptr;
+        } else {
+            const size_t cap = it->second;
+            g_pool_live.erase(it);
+            if (g_pool_free.size() < POOL_KEEP) {
+                g_pool_free.emplace(cap, p);
+                return;
+            }
+            drop = p;
+        }
+    }
+    if (drop) (void)hipHostFree(drop);
+    else free(p);
+}
 
 int cornetto_accel_last_timing(const cornetto_accel_t *h, const char **names, float *ms, int cap)
 {

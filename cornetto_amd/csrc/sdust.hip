@@ -444,34 +444,47 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
         if (occ) minstart = start + __builtin_ctzll(rotr64(occ, start & 63));
     };
 
-    int i = u;
     uint32_t word = 0, nextw = 0;
     if (active && u < len) {
         word = *reinterpret_cast<const uint32_t *>(seq + u);
         if (u + 4 < len) nextw = *reinterpret_cast<const uint32_t *>(seq + u + 4);
     }
-    active = active && i < stop;
+    active = active && u < stop;
     const bool small_t = T <= 100000;   // L*T < 2^24: 24-bit multiplies are exact
+    const int hshift = m >= 1 && m <= 4 ? 6 * (m - 1) : 0;
 
     unsigned st_steps = 0, st_fp = 0, st_trim = 0;
-    for (unsigned k = 0; __any(active); ++k) {
+    // Everything in the loop body is predicated arithmetic except three regions: the two rare P-maintenance
+    // paths (entered on a wave-uniform test) and the word step itself.  Lanes that are done (or never had a
+    // chunk) see b = 4 with an empty P and change nothing.
+    for (int k4 = 0; __any(active); k4 += 4) {
+        // one dword per lane per 4 steps, fetched 4 steps ahead (the wait lands here, a whole group later)
+        if (k4 != 0) word = nextw;
+        if (active && u + k4 + 4 < len) nextw = *reinterpret_cast<const uint32_t *>(seq + u + k4 + 4);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
         ++st_steps;
-        if ((k & 3) == 0 && k != 0) {                // wave-uniform: one dword per 4 steps, fetched 4 steps ahead
-            word = nextw;
-            if (active && i + 4 < len) nextw = *reinterpret_cast<const uint32_t *>(seq + i + 4);
-        }
-        const int b = (active && i < len) ? nt4_code(word & 0xFFu) : 4;
-        word >>= 8;
+        const int i = u + k4 + kk;                   // position of this lane; all lanes share i & 3
+        const uint32_t c = (word >> (8 * kk)) & 0xFFu;
+        // seq_nt4_table (:23-40): A/a C/c G/g T/t -> 0..3, bytes 0..3 -> themselves, everything else 4
+        const uint32_t cl = c | 0x20u, idx = cl - 0x61u;                    // a=0 c=2 g=6 t=19
+        uint32_t code = (cl >> 1) & 3u;                                      // a0 c1 g3 t2
+        code ^= code >> 1;                                                   // a0 c1 g2 t3
+        const uint32_t acgt = (uint32_t)(idx < 20u) & ((0x80045u >> (idx & 31u)) & 1u);
+        const uint32_t other = c < 4u ? c : 4u;
+        const uint32_t msk = 0u - (acgt & (uint32_t)(active & (i < len)));   // all ones: an A/C/G/T inside the contig
+        const uint32_t inb = 0u - (uint32_t)(active & (i < len));
+        const int b = (int)((code & msk) | (((other & inb) | (4u & ~inb)) & ~msk));
         const bool isbase = b < 4;
         const int l_old = l;
         l = isbase ? l + 1 : 0;
         t = isbase ? ((t << 2 | (unsigned)b) & 63u) : 0u;                     // :144 / :154
-        const bool isword = active && isbase && l >= 3;
+        const bool isword = isbase & (l >= 3);
+        const int start = (l - W > 0 ? l - W : 0) + (i + 1 - l);             // :146 (meaningful when isword)
         bool need_trim = false, need_fp = false;
-        int start = 0;
 
         // ---- N or end of sequence with a non-empty P: flush (:152-153).  Rare: one wave-uniform test.
-        if (__any(active && !isbase && occ != 0)) {
+        if (__any(active & !isbase & (occ != 0))) {
             if (active && !isbase) {
                 int st = (l_old - W + 1 > 0 ? l_old - W + 1 : 0) + (i + 1 - l_old);
                 while (occ) {
@@ -481,11 +494,8 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
                 }
             }
         }
-        if (isword) {
-            start = (l - W > 0 ? l - W : 0) + (i + 1 - l);                  // :146
-        }
         // ---- save_masked_regions (:147).  Rare as well.
-        if (__any(isword && occ != 0 && minstart < start)) {
+        if (__any(isword & (occ != 0) & (minstart < start))) {
             if (isword && occ != 0 && minstart < start) save_evict(start, i);
         }
         if (isword) {
@@ -497,27 +507,25 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
             uint32_t et = CWQ(t);
             es -= pop;                               // --cw[s]   (:71)
             CWQ(s) = es;
-            if (s == t) et = es;
-            rw -= pop ? (int)(es & 127u) : 0;
+            et = s == t ? es : et;
+            rw -= (int)((es & 127u) * pop);
             size += 1 - (int)pop;
             ++p;
             RINGL(p) = (uint8_t)t;                   // :75
-            const int c = (int)(et & 127u);
-            rw += c;                                 // rw += cw[t]++   (:77)
+            const int c1 = (int)(et & 127u);
+            rw += c1;                                // rw += cw[t]++   (:77)
             const uint32_t hist = et >> 7;           // last pushes of t, newest in the low 6 bits
-            CWQ(t) = (uint32_t)(c + 1) | ((((hist << 6) | ((uint32_t)p & 63u)) & 0xFFFFFFu) << 7);
-            if (m <= 4) {
+            CWQ(t) = (uint32_t)(c1 + 1) | ((((hist << 6) | ((uint32_t)p & 63u)) & 0xFFFFFFu) << 7);
+            if (m <= 4) {                            // wave-uniform
                 // v must not hold more than m copies of t: if the window held >= m before this push, v now
                 // starts no earlier than just after the m-th most recent earlier push of t (inside the
                 // <= 64-word window, so 6 bits identify it)
-                if (m == 0) {
-                    vs = p + 1;
-                } else if (c >= m) {
-                    const int o = p - (int)(((uint32_t)p - (hist >> (6 * (m - 1)))) & 63u);
-                    vs = o + 1 > vs ? o + 1 : vs;
-                }
+                const int o1 = p - (int)(((uint32_t)p - (hist >> hshift)) & 63u) + 1;
+                int cand_vs = c1 >= m ? o1 : vs;
+                cand_vs = m == 0 ? p + 1 : cand_vs;
+                vs = cand_vs > vs ? cand_vs : vs;
             } else {
-                need_trim = c + 1 > m;               // only then can the count inside v exceed m
+                need_trim = c1 + 1 > m;              // only then can the count inside v exceed m
             }
             s_pref = RINGL(p - size + 1);            // the word the next pop removes
         }
@@ -545,11 +553,11 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
                 }
             }
         }
-        if (isword) {
+        {
             const int ws = p - size + 1;
             const int first = vs > ws ? vs : ws;
             const int L = p - first + 1;
-            need_fp = small_t ? (rw * 10 > __mul24(L, T)) : (rw * 10 > L * T);     // :149
+            need_fp = isword & (small_t ? (rw * 10 > __mul24(L, T)) : (rw * 10 > L * T));     // :149
         }
         // ---- cooperative find_perfect (:104-128) ------------------------------------------------------
         // lane <-> window position j = 63 - lane, so that "suffix of the window" = "prefix of the wave" and
@@ -606,18 +614,16 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
                 occ |= rotl64(insj, o_start & 63);
             }
         }
-        if (active) {
-            ++i;
-            if (i >= stop) {
-                active = false;
-                if (have_last) {
-                    if (n_out < A.cap) out[n_out] = make_uint2(last_s, last_f);
-                    ++n_out;
-                }
-                A.out_n[cid] = n_out;
-                if (n_out > A.cap) atomicMax(A.ovf, n_out);
-            }
+        active = active & (i + 1 < stop);
+      }
+    }
+    if (cid < A.n_chunks) {                          // every lane that owned a chunk publishes its list
+        if (have_last) {
+            if (n_out < A.cap) out[n_out] = make_uint2(last_s, last_f);
+            ++n_out;
         }
+        A.out_n[cid] = n_out;
+        if (n_out > A.cap) atomicMax(A.ovf, n_out);
     }
     if (A.stats && lane == 0) {
         atomicAdd(&A.stats[0], (unsigned long long)st_steps);
@@ -667,7 +673,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
     // enough that the ~3W-base speculative warm-up stays a few percent.  CORNETTO_SDUST_CHUNK overrides
     // (tests use tiny chunks to stress the speculative start).
     int64_t chunk = env_int("CORNETTO_SDUST_CHUNK", 0);
-    if (chunk <= 0) chunk = 2048;
+    if (chunk <= 0) chunk = 1536;
     chunk = std::max<int64_t>(16, chunk);
     if (a->sd_chunk != chunk) {
         std::vector<SdChunk> chunks;
@@ -735,12 +741,12 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             cap = ovf;   // rerun with room for the densest chunk: results are never truncated
         }
         if (tot > 0x7fffffffull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "sdust: %llu intervals", tot);
-        o = (cornetto_ivl_t *)malloc((tot ? tot : 1) * sizeof(cornetto_ivl_t));
+        o = (cornetto_ivl_t *)cn_result_alloc((tot ? tot : 1) * sizeof(cornetto_ivl_t));
         if (!o) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: host allocation failed");
         if (tot > 0) {
             cornetto_ivl_t *d_dst = (cornetto_ivl_t *)cn_ws(h, WS_SD_DST, (size_t)tot * sizeof(cornetto_ivl_t));
             cornetto_ivl_t *p_dst = (cornetto_ivl_t *)cn_pin(h, PIN_A, (size_t)tot * sizeof(cornetto_ivl_t));
-            if (!d_dst || !p_dst) { free(o); return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed"); }
+            if (!d_dst || !p_dst) { cornetto_free(o); return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed"); }
             const unsigned nbg = (unsigned)((nc + 3) / 4);
             hipEvent_t ea = cn_event(h), eb = cn_event(h);
             (void)hipEventRecord(ea, h->stream);
@@ -750,7 +756,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             if (hipGetLastError() != hipSuccess ||
                 hipMemcpyAsync(p_dst, d_dst, (size_t)tot * sizeof(cornetto_ivl_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
                 hipStreamSynchronize(h->stream) != hipSuccess) {
-                free(o);
+                cornetto_free(o);
                 return cn_fail(h, CORNETTO_E_HIP, "sdust: gather / copy back failed");
             }
             // stitch chunk lists in order with the reference's merge rule (src/sdust/sdust.c:94-98)

@@ -619,7 +619,7 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
                 uint32_t *d_coff = (uint32_t *)cn_ws(h, WS_TF_ROFF, 4 * ((size_t)a->n + 1) * 4);
                 cornetto_hit_t *d_hits = (cornetto_hit_t *)cn_ws(h, WS_TF_HITS, tot * sizeof(cornetto_hit_t));
                 if (!d_coff || !d_hits) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: workspace allocation failed");
-                out = (cornetto_hit_t *)malloc((tot ? tot : 1) * sizeof(cornetto_hit_t));
+                out = (cornetto_hit_t *)cn_result_alloc((tot ? tot : 1) * sizeof(cornetto_hit_t));
                 if (!out) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: host allocation failed");
                 hipEvent_t ea = cn_event(h), eb = cn_event(h);
                 (void)hipEventRecord(ea, h->stream);
@@ -635,7 +635,7 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
                 if (tot) ok = ok && hipMemcpyAsync(out, d_hits, tot * sizeof(cornetto_hit_t), hipMemcpyDeviceToHost, h->stream) == hipSuccess;
                 ok = ok && hipStreamSynchronize(h->stream) == hipSuccess;
                 if (!ok || (p_cnt[4] >> 32) != 0) {
-                    free(out);
+                    cornetto_free(out);
                     return cn_fail(h, CORNETTO_E_HIP, "telofind: pairing run heads with tails failed%s", ok ? " (a contig has unequal heads and tails)" : "");
                 }
                 n_out = (int64_t)tot;

@@ -12,7 +12,9 @@
  * Conventions
  *   - every function returns 0 (CORNETTO_OK) or a negative CORNETTO_E_* status; nothing calls exit()
  *     (the reference's ERROR()+exit(EXIT_FAILURE), src/error.h:97-103, is done by the CLI mains);
- *   - result arrays are malloc'd by the library and released with cornetto_free();
+ *   - result arrays are allocated by the library (malloc, or pinned host memory from a pool for large
+ *     results) and MUST be released with cornetto_free(), never free(); the one exception is
+ *     cornetto_sdust(), which keeps the reference's contract (caller free()s);
  *   - calls are synchronous; one cornetto_accel_t may be used by one host thread at a time;
  *   - coordinates are 0-based, half-open, per contig, 32-bit (kseq_read returns int: src/kseq.h:185).
  */
@@ -107,7 +109,7 @@ int cornetto_asm_upload(cornetto_accel_t *h, const uint8_t *const *seqs, const i
                         cornetto_asm_t **out);
 
 /* Wrap bases that already are in device memory: contig i occupies d_bases[offsets[i] .. offsets[i]+lens[i]).
- * Every offset must be a multiple of 64 and the buffer must stay readable for 64 bytes past the last
+ * Every offset must be a multiple of 64 and the buffer must stay readable for 128 bytes past the last
  * contig (padding content is ignored).  The buffer is borrowed, never freed. */
 int cornetto_asm_wrap(cornetto_accel_t *h, const void *d_bases, const int64_t *offsets, const int64_t *lens,
                       int32_t n, cornetto_asm_t **out);

@@ -280,16 +280,13 @@ __global__ __launch_bounds__(64) void sdust_kernel(SdArgs A)
 //     P entries / earlier candidates is a suffix-max scan with exact cross-multiplied ratio compares.
 //   * P occupancy is a 64-bit mask per lane (bit = start & 63), so save_masked_regions (:88-102) and the
 //     N flush (:153) are rotates / ctz instead of list walks.
-//   * for m <= 4 (T <= 24, the default) even that ballot is avoided: per 3-mer the low bytes of the
-//     positions of its last 4 pushes are kept in one LDS dword; they are trusted only when cw[t] >= m,
-//     which guarantees those pushes lie inside the <= 64-word window, so 8 bits identify them.
+//     Per-lane LDS state is just the ring and the 64 byte counters (8 KB per wave): 20 waves per CU.
 // Chunks are dealt to lanes strided over the whole grid, so that a long low-complexity array (telomere,
 // satellite) is spread over many waves instead of serialising inside one.
 // ---------------------------------------------------------------------------------------------------
 struct SdLds64 {
     uint8_t ring[16][64][4];   // [slot >> 2][lane][slot & 3], slot = absolute word index & 63
-    uint32_t cwq[64][64];      // [3-mer][lane]: bits 6:0 = cw (copies in the window); bits 30:7 = (absolute index & 63)
-                               //   of its last 4 pushes, 6 bits each, newest lowest
+    uint8_t cw[16][64][4];     // [3-mer >> 2][lane][3-mer & 3] = copies of the 3-mer in the window
 };
 
 // seq_nt4_table (src/sdust/sdust.c:23-40) without a table: A/a C/c G/g T/t -> 0..3, bytes 0..3 -> themselves, else 4
@@ -356,7 +353,7 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
 {
     __shared__ SdLds64 S;
     const int lane = threadIdx.x;
-    for (int i = 0; i < 64; ++i) S.cwq[i][lane] = 0;
+    for (int i = 0; i < 16; ++i) *reinterpret_cast<uint32_t *>(S.cw[i][lane]) = 0;
     __syncthreads();
 
     // chunk of this lane: strided over the whole grid (lane l of wave w owns chunk l * waves + w).  A wave's 64
@@ -383,7 +380,7 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
     // find_perfect / save_masked_regions), which keeps the per-wave LDS at 20 KB = 8 waves per CU
     uint32_t *myslots = A.slots + (size_t)(active ? cid : 0) * 64;
 #define RINGL(sl) S.ring[((sl) & 63) >> 2][lane][(sl) & 3]
-#define CWQ(t) S.cwq[(t)][lane]
+#define CWL(t) S.cw[(t) >> 2][lane][(t) & 3]
 
     // ---- warm-up start: W-2 word emissions before (chunk start - 2W) --------------------------------
     int u = 0;
@@ -451,7 +448,6 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
     }
     active = active && u < stop;
     const bool small_t = T <= 100000;   // L*T < 2^24: 24-bit multiplies are exact
-    const int hshift = m >= 1 && m <= 4 ? 6 * (m - 1) : 0;
 
     unsigned st_steps = 0, st_fp = 0, st_trim = 0;
     // Everything in the loop body is predicated arithmetic except three regions: the two rare P-maintenance
@@ -501,37 +497,30 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
         if (isword) {
             // shift_window (:66-86) without cv / rv, straight-line: both table entries are read at once
             // (the oldest word was prefetched at the end of the previous word step)
-            const uint32_t pop = size >= CAPW ? 1u : 0u;
+            const int pop = size >= CAPW ? 1 : 0;
             const unsigned s = s_pref;
-            uint32_t es = CWQ(s);
-            uint32_t et = CWQ(t);
-            es -= pop;                               // --cw[s]   (:71)
-            CWQ(s) = es;
-            et = s == t ? es : et;
-            rw -= (int)((es & 127u) * pop);
-            size += 1 - (int)pop;
+            int cs = CWL(s);
+            int ct = CWL(t);
+            cs -= pop;                               // --cw[s]   (:71)
+            CWL(s) = (uint8_t)cs;
+            ct = s == t ? cs : ct;
+            rw -= cs * pop;
+            size += 1 - pop;
             ++p;
             RINGL(p) = (uint8_t)t;                   // :75
-            const int c1 = (int)(et & 127u);
-            rw += c1;                                // rw += cw[t]++   (:77)
-            const uint32_t hist = et >> 7;           // last pushes of t, newest in the low 6 bits
-            CWQ(t) = (uint32_t)(c1 + 1) | ((((hist << 6) | ((uint32_t)p & 63u)) & 0xFFFFFFu) << 7);
-            if (m <= 4) {                            // wave-uniform
-                // v must not hold more than m copies of t: if the window held >= m before this push, v now
-                // starts no earlier than just after the m-th most recent earlier push of t (inside the
-                // <= 64-word window, so 6 bits identify it)
-                const int o1 = p - (int)(((uint32_t)p - (hist >> hshift)) & 63u) + 1;
-                int cand_vs = c1 >= m ? o1 : vs;
-                cand_vs = m == 0 ? p + 1 : cand_vs;
-                vs = cand_vs > vs ? cand_vs : vs;
-            } else {
-                need_trim = c1 + 1 > m;              // only then can the count inside v exceed m
-            }
+            rw += ct;                                // rw += cw[t]++   (:77)
+            CWL(t) = (uint8_t)(ct + 1);
+            // v must not hold more than m copies of t.  Only when the window now holds more than m can v,
+            // a suffix of it, do so: those lanes get their v start moved by the cooperative pass below.
+            need_trim = ct + 1 > m;
+            if (m == 0) vs = p + 1;
             s_pref = RINGL(p - size + 1);            // the word the next pop removes
         }
-        // ---- cooperative trim for m > 4: vs moves just past the (m+1)-th most recent occurrence of t in v ----
+        // ---- cooperative trim: vs moves just past the (m+1)-th most recent occurrence of t inside v --------
+        // (one ballot over the owner's ring: lane j reads ring slot j; about one lane per wave-step needs it
+        // in non-repetitive sequence)
         unsigned long long todo = 0;
-        if (m > 4) {
+        if (m > 0) {
             todo = __ballot(need_trim);
             st_trim += (unsigned)__popcll(todo);
             while (todo) {
@@ -549,7 +538,7 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
                 const unsigned long long inv = chron & (Lc >= 64 ? ~0ull : ~0ull << (64 - Lc));
                 if (__popcll(inv) > m) {
                     const int oldest = __builtin_ctzll(inv);                       // oldest occurrence of t inside v
-                    if (lane == o) vs = o_p - 63 + oldest + 1;
+                    vs = lane == o ? o_p - 63 + oldest + 1 : vs;
                 }
             }
         }
@@ -631,7 +620,7 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
         atomicAdd(&A.stats[2], (unsigned long long)st_trim);
     }
 #undef RINGL
-#undef CWQ
+#undef CWL
 }
 
 // chunk rows (fixed capacity) -> one dense list in chunk order, tagged with the contig: one wavefront per chunk

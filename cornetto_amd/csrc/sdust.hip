@@ -398,7 +398,7 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
             u = p > 0 ? p : 0;
         }
     }
-    u &= ~3;   // starting a little earlier is still exact, and keeps every lane on the same 4-byte phase
+    u &= ~63;  // starting a little earlier is still exact, and keeps every lane on the same 64-byte phase
 
     // ---- per-lane sequential state --------------------------------------------------------------------
     int l = 0, size = 0, rw = 0;
@@ -441,10 +441,14 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
         if (occ) minstart = start + __builtin_ctzll(rotr64(occ, start & 63));
     };
 
-    uint32_t word = 0, nextw = 0;
+    // Bases are consumed one 64-byte block per lane per 64 steps (4 x dwordx4, fetched a whole block ahead), so
+    // that every 64-byte sector is requested from L2 / the fabric once: with one dword per 4 steps the ~40 k
+    // concurrent per-lane streams of an XCD overflowed its 4 MB L2 and each line was re-fetched ~6 times
+    // (rocprofv3 FETCH_SIZE, profiles/).  A block never leaves its contig: contigs start 64-byte aligned.
+    uint4 nb0 = make_uint4(0, 0, 0, 0), nb1 = nb0, nb2 = nb0, nb3 = nb0;
     if (active && u < len) {
-        word = *reinterpret_cast<const uint32_t *>(seq + u);
-        if (u + 4 < len) nextw = *reinterpret_cast<const uint32_t *>(seq + u + 4);
+        const uint4 *q = reinterpret_cast<const uint4 *>(seq + u);
+        nb0 = q[0]; nb1 = q[1]; nb2 = q[2]; nb3 = q[3];
     }
     active = active && u < stop;
     const bool small_t = T <= 100000;   // L*T < 2^24: 24-bit multiplies are exact
@@ -453,14 +457,22 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
     // Everything in the loop body is predicated arithmetic except three regions: the two rare P-maintenance
     // paths (entered on a wave-uniform test) and the word step itself.  Lanes that are done (or never had a
     // chunk) see b = 4 with an empty P and change nothing.
-    for (int k4 = 0; __any(active); k4 += 4) {
-        // one dword per lane per 4 steps, fetched 4 steps ahead (the wait lands here, a whole group later)
-        if (k4 != 0) word = nextw;
-        if (active && u + k4 + 4 < len) nextw = *reinterpret_cast<const uint32_t *>(seq + u + k4 + 4);
+    for (int k64 = 0; __any(active); k64 += 64) {
+      // current block -> 16 dwords that are rotated down by one per group of 4 steps; next block in flight
+      uint32_t c0 = nb0.x, c1 = nb0.y, c2 = nb0.z, c3 = nb0.w, c4 = nb1.x, c5 = nb1.y, c6 = nb1.z, c7 = nb1.w;
+      uint32_t c8 = nb2.x, c9 = nb2.y, c10 = nb2.z, c11 = nb2.w, c12 = nb3.x, c13 = nb3.y, c14 = nb3.z, c15 = nb3.w;
+      if (active && u + k64 + 64 < len) {
+          const uint4 *q = reinterpret_cast<const uint4 *>(seq + u + k64 + 64);
+          nb0 = q[0]; nb1 = q[1]; nb2 = q[2]; nb3 = q[3];
+      }
+      for (int k4 = k64; k4 < k64 + 64; k4 += 4) {
+        const uint32_t word = c0;
+        c0 = c1; c1 = c2; c2 = c3; c3 = c4; c4 = c5; c5 = c6; c6 = c7; c7 = c8;
+        c8 = c9; c9 = c10; c10 = c11; c11 = c12; c12 = c13; c13 = c14; c14 = c15;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         ++st_steps;
-        const int i = u + k4 + kk;                   // position of this lane; all lanes share i & 3
+        const int i = u + k4 + kk;                   // position of this lane; all lanes share i & 63
         const uint32_t c = (word >> (8 * kk)) & 0xFFu;
         // seq_nt4_table (:23-40): A/a C/c G/g T/t -> 0..3, bytes 0..3 -> themselves, everything else 4
         const uint32_t cl = c | 0x20u, idx = cl - 0x61u;                    // a=0 c=2 g=6 t=19
@@ -604,6 +616,7 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
             }
         }
         active = active & (i + 1 < stop);
+      }
       }
     }
     if (cid < A.n_chunks) {                          // every lane that owned a chunk publishes its list

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--features", type=int, default=1)
     ap.add_argument("--chunk", type=str, default="")
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--simple-cov", type=int, default=0, help="uniform random depth (rocprofv3 --pmc crashes inside torch.poisson)")
     a = ap.parse_args()
     if a.chunk:
         os.environ["CORNETTO_SDUST_CHUNK"] = a.chunk
@@ -48,7 +49,12 @@ def main():
             h, w = acc.telo_scan(asm, b"TTAGGG", 0.3976)
             print("telo", [(k, round(v, 3)) for k, v in acc.last_timing()], len(h), len(w), flush=True)
         if a.stage in ("cov", "all"):
-            depth, mq = bench.make_coverage(torch, dev, lens, offs, 1)
+            if a.simple_cov:
+                tot = int(offs[-1] + (lens[-1] + 63) // 64 * 64 + 256)
+                depth = torch.randint(0, 60, (tot,), dtype=torch.int16, device=dev)
+                mq = depth.clone()
+            else:
+                depth, mq = bench.make_coverage(torch, dev, lens, offs, 1)
             torch.cuda.synchronize()
             cov = acc.cov_wrap(depth.data_ptr(), mq.data_ptr(), offs, np.array(lens, dtype=np.int32))
             s = acc.cov_prepare(cov, 2500, 50)

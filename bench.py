@@ -279,6 +279,16 @@ def main():
                 kern[k]["algorithmic_GBps"] = round(alg[k] / (ms * 1e-3) / 1e9, 2)
         dom = "sdust_kernel"
         ach = alg[dom] / (kavg[dom] * 1e-3) / 1e9 if kavg.get(dom, 0) > 0 else 0.0
+        # HBM/fabric bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
+        # workload (profiles/README.md: FETCH_SIZE and WRITE_SIZE collected in separate passes; for this
+        # kernel's access pattern - one 64-byte sector per lane - FETCH_SIZE is exact, checked against the known
+        # byte count, so no x2 correction is applied), scaled to the bases of this run
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["sdust_w64"]
+            traffic = round((pmc["fetch_bytes_raw"] + pmc["write_bytes"]) * n_bases / pmc.get("bases", 3160108082), 0)
+        except Exception:
+            pass
         line = {
             "metric": "Gbases/s scanned (telowin+sdust+boringbits)", "value": round(value, 4), "unit": "Gbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -289,7 +299,7 @@ def main():
                        "bases_per_gpu": n_bases, "contigs": len(lens), "motif": "TTAGGG", "sdust": "-w 64 -t 20",
                        "windows": "-w 2500 -i 50", "parallelism": "contig-sharded, %d process(es), 1 GPU each" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "note": "sdust is an integer recurrence (LDS-latency/VALU bound), reported against HBM as the contract asks"},
             "kernels": kern,
             "stage_wall_ms": {k: round(float(np.mean(v)), 3) for k, v in wall.items()},

@@ -183,11 +183,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    ndev = torch.cuda.device_count()
+    local_dev = local % max(1, ndev)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    cdev = dev                                   # device of the tensors handed to collectives
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if ndev >= world:
+            dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI, one GPU per rank
+        else:
+            # fewer GPUs than ranks (a 1-GPU test box): ranks share devices and the collectives go over gloo;
+            # exercises the same multi-process control flow, not a performance configuration
+            dist.init_process_group("gloo")
+            cdev = torch.device("cpu")
 
     lens = contig_lengths(int(args.gbases * 1e9) if args.gbases > 0 else 0)
     n_bases = int(sum(lens))
@@ -196,7 +205,7 @@ def main():
     torch.cuda.synchronize()
 
     stream = torch.cuda.current_stream()
-    acc = cornetto_amd.Accel(local, stream.cuda_stream)
+    acc = cornetto_amd.Accel(local_dev, stream.cuda_stream)
     asm = acc.asm_wrap(bases.data_ptr(), offs, np.array(lens, dtype=np.int64))
     cov = acc.cov_wrap(depth.data_ptr(), mq.data_ptr(), offs, np.array(lens, dtype=np.int32))
     thr = acc.telowin_threshold(0.4, 99.9)
@@ -227,7 +236,7 @@ def main():
         if record:
             note()
         # the one real exchange: the assembly-wide mean depth behind the thresholds
-        sd, sq, n = allreduce_sums(sums, device=dev) if world > 1 else sums
+        sd, sq, n = allreduce_sums(sums, device=cdev) if world > 1 else sums
         mean = int(np.floor(sd / n + 0.5))
         lo, hi = acc.cov_threshold(0.4, mean), acc.cov_threshold(2.5, mean)
         if record:
@@ -239,7 +248,7 @@ def main():
         if world > 1:                                 # gather of the BED/TSV records to rank 0 over RCCL
             t0 = time.perf_counter()
             for arr in (hits, wins, ivls, recs):
-                gather_records(arr, gl_ctg, device=dev)
+                gather_records(arr, gl_ctg, device=cdev, concat=False)
             if record:
                 lap("gather", t0)
         return [len(hits), len(wins), len(ivls), len(recs)]
@@ -260,7 +269,7 @@ def main():
         counts = step(True)
     fence()
     elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())

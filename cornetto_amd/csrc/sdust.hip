@@ -285,6 +285,7 @@ __global__ __launch_bounds__(64) void sdust_kernel(SdArgs A)
 // satellite) is spread over many waves instead of serialising inside one.
 // ---------------------------------------------------------------------------------------------------
 struct SdLds64 {
+    uint8_t lut[256];          // seq_nt4_table
     uint8_t ring[16][64][4];   // [slot >> 2][lane][slot & 3], slot = absolute word index & 63
     uint8_t cw[16][64][4];     // [3-mer >> 2][lane][3-mer & 3] = copies of the 3-mer in the window
 };
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
     __shared__ SdLds64 S;
     const int lane = threadIdx.x;
     for (int i = 0; i < 16; ++i) *reinterpret_cast<uint32_t *>(S.cw[i][lane]) = 0;
+    for (int c = lane; c < 256; c += 64) S.lut[c] = (uint8_t)nt4_code((uint32_t)c);
     __syncthreads();
 
     // chunk of this lane: strided over the whole grid (lane l of wave w owns chunk l * waves + w).  A wave's 64
@@ -469,30 +471,24 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
         const uint32_t word = c0;
         c0 = c1; c1 = c2; c2 = c3; c3 = c4; c4 = c5; c5 = c6; c6 = c7; c7 = c8;
         c8 = c9; c9 = c10; c10 = c11; c11 = c12; c12 = c13; c13 = c14; c14 = c15;
+        // seq_nt4_table (:23-40) for the 4 bytes of the group at once: four independent LDS reads
+        const uint32_t codes4 = (uint32_t)S.lut[word & 0xFFu] | ((uint32_t)S.lut[(word >> 8) & 0xFFu] << 8) |
+                                ((uint32_t)S.lut[(word >> 16) & 0xFFu] << 16) | ((uint32_t)S.lut[word >> 24] << 24);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         ++st_steps;
         const int i = u + k4 + kk;                   // position of this lane; all lanes share i & 63
-        const uint32_t c = (word >> (8 * kk)) & 0xFFu;
-        // seq_nt4_table (:23-40): A/a C/c G/g T/t -> 0..3, bytes 0..3 -> themselves, everything else 4
-        const uint32_t cl = c | 0x20u, idx = cl - 0x61u;                    // a=0 c=2 g=6 t=19
-        uint32_t code = (cl >> 1) & 3u;                                      // a0 c1 g3 t2
-        code ^= code >> 1;                                                   // a0 c1 g2 t3
-        const uint32_t acgt = (uint32_t)(idx < 20u) & ((0x80045u >> (idx & 31u)) & 1u);
-        const uint32_t other = c < 4u ? c : 4u;
-        const uint32_t msk = 0u - (acgt & (uint32_t)(active & (i < len)));   // all ones: an A/C/G/T inside the contig
-        const uint32_t inb = 0u - (uint32_t)(active & (i < len));
-        const int b = (int)((code & msk) | (((other & inb) | (4u & ~inb)) & ~msk));
+        const int b = (active & (i < len)) ? (int)((codes4 >> (8 * kk)) & 7u) : 4;
         const bool isbase = b < 4;
         const int l_old = l;
         l = isbase ? l + 1 : 0;
         t = isbase ? ((t << 2 | (unsigned)b) & 63u) : 0u;                     // :144 / :154
         const bool isword = isbase & (l >= 3);
-        const int start = (l - W > 0 ? l - W : 0) + (i + 1 - l);             // :146 (meaningful when isword)
         bool need_trim = false, need_fp = false;
 
-        // ---- N or end of sequence with a non-empty P: flush (:152-153).  Rare: one wave-uniform test.
-        if (__any(active & !isbase & (occ != 0))) {
+        // ---- P maintenance, rare (one wave-uniform test): the flush at an N or at the end of the sequence
+        // (:152-153) and save_masked_regions (:147); both only matter while P is non-empty
+        if (__any(active & (occ != 0) & (!isbase | isword))) {
             if (active && !isbase) {
                 int st = (l_old - W + 1 > 0 ? l_old - W + 1 : 0) + (i + 1 - l_old);
                 while (occ) {
@@ -501,10 +497,10 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
                     ++st;
                 }
             }
-        }
-        // ---- save_masked_regions (:147).  Rare as well.
-        if (__any(isword & (occ != 0) & (minstart < start))) {
-            if (isword && occ != 0 && minstart < start) save_evict(start, i);
+            if (isword && occ != 0) {
+                const int start = (l - W > 0 ? l - W : 0) + (i + 1 - l);     // :146
+                if (minstart < start) save_evict(start, i);
+            }
         }
         if (isword) {
             // shift_window (:66-86) without cv / rv, straight-line: both table entries are read at once
@@ -589,7 +585,8 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
             const bool cand = inwin && j <= i0 && r * 10 > __mul24(T, new_l);  // :112 (new_l < 64, T < 2^21)
             const unsigned long long candmask = __ballot(cand);
             if (candmask == 0) continue;                                       // nothing can be inserted
-            const int o_start = rdlane(start, o);
+            const int o_l = rdlane(l, o), o_i = rdlane(i, o);
+            const int o_start = (o_l - W > 0 ? o_l - W : 0) + (o_i + 1 - o_l);          // :146
             const unsigned long long o_occ = rdlane64(occ, o);
             const int o_cid = rdlane(cid, o);
             uint32_t *orow = A.slots + (size_t)o_cid * 64;

@@ -31,6 +31,8 @@
 
 namespace {
 
+__device__ __forceinline__ int nt4_code(uint32_t c);
+
 struct SdChunk {
     int32_t ctg, start, end;
 };
@@ -49,7 +51,39 @@ struct SdArgs {
     uint32_t *ovf;               // max over chunks of (intervals produced) when that exceeds cap, else untouched
     uint32_t *slots;             // sdust_w64: [n_chunks][64] P slots (start & 63 -> r | l << 16), global memory
     int32_t map_stride;          // chunk -> lane mapping (0: 64-wave groups, 1: strided over the grid)
+    // bounded warm-up search (sdust_w64): the local backward scan gives up after SD_SCAN_CAP bases; then
+    const uint32_t *wtab;        //   exclusive prefix of per-256-base-block word-emission counts, or NULL
+    const int64_t *wtab_base;    //   first table entry of each contig
+    uint32_t *need_wtab;         //   set when a lane gave up and no table was supplied (host builds it and reruns)
 };
+
+constexpr int SD_SCAN_CAP = 1024;   // bases a lane scans backwards by itself before using the table
+constexpr int SD_WBLK = 256;        // bases per table block
+
+// word-emission counts per 256-base block of every contig: a word "ends" at q when bases q-2..q are A/C/G/T
+// (this is what the recurrence pushes, src/sdust/sdust.c:144-145, independent of its state)
+__global__ void sd_wordcount(const uint8_t *bases, const int64_t *ctg_off, const int32_t *ctg_len, const int64_t *wtab_base,
+                             int32_t n_ctg, int64_t n_blocks, uint32_t *cnt)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_blocks) return;
+    int lo = 0, hi = n_ctg - 1;                 // contig of this block: largest c with wtab_base[c] <= g
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (wtab_base[mid] <= g) lo = mid; else hi = mid - 1;
+    }
+    const int c = lo;
+    const int len = ctg_len[c];
+    const uint8_t *seq = bases + ctg_off[c];
+    const int q0 = (int)(g - wtab_base[c]) * SD_WBLK;
+    int run = 0, n = 0;
+    for (int q = q0 - 2 < 0 ? 0 : q0 - 2; q < q0 + SD_WBLK && q < len; ++q) {
+        run = nt4_code(seq[q]) < 4 ? run + 1 : 0;
+        n += (q >= q0) & (run >= 3);
+    }
+    cnt[g] = (uint32_t)n;
+}
+
 
 template <int RC>  // ring / slot capacity, power of two >= W - 2
 struct SdLds {
@@ -390,14 +424,50 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
         const int y = ch.start - 2 * W;
         if (y > 2) {
             int need = CAPW, run = 0, p = y - 1;
-            for (; p >= 0; --p) {
+            const int floor_p = y - SD_SCAN_CAP > 0 ? y - SD_SCAN_CAP : 0;
+            for (; p >= floor_p; --p) {
                 if (nt4_code(seq[p]) < 4) {
                     if (++run >= 3 && --need == 0) break;
                 } else {
                     run = 0;
                 }
             }
-            u = p > 0 ? p : 0;
+            if (need == 0 || floor_p == 0) {
+                u = p > 0 ? p : 0;
+            } else if (A.wtab == nullptr) {
+                // N-dense stretch longer than the local scan: ask the host for the word-count table and a rerun
+                atomicOr(A.need_wtab, 1u);
+                active = false;
+            } else {
+                // rank of the wanted word among the word emissions of the contig, from the block table
+                const uint32_t *tab = A.wtab + A.wtab_base[ch.ctg];
+                const uint32_t t0 = tab[0];
+                const int yb = y / SD_WBLK;
+                int wy = (int)(tab[yb] - t0);                     // emissions ending before block yb
+                {
+                    int r2 = 0;
+                    for (int q = yb * SD_WBLK - 2 < 0 ? 0 : yb * SD_WBLK - 2; q < y; ++q) {
+                        r2 = nt4_code(seq[q]) < 4 ? r2 + 1 : 0;
+                        wy += (q >= yb * SD_WBLK) & (r2 >= 3);
+                    }
+                }
+                if (wy < CAPW) {
+                    u = 0;
+                } else {
+                    const int rank = wy - CAPW + 1;               // 1-based rank of the oldest word that must be replayed
+                    int lo = 0, hi = yb;                          // largest block b with (tab[b] - t0) < rank
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if ((int)(tab[mid] - t0) < rank) lo = mid; else hi = mid - 1;
+                    }
+                    int seen = (int)(tab[lo] - t0), r2 = 0, q = lo * SD_WBLK - 2 < 0 ? 0 : lo * SD_WBLK - 2;
+                    for (; q < y; ++q) {
+                        r2 = nt4_code(seq[q]) < 4 ? r2 + 1 : 0;
+                        if (q >= lo * SD_WBLK && r2 >= 3 && ++seen == rank) break;
+                    }
+                    u = q - 2 > 0 ? q - 2 : 0;                     // first base of that word
+                }
+            }
         }
     }
     u &= ~63;  // starting a little earlier is still exact, and keeps every lane on the same 64-byte phase
@@ -707,14 +777,15 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
         if (h->dev[WS_SD_OUT].bytes / (nc * sizeof(uint2)) > cap) cap = h->dev[WS_SD_OUT].bytes / (nc * sizeof(uint2));
         unsigned long long tot = 0;
         uint2 *d_out = nullptr;
-        for (int attempt = 0; attempt < 2; ++attempt) {
+        for (int attempt = 0; attempt < 4; ++attempt) {
             d_out = (uint2 *)cn_ws(h, WS_SD_OUT, nc * cap * sizeof(uint2));
             if (!d_out) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation of %zu bytes failed", nc * cap * sizeof(uint2));
             CN_HIP(h, hipMemsetAsync(d_tot, 0, 64, h->stream));
             uint32_t *d_slots = (uint32_t *)cn_ws(h, WS_SD_OFF, nc * 64 * sizeof(uint32_t));
             if (!d_slots) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
             SdArgs A{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, d_out, d_cnt, (uint32_t)cap,
-                     want_stats ? d_tot + 2 : nullptr, reinterpret_cast<uint32_t *>(d_tot + 1), d_slots, env_int("CORNETTO_SDUST_MAP", 1)};
+                     want_stats ? d_tot + 2 : nullptr, reinterpret_cast<uint32_t *>(d_tot + 1), d_slots, env_int("CORNETTO_SDUST_MAP", 1),
+                     a->d_wtab, a->d_wtab_base, reinterpret_cast<uint32_t *>(d_tot + 1) + 1};
             unsigned nb = (unsigned)((nc + 63) / 64);
             const int variant = env_int("CORNETTO_SDUST_VARIANT", 0);   // 1 = force the per-lane reference-shaped kernel
             if (W - 2 <= 64 && variant == 0) {
@@ -732,11 +803,36 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             if (want_stats)
                 fprintf(stderr, "[sdust stats] chunks %zu waves %u wave-steps %llu find_perfect calls %llu trims %llu\n", nc, nb, p_tot[2], p_tot[3], p_tot[4]);
             const uint32_t ovf = (uint32_t)(p_tot[1] & 0xFFFFFFFFull);
+            const bool need_wtab = (p_tot[1] >> 32) != 0;
+            if (need_wtab) {
+                // some lane met more than SD_SCAN_CAP bases without W-2 word emissions (N-dense input): build the
+                // word-count table once for this assembly and run again — bounded work whatever the input
+                if (a->d_wtab) return cn_fail(h, CORNETTO_E_HIP, "sdust: word-count table requested twice");
+                std::vector<int64_t> base(a->n + 1, 0);
+                for (int32_t c = 0; c < a->n; ++c) base[c + 1] = base[c] + a->len[c] / SD_WBLK + 2;
+                a->n_wblocks = base[a->n];
+                const size_t npart = ((size_t)a->n_wblocks + 4095) / 4096 + 1;
+                uint32_t *d_wcnt = nullptr;
+                if (hipMalloc((void **)&a->d_wtab, ((size_t)a->n_wblocks + 1) * 4) != hipSuccess ||
+                    hipMalloc((void **)&a->d_wtab_base, ((size_t)a->n + 1) * 8) != hipSuccess ||
+                    hipMalloc((void **)&d_wcnt, ((size_t)a->n_wblocks + npart + 1) * 4) != hipSuccess)
+                    return cn_fail(h, CORNETTO_E_NOMEM, "sdust: word-count table allocation failed");
+                CN_HIP(h, hipMemcpyAsync(a->d_wtab_base, base.data(), ((size_t)a->n + 1) * 8, hipMemcpyHostToDevice, h->stream));
+                const unsigned nbw = (unsigned)((a->n_wblocks + 255) / 256);
+                CN_LAUNCH(h, "sd_wordcount", sd_wordcount<<<dim3(nbw), dim3(256), 0, h->stream>>>(a->d_bases, a->d_off, a->d_len, a->d_wtab_base, a->n,
+                                                                                         a->n_wblocks, d_wcnt));
+                int rc = cnscan::exclusive_u32(h, "sd_wordscan", d_wcnt, a->n_wblocks, 1, a->d_wtab, d_wcnt + a->n_wblocks, nullptr);
+                hipError_t e = hipStreamSynchronize(h->stream);   // `base` is a local
+                (void)hipFree(d_wcnt);
+                if (rc != CORNETTO_OK) return rc;
+                if (e != hipSuccess) return cn_fail(h, CORNETTO_E_HIP, "sdust: word-count table build failed");
+                continue;
+            }
             if (ovf <= cap) {
                 tot = p_tot[0];
                 break;
             }
-            if (attempt == 1) return cn_fail(h, CORNETTO_E_HIP, "sdust: a chunk produced %u intervals after resizing to %zu", ovf, cap);
+            if (attempt >= 2) return cn_fail(h, CORNETTO_E_HIP, "sdust: a chunk produced %u intervals after resizing to %zu", ovf, cap);
             cap = ovf;   // rerun with room for the densest chunk: results are never truncated
         }
         if (tot > 0x7fffffffull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "sdust: %llu intervals", tot);

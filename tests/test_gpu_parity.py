@@ -263,3 +263,38 @@ def test_cov_regs_vs_oracle(acc, w, inc):
         exp = ob.get_regs(depths[ci], mqs[ci], w, inc)
         assert np.array_equal(got, exp.astype(got.dtype)), (w, inc, lens[ci])
     cov.close()
+
+
+@pytest.mark.parametrize("chunk", ["64", "500", "1536"])
+def test_sdust_long_word_free_stretches_vs_oracle(acc, monkeypatch, chunk):
+    """more than 1024 bases without W-2 word emissions before a chunk: the lane's local backward scan gives
+    up, the host builds the word-count table and reruns (sdust.hip, SD_SCAN_CAP) — still exact, including the
+    stale-window quirk across the N-dense stretch"""
+    monkeypatch.setenv("CORNETTO_SDUST_CHUNK", chunk)
+    rng = np.random.default_rng(int(chunk))
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def rnd(n):
+        return acgt[rng.integers(0, 4, size=n)].tobytes()
+
+    seqs = [
+        rnd(3000) + b"N" * 5000 + rnd(3000),
+        b"AC" * 40 + b"ACN" * 1500 + b"AC" * 60 + rnd(500) + b"N" * 2000 + b"ACGN" * 800 + b"A" * 100 + rnd(2000),
+        b"N" * 4000 + b"ACACACACACACACACACACACAC" + b"N" * 3000 + b"ACACACACACACAC" + rnd(1000),
+        (b"ACG" + b"N" * 40) * 100 + b"T" * 80 + rnd(800),           # one word every 43 bases: 62 words span 2.6 kb
+        rnd(200) + b"ACN" * 3000,
+        b"ACN" * 3000,
+    ]
+    seqs = [np.frombuffer(s, dtype=np.uint8) for s in seqs]
+    asm = acc.asm_upload(seqs)
+    iv = acc.sdust(asm, 20, 64)
+    iv2 = acc.sdust(asm, 20, 64)            # second call reuses the cached table
+    asm.close()
+    got = [(int(x["ctg"]), int(x["start"]), int(x["finish"])) for x in iv]
+    assert got == [(int(x["ctg"]), int(x["start"]), int(x["finish"])) for x in iv2]
+    exp = []
+    for ci, s in enumerate(seqs):
+        for r in ob.sdust(s, 20, 64):
+            r = int(r)
+            exp.append((ci, r >> 32, r & 0xFFFFFFFF))
+    assert got == exp

@@ -25,6 +25,18 @@ REG_DT = np.dtype([("st", "<i4"), ("end", "<i4"), ("depth", "<i4"), ("mq_depth",
 REGREC_DT = np.dtype([("ctg", "<i4"), ("st", "<i4"), ("end", "<i4"), ("depth", "<i4"), ("mq_depth", "<i4")])
 
 
+class BgErr(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("record", C.c_int64), ("a", C.c_int32), ("b", C.c_int32)]
+
+
+class BedgraphFormatError(ValueError):
+    """a check of the reference's get_depths() failed (kind / record / numbers as in cornetto_bgerr_t)"""
+
+    def __init__(self, kind, record, a, b):
+        super().__init__("bedgraph check %d failed at record %d (%d, %d)" % (kind, record, a, b))
+        self.kind, self.record, self.a, self.b = kind, record, a, b
+
+
 class AccelError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__("cornetto_accel status %d: %s" % (status, msg))
@@ -76,6 +88,17 @@ def lib():
         "cornetto_cov_regs": (C.c_int, [vp, vp, i32, vp]),
         "cornetto_cov_threshold": (i32, [C.c_float, i32]),
         "cornetto_cov_select": (C.c_int, [vp, vp, i32, i32, C.c_float, i32, i32, C.c_int, pp, C.POINTER(i64)]),
+        "cornetto_cov_n": (i32, [vp]),
+        "cornetto_cov_lens": (C.POINTER(i32), [vp]),
+        "cornetto_pinned_alloc": (vp, [C.c_size_t]),
+        "cornetto_pinned_free": (None, [vp]),
+        "cornetto_bgin_open": (C.c_int, [vp, pp]),
+        "cornetto_bgin_close": (None, [vp, vp]),
+        "cornetto_bgin_feed": (C.c_int, [vp, vp, cp, i64, cp, i64, C.c_int]),
+        "cornetto_bgin_pending": (None, [vp, C.POINTER(i64), C.POINTER(i64)]),
+        "cornetto_bgin_error": (C.POINTER(BgErr), [vp]),
+        "cornetto_bgin_done": (C.c_int, [vp]),
+        "cornetto_bgin_finish": (C.c_int, [vp, vp, pp, C.POINTER(i32), C.POINTER(C.POINTER(cp)), C.POINTER(i64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
@@ -251,3 +274,39 @@ class Accel:
         self._chk(self.L.cornetto_cov_select(self.h, cov.ptr, lo, hi, low_mq, edge_len, min_ctg_len, int(boring),
                                              C.byref(p), C.byref(n)))
         return _take(p, n.value, REGREC_DT)
+
+    # ---- bedgraph ingest ---------------------------------------------------------------------------
+    def bedgraph_ingest(self, tot_pieces, mq_pieces):
+        """stream the two per-base bedgraphs (iterables of bytes pieces, any split points) through the device
+        parser; returns (resident coverage, [contig names], clamped count).  Raises BedgraphFormatError."""
+        L = self.L
+        bg = C.c_void_p()
+        self._chk(L.cornetto_bgin_open(self.h, C.byref(bg)))
+        try:
+            ta, qa = list(tot_pieces), list(mq_pieces)
+            n = max(len(ta), len(qa), 1)
+            for i in range(n):
+                t = ta[i] if i < len(ta) else b""
+                q = qa[i] if i < len(qa) else b""
+                fin = (1 if i >= len(ta) - 1 else 0) | (2 if i >= len(qa) - 1 else 0)
+                rc = L.cornetto_bgin_feed(self.h, bg, t, len(t), q, len(q), fin)
+                if rc == -6:
+                    e = L.cornetto_bgin_error(bg).contents
+                    raise BedgraphFormatError(e.kind, e.record, e.a, e.b)
+                self._chk(rc)
+                if L.cornetto_bgin_done(bg):
+                    break
+            cov, nc, names, ncl = C.c_void_p(), C.c_int32(), C.POINTER(C.c_char_p)(), C.c_int64()
+            self._chk(L.cornetto_bgin_finish(self.h, bg, C.byref(cov), C.byref(nc), C.byref(names), C.byref(ncl)))
+            nm = [names[i] for i in range(nc.value)]
+            lens = [L.cornetto_cov_lens(cov)[i] for i in range(nc.value)]
+            # the name strings are malloc'd by the library: release them with libc free
+            libc = C.CDLL(None)
+            libc.free.argtypes = [C.c_void_p]
+            arr = C.cast(names, C.POINTER(C.c_void_p))
+            for i in range(nc.value):
+                libc.free(arr[i])
+            libc.free(C.cast(names, C.c_void_p))
+            return _Resident(self, cov, L.cornetto_cov_free, lens), nm, ncl.value
+        finally:
+            L.cornetto_bgin_close(self.h, bg)

@@ -1,8 +1,9 @@
 /* boringbits_main.c — `cornetto noboringbits|boringbits cov-total.bg -q cov-mq20.bg [options]`.
  * Reference: src/boringbits_main.c:558-660 (options), :180-301 (get_depths: lock-step parse + validation),
  * :483-536 (the_boring_bits), :425-445 / :463-481 (printing).
- * Host: streaming text parse of the two per-base bedgraphs into uint16 arrays with the reference's checks.
- * Device: block sums, totals for the mean, window means, classification, ordered selection. */
+ * Host: reads the two files in large pieces into pinned buffers and streams them to the device.
+ * Device: tokenising + parsing + the reference's lock-step checks (cornetto_bgin_*), block sums, totals for the
+ * mean, window means, classification, ordered selection. */
 #include <getopt.h>
 #include <math.h>
 #include <stdlib.h>
@@ -15,89 +16,6 @@ typedef struct {
     float low_cov_thresh, high_cov_thresh, low_mq_cov_thresh;
     int min_ctg_len, edge_len;
 } optp_t;
-
-/* ---- buffered token reader equivalent to fscanf(fp, "%s\t%d\t%d\t%d\n", ...) (:205,:214) ---- */
-typedef struct {
-    FILE *fp;
-    char *buf;
-    size_t begin, end, cap;
-    int eof;
-} trd_t;
-
-static void trd_open(trd_t *t, const char *path)
-{
-    memset(t, 0, sizeof(*t));
-    t->fp = fopen(path, "r");
-    if (!t->fp) {
-        CLI_ERROR("Failed to open %s : No such file or directory.", path);
-        exit(EXIT_FAILURE);
-    }
-    t->cap = 1 << 24;
-    t->buf = (char *)cli_xmalloc(t->cap + 1);
-}
-
-static int trd_fill(trd_t *t)
-{
-    if (t->eof) return 0;
-    size_t keep = t->end - t->begin;
-    memmove(t->buf, t->buf + t->begin, keep);
-    t->begin = 0;
-    t->end = keep;
-    size_t got = fread(t->buf + t->end, 1, t->cap - t->end, t->fp);
-    if (got == 0) {
-        t->eof = 1;
-        return 0;
-    }
-    t->end += got;
-    return 1;
-}
-
-static inline int is_ws(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
-
-/* make sure a whole token (up to 10000 bytes, like the reference's buffers) starting at begin is in memory */
-static inline void trd_need(trd_t *t)
-{
-    if (t->end - t->begin < 12000 && !t->eof) trd_fill(t);
-}
-
-/* returns the number of fields converted (0..4) or EOF (-1) exactly like the fscanf call */
-static int trd_record(trd_t *t, char **name, size_t *name_len, int *st, int *end, int *depth)
-{
-    trd_need(t);
-    while (t->begin < t->end && is_ws(t->buf[t->begin])) {
-        ++t->begin;
-        if (t->begin == t->end) trd_need(t);
-    }
-    if (t->begin >= t->end) return -1; /* EOF before any conversion */
-    trd_need(t);
-    size_t p = t->begin;
-    while (p < t->end && !is_ws(t->buf[p])) ++p;
-    *name = t->buf + t->begin;
-    *name_len = p - t->begin;
-    int got = 1;
-    int *out[3] = {st, end, depth};
-    for (int k = 0; k < 3; ++k) {
-        while (p < t->end && is_ws(t->buf[p])) ++p;
-        if (p >= t->end) break;
-        size_t q = p;
-        int neg = 0;
-        if (t->buf[q] == '-' || t->buf[q] == '+') neg = t->buf[q++] == '-';
-        if (q >= t->end || t->buf[q] < '0' || t->buf[q] > '9') break;
-        long v = 0;
-        while (q < t->end && t->buf[q] >= '0' && t->buf[q] <= '9') v = v * 10 + (t->buf[q++] - '0');
-        *out[k] = (int)(neg ? -v : v);
-        p = q;
-        ++got;
-    }
-    t->begin = p; /* the trailing "\n" of the format eats white space before the next record */
-    return got;
-}
-
-typedef struct {
-    char *name;
-    int32_t len, cap;
-    uint16_t *depth, *mq;
-} ctgd_t;
 
 static void print_help(FILE *fp, const optp_t *o)
 {
@@ -187,88 +105,70 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
         exit(EXIT_FAILURE);
     }
 
-    /* ---------------- get_depths (:180-301) ---------------- */
+    /* ---------------- get_depths (:180-301): text -> uint16 arrays, on the device ---------------- */
     double t0 = cli_realtime();
-    trd_t ft, fq;
-    trd_open(&ft, covtotal);
-    trd_open(&fq, covmq);
-    ctgd_t *ctg = NULL;
-    int32_t n_ctg = 0, cap_ctg = 0;
-    int prev_pos = 0;
-    for (;;) {
-        char *n1, *n2;
-        size_t l1, l2;
-        int st1 = 0, end1 = 0, d1 = 0, st2 = 0, end2 = 0, d2 = 0;
-        int ret = trd_record(&ft, &n1, &l1, &st1, &end1, &d1);
-        if (ret == -1) break;
-        if (ret != 4) {
-            CLI_ERROR("The depth files should have 4 columns. Had %d.", ret);
-            exit(EXIT_FAILURE);
-        }
-        ret = trd_record(&fq, &n2, &l2, &st2, &end2, &d2);
-        if (ret == -1) {
-            CLI_ERROR("%s", "The two files are not in the same order");
-            exit(EXIT_FAILURE);
-        }
-        if (ret != 4) {
-            CLI_ERROR("The depth files should have 4 columns. Had %d.", ret);
-            exit(EXIT_FAILURE);
-        }
-        if (l1 != l2 || memcmp(n1, n2, l1) != 0 || st1 != st2 || end1 != end2) { /* :224 */
-            CLI_ERROR("%s", "The two files are not in the same order");
-            exit(EXIT_FAILURE);
-        }
-        ctgd_t *cur = n_ctg ? &ctg[n_ctg - 1] : NULL;
-        if (!cur || strlen(cur->name) != l1 || memcmp(cur->name, n1, l1) != 0) { /* :229 new contig */
-            if (n_ctg == cap_ctg) {
-                cap_ctg = cap_ctg ? cap_ctg * 2 : 16;
-                ctg = (ctgd_t *)cli_xrealloc(ctg, (size_t)cap_ctg * sizeof(ctgd_t));
-            }
-            cur = &ctg[n_ctg++];
-            cur->name = (char *)cli_xmalloc(l1 + 1);
-            memcpy(cur->name, n1, l1);
-            cur->name[l1] = 0;
-            cur->len = 0;
-            cur->cap = 1 << 16;
-            cur->depth = (uint16_t *)cli_xmalloc((size_t)cur->cap * 2);
-            cur->mq = (uint16_t *)cli_xmalloc((size_t)cur->cap * 2);
-            prev_pos = 0; /* the first record of a contig is not checked for st == 0 */
-        } else {
-            if (prev_pos + 1 != st1) { /* :249 */
-                CLI_ERROR("The depth files should be incremantal at one base resolution. Found %d to %d", prev_pos, st1);
-                exit(EXIT_FAILURE);
-            }
-            prev_pos++;
-        }
-        if (st1 + 1 != end1) { /* :256 */
-            CLI_ERROR("The depth files should have end=start+1. Found %d to %d", st1, end1);
-            exit(EXIT_FAILURE);
-        }
-        if (d1 > 65535) { /* :261-268 */
-            CLI_WARNING("The depth at %s:%d-%d was truncated to 65535. Found %d", cur->name, st1, end1, d1);
-            d1 = 65535;
-        }
-        if (d2 > 65535) {
-            CLI_WARNING("The depth at %s:%d-%d was truncated to 65535. Found %d", cur->name, st2, end2, d2);
-            d2 = 65535;
-        }
-        if (cur->len == cur->cap) {
-            if (cur->cap > 0x3fffffff) {
-                CLI_ERROR("contig %s has more than 2^30 positions", cur->name);
-                exit(EXIT_FAILURE);
-            }
-            cur->cap *= 2;
-            cur->depth = (uint16_t *)cli_xrealloc(cur->depth, (size_t)cur->cap * 2);
-            cur->mq = (uint16_t *)cli_xrealloc(cur->mq, (size_t)cur->cap * 2);
-        }
-        cur->depth[cur->len] = (uint16_t)d1; /* negative values wrap through uint16_t as in the reference */
-        cur->mq[cur->len] = (uint16_t)d2;
-        cur->len++;
+    FILE *ft = fopen(covtotal, "r");
+    if (!ft) {
+        CLI_ERROR("Failed to open %s : No such file or directory.", covtotal);
+        exit(EXIT_FAILURE);
     }
-    fclose(ft.fp);
-    fclose(fq.fp);
-    free(ft.buf);
-    free(fq.buf);
+    FILE *fq = fopen(covmq, "r");
+    if (!fq) {
+        CLI_ERROR("Failed to open %s : No such file or directory.", covmq);
+        exit(EXIT_FAILURE);
+    }
+    cornetto_accel_t *h = cli_accel_open();
+    cornetto_bgin_t *bg = NULL;
+    cli_accel_check(h, cornetto_bgin_open(h, &bg), "bedgraph ingest");
+    int64_t piece = 256ll << 20; /* bytes of each file kept in flight; $CORNETTO_BG_PIECE overrides (tests) */
+    if (getenv("CORNETTO_BG_PIECE") && atoll(getenv("CORNETTO_BG_PIECE")) > 0) piece = atoll(getenv("CORNETTO_BG_PIECE"));
+    char *buf_t = (char *)cornetto_pinned_alloc((size_t)piece), *buf_q = (char *)cornetto_pinned_alloc((size_t)piece);
+    if (!buf_t || !buf_q) {
+        CLI_ERROR("%s", "cannot allocate pinned read buffers");
+        exit(EXIT_FAILURE);
+    }
+    int eof_t = 0, eof_q = 0;
+    while (!cornetto_bgin_done(bg)) {
+        int64_t pend_t = 0, pend_q = 0;
+        cornetto_bgin_pending(bg, &pend_t, &pend_q);
+        /* top both files up to the same number of pending bytes, so the unmatched tail of either stays small */
+        size_t want_t = eof_t ? 0 : (size_t)(pend_t < piece ? piece - pend_t : 4096);
+        size_t want_q = eof_q ? 0 : (size_t)(pend_q < piece ? piece - pend_q : 4096);
+        size_t got_t = want_t ? fread(buf_t, 1, want_t, ft) : 0, got_q = want_q ? fread(buf_q, 1, want_q, fq) : 0;
+        if (got_t < want_t) eof_t = 1;
+        if (got_q < want_q) eof_q = 1;
+        int rc = cornetto_bgin_feed(h, bg, buf_t, (int64_t)got_t, buf_q, (int64_t)got_q, eof_t | (eof_q << 1));
+        if (rc == CORNETTO_E_FORMAT) {
+            const cornetto_bgerr_t *e = cornetto_bgin_error(bg);
+            if (e->kind == 1 || e->kind == 2) {
+                CLI_ERROR("The depth files should have 4 columns. Had %d.", e->a);
+            } else if (e->kind == 3) {
+                CLI_ERROR("%s", "The two files are not in the same order");
+            } else if (e->kind == 4) {
+                CLI_ERROR("The depth files should be incremantal at one base resolution. Found %d to %d", e->a, e->b);
+            } else {
+                CLI_ERROR("The depth files should have end=start+1. Found %d to %d", e->a, e->b);
+            }
+            exit(EXIT_FAILURE);
+        }
+        cli_accel_check(h, rc, "bedgraph ingest");
+        if (eof_t && eof_q && !cornetto_bgin_done(bg)) { /* cannot happen: the final feed either finishes or fails */
+            CLI_ERROR("%s", "bedgraph ingest did not finish");
+            exit(EXIT_FAILURE);
+        }
+    }
+    fclose(ft);
+    fclose(fq);
+    cornetto_pinned_free(buf_t);
+    cornetto_pinned_free(buf_q);
+    cornetto_cov_t *cov = NULL;
+    int32_t n_ctg = 0;
+    char **names = NULL;
+    int64_t n_clamped = 0;
+    cli_accel_check(h, cornetto_bgin_finish(h, bg, &cov, &n_ctg, &names, &n_clamped), "bedgraph ingest");
+    cornetto_bgin_close(h, bg);
+    if (n_clamped) CLI_WARNING("%lld depth values were truncated to 65535", (long long)n_clamped);
+    const int32_t *lens = cornetto_cov_lens(cov);
     CLI_VERBOSE("Loaded depth files in %.2f seconds", cli_realtime() - t0);
 
     /* ---------------- device: totals, windows, selection ---------------- */
@@ -276,17 +176,6 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
     cornetto_regrec_t *recs = NULL;
     int64_t n_recs = 0;
     if (n_ctg > 0) {
-        cornetto_accel_t *h = cli_accel_open();
-        const uint16_t **pd = (const uint16_t **)cli_xmalloc((size_t)n_ctg * sizeof(*pd));
-        const uint16_t **pq = (const uint16_t **)cli_xmalloc((size_t)n_ctg * sizeof(*pq));
-        int32_t *lens = (int32_t *)cli_xmalloc((size_t)n_ctg * sizeof(int32_t));
-        for (int32_t i = 0; i < n_ctg; ++i) {
-            pd[i] = ctg[i].depth;
-            pq[i] = ctg[i].mq;
-            lens[i] = ctg[i].len;
-        }
-        cornetto_cov_t *cov = NULL;
-        cli_accel_check(h, cornetto_cov_upload(h, pd, pq, lens, n_ctg, &cov), "copying depth arrays to the GPU");
         t0 = cli_realtime();
         uint64_t sums[3];
         cli_accel_check(h, cornetto_cov_prepare(h, cov, opt.window_size, opt.window_inc, sums), "window block sums");
@@ -298,11 +187,6 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
         cli_accel_check(h, cornetto_cov_select(h, cov, lo_t, hi_t, opt.low_mq_cov_thresh, opt.edge_len, opt.min_ctg_len, boring, &recs, &n_recs),
                         "window classification");
         CLI_VERBOSE("Found regions in %.2f seconds", cli_realtime() - t0);
-        cornetto_cov_free(h, cov);
-        cornetto_accel_close(h);
-        free(pd);
-        free(pq);
-        free(lens);
     } else {
         /* the reference divides 0/0 here: round(NaN) -> INT_MIN; nothing is printed either way */
         mean_depth = mean_mq = (int32_t)0x80000000;
@@ -322,8 +206,8 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
     t0 = cli_realtime();
     int64_t k = 0;
     for (int32_t i = 0; i < n_ctg; ++i) {
-        const char *name = ctg[i].name;
-        const int len = ctg[i].len;
+        const char *name = names[i];
+        const int len = lens[i];
         if (!boring) {
             if (len < opt.min_ctg_len) {
                 printf("%s\t%d\t%d\t.\t.\n", name, 0, opt.min_ctg_len); /* :430 prints min_ctg_len, not len */
@@ -337,11 +221,9 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
     }
     CLI_VERBOSE("Printed the bits in %.2f seconds", cli_realtime() - t0);
     cornetto_free(recs);
-    for (int32_t i = 0; i < n_ctg; ++i) {
-        free(ctg[i].name);
-        free(ctg[i].depth);
-        free(ctg[i].mq);
-    }
-    free(ctg);
+    for (int32_t i = 0; i < n_ctg; ++i) free(names[i]);
+    free(names);
+    cornetto_cov_free(h, cov);
+    cornetto_accel_close(h);
     return 0;
 }

@@ -73,7 +73,8 @@ enum {   // device workspace slots
     WS_SD_OUT, WS_SD_CNT, WS_SD_OFF, WS_SD_DST, WS_SD_STATS,
     WS_CB_T32, WS_CB_T64, WS_CB_GRAND,
     WS_CW_REGS, WS_CW_SEL, WS_CW_CNT, WS_CW_TRES,
-    WS_TF_HITS
+    WS_TF_HITS,
+    WS_BG_TEXT_A, WS_BG_TEXT_B, WS_BG_TOK_A, WS_BG_TOK_B, WS_BG_CNT_A, WS_BG_CNT_B, WS_BG_SMALL, WS_BG_BRK
 };
 enum {   // pinned host slots
     PIN_A, PIN_B, PIN_C, PIN_D, PIN_E, PIN_F, PIN_SMALL

@@ -98,6 +98,7 @@ const char *cornetto_accel_strerror(int status)
     case CORNETTO_E_ARG: return "invalid argument";
     case CORNETTO_E_NOMEM: return "out of memory";
     case CORNETTO_E_UNSUPPORTED: return "parameter outside the supported range";
+    case CORNETTO_E_FORMAT: return "malformed input text";
     default: return "unknown status";
     }
 }
@@ -256,6 +257,10 @@ void cornetto_cov_free(cornetto_accel_t *h, cornetto_cov_t *c)
     if (c->d_cw_tiles) (void)hipFree(c->d_cw_tiles);
     delete c;
 }
+
+int32_t cornetto_cov_n(const cornetto_cov_t *c) { return c ? c->n : 0; }
+
+const int32_t *cornetto_cov_lens(const cornetto_cov_t *c) { return c ? c->len.data() : nullptr; }
 
 static int cov_finish_table(cornetto_accel_t *h, cornetto_cov_t *c)
 {

@@ -21,6 +21,7 @@
 #ifndef CORNETTO_ACCEL_H
 #define CORNETTO_ACCEL_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -35,7 +36,8 @@ enum {
     CORNETTO_E_HIP = -2,      /* a HIP call or kernel failed; see cornetto_accel_last_error() */
     CORNETTO_E_ARG = -3,      /* invalid argument (NULL, negative length, misaligned device offset, ...) */
     CORNETTO_E_NOMEM = -4,    /* host or device allocation failed */
-    CORNETTO_E_UNSUPPORTED = -5 /* parameter outside the implemented range (motif > 32, W > 256, ...) */
+    CORNETTO_E_UNSUPPORTED = -5, /* parameter outside the implemented range (motif > 32, W > 256, ...) */
+    CORNETTO_E_FORMAT = -6       /* malformed input text; see cornetto_bgin_error() */
 };
 
 typedef struct cornetto_accel cornetto_accel_t; /* device + stream + workspaces */
@@ -173,6 +175,10 @@ int cornetto_cov_wrap(cornetto_accel_t *h, const void *d_depth, const void *d_mq
                       const int32_t *lens, int32_t n, cornetto_cov_t **out);
 void cornetto_cov_free(cornetto_accel_t *h, cornetto_cov_t *c);
 
+/* number of contigs and their lengths (owned by the object) */
+int32_t cornetto_cov_n(const cornetto_cov_t *c);
+const int32_t *cornetto_cov_lens(const cornetto_cov_t *c);
+
 /* number of windows of a contig: src/boringbits_main.c:338-339 */
 int32_t cornetto_n_reg(int32_t length, int32_t window_size, int32_t window_inc);
 
@@ -199,6 +205,50 @@ int32_t cornetto_cov_threshold(float factor, int32_t mean);
 int cornetto_cov_select(cornetto_accel_t *h, const cornetto_cov_t *c, int32_t lo, int32_t hi, float low_mq,
                         int32_t edge_len, int32_t min_ctg_len, int boring, cornetto_regrec_t **recs,
                         int64_t *n_recs);
+
+/* ---------------------------------------------------------------------------------------------------
+ * bedgraph ingest on the device (the text parse of get_depths(), src/boringbits_main.c:204-287)
+ * ------------------------------------------------------------------------------------------------- */
+
+typedef struct cornetto_bgin cornetto_bgin_t; /* streaming state of one pair of per-base bedgraphs */
+
+/* which of the reference's checks failed first (smallest record index), with the numbers its message prints */
+typedef struct {
+    int32_t kind;   /* 1: cov-total record has != 4 columns (a = converted fields)   :209-212
+                       2: cov-mq record has != 4 columns (a = converted fields)      :219-222
+                       3: "The two files are not in the same order"                  :214-217,:224-227
+                       4: not incremental at one base resolution (a = prev_pos, b = start)  :249-252
+                       5: end != start + 1 (a = start, b = end)                      :256-259 */
+    int64_t record; /* 0-based index of the record */
+    int32_t a, b;
+} cornetto_bgerr_t;
+
+/* host buffers the device can read at full PCIe rate (for the file pieces handed to cornetto_bgin_feed) */
+void *cornetto_pinned_alloc(size_t bytes);
+void cornetto_pinned_free(void *p);
+
+int cornetto_bgin_open(cornetto_accel_t *h, cornetto_bgin_t **out);
+void cornetto_bgin_close(cornetto_accel_t *h, cornetto_bgin_t *b);
+
+/* Feed the next bytes of cov-total (tot) and cov-mq (mq); any split points, either length may be 0.  Records
+ * are four white-space separated tokens exactly as fscanf("%s\t%d\t%d\t%d\n") reads them.  `final` is a bit set:
+ * bit 0 = no more cov-total bytes will follow, bit 1 = no more cov-mq bytes.  Like the reference's loop the
+ * ingest is done as soon as cov-total is exhausted and every one of its records found its partner
+ * (cornetto_bgin_done()).  Returns CORNETTO_OK, or CORNETTO_E_FORMAT when a check of the reference fails
+ * (details: cornetto_bgin_error()). */
+int cornetto_bgin_feed(cornetto_accel_t *h, cornetto_bgin_t *b, const char *tot, int64_t n_tot, const char *mq, int64_t n_mq,
+                       int final);
+/* bytes of each file handed over but not consumed yet (records without a partner in the other file): a
+ * caller that tops both up to the same amount keeps them bounded */
+void cornetto_bgin_pending(const cornetto_bgin_t *b, int64_t *pend_tot, int64_t *pend_mq);
+const cornetto_bgerr_t *cornetto_bgin_error(const cornetto_bgin_t *b);
+int cornetto_bgin_done(const cornetto_bgin_t *b);
+
+/* After a successful final feed: the resident coverage object (ready for cornetto_cov_prepare), the contig
+ * names in file order (malloc'd array of malloc'd strings: free() each, then the array) and the number of
+ * depth values that were clamped to 65535 (the reference prints a WARNING for each, :261-268). */
+int cornetto_bgin_finish(cornetto_accel_t *h, cornetto_bgin_t *b, cornetto_cov_t **cov, int32_t *n_ctg, char ***names,
+                         int64_t *n_clamped);
 
 #ifdef __cplusplus
 }

@@ -118,3 +118,12 @@ def test_panel_malformed_inputs_exit_1(cli, plain, tmp_path):
     assert attempt(tot[:20] + tot[21:50], mq[:20] + mq[21:50])[0] == 1   # not incremental
     rl = [b"ptg000001l\t0\t5\t30\n"]
     assert attempt(rl, rl)[0] == 1                                 # run-length line: end != start+1
+
+
+@pytest.mark.parametrize("piece", ["97", "5000", "1000003"])
+def test_panel_streamed_in_small_pieces(cli, golden_dir, plain, piece):
+    """the CLI streams both bedgraphs to the device parser; piece boundaries anywhere must not matter"""
+    args = ["noboringbits", "-H", "2.5", "-L", "0.5", "-Q", "0.5", plain["cov-total.bg"], "-q", plain["cov-mq20.bg"], "-m", "10000", "-e", "1000"]
+    rc, out, err = run(cli, args, env={"CORNETTO_BG_PIECE": piece})
+    assert rc == 0, err.decode()
+    assert out == golden(golden_dir, "bg.fun_t2.exp")

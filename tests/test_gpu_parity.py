@@ -298,3 +298,93 @@ def test_sdust_long_word_free_stretches_vs_oracle(acc, monkeypatch, chunk):
             r = int(r)
             exp.append((ci, r >> 32, r & 0xFFFFFFFF))
     assert got == exp
+
+
+# ---------------------------------------------------------------------------------------------------
+# bedgraph ingest on the device
+# ---------------------------------------------------------------------------------------------------
+def _bg_text(golden_dir):
+    import gzip
+    t = gzip.open(os.path.join(golden_dir, "cov-total.bg.gz")).read()
+    q = gzip.open(os.path.join(golden_dir, "cov-mq20.bg.gz")).read()
+    return t, q
+
+
+def _split(data, rng, mean):
+    cuts = sorted(set(int(x) for x in rng.integers(0, len(data) + 1, size=max(1, len(data) // mean))))
+    out, prev = [], 0
+    for c in cuts + [len(data)]:
+        out.append(data[prev:c])
+        prev = c
+    return out
+
+
+@pytest.mark.parametrize("mean", [10**9, 200000, 3000, 37])
+def test_bedgraph_ingest_matches_host_parse(acc, golden_dir, bg_ctgs, mean):
+    """any split of the two byte streams gives the arrays the reference's reader builds"""
+    t, q = _bg_text(golden_dir)
+    if mean < 1000:                       # tiny pieces: keep the run short
+        nlines = 4000
+        t = b"".join(t.splitlines(True)[:nlines])
+        q = b"".join(q.splitlines(True)[:nlines])
+    rng = np.random.default_rng(mean)
+    cov, names, ncl = acc.bedgraph_ingest(_split(t, rng, mean), _split(q, rng, mean + 7))
+    exp = bg_ctgs
+    if mean < 1000:
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            open(os.path.join(d, "t.bg"), "wb").write(t)
+            open(os.path.join(d, "q.bg"), "wb").write(q)
+            exp = read_bedgraph_pair(os.path.join(d, "t.bg"), os.path.join(d, "q.bg"))
+    assert names == [c[0] for c in exp]
+    assert list(cov.lens) == [len(c[1]) for c in exp]
+    w, inc = 64, 1                          # window = the position itself would need w=1; use sums to compare arrays
+    sd, sq, n = acc.cov_prepare(cov, w, inc)
+    assert sd == sum(int(c[1].astype(np.int64).sum()) for c in exp)
+    assert sq == sum(int(c[2].astype(np.int64).sum()) for c in exp)
+    assert n == sum(len(c[1]) for c in exp)
+    for ci, c in enumerate(exp):            # every window of every contig == oracle on the host-parsed arrays
+        got = acc.cov_regs(cov, ci)
+        ex = ob.get_regs(c[1], c[2], w, inc)
+        assert np.array_equal(got, ex.astype(got.dtype)), ci
+    assert ncl == sum(int((np.array(v) > 65535).sum()) for v in _raw_depths(t, q))
+    cov.close()
+
+
+def _raw_depths(t, q):
+    return ([int(l.split()[3]) for l in t.splitlines()], [int(l.split()[3]) for l in q.splitlines()])
+
+
+def test_bedgraph_ingest_errors(acc, golden_dir):
+    import cornetto_amd
+    t, q = _bg_text(golden_dir)
+    tl, ql = t.splitlines(True)[:200], q.splitlines(True)[:200]
+
+    def kind(tt, qq, pieces=1):
+        tt, qq = b"".join(tt), b"".join(qq)
+        tp = [tt[i::1] for i in [0]] if pieces == 1 else _split(tt, np.random.default_rng(1), 50)
+        qp = [qq] if pieces == 1 else _split(qq, np.random.default_rng(2), 50)
+        try:
+            cov, _n, _c = acc.bedgraph_ingest(tp, qp)
+            cov.close()
+            return 0, -1
+        except cornetto_amd.BedgraphFormatError as e:
+            return e.kind, e.record
+
+    for pieces in (1, 9):
+        assert kind(tl, ql, pieces) == (0, -1)
+        assert kind([b"track type=bedGraph\n"] + tl, [b"track type=bedGraph\n"] + ql, pieces)[0] == 1      # 4 columns
+        assert kind(tl, ql[:150], pieces) == (3, 150)                                                        # cov-mq ends first
+        assert kind(tl[:150], ql, pieces) == (0, -1)                                                         # extra cov-mq records are ignored
+        assert kind(tl, ql[:40] + ql[41:], pieces)[0] == 3                                                   # not in the same order
+        assert kind(tl[:20] + tl[21:], ql[:20] + ql[21:], pieces) == (4, 20)                                 # not incremental
+        assert kind([b"ptg000001l\t0\t5\t30\n"], [b"ptg000001l\t0\t5\t30\n"], pieces) == (5, 0)              # end != start + 1
+        assert kind(tl + [b"ptg000001l\t7\n"], ql + [b"ptg000001l\t7\t8\t1\n"], pieces) == (1, 200)          # trailing partial record
+        assert kind(tl[:50] + [b"x\t1\t2\tabc\n"], ql[:51], pieces) == (1, 50)
+        assert kind(tl[:51], ql[:50] + [b"ptg000001l\t50\t51\n"], pieces) == (2, 50)
+    # records need not be lines: four white-space separated tokens, as fscanf reads them
+    flat_t = b" ".join(b"".join(tl).split()) + b"\n"
+    flat_q = b"\n".join(b"".join(ql).split())
+    assert kind([flat_t], [flat_q]) == (0, -1)
+    assert kind([b""], [b""]) == (0, -1)
+    assert kind([b"\n\n  \n"], [b""]) == (0, -1)

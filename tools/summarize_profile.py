@@ -12,7 +12,8 @@ import json
 import sys
 
 OURS = ("sdust_w64", "sdust_kernel", "sdust_gather", "tf_scan", "tf_gather", "tf_pair", "tf_ctgoff", "tf_greedy", "tw_scan", "tw_fill",
-        "cov_blocks", "cov_windows", "cov_order", "cov_total64", "scan_local", "scan_partials", "scan_add")
+        "cov_blocks", "cov_windows", "cov_order", "cov_total64", "scan_local", "scan_partials", "scan_add",
+        "tk_count", "tk_scatter", "bg_records", "bg_layout", "sd_wordcount")
 
 
 def short(name):

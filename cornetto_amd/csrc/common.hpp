@@ -70,7 +70,7 @@ enum {   // device workspace slots
     WS_TF_LUT, WS_TF_CNT, WS_TF_TB, WS_TF_TC, WS_TF_L0, WS_TF_L1, WS_TF_L2, WS_TF_L3, WS_TF_BITMAP,
     WS_TF_ROFF, WS_TF_RUNS, WS_TF_NRUNS,
     WS_TW_BOFF, WS_TW_TILES, WS_TW_OUT, WS_TW_CNT, WS_TW_HITS, WS_TW_LEN, WS_TW_BITMAP,
-    WS_SD_OUT, WS_SD_CNT, WS_SD_OFF, WS_SD_DST, WS_SD_STATS,
+    WS_SD_OUT, WS_SD_CNT, WS_SD_OFF, WS_SD_DST, WS_SD_STATS, WS_SD_PERM,
     WS_CB_T32, WS_CB_T64, WS_CB_GRAND,
     WS_CW_REGS, WS_CW_SEL, WS_CW_CNT, WS_CW_TRES,
     WS_TF_HITS,

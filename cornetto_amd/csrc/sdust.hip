@@ -51,6 +51,7 @@ struct SdArgs {
     uint32_t *ovf;               // max over chunks of (intervals produced) when that exceeds cap, else untouched
     uint32_t *slots;             // sdust_w64: [n_chunks][64] P slots (start & 63 -> r | l << 16), global memory
     int32_t map_stride;          // chunk -> lane mapping (0: 64-wave groups, 1: strided over the grid)
+    const uint32_t *perm;        // map_stride = 1: slot (lane * waves + wave) -> chunk, low-complexity chunks first; or NULL
     // bounded warm-up search (sdust_w64): the local backward scan gives up after SD_SCAN_CAP bases; then
     const uint32_t *wtab;        //   exclusive prefix of per-256-base-block word-emission counts, or NULL
     const int64_t *wtab_base;    //   first table entry of each contig
@@ -319,9 +320,8 @@ __global__ __launch_bounds__(64) void sdust_kernel(SdArgs A)
 // satellite) is spread over many waves instead of serialising inside one.
 // ---------------------------------------------------------------------------------------------------
 struct SdLds64 {
-    uint8_t lut[256];          // seq_nt4_table
-    uint8_t ring[16][64][4];   // [slot >> 2][lane][slot & 3], slot = absolute word index & 63
-    uint8_t cw[16][64][4];     // [3-mer >> 2][lane][3-mer & 3] = copies of the 3-mer in the window
+    uint32_t cw[16][64];       // [3-mer >> 2][lane]: four byte counters (3-mer & 3) = copies of the 3-mer in the window
+    uint8_t ring[64][68];      // [lane][absolute word index & 63]; 68-byte rows: lanes in phase fall on distinct banks
 };
 
 // seq_nt4_table (src/sdust/sdust.c:23-40) without a table: A/a C/c G/g T/t -> 0..3, bytes 0..3 -> themselves, else 4
@@ -384,13 +384,19 @@ __device__ __forceinline__ void wave_scan_ratio_max(int &xr, int &xl)
     RATIO_SCAN_STEP(DPP_ROW_BCAST31, 0xC, false)
 }
 
-__global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
+typedef uint32_t sd_v16u __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ unsigned long long sd_ballot(bool x) { return __builtin_amdgcn_ballot_w64(x); }
+__device__ __forceinline__ bool sd_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0; }
+constexpr int SD_NEVER = 0x7fffffff;
+
+// Requires 1 <= m = 2T/10 and T <= 100000 (24-bit products exact); other thresholds take the legacy kernel.
+template <bool STATS>
+__global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
 {
     __shared__ SdLds64 S;
     const int lane = threadIdx.x;
-    for (int i = 0; i < 16; ++i) *reinterpret_cast<uint32_t *>(S.cw[i][lane]) = 0;
-    for (int c = lane; c < 256; c += 64) S.lut[c] = (uint8_t)nt4_code((uint32_t)c);
-    __syncthreads();
+    const uint32_t lt_lo = lane < 32 ? (1u << lane) - 1u : ~0u, lt_hi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;   // lanes below this one
+    for (int i = 0; i < 16; ++i) S.cw[i][lane] = 0;
 
     // chunk of this lane: strided over the whole grid (lane l of wave w owns chunk l * waves + w).  A wave's 64
     // lanes then sample 64 far-apart places of the input, so the share of low-complexity lanes in a wave is the
@@ -400,27 +406,31 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
     // older 64-wave group interleave for comparison.
     int cid = lane * (int)gridDim.x + (int)blockIdx.x;
     if (!A.map_stride) cid = (((int)blockIdx.x >> 6) << 12) + lane * 64 + ((int)blockIdx.x & 63);
-    bool active = cid < A.n_chunks;
+    const bool owned = cid < A.n_chunks;
+    // Chunks sampled as low-complexity come first in `perm`: they land one per wave in the waves dispatched first.
+    // A lane inside a satellite or telomere array makes every step of its wave several times dearer (find_perfect
+    // runs, and inserts, at every base), so such a wave runs several times longer than the average one; started
+    // in the last round it alone would set the kernel's duration.
+    if (owned && A.map_stride && A.perm) cid = (int)A.perm[cid];
+    bool haschunk = owned;
 
     const int T = A.T, W = A.W, CAPW = W - 2;
     const int m = (T << 1) / 10;                     // cv[t]*10 > T<<1  <=>  cv[t] > m   (:79)
     SdChunk ch{0, 0, 0};
     int len = 0;
     const uint8_t *seq = A.bases;
-    if (active) {
+    if (haschunk) {
         ch = A.chunks[cid];
         len = A.ctg_len[ch.ctg];
         seq = A.bases + A.ctg_off[ch.ctg];
     }
     // P slots of this lane: one 256-byte row in global memory (L2 resident; touched only around
-    // find_perfect / save_masked_regions), which keeps the per-wave LDS at 20 KB = 8 waves per CU
-    uint32_t *myslots = A.slots + (size_t)(active ? cid : 0) * 64;
-#define RINGL(sl) S.ring[((sl) & 63) >> 2][lane][(sl) & 3]
-#define CWL(t) S.cw[(t) >> 2][lane][(t) & 3]
+    // find_perfect / save_masked_regions), which keeps the per-wave LDS at 8.3 KB = 19 waves per CU
+    uint32_t *myslots = A.slots + (size_t)(haschunk ? cid : 0) * 64;
 
     // ---- warm-up start: W-2 word emissions before (chunk start - 2W) --------------------------------
     int u = 0;
-    if (active && ch.start > 0) {
+    if (haschunk && ch.start > 0) {
         const int y = ch.start - 2 * W;
         if (y > 2) {
             int need = CAPW, run = 0, p = y - 1;
@@ -437,7 +447,7 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
             } else if (A.wtab == nullptr) {
                 // N-dense stretch longer than the local scan: ask the host for the word-count table and a rerun
                 atomicOr(A.need_wtab, 1u);
-                active = false;
+                haschunk = false;
             } else {
                 // rank of the wanted word among the word emissions of the contig, from the block table
                 const uint32_t *tab = A.wtab + A.wtab_base[ch.ctg];
@@ -472,18 +482,26 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
     }
     u &= ~63;  // starting a little earlier is still exact, and keeps every lane on the same 64-byte phase
 
-    // ---- per-lane sequential state --------------------------------------------------------------------
-    int l = 0, size = 0, rw = 0;
-    int p = -1;                 // absolute index of the newest word in the window
-    int vs = 0;                 // absolute index of the first word of v (the suffix with all counts <= m)
-    unsigned t = 0, s_pref = 0;
+    // ---- per-lane sequential state.  Positions are kept relative to u (step k <-> position u + k), word
+    // indices are absolute counts of pushed words.
+    int p = -1;                 // index of the newest word in the window
+    int o = 0;                  // index of the oldest word in the window (size = p - o + 1)
+    int vs = 0;                 // index of the first word of v (the suffix with all counts <= m)
+    int rw10 = 0;               // 10 * rw
+    unsigned s_pref = 0;        // ring[o]: the word the next pop removes
     unsigned long long occ = 0; // occupied P slots, bit = start & 63
     int minstart = 0;
+    int evict_k = SD_NEVER;     // first step at which P needs attention (eviction, or a flush at a non-base)
+    int LN = -1;                // step of the last non-base before the current group of 4 steps
     bool have_last = false;
     uint32_t last_s = 0, last_f = 0, n_out = 0;
-    uint2 *out = A.out + (size_t)(active ? cid : 0) * A.cap;
-    const int rec_from = ch.start;
-    const int stop = (ch.end == len) ? len + 1 : ch.end;
+    uint2 *out = A.out + (size_t)(haschunk ? cid : 0) * A.cap;
+    // steps >= endk see a non-base: the end of the sequence (:141, flushes P and records it) or the end of the
+    // chunk (flushes P without recording: those intervals belong to the next chunk).  Only steps
+    // recfrom_k <= k < nrun record.
+    const int endk = haschunk ? ch.end - u : 0;
+    const int nrun = haschunk ? (ch.end == len ? endk + 1 : endk) : 0;
+    const int recfrom_k = ch.start - u;
 
     auto emit = [&](int ps, int pf) {               // :93-99 on the lane-local list
         if (have_last && ps <= (int)last_f) {
@@ -499,9 +517,9 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
         }
     };
     // save_masked_regions(start) when it does something: occ != 0 && minstart < start   (:88-102)
-    auto save_evict = [&](int start, int now) {
+    auto save_evict = [&](int start, int nowk) {
         const uint32_t sl = __hip_atomic_load(&myslots[minstart & 63], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (now >= rec_from) emit(minstart, minstart + (int)(sl >> 16) + 3);
+        if (nowk >= recfrom_k && nowk < nrun) emit(minstart, minstart + (int)(sl >> 16) + 3);
         const int gone = start - minstart;           // starts minstart .. start-1 leave the window
         if (gone >= 64) {
             occ = 0;
@@ -518,175 +536,228 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
     // concurrent per-lane streams of an XCD overflowed its 4 MB L2 and each line was re-fetched ~6 times
     // (rocprofv3 FETCH_SIZE, profiles/).  A block never leaves its contig: contigs start 64-byte aligned.
     uint4 nb0 = make_uint4(0, 0, 0, 0), nb1 = nb0, nb2 = nb0, nb3 = nb0;
-    if (active && u < len) {
+    if (haschunk && u < len) {
         const uint4 *q = reinterpret_cast<const uint4 *>(seq + u);
         nb0 = q[0]; nb1 = q[1]; nb2 = q[2]; nb3 = q[3];
     }
-    active = active && u < stop;
-    const bool small_t = T <= 100000;   // L*T < 2^24: 24-bit multiplies are exact
+    uint32_t pcn = 0x04040404u;                      // codes of the previous 4 positions (before u: non-bases, l = 0)
+    uint8_t *const myring = &S.ring[lane][0];
 
     unsigned st_steps = 0, st_fp = 0, st_trim = 0;
-    // Everything in the loop body is predicated arithmetic except three regions: the two rare P-maintenance
-    // paths (entered on a wave-uniform test) and the word step itself.  Lanes that are done (or never had a
-    // chunk) see b = 4 with an empty P and change nothing.
-    for (int k64 = 0; __any(active); k64 += 64) {
-      // current block -> 16 dwords that are rotated down by one per group of 4 steps; next block in flight
-      uint32_t c0 = nb0.x, c1 = nb0.y, c2 = nb0.z, c3 = nb0.w, c4 = nb1.x, c5 = nb1.y, c6 = nb1.z, c7 = nb1.w;
-      uint32_t c8 = nb2.x, c9 = nb2.y, c10 = nb2.z, c11 = nb2.w, c12 = nb3.x, c13 = nb3.y, c14 = nb3.z, c15 = nb3.w;
-      if (active && u + k64 + 64 < len) {
+    const unsigned long long st_t0 = STATS ? wall_clock64() : 0ull;
+    for (int k64 = 0; sd_any(k64 < nrun); k64 += 64) {
+      sd_v16u blk;
+      blk.s0 = nb0.x; blk.s1 = nb0.y; blk.s2 = nb0.z; blk.s3 = nb0.w; blk.s4 = nb1.x; blk.s5 = nb1.y; blk.s6 = nb1.z; blk.s7 = nb1.w;
+      blk.s8 = nb2.x; blk.s9 = nb2.y; blk.sa = nb2.z; blk.sb = nb2.w; blk.sc = nb3.x; blk.sd = nb3.y; blk.se = nb3.z; blk.sf = nb3.w;
+      if (k64 + 64 < nrun && u + k64 + 64 < len) {
           const uint4 *q = reinterpret_cast<const uint4 *>(seq + u + k64 + 64);
           nb0 = q[0]; nb1 = q[1]; nb2 = q[2]; nb3 = q[3];
       }
-      for (int k4 = k64; k4 < k64 + 64; k4 += 4) {
-        const uint32_t word = c0;
-        c0 = c1; c1 = c2; c2 = c3; c3 = c4; c4 = c5; c5 = c6; c6 = c7; c7 = c8;
-        c8 = c9; c9 = c10; c10 = c11; c11 = c12; c12 = c13; c13 = c14; c14 = c15;
-        // seq_nt4_table (:23-40) for the 4 bytes of the group at once: four independent LDS reads
-        const uint32_t codes4 = (uint32_t)S.lut[word & 0xFFu] | ((uint32_t)S.lut[(word >> 8) & 0xFFu] << 8) |
-                                ((uint32_t)S.lut[(word >> 16) & 0xFFu] << 16) | ((uint32_t)S.lut[word >> 24] << 24);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        ++st_steps;
-        const int i = u + k4 + kk;                   // position of this lane; all lanes share i & 63
-        const int b = (active & (i < len)) ? (int)((codes4 >> (8 * kk)) & 7u) : 4;
-        const bool isbase = b < 4;
-        const int l_old = l;
-        l = isbase ? l + 1 : 0;
-        t = isbase ? ((t << 2 | (unsigned)b) & 63u) : 0u;                     // :144 / :154
-        const bool isword = isbase & (l >= 3);
-        bool need_trim = false, need_fp = false;
-
-        // ---- P maintenance, rare (one wave-uniform test): the flush at an N or at the end of the sequence
-        // (:152-153) and save_masked_regions (:147); both only matter while P is non-empty
-        if (__any(active & (occ != 0) & (!isbase | isword))) {
-            if (active && !isbase) {
-                int st = (l_old - W + 1 > 0 ? l_old - W + 1 : 0) + (i + 1 - l_old);
-                while (occ) {
-                    if (minstart >= st) st = minstart + 1;
-                    save_evict(st, i);
-                    ++st;
-                }
-            }
-            if (isword && occ != 0) {
-                const int start = (l - W > 0 ? l - W : 0) + (i + 1 - l);     // :146
-                if (minstart < start) save_evict(start, i);
-            }
-        }
-        if (isword) {
-            // shift_window (:66-86) without cv / rv, straight-line: both table entries are read at once
-            // (the oldest word was prefetched at the end of the previous word step)
-            const int pop = size >= CAPW ? 1 : 0;
-            const unsigned s = s_pref;
-            int cs = CWL(s);
-            int ct = CWL(t);
-            cs -= pop;                               // --cw[s]   (:71)
-            CWL(s) = (uint8_t)cs;
-            ct = s == t ? cs : ct;
-            rw -= cs * pop;
-            size += 1 - pop;
-            ++p;
-            RINGL(p) = (uint8_t)t;                   // :75
-            rw += ct;                                // rw += cw[t]++   (:77)
-            CWL(t) = (uint8_t)(ct + 1);
-            // v must not hold more than m copies of t.  Only when the window now holds more than m can v,
-            // a suffix of it, do so: those lanes get their v start moved by the cooperative pass below.
-            need_trim = ct + 1 > m;
-            if (m == 0) vs = p + 1;
-            s_pref = RINGL(p - size + 1);            // the word the next pop removes
-        }
-        // ---- cooperative trim: vs moves just past the (m+1)-th most recent occurrence of t inside v --------
-        // (one ballot over the owner's ring: lane j reads ring slot j; about one lane per wave-step needs it
-        // in non-repetitive sequence)
-        unsigned long long todo = 0;
-        if (m > 0) {
-            todo = __ballot(need_trim);
-            st_trim += (unsigned)__popcll(todo);
-            while (todo) {
-                const int o = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
-                todo &= todo - 1;
-                const int o_p = rdlane(p, o), o_size = rdlane(size, o), o_vs = rdlane(vs, o);
-                const unsigned o_t = (unsigned)rdlane((int)t, o);
-                const unsigned mine = S.ring[lane >> 2][o][lane & 3];             // ring slot `lane` of the owner
-                const unsigned long long eq = __ballot(mine == o_t);
-                // chronological order: bit k <-> absolute word index o_p - 63 + k
-                const unsigned long long chron = rotr64(eq, (o_p + 1) & 63);
-                const int ws = o_p - o_size + 1;
-                const int first = o_vs > ws ? o_vs : ws;                           // first word of v before the trim
-                const int Lc = o_p - first + 1;                                    // 1..64
-                const unsigned long long inv = chron & (Lc >= 64 ? ~0ull : ~0ull << (64 - Lc));
-                if (__popcll(inv) > m) {
-                    const int oldest = __builtin_ctzll(inv);                       // oldest occurrence of t inside v
-                    vs = lane == o ? o_p - 63 + oldest + 1 : vs;
-                }
-            }
-        }
-        {
-            const int ws = p - size + 1;
-            const int first = vs > ws ? vs : ws;
-            const int L = p - first + 1;
-            need_fp = isword & (small_t ? (rw * 10 > __mul24(L, T)) : (rw * 10 > L * T));     // :149
-        }
-        // ---- cooperative find_perfect (:104-128) ------------------------------------------------------
-        // lane <-> window position j = 63 - lane, so that "suffix of the window" = "prefix of the wave" and
-        // both scans are forward DPP scans (no LDS round trips).
-        todo = __ballot(need_fp);
-        st_fp += (unsigned)__popcll(todo);
-        while (todo) {
-            const int o = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
-            todo &= todo - 1;
-            const int o_p = rdlane(p, o), o_size = rdlane(size, o), o_vs = rdlane(vs, o);
-            const int ws = o_p - o_size + 1;
-            const int first = o_vs > ws ? o_vs : ws;
-            const int i0 = first - ws - 1;                                     // = size - L - 1
-            const int j = 63 - lane;                                           // window position (0 = oldest)
-            const bool inwin = j < o_size;
-            const int rslot = (ws + j) & 63;
-            const unsigned wj = inwin ? S.ring[rslot >> 2][o][rslot & 3] : 0u;
-            unsigned long long eq = __ballot(inwin);
-#pragma unroll
-            for (int bb = 0; bb < 6; ++bb) {
-                const bool bit = (wj >> bb) & 1u;
-                const unsigned long long bal = __ballot(bit);
-                eq &= bit ? bal : ~bal;
-            }
-            // equal words at later window positions = lower lanes; suffix score r_j = inclusive prefix sum
-            const int r = wave_scan_add(inwin ? __popcll(eq & ((1ull << lane) - 1ull)) : 0);
-            const int new_l = o_size - j - 1;                                  // :111
-            const bool cand = inwin && j <= i0 && r * 10 > __mul24(T, new_l);  // :112 (new_l < 64, T < 2^21)
-            const unsigned long long candmask = __ballot(cand);
-            if (candmask == 0) continue;                                       // nothing can be inserted
-            const int o_l = rdlane(l, o), o_i = rdlane(i, o);
-            const int o_start = (o_l - W > 0 ? o_l - W : 0) + (o_i + 1 - o_l);          // :146
-            const unsigned long long o_occ = rdlane64(occ, o);
-            const int o_cid = rdlane(cid, o);
-            uint32_t *orow = A.slots + (size_t)o_cid * 64;
-            const int sidx = (o_start + j) & 63;
-            const bool has_e = inwin && ((o_occ >> sidx) & 1ull);
-            const uint32_t e = has_e ? __hip_atomic_load(&orow[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            const int er = (int)(e & 0xFFFFu), el = (int)(e >> 16);
-            // X_j = better of (existing entry with this start, candidate j); inclusive maximum over positions >= j
-            int xr = er, xl = el;
-            if (cand && (er == 0 || __mul24(r, el) >= __mul24(er, new_l))) { xr = r; xl = new_l; }
-            wave_scan_ratio_max(xr, xl);
-            // maximum over positions > j = the scan value one lane down (wave_shr:1; lane 0 gets 0)
-            const int sr = __builtin_amdgcn_update_dpp(0, xr, 0x138, 0xF, 0xF, true);
-            const int sl2 = __builtin_amdgcn_update_dpp(0, xl, 0x138, 0xF, 0xF, true);
-            int mr = sr, ml = sl2;                                             // :113-117: entries with start >= i + start
-            if (er != 0 && (sr == 0 || __mul24(er, sl2) > __mul24(sr, el))) { mr = er; ml = el; }
-            const bool ins = cand && (mr == 0 || __mul24(r, ml) >= __mul24(mr, new_l));   // :118
-            if (ins) orow[sidx] = (uint32_t)r | ((uint32_t)new_l << 16);       // start = i + start, finish = start + l + 3
-            const unsigned long long insj = __brevll(__ballot(ins));           // bit j <-> window position j
-            if (insj && lane == o) {
-                const int lowest = o_start + __builtin_ctzll(insj);
-                if (occ == 0 || lowest < minstart) minstart = lowest;
-                occ |= rotl64(insj, o_start & 63);
-            }
-        }
-        active = active & (i + 1 < stop);
+      // The packed decode below knows letters only.  A byte <= 3 (seq_nt4_table maps 0..3 to themselves) clears the
+      // top six bits of its byte lane in the AND of the block; letters never do (they all carry 0x40): such a block
+      // (and, harmlessly, a few others: zero padding behind a contig, '-' or '*' next to letters) is decoded byte by byte.
+      bool slow;
+      {
+          uint32_t a = blk.s0 & blk.s1 & blk.s2 & blk.s3 & blk.s4 & blk.s5 & blk.s6 & blk.s7 & blk.s8 & blk.s9 & blk.sa & blk.sb & blk.sc & blk.sd & blk.se & blk.sf;
+          a &= 0xFCFCFCFCu;
+          slow = ((a - 0x01010101u) & ~a & 0x80808080u) != 0;
       }
+      const bool slow_any = sd_any(slow);
+#pragma clang loop unroll(disable)
+      for (int g = 0; g < 16; ++g) {
+        const int k4 = k64 + 4 * g;
+        const uint32_t word = blk[g];
+        // ---- 4 positions -> 4 codes (bits 0-1 base, bit 2 non-base) ------------------------------------
+        uint32_t cn;
+        if (!slow_any) {
+            // fold case, look the low 3 bits up (A1 C3 T4 G7): the code, and the letter that must be there
+            const uint32_t y = word & 0xDFDFDFDFu, idx = y & 0x07070707u;
+            const uint32_t code = __builtin_amdgcn_perm(0x02000003u, 0x01000000u, idx);      // idx 7..4 | 3..0
+            const uint32_t expd = __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, idx);
+            const uint32_t d = y ^ expd;
+            const uint32_t nz = ((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d;                        // bit 7 of a byte: byte != 0
+            cn = code | ((nz >> 5) & 0x04040404u);
+        } else {
+            cn = (uint32_t)nt4_code(word & 0xFFu) | ((uint32_t)nt4_code((word >> 8) & 0xFFu) << 8) |
+                 ((uint32_t)nt4_code((word >> 16) & 0xFFu) << 16) | ((uint32_t)nt4_code(word >> 24) << 24);
+        }
+        if (sd_any(k4 + 4 > endk)) {                  // end of the sequence / of the chunk inside this group
+            const int rem = endk - k4 > 0 ? endk - k4 : 0;
+            if (rem < 4) cn |= 0x04040404u << (8 * rem);
+        }
+        // ---- 4 words: t = three consecutive codes (:144), bit 6 = not a word (l < 3), bit 7 = non-base ----
+        uint32_t tw;
+        {
+            const uint32_t y1 = __builtin_amdgcn_alignbyte(cn, pcn, 3);      // code of the previous position
+            const uint32_t y2 = __builtin_amdgcn_alignbyte(cn, pcn, 2);      // and of the one before
+            const uint32_t t = (cn & 0x03030303u) | ((y1 & 0x03030303u) << 2) | ((y2 & 0x03030303u) << 4);
+            const uint32_t nany = (cn | y1 | y2) & 0x04040404u;
+            tw = t | (nany << 4) | ((cn & 0x04040404u) << 5);
+            pcn = cn;
+        }
+        const uint32_t nmask = tw & 0x80808080u;
+        const bool grp_n = sd_any(nmask != 0);
+        // next step at which P needs attention: the oldest start leaves the window (i >= minstart + W, :146-147), or
+        // the next non-base of this group among the bytes selected by `above`
+        auto next_evict = [&](uint32_t above) {
+            const uint32_t mm = nmask & above;
+            const int nn = mm ? k4 + (__builtin_ctz(mm) >> 3) : SD_NEVER;
+            const int ev = minstart + W - u;
+            return occ ? (ev < nn ? ev : nn) : SD_NEVER;
+        };
+        if (grp_n) evict_k = next_evict(0xFFFFFFFFu);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int k = k4 + kk;
+          if (STATS) ++st_steps;
+          const unsigned f = (tw >> (8 * kk)) & 0xFFu;
+          // ---- P maintenance, rare: save_masked_regions (:147) when the oldest start leaves the window, and the
+          // flush at a non-base (:152-153)
+          if (sd_any(k >= evict_k)) {
+              if (k >= evict_k) {
+                  const uint32_t nb4 = nmask & (kk == 0 ? 0u : 0xFFFFFFFFu >> (32 - 8 * kk));          // non-bases before this step
+                  const int lastN = u + (nb4 ? k4 + ((31 - __builtin_clz(nb4)) >> 3) : LN);
+                  const int i = u + k;
+                  if (f & 0x80u) {
+                      const int l_old = i - 1 - lastN;
+                      int st = (l_old - W + 1 > 0 ? l_old - W + 1 : 0) + (i + 1 - l_old);
+                      while (occ) {
+                          if (minstart >= st) st = minstart + 1;
+                          save_evict(st, k);
+                          ++st;
+                      }
+                  } else if (f < 64u) {
+                      const int start = i + 1 - W > lastN + 1 ? i + 1 - W : lastN + 1;                            // :146
+                      if (occ != 0 && minstart < start) save_evict(start, k);
+                  }
+                  evict_k = next_evict(kk >= 3 ? 0u : 0xFFFFFFFFu << (8 * (kk + 1)));
+              }
+          }
+          const bool isword = f < 64u;
+          const unsigned long long wordmask = sd_ballot(f < 64u);
+          int ct = 0;
+          if (isword) {
+              // shift_window (:66-86) without cv / rv: the two counters are byte fields of LDS dwords, updated by
+              // returning atomics (one LDS op each instead of a read and a write)
+              const bool pop = p - o >= CAPW - 1;                                              // size >= W - 2  (:68)
+              const unsigned s = s_pref;
+              const unsigned sh_s = (s & 3u) << 3, sh_t = (f & 3u) << 3;
+              const uint32_t old_s = __hip_atomic_fetch_sub(&S.cw[s >> 2][lane], pop ? 1u << sh_s : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              const uint32_t old_t = __hip_atomic_fetch_add(&S.cw[f >> 2][lane], 1u << sh_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              o += pop ? 1 : 0;
+              ++p;
+              myring[p & 63] = (uint8_t)f;                                                     // :75
+              s_pref = myring[o & 63];
+              const int cs = (int)((old_s >> sh_s) & 0xFFu) - 1;                               // --cw[s]   (:71)
+              ct = (int)((old_t >> sh_t) & 0xFFu);                                             // cw[t]++   (:77), after the pop
+              rw10 = __mul24(ct - (pop ? cs : 0), 10) + rw10;
+          }
+          // v must not hold more than m copies of t.  Only when the window now holds more than m can v,
+          // a suffix of it, do so: those lanes get their v start moved by the cooperative pass below.
+          const unsigned long long trim_todo = sd_ballot(ct >= m);                      // ct = 0 < m in lanes without a word
+          // ---- cooperative trim: vs moves just past the (m+1)-th most recent occurrence of t inside v --------
+          // (one ballot over the owner's ring: lane j reads ring slot j; about one lane per wave-step needs it
+          // in non-repetitive sequence)
+          if (trim_todo) {
+              if (STATS) st_trim += (unsigned)__popcll(trim_todo);
+              unsigned long long todo = trim_todo;
+              while (todo) {
+                  const int ol = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+                  todo &= todo - 1;
+                  const int o_p = rdlane(p, ol), o_o = rdlane(o, ol), o_vs = rdlane(vs, ol);
+                  const unsigned o_t = (unsigned)rdlane((int)f, ol);
+                  const unsigned mine = S.ring[ol][lane];                                    // ring slot `lane` of the owner
+                  const unsigned long long eq = sd_ballot(mine == o_t);
+                  // chronological order: bit k <-> absolute word index o_p - 63 + k
+                  const unsigned long long chron = rotr64(eq, (o_p + 1) & 63);
+                  const int first = o_vs > o_o ? o_vs : o_o;                                 // first word of v before the trim
+                  const int Lc = o_p - first + 1;                                            // 1..64
+                  const unsigned long long inv = chron & (Lc >= 64 ? ~0ull : ~0ull << (64 - Lc));
+                  if (__popcll(inv) > m) {
+                      const int oldest = __builtin_ctzll(inv);                               // oldest occurrence of t inside v
+                      vs = lane == ol ? o_p - 63 + oldest + 1 : vs;
+                  }
+              }
+          }
+          unsigned long long fp_todo;
+          {
+              const int first = vs > o ? vs : o;
+              fp_todo = sd_ballot(rw10 > __mul24(p - first, T) + T) & wordmask;         // :149
+          }
+          // ---- cooperative find_perfect (:104-128) ------------------------------------------------------
+          // lane <-> window position j = 63 - lane, so that "suffix of the window" = "prefix of the wave" and
+          // both scans are forward DPP scans (no LDS round trips).
+          if (fp_todo) {
+              if (STATS) st_fp += (unsigned)__popcll(fp_todo);
+              unsigned long long todo = fp_todo;
+              while (todo) {
+                  const int ol = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+                  todo &= todo - 1;
+                  const int o_p = rdlane(p, ol), ws = rdlane(o, ol), o_vs = rdlane(vs, ol);
+                  const int o_size = o_p - ws + 1;
+                  const int first = o_vs > ws ? o_vs : ws;
+                  const int i0 = first - ws - 1;                                     // = size - L - 1
+                  const int j = 63 - lane;                                           // window position (0 = oldest)
+                  const bool inwin = j < o_size;
+                  const unsigned wj = S.ring[ol][(ws + j) & 63];
+                  // lanes holding the same word at a later window position (= lower lanes): one ballot per bit of the
+                  // word, kept as two 32-bit halves (per bit: sign-extended bit, compare, two 3-input logic ops)
+                  const unsigned long long inb = sd_ballot(inwin);
+                  uint32_t eq_lo = lt_lo & (uint32_t)inb, eq_hi = lt_hi & (uint32_t)(inb >> 32);
+#pragma unroll
+                  for (int bb = 0; bb < 6; ++bb) {
+                      const int ext = __builtin_amdgcn_sbfe((int)wj, bb, 1);                     // all ones / zero
+                      unsigned long long bal;
+                      asm("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(bal) : "v"(ext));                  // ballot of the bit
+                      eq_lo &= ~((uint32_t)ext ^ (uint32_t)bal);
+                      eq_hi &= ~((uint32_t)ext ^ (uint32_t)(bal >> 32));
+                  }
+                  // suffix score r_j = inclusive prefix sum
+                  const int r = wave_scan_add(inwin ? __popc(eq_lo) + __popc(eq_hi) : 0);
+                  const int new_l = o_size - j - 1;                                  // :111
+                  // :112 (new_l < 64, T < 2^17)
+                  const unsigned long long candmask = sd_ballot(__mul24(r, 10) > __mul24(T, new_l)) & sd_ballot(j <= i0) & inb;
+                  if (candmask == 0) continue;                                       // nothing can be inserted
+                  const bool cand = (candmask >> lane) & 1ull;
+                  int startv;                                                        // :146 for every lane's own state
+                  {
+                      const uint32_t nb4 = nmask & (kk == 0 ? 0u : 0xFFFFFFFFu >> (32 - 8 * kk));
+                      const int lastN = u + (nb4 ? k4 + ((31 - __builtin_clz(nb4)) >> 3) : LN);
+                      startv = u + k + 1 - W > lastN + 1 ? u + k + 1 - W : lastN + 1;
+                  }
+                  const int o_start = rdlane(startv, ol);
+                  const unsigned long long o_occ = rdlane64(occ, ol);
+                  const int o_cid = rdlane(cid, ol);
+                  uint32_t *orow = A.slots + (size_t)o_cid * 64;
+                  const int sidx = (o_start + j) & 63;
+                  const bool has_e = inwin && ((o_occ >> sidx) & 1ull);
+                  const uint32_t e = has_e ? __hip_atomic_load(&orow[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                  const int er = (int)(e & 0xFFFFu), el = (int)(e >> 16);
+                  // X_j = better of (existing entry with this start, candidate j); inclusive maximum over positions >= j
+                  int xr = er, xl = el;
+                  if (cand && (er == 0 || __mul24(r, el) >= __mul24(er, new_l))) { xr = r; xl = new_l; }
+                  wave_scan_ratio_max(xr, xl);
+                  // maximum over positions > j = the scan value one lane down (wave_shr:1; lane 0 gets 0)
+                  const int sr = __builtin_amdgcn_update_dpp(0, xr, 0x138, 0xF, 0xF, true);
+                  const int sl2 = __builtin_amdgcn_update_dpp(0, xl, 0x138, 0xF, 0xF, true);
+                  int mr = sr, ml = sl2;                                             // :113-117: entries with start >= i + start
+                  if (er != 0 && (sr == 0 || __mul24(er, sl2) > __mul24(sr, el))) { mr = er; ml = el; }
+                  const bool ins = cand && (mr == 0 || __mul24(r, ml) >= __mul24(mr, new_l));   // :118
+                  if (ins) orow[sidx] = (uint32_t)r | ((uint32_t)new_l << 16);       // start = i + start, finish = start + l + 3
+                  const unsigned long long insj = __brevll(sd_ballot(ins));           // bit j <-> window position j
+                  if (insj && lane == ol) {
+                      const int lowest = o_start + __builtin_ctzll(insj);
+                      if (occ == 0 || lowest < minstart) minstart = lowest;
+                      occ |= rotl64(insj, o_start & 63);
+                      evict_k = next_evict(kk >= 3 ? 0u : 0xFFFFFFFFu << (8 * (kk + 1)));
+                  }
+              }
+          }
+        }
+        if (grp_n && nmask) LN = k4 + ((31 - __builtin_clz(nmask)) >> 3);
       }
     }
-    if (cid < A.n_chunks) {                          // every lane that owned a chunk publishes its list
+    if (owned) {                                     // every lane that owned a chunk publishes its list
         if (have_last) {
             if (n_out < A.cap) out[n_out] = make_uint2(last_s, last_f);
             ++n_out;
@@ -694,13 +765,58 @@ __global__ __launch_bounds__(64) void sdust_w64(SdArgs A)
         A.out_n[cid] = n_out;
         if (n_out > A.cap) atomicMax(A.ovf, n_out);
     }
-    if (A.stats && lane == 0) {
+    if (STATS && A.stats && lane == 0) {
         atomicAdd(&A.stats[0], (unsigned long long)st_steps);
         atomicAdd(&A.stats[1], (unsigned long long)st_fp);
         atomicAdd(&A.stats[2], (unsigned long long)st_trim);
+        const unsigned long long dt = wall_clock64() - st_t0;      // 100 MHz ticks this wave spent in the loop
+        atomicAdd(&A.stats[3], dt);
+        atomicMax(&A.stats[4], dt);
     }
-#undef RINGL
-#undef CWL
+}
+
+// ---- scheduling hint: which chunks look low-complexity?  Two 64-byte samples per chunk (at 1/4 and 3/4 of it); a
+// sample whose 62 3-mers take few distinct values (random sequence: ~40 of 64) lies in a repeat array.  The flag
+// only orders the work (flagged chunks first, one per wave); results do not depend on it.
+__global__ void sd_sample(const uint8_t *bases, const int64_t *ctg_off, const SdChunk *chunks, int32_t n_chunks, uint32_t *flag)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const SdChunk ch = chunks[c];
+    const uint8_t *seq = bases + ctg_off[ch.ctg];
+    const int clen = ch.end - ch.start;
+    uint32_t heavy = 0;
+    for (int q = 1; q <= 3; q += 2) {
+        const int at = (ch.start + (clen >> 2) * q) & ~63;                 // blocks never leave the (64-byte padded) contig
+        const uint4 *src = reinterpret_cast<const uint4 *>(seq + at);
+        unsigned long long seen = 0;
+        int l = 0, nw = 0;
+        unsigned t = 0;
+        for (int v = 0; v < 4; ++v) {
+            const uint4 x = src[v];
+            const uint32_t w4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int code = nt4_code((w4[d] >> (8 * b)) & 0xFFu);
+                    l = code < 4 ? l + 1 : 0;
+                    t = ((t << 2) | (unsigned)(code & 3)) & 63u;
+                    if (l >= 3) { seen |= 1ull << t; ++nw; }
+                }
+        }
+        if (nw >= 32 && __popcll(seen) <= 20) heavy = 1;
+    }
+    flag[c] = heavy;
+}
+
+// stable partition: flagged chunks first (rank among the flagged), then the others in order
+__global__ void sd_order(const uint32_t *flag, const uint32_t *rank, const unsigned long long *n_flagged, int32_t n_chunks, uint32_t *perm)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const uint32_t r = rank[c];
+    perm[flag[c] ? r : (uint32_t)*n_flagged + ((uint32_t)c - r)] = (uint32_t)c;
 }
 
 // chunk rows (fixed capacity) -> one dense list in chunk order, tagged with the contig: one wavefront per chunk
@@ -783,14 +899,29 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             CN_HIP(h, hipMemsetAsync(d_tot, 0, 64, h->stream));
             uint32_t *d_slots = (uint32_t *)cn_ws(h, WS_SD_OFF, nc * 64 * sizeof(uint32_t));
             if (!d_slots) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
+            const int variant = env_int("CORNETTO_SDUST_VARIANT", 0);   // 1 = force the per-lane reference-shaped kernel
+            const bool use_w64 = W - 2 <= 64 && T >= 5 && T <= 100000 && variant == 0;
+            const int map_stride = env_int("CORNETTO_SDUST_MAP", 1);
+            uint32_t *d_perm = nullptr;
+            if (use_w64 && map_stride && env_int("CORNETTO_SDUST_ORDER", 1)) {
+                // flag (nc) + rank (nc) + perm (nc) + scan partials
+                uint32_t *d_flag = (uint32_t *)cn_ws(h, WS_SD_PERM, nc * 12 + ((nc + 4095) / 4096 + 1) * 4);
+                if (!d_flag) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
+                uint32_t *d_rank = d_flag + nc, *d_pp = d_rank + nc + nc;
+                d_perm = d_rank + nc;
+                const unsigned nbs = (unsigned)((nc + 255) / 256);
+                CN_LAUNCH(h, "sdust_order", sd_sample<<<dim3(nbs), dim3(256), 0, h->stream>>>(a->d_bases, a->d_off, d_chunks, (int32_t)nc, d_flag));
+                CN_TRY(cnscan::exclusive_u32(h, "sdust_order", d_flag, (int64_t)nc, 1, d_rank, d_pp, d_tot + 7));
+                CN_LAUNCH(h, "sdust_order", sd_order<<<dim3(nbs), dim3(256), 0, h->stream>>>(d_flag, d_rank, d_tot + 7, (int32_t)nc, d_perm));
+            }
             SdArgs A{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, d_out, d_cnt, (uint32_t)cap,
-                     want_stats ? d_tot + 2 : nullptr, reinterpret_cast<uint32_t *>(d_tot + 1), d_slots, env_int("CORNETTO_SDUST_MAP", 1),
+                     want_stats ? d_tot + 2 : nullptr, reinterpret_cast<uint32_t *>(d_tot + 1), d_slots, map_stride, d_perm,
                      a->d_wtab, a->d_wtab_base, reinterpret_cast<uint32_t *>(d_tot + 1) + 1};
             unsigned nb = (unsigned)((nc + 63) / 64);
-            const int variant = env_int("CORNETTO_SDUST_VARIANT", 0);   // 1 = force the per-lane reference-shaped kernel
-            if (W - 2 <= 64 && variant == 0) {
-                if (env_int("CORNETTO_SDUST_MAP", 1) == 0) nb = (unsigned)((nc + 4095) / 4096) * 64;   // whole groups of 64 waves
-                CN_LAUNCH(h, "sdust_kernel", sdust_w64<<<dim3(nb), dim3(64), 0, h->stream>>>(A));
+            if (use_w64) {
+                if (map_stride == 0) nb = (unsigned)((nc + 4095) / 4096) * 64;   // whole groups of 64 waves
+                if (want_stats) CN_LAUNCH(h, "sdust_kernel", sdust_w64<true><<<dim3(nb), dim3(64), 0, h->stream>>>(A));
+                else CN_LAUNCH(h, "sdust_kernel", sdust_w64<false><<<dim3(nb), dim3(64), 0, h->stream>>>(A));
             } else if (W - 2 <= 64) {
                 CN_LAUNCH(h, "sdust_kernel", sdust_kernel<64><<<dim3(nb), dim3(64), 0, h->stream>>>(A));
             } else {
@@ -801,7 +932,8 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             CN_HIP(h, hipMemcpyAsync(p_tot, d_tot, 64, hipMemcpyDeviceToHost, h->stream));
             CN_HIP(h, hipStreamSynchronize(h->stream));
             if (want_stats)
-                fprintf(stderr, "[sdust stats] chunks %zu waves %u wave-steps %llu find_perfect calls %llu trims %llu\n", nc, nb, p_tot[2], p_tot[3], p_tot[4]);
+                fprintf(stderr, "[sdust stats] flagged low-complexity %llu; chunks %zu waves %u wave-steps %llu find_perfect calls %llu trims %llu; wave time avg %.1f us max %.1f us\n", p_tot[7], nc, nb,
+                        p_tot[2], p_tot[3], p_tot[4], nb ? (double)p_tot[5] / nb / 100.0 : 0.0, (double)p_tot[6] / 100.0);
             const uint32_t ovf = (uint32_t)(p_tot[1] & 0xFFFFFFFFull);
             const bool need_wtab = (p_tot[1] >> 32) != 0;
             if (need_wtab) {

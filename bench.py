@@ -170,6 +170,7 @@ def main():
     ap.add_argument("--gbases", type=float, default=0.0, help="assembly size per GPU in Gbases (0 = the full 3.16 Gbp fixture)")
     ap.add_argument("--cpu-sample-mbases", type=float, default=500.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sdust-share", type=int, default=75, help="percent of every CU the sdust kernel may occupy while the other stream runs beside it")
     ap.add_argument("--serial", action="store_true", help="run the stages one after the other on one stream (per-kernel timing without overlap)")
     args = ap.parse_args()
 
@@ -232,6 +233,9 @@ def main():
     acc2 = cornetto_amd.Accel(local_dev, None)                       # second stream, same device
     asm2 = acc2.asm_wrap(bases.data_ptr(), offs, np.array(lens, dtype=np.int64))
     overlap = not args.serial
+    if overlap:
+        # the sdust waves stay resident until their queue is empty: leave part of every CU to the other stream
+        acc2.set_share(args.sdust_share)
 
     def note2():
         for name, ms in acc2.last_timing():

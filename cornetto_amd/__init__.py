@@ -71,6 +71,7 @@ def lib():
         "cornetto_accel_strerror": (cp, [C.c_int]),
         "cornetto_free": (None, [vp]),
         "cornetto_accel_last_timing": (C.c_int, [vp, C.POINTER(cp), C.POINTER(C.c_float), C.c_int]),
+        "cornetto_accel_set_share": (C.c_int, [vp, C.c_int]),
         "cornetto_asm_upload": (C.c_int, [vp, vp, vp, i32, pp]),
         "cornetto_asm_wrap": (C.c_int, [vp, vp, vp, vp, i32, pp]),
         "cornetto_asm_free": (None, [vp, vp]),
@@ -177,6 +178,10 @@ class Accel:
         if rc != 0:
             raise AccelError(rc, self.L.cornetto_accel_last_error(self.h).decode() or
                              self.L.cornetto_accel_strerror(rc).decode())
+
+    def set_share(self, percent):
+        """percent of every CU the resident sdust kernel may occupy (another handle computes beside this one)"""
+        self._chk(self.L.cornetto_accel_set_share(self.h, int(percent)))
 
     def last_timing(self):
         """[(kernel name, ms)] of the most recent compute call (HIP events on the handle's stream)"""

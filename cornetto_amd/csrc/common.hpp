@@ -33,6 +33,9 @@ struct cornetto_accel {
     };
     Ws dev[64];
     Ws pin[32];
+    int sd_slots = 0;   // sdust: waves the device holds at once (occupancy query, cached)
+    int sd_cus = 0;
+    int share = 100;    // percent of every CU the resident sdust kernel may take (cornetto_accel_set_share)
 };
 
 // device workspace slot `slot` with at least `bytes` bytes (contents undefined); nullptr on failure

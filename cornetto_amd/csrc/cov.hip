@@ -26,7 +26,7 @@
 namespace {
 
 constexpr int CB_THREADS = 256;
-constexpr int CB_MAX_INC_LDS = 128;   // inc <= this: LDS staging path (2 x 256 x inc x 2 B <= 128 KiB)
+constexpr int CB_MAX_INC_LDS = 128;   // inc <= this: LDS staging path (256 x inc x 2 B <= 64 KiB)
 
 struct CbArgs {
     const uint16_t *depth, *mq;
@@ -52,6 +52,8 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 template <bool STAGE>
 __global__ __launch_bounds__(CB_THREADS) void cov_blocks(CbArgs A)
 {
+    __builtin_amdgcn_s_setprio(3);   // short streaming kernel: issue ahead of a long compute-bound kernel of another stream
+
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t wsum[2][CB_THREADS / 64];
     __shared__ unsigned long long wsum64[2][CB_THREADS / 64];
@@ -67,41 +69,46 @@ __global__ __launch_bounds__(CB_THREADS) void cov_blocks(CbArgs A)
     uint32_t fd = 0, fq = 0, hd = 0, hq = 0;
     unsigned long long xd = 0, xq = 0;                  // exact block sums
     if (STAGE) {
-        uint16_t *sd = reinterpret_cast<uint16_t *>(smem);
-        uint16_t *sq = sd + CB_THREADS * inc;           // 256*inc*2 bytes: multiple of 16
-        const int nvec = CB_THREADS * inc / 8;          // 16-byte vectors per array
-        const uint4 *gd = reinterpret_cast<const uint4 *>(A.depth + off + e0);
-        const uint4 *gq = reinterpret_cast<const uint4 *>(A.mq + off + e0);
-        for (int v = t; v < nvec; v += CB_THREADS) {
-            uint4 a = make_uint4(0, 0, 0, 0), b = a;
-            if (e0 + 8LL * v < len) {                   // vectors at or past the contig end are zeros
-                a = gd[v];
-                b = gq[v];
-            }
-            reinterpret_cast<uint4 *>(sd)[v] = a;
-            reinterpret_cast<uint4 *>(sq)[v] = b;
-        }
-        __syncthreads();
+        // One array at a time through the same LDS buffer (256 * inc * 2 bytes): half the footprint, so that twice as
+        // many workgroups fit, also next to another stream's kernel that owns most of the CU's LDS.
+        uint16_t *sv = reinterpret_cast<uint16_t *>(smem);
+        const int nvec = CB_THREADS * inc / 8;          // 16-byte vectors per array (256 * inc * 2 bytes: multiple of 16)
         const int base = t * inc;
         const int nval = p0 >= len ? 0 : (int)(len - p0 < inc ? len - p0 : inc);   // elements of my block inside the contig
-        if (nval == inc && (inc & 1) == 0) {
-            const uint32_t *wd = reinterpret_cast<const uint32_t *>(sd + base);
-            const uint32_t *wq = reinterpret_cast<const uint32_t *>(sq + base);
-            for (int i = 0; i < inc / 2; ++i) {
-                const uint32_t a = wd[i], b = wq[i];
-                fd += (a & 0xFFFFu) + (a >> 16);
-                fq += (b & 0xFFFFu) + (b >> 16);
-            }
-        } else {
-            for (int i = 0; i < nval; ++i) {
-                fd += sd[base + i];
-                fq += sq[base + i];
-            }
-        }
         const int nh = r < nval ? r : nval;
-        for (int i = 0; i < nh; ++i) {
-            hd += sd[base + i];
-            hq += sq[base + i];
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const uint4 *g = reinterpret_cast<const uint4 *>((which ? A.mq : A.depth) + off + e0);
+            if (which) __syncthreads();                 // everyone is done reading the first array
+            // eight 16-byte loads in flight per thread before the first LDS store: a single resident workgroup per CU
+            // (all that fits beside another stream's kernel) still keeps 32 KB on the wire
+            for (int v0 = t; v0 < nvec; v0 += 8 * CB_THREADS) {
+                uint4 a[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int v = v0 + k * CB_THREADS;
+                    a[k] = make_uint4(0, 0, 0, 0);
+                    if (v < nvec && e0 + 8LL * v < len) a[k] = g[v];       // vectors at or past the contig end are zeros
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int v = v0 + k * CB_THREADS;
+                    if (v < nvec) reinterpret_cast<uint4 *>(sv)[v] = a[k];
+                }
+            }
+            __syncthreads();
+            uint32_t f = 0, hh = 0;
+            if (nval == inc && (inc & 1) == 0) {
+                const uint32_t *wd = reinterpret_cast<const uint32_t *>(sv + base);
+                for (int i = 0; i < inc / 2; ++i) {
+                    const uint32_t a = wd[i];
+                    f += (a & 0xFFFFu) + (a >> 16);
+                }
+            } else {
+                for (int i = 0; i < nval; ++i) f += sv[base + i];
+            }
+            for (int i = 0; i < nh; ++i) hh += sv[base + i];
+            if (which) { fq = f; hq = hh; } else { fd = f; hd = hh; }
         }
         xd = fd;
         xq = fq;
@@ -209,6 +216,8 @@ __device__ __forceinline__ uint2 cw_prefix(const CwArgs &A, int64_t x)   // incl
 
 __global__ __launch_bounds__(256) void cov_windows(CwArgs A)
 {
+    __builtin_amdgcn_s_setprio(3);   // short streaming kernel: issue ahead of a long compute-bound kernel of another stream
+
     __shared__ uint32_t wcnt[4];
     __shared__ unsigned long long sbase;
     const int t = threadIdx.x;
@@ -359,7 +368,7 @@ int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int3
     CN_HIP(h, hipMemsetAsync(d_grand, 0, 16, h->stream));
     CbArgs A{c->d_depth, c->d_mq, c->d_off, c->d_len, c->d_cb_tiles, inc, r, d_blk, d_t32, d_t64};
     if (inc <= CB_MAX_INC_LDS) {
-        const size_t lds = (size_t)2 * CB_THREADS * inc * sizeof(uint16_t);
+        const size_t lds = (size_t)CB_THREADS * inc * sizeof(uint16_t);
         CN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&cov_blocks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CN_LAUNCH(h, "cov_blocks", cov_blocks<true><<<dim3((unsigned)nt), dim3(CB_THREADS), lds, h->stream>>>(A));
     } else {

@@ -126,6 +126,14 @@ void cornetto_free(void *p)
     else free(p);
 }
 
+int cornetto_accel_set_share(cornetto_accel_t *h, int percent)
+{
+    if (!h) return CORNETTO_E_ARG;
+    if (percent < 10 || percent > 100) return cn_fail(h, CORNETTO_E_ARG, "set_share: %d outside 10..100", percent);
+    h->share = percent;
+    return CORNETTO_OK;
+}
+
 int cornetto_accel_last_timing(const cornetto_accel_t *h, const char **names, float *ms, int cap)
 {
     if (!h) return 0;

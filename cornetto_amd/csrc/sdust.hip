@@ -49,9 +49,11 @@ struct SdArgs {
     uint32_t cap;
     unsigned long long *stats;   // optional [4]: wave steps, cooperative find_perfect calls, cooperative trims, save/evicts
     uint32_t *ovf;               // max over chunks of (intervals produced) when that exceeds cap, else untouched
-    uint32_t *slots;             // sdust_w64: [n_chunks][64] P slots (start & 63 -> r | l << 16), global memory
-    int32_t map_stride;          // chunk -> lane mapping (0: 64-wave groups, 1: strided over the grid)
-    const uint32_t *perm;        // map_stride = 1: slot (lane * waves + wave) -> chunk, low-complexity chunks first; or NULL
+    uint32_t *slots;             // sdust_w64: [n_chunks][64] P slots (start & 63 -> ratio key | l << 24), global memory
+    const uint32_t *perm;        // sdust_w64: queue position -> chunk (low-complexity chunks first), or NULL
+    const int32_t *ustart;       // sdust_w64: warm-up start of every chunk (sd_prep)
+    uint32_t *queue;             // sdust_w64: next queue position
+    int32_t max_jobs;            // sdust_w64: chunks a lane takes before its wave retires (makes room for other streams' work)
     // bounded warm-up search (sdust_w64): the local backward scan gives up after SD_SCAN_CAP bases; then
     const uint32_t *wtab;        //   exclusive prefix of per-256-base-block word-emission counts, or NULL
     const int64_t *wtab_base;    //   first table entry of each contig
@@ -384,6 +386,22 @@ __device__ __forceinline__ void wave_scan_ratio_max(int &xr, int &xl)
     RATIO_SCAN_STEP(DPP_ROW_BCAST31, 0xC, false)
 }
 
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t x)
+{
+#define SD_MAX_STEP(ctrl, rmask, bound) { const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, (ctrl), (rmask), 0xF, (bound)); x = y > x ? y : x; }
+    SD_MAX_STEP(DPP_ROW_SHR(1), 0xF, true)
+    SD_MAX_STEP(DPP_ROW_SHR(2), 0xF, true)
+    SD_MAX_STEP(DPP_ROW_SHR(4), 0xF, true)
+    SD_MAX_STEP(DPP_ROW_SHR(8), 0xF, true)
+    SD_MAX_STEP(DPP_ROW_BCAST15, 0xA, false)
+    SD_MAX_STEP(DPP_ROW_BCAST31, 0xC, false)
+#undef SD_MAX_STEP
+    return x;
+}
+// Order-preserving integer key of the ratio r / l, 0 <= r < 2^11, 1 <= l <= 64: floor(r * 2^13 / l) < 2^24.  Two different
+// ratios with denominators <= 64 differ by at least 1 / 4096, i.e. by at least 2 after scaling: their keys differ and
+// are ordered like the ratios; equal ratios give equal keys.  (The reference cross-multiplies, src/sdust/sdust.c:115,118.)
+__device__ __forceinline__ uint32_t sd_ratio_key(uint32_t r, uint32_t l) { return ((r & 0x7FFu) << 13) / (l & 0x7Fu); }
 typedef uint32_t sd_v16u __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ unsigned long long sd_ballot(bool x) { return __builtin_amdgcn_ballot_w64(x); }
 __device__ __forceinline__ bool sd_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0; }
@@ -398,92 +416,28 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
     const uint32_t lt_lo = lane < 32 ? (1u << lane) - 1u : ~0u, lt_hi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;   // lanes below this one
     for (int i = 0; i < 16; ++i) S.cw[i][lane] = 0;
 
-    // chunk of this lane: strided over the whole grid (lane l of wave w owns chunk l * waves + w).  A wave's 64
-    // lanes then sample 64 far-apart places of the input, so the share of low-complexity lanes in a wave is the
-    // global average instead of the local one (a telomere array or a satellite-rich small contig no longer
-    // serialises inside one wave: 50 -> 28 ms on the 3.16 Gbp assembly), while the waves resident at any time
-    // still advance through 64 compact regions (no measurable memory penalty).  map_stride = 0 keeps the
-    // older 64-wave group interleave for comparison.
-    int cid = lane * (int)gridDim.x + (int)blockIdx.x;
-    if (!A.map_stride) cid = (((int)blockIdx.x >> 6) << 12) + lane * 64 + ((int)blockIdx.x & 63);
-    const bool owned = cid < A.n_chunks;
-    // Chunks sampled as low-complexity come first in `perm`: they land one per wave in the waves dispatched first.
-    // A lane inside a satellite or telomere array makes every step of its wave several times dearer (find_perfect
-    // runs, and inserts, at every base), so such a wave runs several times longer than the average one; started
-    // in the last round it alone would set the kernel's duration.
-    if (owned && A.map_stride && A.perm) cid = (int)A.perm[cid];
-    bool haschunk = owned;
-
     const int T = A.T, W = A.W, CAPW = W - 2;
     const int m = (T << 1) / 10;                     // cv[t]*10 > T<<1  <=>  cv[t] > m   (:79)
-    SdChunk ch{0, 0, 0};
-    int len = 0;
+
+    // ---- jobs.  The grid is as many waves as fit on the chip at once; every LANE takes chunks from one global
+    // queue (A.perm order: chunks sampled as low-complexity first) until it is empty, so nothing waits for a
+    // "round" of workgroups to retire and a wave slowed down by a lane inside a satellite or telomere array
+    // (find_perfect runs, and inserts, at every base there) just takes fewer chunks.  K counts the steps of the
+    // wave; a lane that starts a chunk at step K0 from position u keeps ubase = u - K0, so that step K is
+    // position ubase + K for it.  Chunks start on 64-step boundaries (u is 64-byte aligned: all lanes stay on
+    // the same phase of the 64-byte blocks).
+    bool done = false, hasjob = false;
+    int jobs_left = A.max_jobs;
+    int cid = 0, ubase = 0, len = 0;
     const uint8_t *seq = A.bases;
-    if (haschunk) {
-        ch = A.chunks[cid];
-        len = A.ctg_len[ch.ctg];
-        seq = A.bases + A.ctg_off[ch.ctg];
-    }
-    // P slots of this lane: one 256-byte row in global memory (L2 resident; touched only around
-    // find_perfect / save_masked_regions), which keeps the per-wave LDS at 8.3 KB = 19 waves per CU
-    uint32_t *myslots = A.slots + (size_t)(haschunk ? cid : 0) * 64;
+    uint32_t *myslots = A.slots;                     // P slots of the lane's chunk: one 256-byte row in global memory
+    uint2 *out = A.out;
+    // steps >= endk see a non-base: the end of the sequence (:141, flushes P and records it) or the end of the
+    // chunk (flushes P without recording: those intervals belong to the next chunk).  Only steps
+    // recfrom_k <= k < nrun record.
+    int endk = 0, nrun = 0, recfrom_k = 0;
 
-    // ---- warm-up start: W-2 word emissions before (chunk start - 2W) --------------------------------
-    int u = 0;
-    if (haschunk && ch.start > 0) {
-        const int y = ch.start - 2 * W;
-        if (y > 2) {
-            int need = CAPW, run = 0, p = y - 1;
-            const int floor_p = y - SD_SCAN_CAP > 0 ? y - SD_SCAN_CAP : 0;
-            for (; p >= floor_p; --p) {
-                if (nt4_code(seq[p]) < 4) {
-                    if (++run >= 3 && --need == 0) break;
-                } else {
-                    run = 0;
-                }
-            }
-            if (need == 0 || floor_p == 0) {
-                u = p > 0 ? p : 0;
-            } else if (A.wtab == nullptr) {
-                // N-dense stretch longer than the local scan: ask the host for the word-count table and a rerun
-                atomicOr(A.need_wtab, 1u);
-                haschunk = false;
-            } else {
-                // rank of the wanted word among the word emissions of the contig, from the block table
-                const uint32_t *tab = A.wtab + A.wtab_base[ch.ctg];
-                const uint32_t t0 = tab[0];
-                const int yb = y / SD_WBLK;
-                int wy = (int)(tab[yb] - t0);                     // emissions ending before block yb
-                {
-                    int r2 = 0;
-                    for (int q = yb * SD_WBLK - 2 < 0 ? 0 : yb * SD_WBLK - 2; q < y; ++q) {
-                        r2 = nt4_code(seq[q]) < 4 ? r2 + 1 : 0;
-                        wy += (q >= yb * SD_WBLK) & (r2 >= 3);
-                    }
-                }
-                if (wy < CAPW) {
-                    u = 0;
-                } else {
-                    const int rank = wy - CAPW + 1;               // 1-based rank of the oldest word that must be replayed
-                    int lo = 0, hi = yb;                          // largest block b with (tab[b] - t0) < rank
-                    while (lo < hi) {
-                        const int mid = (lo + hi + 1) >> 1;
-                        if ((int)(tab[mid] - t0) < rank) lo = mid; else hi = mid - 1;
-                    }
-                    int seen = (int)(tab[lo] - t0), r2 = 0, q = lo * SD_WBLK - 2 < 0 ? 0 : lo * SD_WBLK - 2;
-                    for (; q < y; ++q) {
-                        r2 = nt4_code(seq[q]) < 4 ? r2 + 1 : 0;
-                        if (q >= lo * SD_WBLK && r2 >= 3 && ++seen == rank) break;
-                    }
-                    u = q - 2 > 0 ? q - 2 : 0;                     // first base of that word
-                }
-            }
-        }
-    }
-    u &= ~63;  // starting a little earlier is still exact, and keeps every lane on the same 64-byte phase
-
-    // ---- per-lane sequential state.  Positions are kept relative to u (step k <-> position u + k), word
-    // indices are absolute counts of pushed words.
+    // ---- per-lane sequential state; word indices are counts of pushed words since the chunk's warm-up start
     int p = -1;                 // index of the newest word in the window
     int o = 0;                  // index of the oldest word in the window (size = p - o + 1)
     int vs = 0;                 // index of the first word of v (the suffix with all counts <= m)
@@ -495,13 +449,6 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
     int LN = -1;                // step of the last non-base before the current group of 4 steps
     bool have_last = false;
     uint32_t last_s = 0, last_f = 0, n_out = 0;
-    uint2 *out = A.out + (size_t)(haschunk ? cid : 0) * A.cap;
-    // steps >= endk see a non-base: the end of the sequence (:141, flushes P and records it) or the end of the
-    // chunk (flushes P without recording: those intervals belong to the next chunk).  Only steps
-    // recfrom_k <= k < nrun record.
-    const int endk = haschunk ? ch.end - u : 0;
-    const int nrun = haschunk ? (ch.end == len ? endk + 1 : endk) : 0;
-    const int recfrom_k = ch.start - u;
 
     auto emit = [&](int ps, int pf) {               // :93-99 on the lane-local list
         if (have_last && ps <= (int)last_f) {
@@ -519,7 +466,7 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
     // save_masked_regions(start) when it does something: occ != 0 && minstart < start   (:88-102)
     auto save_evict = [&](int start, int nowk) {
         const uint32_t sl = __hip_atomic_load(&myslots[minstart & 63], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (nowk >= recfrom_k && nowk < nrun) emit(minstart, minstart + (int)(sl >> 16) + 3);
+        if (nowk >= recfrom_k && nowk < nrun) emit(minstart, minstart + (int)(sl >> 24) + 3);
         const int gone = start - minstart;           // starts minstart .. start-1 leave the window
         if (gone >= 64) {
             occ = 0;
@@ -536,21 +483,75 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
     // concurrent per-lane streams of an XCD overflowed its 4 MB L2 and each line was re-fetched ~6 times
     // (rocprofv3 FETCH_SIZE, profiles/).  A block never leaves its contig: contigs start 64-byte aligned.
     uint4 nb0 = make_uint4(0, 0, 0, 0), nb1 = nb0, nb2 = nb0, nb3 = nb0;
-    if (haschunk && u < len) {
-        const uint4 *q = reinterpret_cast<const uint4 *>(seq + u);
-        nb0 = q[0]; nb1 = q[1]; nb2 = q[2]; nb3 = q[3];
-    }
     uint32_t pcn = 0x04040404u;                      // codes of the previous 4 positions (before u: non-bases, l = 0)
     uint8_t *const myring = &S.ring[lane][0];
 
     unsigned st_steps = 0, st_fp = 0, st_trim = 0;
     const unsigned long long st_t0 = STATS ? wall_clock64() : 0ull;
-    for (int k64 = 0; sd_any(k64 < nrun); k64 += 64) {
+    for (int k64 = 0;; k64 += 64) {
+      // ---- lanes whose chunk is finished publish it and take the next one from the queue
+      const bool need = !done && k64 >= nrun;
+      if (sd_any(need)) {
+          const bool fetch = need && jobs_left > 0;
+          const unsigned long long needmask = sd_ballot(fetch);
+          int base = 0;
+          if (needmask) {
+              const int first = __builtin_ctzll(needmask);
+              if (lane == first) base = (int)atomicAdd(A.queue, (uint32_t)__popcll(needmask));
+              base = rdlane(base, first);
+          }
+          if (need) {
+              if (hasjob) {
+                  if (have_last) {
+                      if (n_out < A.cap) out[n_out] = make_uint2(last_s, last_f);
+                      ++n_out;
+                  }
+                  A.out_n[cid] = n_out;
+                  if (n_out > A.cap) atomicMax(A.ovf, n_out);
+              }
+              const int idx = base + __popc(lt_lo & (uint32_t)needmask) + __popc(lt_hi & (uint32_t)(needmask >> 32));
+              hasjob = fetch && idx >= 0 && idx < A.n_chunks;     // (idx < 0: more than 2^31 fetches, impossible)
+              --jobs_left;
+              done = !hasjob;
+              endk = nrun = 0;
+              nb0 = nb1 = nb2 = nb3 = make_uint4(0, 0, 0, 0);
+              occ = 0;
+              evict_k = SD_NEVER;
+              if (hasjob) {
+                  cid = A.perm ? (int)A.perm[idx] : idx;
+                  const SdChunk ch = A.chunks[cid];
+                  const int u = A.ustart[cid];           // warm-up start (sd_prep), 64-byte aligned; < 0: not known
+                  len = A.ctg_len[ch.ctg];
+                  seq = A.bases + A.ctg_off[ch.ctg];
+                  myslots = A.slots + (size_t)cid * 64;
+                  out = A.out + (size_t)cid * A.cap;
+                  have_last = false;
+                  n_out = 0;
+                  if (u >= 0) {
+                      ubase = u - k64;
+                      endk = (ch.end - u) + k64;
+                      nrun = ch.end == len ? endk + 1 : endk;
+                      recfrom_k = (ch.start - u) + k64;
+                      p = -1; o = 0; vs = 0; rw10 = 0; s_pref = 0;
+                      LN = k64 - 1;
+                      pcn = 0x04040404u;
+                      for (int i = 0; i < 16; ++i) S.cw[i][lane] = 0;
+                      if (u < len) {
+                          const uint4 *q = reinterpret_cast<const uint4 *>(seq + u);
+                          nb0 = q[0]; nb1 = q[1]; nb2 = q[2]; nb3 = q[3];
+                      }
+                  } else {
+                      endk = nrun = k64;                 // empty job (the host reruns with the word-count table)
+                  }
+              }
+          }
+          if (sd_ballot(!done) == 0) break;
+      }
       sd_v16u blk;
       blk.s0 = nb0.x; blk.s1 = nb0.y; blk.s2 = nb0.z; blk.s3 = nb0.w; blk.s4 = nb1.x; blk.s5 = nb1.y; blk.s6 = nb1.z; blk.s7 = nb1.w;
       blk.s8 = nb2.x; blk.s9 = nb2.y; blk.sa = nb2.z; blk.sb = nb2.w; blk.sc = nb3.x; blk.sd = nb3.y; blk.se = nb3.z; blk.sf = nb3.w;
-      if (k64 + 64 < nrun && u + k64 + 64 < len) {
-          const uint4 *q = reinterpret_cast<const uint4 *>(seq + u + k64 + 64);
+      if (k64 + 64 < nrun && ubase + k64 + 64 < len) {
+          const uint4 *q = reinterpret_cast<const uint4 *>(seq + ubase + k64 + 64);
           nb0 = q[0]; nb1 = q[1]; nb2 = q[2]; nb3 = q[3];
       }
       // The packed decode below knows letters only.  A byte <= 3 (seq_nt4_table maps 0..3 to themselves) clears the
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
         auto next_evict = [&](uint32_t above) {
             const uint32_t mm = nmask & above;
             const int nn = mm ? k4 + (__builtin_ctz(mm) >> 3) : SD_NEVER;
-            const int ev = minstart + W - u;
+            const int ev = minstart - ubase + W;
             return occ ? (ev < nn ? ev : nn) : SD_NEVER;
         };
         if (grp_n) evict_k = next_evict(0xFFFFFFFFu);
@@ -616,8 +617,8 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
           if (sd_any(k >= evict_k)) {
               if (k >= evict_k) {
                   const uint32_t nb4 = nmask & (kk == 0 ? 0u : 0xFFFFFFFFu >> (32 - 8 * kk));          // non-bases before this step
-                  const int lastN = u + (nb4 ? k4 + ((31 - __builtin_clz(nb4)) >> 3) : LN);
-                  const int i = u + k;
+                  const int lastN = ubase + (nb4 ? k4 + ((31 - __builtin_clz(nb4)) >> 3) : LN);
+                  const int i = ubase + k;
                   if (f & 0x80u) {
                       const int l_old = i - 1 - lastN;
                       int st = (l_old - W + 1 > 0 ? l_old - W + 1 : 0) + (i + 1 - l_old);
@@ -722,8 +723,8 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
                   int startv;                                                        // :146 for every lane's own state
                   {
                       const uint32_t nb4 = nmask & (kk == 0 ? 0u : 0xFFFFFFFFu >> (32 - 8 * kk));
-                      const int lastN = u + (nb4 ? k4 + ((31 - __builtin_clz(nb4)) >> 3) : LN);
-                      startv = u + k + 1 - W > lastN + 1 ? u + k + 1 - W : lastN + 1;
+                      const int lastN = ubase + (nb4 ? k4 + ((31 - __builtin_clz(nb4)) >> 3) : LN);
+                      startv = ubase + k + 1 - W > lastN + 1 ? ubase + k + 1 - W : lastN + 1;
                   }
                   const int o_start = rdlane(startv, ol);
                   const unsigned long long o_occ = rdlane64(occ, ol);
@@ -732,18 +733,17 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
                   const int sidx = (o_start + j) & 63;
                   const bool has_e = inwin && ((o_occ >> sidx) & 1ull);
                   const uint32_t e = has_e ? __hip_atomic_load(&orow[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                  const int er = (int)(e & 0xFFFFu), el = (int)(e >> 16);
+                  // Ratios r / l are compared through key = floor(r * 2^13 / l) (sd_ratio_key): exact for l <= 64.  All that
+                  // :113-118 need of P is, for every start, the best ratio among the entries with a start at or after it.
+                  const uint32_t key_e = e & 0xFFFFFFu;                              // 0: no entry with this start
+                  const uint32_t key_c = cand ? sd_ratio_key((uint32_t)r, (uint32_t)new_l) : 0u;
                   // X_j = better of (existing entry with this start, candidate j); inclusive maximum over positions >= j
-                  int xr = er, xl = el;
-                  if (cand && (er == 0 || __mul24(r, el) >= __mul24(er, new_l))) { xr = r; xl = new_l; }
-                  wave_scan_ratio_max(xr, xl);
+                  const uint32_t xs = wave_scan_max(key_e > key_c ? key_e : key_c);
                   // maximum over positions > j = the scan value one lane down (wave_shr:1; lane 0 gets 0)
-                  const int sr = __builtin_amdgcn_update_dpp(0, xr, 0x138, 0xF, 0xF, true);
-                  const int sl2 = __builtin_amdgcn_update_dpp(0, xl, 0x138, 0xF, 0xF, true);
-                  int mr = sr, ml = sl2;                                             // :113-117: entries with start >= i + start
-                  if (er != 0 && (sr == 0 || __mul24(er, sl2) > __mul24(sr, el))) { mr = er; ml = el; }
-                  const bool ins = cand && (mr == 0 || __mul24(r, ml) >= __mul24(mr, new_l));   // :118
-                  if (ins) orow[sidx] = (uint32_t)r | ((uint32_t)new_l << 16);       // start = i + start, finish = start + l + 3
+                  const uint32_t sk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)xs, 0x138, 0xF, 0xF, true);
+                  const uint32_t km = sk > key_e ? sk : key_e;                       // :113-117: entries with start >= i + start
+                  const bool ins = cand && key_c >= km;                              // :118
+                  if (ins) orow[sidx] = key_c | ((uint32_t)new_l << 24);             // start = i + start, finish = start + l + 3
                   const unsigned long long insj = __brevll(sd_ballot(ins));           // bit j <-> window position j
                   if (insj && lane == ol) {
                       const int lowest = o_start + __builtin_ctzll(insj);
@@ -757,14 +757,6 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
         if (grp_n && nmask) LN = k4 + ((31 - __builtin_clz(nmask)) >> 3);
       }
     }
-    if (owned) {                                     // every lane that owned a chunk publishes its list
-        if (have_last) {
-            if (n_out < A.cap) out[n_out] = make_uint2(last_s, last_f);
-            ++n_out;
-        }
-        A.out_n[cid] = n_out;
-        if (n_out > A.cap) atomicMax(A.ovf, n_out);
-    }
     if (STATS && A.stats && lane == 0) {
         atomicAdd(&A.stats[0], (unsigned long long)st_steps);
         atomicAdd(&A.stats[1], (unsigned long long)st_fp);
@@ -775,61 +767,261 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
     }
 }
 
-// ---- scheduling hint: which chunks look low-complexity?  Two 64-byte samples per chunk (at 1/4 and 3/4 of it); a
-// sample whose 62 3-mers take few distinct values (random sequence: ~40 of 64) lies in a repeat array.  The flag
-// only orders the work (flagged chunks first, one per wave); results do not depend on it.
-__global__ void sd_sample(const uint8_t *bases, const int64_t *ctg_off, const SdChunk *chunks, int32_t n_chunks, uint32_t *flag)
+// bit 7 of every byte of the result: that byte of `word` is not one of A C G T a c g t
+__device__ __forceinline__ uint32_t sd_not_acgt(uint32_t word)
+{
+    const uint32_t y = word & 0xDFDFDFDFu, idx = y & 0x07070707u;          // fold case; low 3 bits: A1 C3 T4 G7
+    const uint32_t d = y ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, idx);
+    return ((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d;
+}
+
+// ---- per chunk, before the main kernel: (1) where its lane starts, (2) a scheduling hint.
+// (1) Warm-up start: W-2 word emissions before (chunk start - 2W), found by scanning backwards (see the header
+//     comment); the scan gives up after SD_SCAN_CAP bases of N-dense sequence and uses the word-count table, or asks
+//     the host for it.  Rounded down to 64: starting earlier is still exact, and keeps every lane of the main
+//     kernel on the same phase of the 64-byte blocks.
+// (2) The 64 bytes in the middle of the chunk; a sample whose 62 3-mers take few distinct values (random
+//     sequence: ~40 of 64) lies in a repeat array.  The flag only orders the work; results do not depend on it.
+__global__ void sd_prep(SdArgs A, uint32_t *flag, int32_t *ustart)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_chunks) return;
-    const SdChunk ch = chunks[c];
-    const uint8_t *seq = bases + ctg_off[ch.ctg];
-    const int clen = ch.end - ch.start;
-    uint32_t heavy = 0;
-    for (int q = 1; q <= 3; q += 2) {
-        const int at = (ch.start + (clen >> 2) * q) & ~63;                 // blocks never leave the (64-byte padded) contig
-        const uint4 *src = reinterpret_cast<const uint4 *>(seq + at);
-        unsigned long long seen = 0;
-        int l = 0, nw = 0;
-        unsigned t = 0;
-        for (int v = 0; v < 4; ++v) {
-            const uint4 x = src[v];
-            const uint32_t w4[4] = {x.x, x.y, x.z, x.w};
+    if (c >= A.n_chunks) return;
+    const SdChunk ch = A.chunks[c];
+    const uint8_t *seq = A.bases + A.ctg_off[ch.ctg];
+    const int W = A.W, CAPW = W - 2;
+    int u = 0;
+    if (ch.start > 0) {
+        const int y = ch.start - 2 * W;
+        if (y > 2) {
+            int need = CAPW, run = 0, p = y - 1;
+            const int floor_p = y - SD_SCAN_CAP > 0 ? y - SD_SCAN_CAP : 0;
+            // common case, checked with dword loads: the W bases before y are all letters A/C/G/T, so the W-2 words end
+            // exactly there and the scan would stop at y - W
+            bool plain = y - W > 0;
+            if (plain) {
+                uint32_t bad = 0;
+                const int q0 = (y - W) & ~15;                                  // 16-byte loads, all issued before use
+                if (y - q0 <= 80) {
+                    uint4 v[5];
 #pragma unroll
-            for (int d = 0; d < 4; ++d)
+                    for (int i = 0; i < 5; ++i) v[i] = q0 + 16 * i < y ? *reinterpret_cast<const uint4 *>(seq + q0 + 16 * i) : make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int code = nt4_code((w4[d] >> (8 * b)) & 0xFFu);
-                    l = code < 4 ? l + 1 : 0;
-                    t = ((t << 2) | (unsigned)(code & 3)) & 63u;
-                    if (l >= 3) { seen |= 1ull << t; ++nw; }
+                    for (int i = 0; i < 5; ++i) bad |= sd_not_acgt(v[i].x) | sd_not_acgt(v[i].y) | sd_not_acgt(v[i].z) | sd_not_acgt(v[i].w);
+                } else {
+                    for (int q = q0; q < y; q += 4) bad |= sd_not_acgt(*reinterpret_cast<const uint32_t *>(seq + q));
                 }
+                plain = (bad & 0x80808080u) == 0;
+            }
+            if (plain) {
+                p = y - W;
+                need = 0;
+            } else {
+                for (; p >= floor_p; --p) {
+                    if (nt4_code(seq[p]) < 4) {
+                        if (++run >= 3 && --need == 0) break;
+                    } else {
+                        run = 0;
+                    }
+                }
+            }
+            if (need == 0 || floor_p == 0) {
+                u = p > 0 ? p : 0;
+            } else if (A.wtab == nullptr) {
+                // N-dense stretch longer than the local scan: ask the host for the word-count table and a rerun
+                atomicOr(A.need_wtab, 1u);
+                u = -1;
+            } else {
+                // rank of the wanted word among the word emissions of the contig, from the block table
+                const uint32_t *tab = A.wtab + A.wtab_base[ch.ctg];
+                const uint32_t t0 = tab[0];
+                const int yb = y / SD_WBLK;
+                int wy = (int)(tab[yb] - t0);                     // emissions ending before block yb
+                {
+                    int r2 = 0;
+                    for (int q = yb * SD_WBLK - 2 < 0 ? 0 : yb * SD_WBLK - 2; q < y; ++q) {
+                        r2 = nt4_code(seq[q]) < 4 ? r2 + 1 : 0;
+                        wy += (q >= yb * SD_WBLK) & (r2 >= 3);
+                    }
+                }
+                if (wy < CAPW) {
+                    u = 0;
+                } else {
+                    const int rank = wy - CAPW + 1;               // 1-based rank of the oldest word that must be replayed
+                    int lo = 0, hi = yb;                          // largest block b with (tab[b] - t0) < rank
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if ((int)(tab[mid] - t0) < rank) lo = mid; else hi = mid - 1;
+                    }
+                    int seen = (int)(tab[lo] - t0), r2 = 0, q = lo * SD_WBLK - 2 < 0 ? 0 : lo * SD_WBLK - 2;
+                    for (; q < y; ++q) {
+                        r2 = nt4_code(seq[q]) < 4 ? r2 + 1 : 0;
+                        if (q >= lo * SD_WBLK && r2 >= 3 && ++seen == rank) break;
+                    }
+                    u = q - 2 > 0 ? q - 2 : 0;                     // first base of that word
+                }
+            }
         }
-        if (nw >= 32 && __popcll(seen) <= 20) heavy = 1;
+    }
+    ustart[c] = u < 0 ? -1 : (u & ~63);
+
+    // the middle 64 bytes of the chunk
+    uint32_t heavy = 0;
+    {
+        const int at = (ch.start + ((ch.end - ch.start) >> 1)) & ~63;      // blocks never leave the (64-byte padded) contig
+        const uint4 *src = reinterpret_cast<const uint4 *>(seq + at);
+        const uint4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
+        const uint32_t w16[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
+        uint32_t seen_lo = 0, seen_hi = 0;
+        unsigned t = 0;
+#pragma unroll
+        for (int d = 0; d < 16; ++d)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                // letters only, case folded: (c >> 1) & 3 separates A C G T; anything else just lands on one of them
+                t = ((t << 2) | ((w16[d] >> (8 * b + 1)) & 3u)) & 63u;
+                const uint32_t bit = 1u << (t & 31u);
+                seen_lo |= t < 32u ? bit : 0u;
+                seen_hi |= t < 32u ? 0u : bit;
+            }
+        if (__popc(seen_lo) + __popc(seen_hi) <= 20) heavy = 1;
     }
     flag[c] = heavy;
 }
 
-// stable partition: flagged chunks first (rank among the flagged), then the others in order
+// Queue order: flagged chunks first, but only one in every S = min(64, chunks / flagged) positions, the rest filled
+// with the other chunks in order: a wave fetches 64 consecutive positions at a time, and 64 lanes inside repeat
+// arrays in ONE wave would serialise (every find_perfect of a wave runs on all of its 64 lanes).
 __global__ void sd_order(const uint32_t *flag, const uint32_t *rank, const unsigned long long *n_flagged, int32_t n_chunks, uint32_t *perm)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
-    const uint32_t r = rank[c];
-    perm[flag[c] ? r : (uint32_t)*n_flagged + ((uint32_t)c - r)] = (uint32_t)c;
+    const uint32_t H = (uint32_t)*n_flagged, r = rank[c];
+    uint32_t S = H ? (uint32_t)n_chunks / H : 64u;
+    S = S > 64u ? 64u : (S < 1u ? 1u : S);
+    uint32_t pos;
+    if (flag[c]) {
+        pos = r * S;
+    } else {
+        const uint32_t j = (uint32_t)c - r;                  // rank among the others
+        if (S > 1u && j < H * (S - 1u)) pos = (j / (S - 1u)) * S + 1u + j % (S - 1u);
+        else pos = H * S + (j - H * (S - 1u));
+    }
+    perm[pos] = (uint32_t)c;
 }
 
-// chunk rows (fixed capacity) -> one dense list in chunk order, tagged with the contig: one wavefront per chunk
+// chunk rows (fixed capacity) -> one dense list in chunk order, tagged with the contig
 __global__ void sdust_gather(const uint2 *in, const uint32_t *cnt, const uint32_t *dst_off, uint32_t cap, const SdChunk *chunks,
                              int32_t n_chunks, cornetto_ivl_t *dst)
 {
-    const int cid = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int cid = blockIdx.x * blockDim.x + threadIdx.x;
     if (cid >= n_chunks) return;
     const uint32_t n = cnt[cid];
+    if (n == 0) return;
     const int32_t ctg = chunks[cid].ctg;
     const uint2 *src = in + (size_t)cid * cap;
     cornetto_ivl_t *d = dst + dst_off[cid];
-    for (uint32_t i = threadIdx.x & 63; i < n; i += 64) d[i] = cornetto_ivl_t{ctg, (int32_t)src[i].x, (int32_t)src[i].y};
+    for (uint32_t i = 0; i < n; ++i) d[i] = cornetto_ivl_t{ctg, (int32_t)src[i].x, (int32_t)src[i].y};
+}
+
+// ---- stitch: the reference's merge rule (src/sdust/sdust.c:94-98: an interval that starts at or before the finish
+// of the last saved one extends it) over the dense list, which is ordered by contig and by start.  With
+// K = contig << 32 | finish, the finish the sequential rule compares with is the maximum K over everything before
+// (a plain max-scan: a later contig outranks every finish of an earlier one), when that maximum is of the same contig.
+constexpr int ST_THREADS = 256, ST_ITEMS = 4, ST_TILE = ST_THREADS * ST_ITEMS;
+
+__device__ __forceinline__ unsigned long long st_shfl_up(unsigned long long v, int d)
+{
+    return ((unsigned long long)(unsigned)__shfl_up((int)(v >> 32), d) << 32) | (unsigned)__shfl_up((int)v, d);
+}
+
+// kprev[j] = max K over the elements of j's tile before j (0: none); tile_max[b] = max K of tile b
+__global__ __launch_bounds__(ST_THREADS) void st_local(const cornetto_ivl_t *v, int64_t n, unsigned long long *kprev, unsigned long long *tile_max)
+{
+    __shared__ unsigned long long wmax[ST_THREADS / 64];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int64_t j0 = (int64_t)blockIdx.x * ST_TILE + (int64_t)t * ST_ITEMS;
+    unsigned long long k[ST_ITEMS], run = 0;
+#pragma unroll
+    for (int i = 0; i < ST_ITEMS; ++i) {
+        k[i] = 0;
+        if (j0 + i < n) k[i] = ((unsigned long long)(unsigned)v[j0 + i].ctg << 32) | (unsigned)v[j0 + i].finish;
+        run = k[i] > run ? k[i] : run;
+    }
+    unsigned long long inc = run;                     // inclusive max-scan of the per-thread maxima over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = st_shfl_up(inc, d);
+        if (lane >= d && o > inc) inc = o;
+    }
+    if (lane == 63) wmax[wv] = inc;
+    __syncthreads();
+    unsigned long long before = st_shfl_up(inc, 1);   // maximum over the earlier threads of the tile
+    if (lane == 0) before = 0;
+    for (int i = 0; i < wv; ++i) before = wmax[i] > before ? wmax[i] : before;
+#pragma unroll
+    for (int i = 0; i < ST_ITEMS; ++i) {
+        if (j0 + i < n) kprev[j0 + i] = before;
+        before = k[i] > before ? k[i] : before;
+    }
+    if (t == ST_THREADS - 1) tile_max[blockIdx.x] = before;
+}
+
+// exclusive max-scan of the tile maxima (one workgroup; a few hundred tiles per million intervals)
+__global__ __launch_bounds__(1024) void st_tiles(unsigned long long *tile_max, int64_t n_tiles)
+{
+    __shared__ unsigned long long wmax[16];
+    __shared__ unsigned long long carry_s;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_tiles; base += 1024) {
+        const unsigned long long mine = base + t < n_tiles ? tile_max[base + t] : 0ull;
+        unsigned long long inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long o = st_shfl_up(inc, d);
+            if (lane >= d && o > inc) inc = o;
+        }
+        if (lane == 63) wmax[wv] = inc;
+        __syncthreads();
+        unsigned long long before = st_shfl_up(inc, 1);
+        if (lane == 0) before = 0;
+        for (int i = 0; i < wv; ++i) before = wmax[i] > before ? wmax[i] : before;
+        const unsigned long long carry = carry_s;
+        before = carry > before ? carry : before;
+        if (base + t < n_tiles) tile_max[base + t] = before;
+        __syncthreads();
+        if (t == 1023) carry_s = (mine > before ? mine : before);
+        __syncthreads();
+    }
+}
+
+// head[j] = 1 when interval j starts a new output interval; kprev[j] becomes the INCLUSIVE maximum
+__global__ void st_heads(const cornetto_ivl_t *v, int64_t n, unsigned long long *kprev, const unsigned long long *tile_before, uint32_t *head)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const unsigned long long tb = tile_before[j / ST_TILE];
+    unsigned long long kp = kprev[j];
+    kp = tb > kp ? tb : kp;
+    const cornetto_ivl_t x = v[j];
+    const bool same = kp != 0 && (int32_t)(kp >> 32) == x.ctg;
+    head[j] = (!same || x.start > (int32_t)(kp & 0xFFFFFFFFull)) ? 1u : 0u;
+    const unsigned long long k = ((unsigned long long)(unsigned)x.ctg << 32) | (unsigned)x.finish;
+    kprev[j] = k > kp ? k : kp;
+}
+
+__global__ void st_emit(const cornetto_ivl_t *v, int64_t n, const unsigned long long *kinc, const uint32_t *head, const uint32_t *rank, cornetto_ivl_t *out)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t hd = head[j];
+    const uint32_t g = rank[j] + hd - 1u;             // heads before j, plus j itself when it is one: index of j's group
+    if (hd) {
+        out[g].ctg = v[j].ctg;
+        out[g].start = v[j].start;
+    }
+    if (j == n - 1 || head[j + 1]) out[g].finish = (int32_t)(kinc[j] & 0xFFFFFFFFull);
 }
 
 int env_int(const char *name, int dflt)
@@ -858,13 +1050,25 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
     // enough that the ~3W-base speculative warm-up stays a few percent.  CORNETTO_SDUST_CHUNK overrides
     // (tests use tiny chunks to stress the speculative start).
     int64_t chunk = env_int("CORNETTO_SDUST_CHUNK", 0);
+    // default: 1536 bases, and a third of that over the last eighth of the input.  The queue hands chunks out in
+    // input order (after the low-complexity ones), so the small ones go last and the lanes run dry within a
+    // third of a chunk of each other instead of a whole one.
+    const bool tiered = chunk <= 0;
     if (chunk <= 0) chunk = 1536;
     chunk = std::max<int64_t>(16, chunk);
-    if (a->sd_chunk != chunk) {
+    const int64_t key = tiered ? -chunk : chunk;
+    if (a->sd_chunk != key) {
         std::vector<SdChunk> chunks;
-        for (int32_t c = 0; c < a->n; ++c)
-            for (int64_t s = 0; s < a->len[c]; s += chunk)
-                chunks.push_back(SdChunk{c, (int32_t)s, (int32_t)std::min<int64_t>(a->len[c], s + chunk)});
+        const int64_t tail_from = tiered ? a->total - a->total / 8 : a->total + 1;
+        int64_t before = 0;
+        for (int32_t c = 0; c < a->n; ++c) {
+            for (int64_t s = 0; s < a->len[c];) {
+                const int64_t step = before + s >= tail_from ? chunk / 3 : chunk;
+                chunks.push_back(SdChunk{c, (int32_t)s, (int32_t)std::min<int64_t>(a->len[c], s + step)});
+                s += step;
+            }
+            before += a->len[c];
+        }
         if (chunks.size() > 0x7fffffffull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "sdust: too many chunks");
         if (a->d_sd_chunks) { (void)hipFree(a->d_sd_chunks); a->d_sd_chunks = nullptr; }
         if (!chunks.empty()) {
@@ -873,7 +1077,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             CN_HIP(h, hipMemcpyAsync(a->d_sd_chunks, chunks.data(), chunks.size() * sizeof(SdChunk), hipMemcpyHostToDevice, h->stream));
             CN_HIP(h, hipStreamSynchronize(h->stream));
         }
-        a->sd_chunk = chunk;
+        a->sd_chunk = key;
         a->sd_n_chunks = (int64_t)chunks.size();
     }
     const size_t nc = (size_t)a->sd_n_chunks;
@@ -883,7 +1087,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
         const SdChunk *d_chunks = reinterpret_cast<const SdChunk *>(a->d_sd_chunks);
         // per chunk: count (4 B) + ordered offset (4 B) + scan partials; then {total u64, ovf u32}
         uint32_t *d_cnt = (uint32_t *)cn_ws(h, WS_SD_CNT, nc * 8 + ((nc + 4095) / 4096 + 1) * 4);
-        unsigned long long *d_tot = (unsigned long long *)cn_ws(h, WS_SD_STATS, 64);
+        unsigned long long *d_tot = (unsigned long long *)cn_ws(h, WS_SD_STATS, 128);   // [0] total [1] overflow | table request [2..6] stats [7] flagged [8] queue
         unsigned long long *p_tot = (unsigned long long *)cn_pin(h, PIN_SMALL, 64);
         if (!d_cnt || !d_tot || !p_tot) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
         uint32_t *d_off = d_cnt + nc, *d_part = d_off + nc;
@@ -896,30 +1100,48 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
         for (int attempt = 0; attempt < 4; ++attempt) {
             d_out = (uint2 *)cn_ws(h, WS_SD_OUT, nc * cap * sizeof(uint2));
             if (!d_out) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation of %zu bytes failed", nc * cap * sizeof(uint2));
-            CN_HIP(h, hipMemsetAsync(d_tot, 0, 64, h->stream));
+            CN_HIP(h, hipMemsetAsync(d_tot, 0, 128, h->stream));
             uint32_t *d_slots = (uint32_t *)cn_ws(h, WS_SD_OFF, nc * 64 * sizeof(uint32_t));
             if (!d_slots) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
             const int variant = env_int("CORNETTO_SDUST_VARIANT", 0);   // 1 = force the per-lane reference-shaped kernel
             const bool use_w64 = W - 2 <= 64 && T >= 5 && T <= 100000 && variant == 0;
-            const int map_stride = env_int("CORNETTO_SDUST_MAP", 1);
-            uint32_t *d_perm = nullptr;
-            if (use_w64 && map_stride && env_int("CORNETTO_SDUST_ORDER", 1)) {
-                // flag (nc) + rank (nc) + perm (nc) + scan partials
-                uint32_t *d_flag = (uint32_t *)cn_ws(h, WS_SD_PERM, nc * 12 + ((nc + 4095) / 4096 + 1) * 4);
-                if (!d_flag) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
-                uint32_t *d_rank = d_flag + nc, *d_pp = d_rank + nc + nc;
-                d_perm = d_rank + nc;
-                const unsigned nbs = (unsigned)((nc + 255) / 256);
-                CN_LAUNCH(h, "sdust_order", sd_sample<<<dim3(nbs), dim3(256), 0, h->stream>>>(a->d_bases, a->d_off, d_chunks, (int32_t)nc, d_flag));
-                CN_TRY(cnscan::exclusive_u32(h, "sdust_order", d_flag, (int64_t)nc, 1, d_rank, d_pp, d_tot + 7));
-                CN_LAUNCH(h, "sdust_order", sd_order<<<dim3(nbs), dim3(256), 0, h->stream>>>(d_flag, d_rank, d_tot + 7, (int32_t)nc, d_perm));
-            }
             SdArgs A{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, d_out, d_cnt, (uint32_t)cap,
-                     want_stats ? d_tot + 2 : nullptr, reinterpret_cast<uint32_t *>(d_tot + 1), d_slots, map_stride, d_perm,
-                     a->d_wtab, a->d_wtab_base, reinterpret_cast<uint32_t *>(d_tot + 1) + 1};
+                     want_stats ? d_tot + 2 : nullptr, reinterpret_cast<uint32_t *>(d_tot + 1), d_slots, nullptr, nullptr,
+                     reinterpret_cast<uint32_t *>(d_tot + 8), 0x7fffffff, a->d_wtab, a->d_wtab_base, reinterpret_cast<uint32_t *>(d_tot + 1) + 1};
             unsigned nb = (unsigned)((nc + 63) / 64);
             if (use_w64) {
-                if (map_stride == 0) nb = (unsigned)((nc + 4095) / 4096) * 64;   // whole groups of 64 waves
+                // warm-up starts and the order of the queue: flag (nc) + rank (nc) + perm (nc) + ustart (nc) + scan partials
+                uint32_t *d_flag = (uint32_t *)cn_ws(h, WS_SD_PERM, nc * 16 + ((nc + 4095) / 4096 + 1) * 4);
+                if (!d_flag) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
+                uint32_t *d_rank = d_flag + nc, *d_perm = d_rank + nc, *d_pp = d_perm + nc + nc;
+                int32_t *d_ustart = reinterpret_cast<int32_t *>(d_perm + nc);
+                const unsigned nbs = (unsigned)((nc + 255) / 256);
+                CN_LAUNCH(h, "sdust_prep", sd_prep<<<dim3(nbs), dim3(256), 0, h->stream>>>(A, d_flag, d_ustart));
+                A.ustart = d_ustart;
+                if (env_int("CORNETTO_SDUST_ORDER", 1)) {
+                    CN_TRY(cnscan::exclusive_u32(h, "sdust_prep", d_flag, (int64_t)nc, 1, d_rank, d_pp, d_tot + 7));
+                    CN_LAUNCH(h, "sdust_prep", sd_order<<<dim3(nbs), dim3(256), 0, h->stream>>>(d_flag, d_rank, d_tot + 7, (int32_t)nc, d_perm));
+                    A.perm = d_perm;
+                }
+                // as many waves as the chip holds at once (LDS-bound: ~19 per CU); each lane works through the queue
+                if (h->sd_slots == 0) {
+                    int per_cu = 0, cus = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sdust_w64<false>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 16;
+                    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus < 1) cus = 256;
+                    h->sd_slots = per_cu * cus;
+                    h->sd_cus = cus;
+                }
+                // CORNETTO_SDUST_JOBS = j > 0: a wave retires after j chunks per lane (the grid grows accordingly), so that
+                // work of other streams can move in between; 0: persistent waves
+                const int jobs = env_int("CORNETTO_SDUST_JOBS", 0);
+                if (jobs > 0) {
+                    A.max_jobs = jobs;
+                    nb = (unsigned)((nc + (size_t)64 * jobs - 1) / ((size_t)64 * jobs));
+                } else {
+                    const int per_cu = std::max(1, h->sd_slots / h->sd_cus * h->share / 100);
+                    const int waves = env_int("CORNETTO_SDUST_WAVES", per_cu * h->sd_cus);
+                    if ((unsigned)waves < nb) nb = (unsigned)waves;
+                }
                 if (want_stats) CN_LAUNCH(h, "sdust_kernel", sdust_w64<true><<<dim3(nb), dim3(64), 0, h->stream>>>(A));
                 else CN_LAUNCH(h, "sdust_kernel", sdust_w64<false><<<dim3(nb), dim3(64), 0, h->stream>>>(A));
             } else if (W - 2 <= 64) {
@@ -971,30 +1193,29 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
         o = (cornetto_ivl_t *)cn_result_alloc((tot ? tot : 1) * sizeof(cornetto_ivl_t));
         if (!o) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: host allocation failed");
         if (tot > 0) {
-            cornetto_ivl_t *d_dst = (cornetto_ivl_t *)cn_ws(h, WS_SD_DST, (size_t)tot * sizeof(cornetto_ivl_t));
-            cornetto_ivl_t *p_dst = (cornetto_ivl_t *)cn_pin(h, PIN_A, (size_t)tot * sizeof(cornetto_ivl_t));
-            if (!d_dst || !p_dst) { cornetto_free(o); return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed"); }
-            const unsigned nbg = (unsigned)((nc + 3) / 4);
-            hipEvent_t ea = cn_event(h), eb = cn_event(h);
-            (void)hipEventRecord(ea, h->stream);
-            sdust_gather<<<dim3(nbg), dim3(256), 0, h->stream>>>(d_out, d_cnt, d_off, (uint32_t)cap, d_chunks, (int32_t)nc, d_dst);
-            (void)hipEventRecord(eb, h->stream);
-            h->recs.push_back(cornetto_accel::Rec{"sdust_gather", ea, eb});
-            if (hipGetLastError() != hipSuccess ||
-                hipMemcpyAsync(p_dst, d_dst, (size_t)tot * sizeof(cornetto_ivl_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            // dense list, stitched list, 64-bit scan values, head flags + ranks + scan partials, tile maxima
+            const size_t n = (size_t)tot, nt = (n + ST_TILE - 1) / ST_TILE;
+            const size_t bytes = n * (2 * sizeof(cornetto_ivl_t) + 8 + 8) + ((n + 4095) / 4096 + 1) * 4 + nt * 8 + 64;
+            uint8_t *ws = (uint8_t *)cn_ws(h, WS_SD_DST, bytes);
+            if (!ws) { cornetto_free(o); return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed"); }
+            unsigned long long *d_k = (unsigned long long *)ws;
+            unsigned long long *d_tile = d_k + n;
+            cornetto_ivl_t *d_dst = (cornetto_ivl_t *)(d_tile + nt + 1), *d_st = d_dst + n;
+            uint32_t *d_head = (uint32_t *)(d_st + n), *d_rank = d_head + n, *d_hp = d_rank + n;
+            const unsigned nbg = (unsigned)((nc + 255) / 256), nbn = (unsigned)((n + 255) / 256);
+            CN_LAUNCH(h, "sdust_gather", sdust_gather<<<dim3(nbg), dim3(256), 0, h->stream>>>(d_out, d_cnt, d_off, (uint32_t)cap, d_chunks, (int32_t)nc, d_dst));
+            CN_LAUNCH(h, "sdust_stitch", st_local<<<dim3((unsigned)nt), dim3(ST_THREADS), 0, h->stream>>>(d_dst, (int64_t)n, d_k, d_tile));
+            CN_LAUNCH(h, "sdust_stitch", st_tiles<<<dim3(1), dim3(1024), 0, h->stream>>>(d_tile, (int64_t)nt));
+            CN_LAUNCH(h, "sdust_stitch", st_heads<<<dim3(nbn), dim3(256), 0, h->stream>>>(d_dst, (int64_t)n, d_k, d_tile, d_head));
+            CN_TRY(cnscan::exclusive_u32(h, "sdust_stitch", d_head, (int64_t)n, 1, d_rank, d_hp, d_tot + 9));
+            CN_LAUNCH(h, "sdust_stitch", st_emit<<<dim3(nbn), dim3(256), 0, h->stream>>>(d_dst, (int64_t)n, d_k, d_head, d_rank, d_st));
+            if (hipMemcpyAsync(o, d_st, n * sizeof(cornetto_ivl_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                hipMemcpyAsync(p_tot, d_tot + 9, 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
                 hipStreamSynchronize(h->stream) != hipSuccess) {
                 cornetto_free(o);
-                return cn_fail(h, CORNETTO_E_HIP, "sdust: gather / copy back failed");
+                return cn_fail(h, CORNETTO_E_HIP, "sdust: stitch / copy back failed");
             }
-            // stitch chunk lists in order with the reference's merge rule (src/sdust/sdust.c:94-98)
-            for (unsigned long long j = 0; j < tot; ++j) {
-                const cornetto_ivl_t v = p_dst[j];
-                if (n_out > 0 && o[n_out - 1].ctg == v.ctg && v.start <= o[n_out - 1].finish) {
-                    if (v.finish > o[n_out - 1].finish) o[n_out - 1].finish = v.finish;
-                } else {
-                    o[n_out++] = v;
-                }
-            }
+            n_out = (int64_t)p_tot[0];                 // only the first n_out entries of o are meaningful
         }
     }
     cn_timing_end(h);

@@ -68,6 +68,8 @@ __device__ __forceinline__ unsigned long long smear(unsigned long long cur, unsi
 template <int H>  // halo bytes behind the 64 positions of a thread; motif length k <= H + 1
 __global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
 {
+    __builtin_amdgcn_s_setprio(3);   // short streaming kernel: issue ahead of a long compute-bound kernel of another stream
+
     __shared__ uint2 lut[256];
     __shared__ unsigned long long shF[TF_THREADS], shR[TF_THREADS];
     __shared__ unsigned long long wtot[TF_THREADS / 64];
@@ -341,6 +343,8 @@ __device__ __forceinline__ int popc_range(const unsigned long long *bm, long lon
 
 __global__ __launch_bounds__(256) void tw_scan(TwArgs A)
 {
+    __builtin_amdgcn_s_setprio(3);   // short streaming kernel: issue ahead of a long compute-bound kernel of another stream
+
     const int2 tile = A.tiles[blockIdx.x];
     const int ctg = tile.x;
     const int len = A.ctg_len[ctg];

@@ -101,6 +101,13 @@ void cornetto_free(void *p);
  * the number of kernels recorded.  Used by bench.py for the live roofline figure. */
 int cornetto_accel_last_timing(const cornetto_accel_t *h, const char **names, float *ms, int cap);
 
+/* Share of every compute unit (wave slots and LDS), in percent (10..100, default 100), that the long-running
+ * sdust kernel of this handle may occupy.  Lower it when another handle / stream computes on the same device at
+ * the same time (bench.py runs telofind and the coverage windows beside sdust): the sdust waves stay resident
+ * until their work queue is empty, so what they do not leave free is not available to anybody else meanwhile.
+ * Scheduling only: results do not depend on it. */
+int cornetto_accel_set_share(cornetto_accel_t *h, int percent);
+
 /* ---------------------------------------------------------------------------------------------------
  * sequences in HBM
  * ------------------------------------------------------------------------------------------------- */

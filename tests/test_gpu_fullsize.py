@@ -51,7 +51,8 @@ def test_sdust_decomposition_invariance_and_canonical_form(world, monkeypatch):
     monkeypatch.setenv("CORNETTO_SDUST_CHUNK", "4096")
     b = acc.sdust(asm, 20, 64).copy()
     monkeypatch.setenv("CORNETTO_SDUST_CHUNK", "777")
-    monkeypatch.setenv("CORNETTO_SDUST_MAP", "0")
+    monkeypatch.setenv("CORNETTO_SDUST_ORDER", "0")
+    monkeypatch.setenv("CORNETTO_SDUST_WAVES", "1000")
     c = acc.sdust(asm, 20, 64).copy()
     assert len(a) > 10000
     assert np.array_equal(a, b) and np.array_equal(a, c)

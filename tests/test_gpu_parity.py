@@ -169,6 +169,8 @@ def _rand_seqs(rng, n_seq, kind):
                                        (25, 100, "300"), (20, 8, "50"), (20, 258, "700"), (1, 3, "40")])
 def test_sdust_random_vs_oracle(acc, monkeypatch, T, W, chunk):
     monkeypatch.setenv("CORNETTO_SDUST_CHUNK", chunk)
+    # a small grid: every lane takes many chunks from the queue, of unequal lengths, one after the other
+    monkeypatch.setenv("CORNETTO_SDUST_WAVES", str(1 + (T + W) % 3))
     rng = np.random.default_rng(1234 + T * 1000 + W)
     seqs = _rand_seqs(rng, 120, -1)
     asm = acc.asm_upload(seqs)
@@ -263,6 +265,17 @@ def test_cov_regs_vs_oracle(acc, w, inc):
         exp = ob.get_regs(depths[ci], mqs[ci], w, inc)
         assert np.array_equal(got, exp.astype(got.dtype)), (w, inc, lens[ci])
     cov.close()
+
+
+def test_sdust_queue_and_order_do_not_change_results(acc, golden_dir, monkeypatch):
+    """the chunk queue (persistent waves), its low-complexity-first order and the grid size are scheduling only"""
+    recs = _records(golden_dir, "mix.fa.gz")
+    monkeypatch.setenv("CORNETTO_SDUST_CHUNK", "100")
+    exp = golden(golden_dir, "mix.sdust.exp")
+    for waves, order in (("1", "1"), ("2", "0"), ("5", "1"), ("100000", "0")):
+        monkeypatch.setenv("CORNETTO_SDUST_WAVES", waves)
+        monkeypatch.setenv("CORNETTO_SDUST_ORDER", order)
+        assert gpu_sdust_text(acc, recs, 20, 64) == exp, (waves, order)
 
 
 @pytest.mark.parametrize("chunk", ["64", "500", "1536"])

@@ -53,7 +53,6 @@ struct SdArgs {
     const uint32_t *perm;        // sdust_w64: queue position -> chunk (low-complexity chunks first), or NULL
     const int32_t *ustart;       // sdust_w64: warm-up start of every chunk (sd_prep)
     uint32_t *queue;             // sdust_w64: next queue position
-    int32_t max_jobs;            // sdust_w64: chunks a lane takes before its wave retires (makes room for other streams' work)
     // bounded warm-up search (sdust_w64): the local backward scan gives up after SD_SCAN_CAP bases; then
     const uint32_t *wtab;        //   exclusive prefix of per-256-base-block word-emission counts, or NULL
     const int64_t *wtab_base;    //   first table entry of each contig
@@ -166,7 +165,7 @@ __global__ __launch_bounds__(64) void sdust_kernel(SdArgs A)
             if (pf > (int)last_f) last_f = (uint32_t)pf;
         } else {
             if (have_last) {
-                if (n_out < A.cap) out[n_out] = make_uint2(last_s, last_f);
+                if (n_out < A.cap) A.out[(size_t)cid * A.cap + n_out] = make_uint2(last_s, last_f);
                 ++n_out;
             }
             have_last = true;
@@ -402,6 +401,25 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t x)
 // ratios with denominators <= 64 differ by at least 1 / 4096, i.e. by at least 2 after scaling: their keys differ and
 // are ordered like the ratios; equal ratios give equal keys.  (The reference cross-multiplies, src/sdust/sdust.c:115,118.)
 __device__ __forceinline__ uint32_t sd_ratio_key(uint32_t r, uint32_t l) { return ((r & 0x7FFu) << 13) / (l & 0x7Fu); }
+// vdst[lane] = val (one VALU op instead of compare + select); lane and val are wave-uniform
+__device__ __forceinline__ int sd_writelane(int vdst, int val, int lane)
+{
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(vdst) : "s"(val), "s"(lane) : "m0");
+    return vdst;
+}
+__device__ __forceinline__ int wave_min_all(int x)      // minimum over the wave, in lane 63
+{
+#define SD_MIN_STEP(ctrl, rmask) { const int y = __builtin_amdgcn_update_dpp(x, x, (ctrl), (rmask), 0xF, false); x = y < x ? y : x; }
+    SD_MIN_STEP(DPP_ROW_SHR(1), 0xF)
+    SD_MIN_STEP(DPP_ROW_SHR(2), 0xF)
+    SD_MIN_STEP(DPP_ROW_SHR(4), 0xF)
+    SD_MIN_STEP(DPP_ROW_SHR(8), 0xF)
+    SD_MIN_STEP(DPP_ROW_BCAST15, 0xA)
+    SD_MIN_STEP(DPP_ROW_BCAST31, 0xC)
+#undef SD_MIN_STEP
+    return x;
+}
+constexpr int SD_SLACK_NONE = -(1 << 30);
 typedef uint32_t sd_v16u __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ unsigned long long sd_ballot(bool x) { return __builtin_amdgcn_ballot_w64(x); }
 __device__ __forceinline__ bool sd_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0; }
@@ -409,15 +427,15 @@ constexpr int SD_NEVER = 0x7fffffff;
 
 // Requires 1 <= m = 2T/10 and T <= 100000 (24-bit products exact); other thresholds take the legacy kernel.
 template <bool STATS>
-__global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
+__global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
 {
     __shared__ SdLds64 S;
     const int lane = threadIdx.x;
-    const uint32_t lt_lo = lane < 32 ? (1u << lane) - 1u : ~0u, lt_hi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;   // lanes below this one
     for (int i = 0; i < 16; ++i) S.cw[i][lane] = 0;
 
     const int T = A.T, W = A.W, CAPW = W - 2;
     const int m = (T << 1) / 10;                     // cv[t]*10 > T<<1  <=>  cv[t] > m   (:79)
+    const int capT = CAPW * T;
 
     // ---- jobs.  The grid is as many waves as fit on the chip at once; every LANE takes chunks from one global
     // queue (A.perm order: chunks sampled as low-complexity first) until it is empty, so nothing waits for a
@@ -427,21 +445,23 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
     // position ubase + K for it.  Chunks start on 64-step boundaries (u is 64-byte aligned: all lanes stay on
     // the same phase of the 64-byte blocks).
     bool done = false, hasjob = false;
-    int jobs_left = A.max_jobs;
-    int cid = 0, ubase = 0, len = 0;
-    const uint8_t *seq = A.bases;
-    uint32_t *myslots = A.slots;                     // P slots of the lane's chunk: one 256-byte row in global memory
-    uint2 *out = A.out;
+    int cid = 0, ubase = 0;
+    uint32_t blk64 = 0;                              // (contig offset + ubase) / 64: the lane's stream in 64-byte blocks
     // steps >= endk see a non-base: the end of the sequence (:141, flushes P and records it) or the end of the
     // chunk (flushes P without recording: those intervals belong to the next chunk).  Only steps
     // recfrom_k <= k < nrun record.
-    int endk = 0, nrun = 0, recfrom_k = 0;
+    int endk = 0;
+    bool islast = false;                             // the chunk ends its contig: nrun = endk + 1 steps, else endk
+#define SD_NRUN (endk + (islast ? 1 : 0))
 
     // ---- per-lane sequential state; word indices are counts of pushed words since the chunk's warm-up start
     int p = -1;                 // index of the newest word in the window
     int o = 0;                  // index of the oldest word in the window (size = p - o + 1)
     int vs = 0;                 // index of the first word of v (the suffix with all counts <= m)
     int rw10 = 0;               // 10 * rw
+    int ltv = 0;                // T * (p - vs + 1): T times the length v would have in an unbounded window
+    int ct = 0;                 // copies of the newest word that were in the window before it (kept from the lane's last word step)
+    int sl = SD_SLACK_NONE;     // sl + T * p <= min over the positions find_perfect examines of (T * new_l - 10 * r): >= 0 proves it finds nothing
     unsigned s_pref = 0;        // ring[o]: the word the next pop removes
     unsigned long long occ = 0; // occupied P slots, bit = start & 63
     int minstart = 0;
@@ -455,7 +475,7 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
             if (pf > (int)last_f) last_f = (uint32_t)pf;
         } else {
             if (have_last) {
-                if (n_out < A.cap) out[n_out] = make_uint2(last_s, last_f);
+                if (n_out < A.cap) A.out[(size_t)cid * A.cap + n_out] = make_uint2(last_s, last_f);
                 ++n_out;
             }
             have_last = true;
@@ -465,8 +485,9 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
     };
     // save_masked_regions(start) when it does something: occ != 0 && minstart < start   (:88-102)
     auto save_evict = [&](int start, int nowk) {
-        const uint32_t sl = __hip_atomic_load(&myslots[minstart & 63], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (nowk >= recfrom_k && nowk < nrun) emit(minstart, minstart + (int)(sl >> 24) + 3);
+        // P slots of the lane's chunk: one 256-byte row in global memory
+        const uint32_t sl = __hip_atomic_load(&A.slots[(size_t)cid * 64 + (minstart & 63)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nowk >= A.chunks[cid].start - ubase && nowk < SD_NRUN) emit(minstart, minstart + (int)(sl >> 24) + 3);
         const int gone = start - minstart;           // starts minstart .. start-1 leave the window
         if (gone >= 64) {
             occ = 0;
@@ -486,14 +507,13 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
     uint32_t pcn = 0x04040404u;                      // codes of the previous 4 positions (before u: non-bases, l = 0)
     uint8_t *const myring = &S.ring[lane][0];
 
-    unsigned st_steps = 0, st_fp = 0, st_trim = 0;
+    unsigned st_steps = 0, st_fp = 0, st_trim = 0, st_full = 0;
     const unsigned long long st_t0 = STATS ? wall_clock64() : 0ull;
     for (int k64 = 0;; k64 += 64) {
       // ---- lanes whose chunk is finished publish it and take the next one from the queue
-      const bool need = !done && k64 >= nrun;
+      const bool need = !done && k64 >= SD_NRUN;
       if (sd_any(need)) {
-          const bool fetch = need && jobs_left > 0;
-          const unsigned long long needmask = sd_ballot(fetch);
+          const unsigned long long needmask = sd_ballot(need);
           int base = 0;
           if (needmask) {
               const int first = __builtin_ctzll(needmask);
@@ -503,17 +523,17 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
           if (need) {
               if (hasjob) {
                   if (have_last) {
-                      if (n_out < A.cap) out[n_out] = make_uint2(last_s, last_f);
+                      if (n_out < A.cap) A.out[(size_t)cid * A.cap + n_out] = make_uint2(last_s, last_f);
                       ++n_out;
                   }
                   A.out_n[cid] = n_out;
                   if (n_out > A.cap) atomicMax(A.ovf, n_out);
               }
-              const int idx = base + __popc(lt_lo & (uint32_t)needmask) + __popc(lt_hi & (uint32_t)(needmask >> 32));
-              hasjob = fetch && idx >= 0 && idx < A.n_chunks;     // (idx < 0: more than 2^31 fetches, impossible)
-              --jobs_left;
+              const int idx = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(needmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needmask, 0u));
+              hasjob = idx >= 0 && idx < A.n_chunks;     // (idx < 0: more than 2^31 fetches, impossible)
               done = !hasjob;
-              endk = nrun = 0;
+              endk = 0;
+              islast = false;
               nb0 = nb1 = nb2 = nb3 = make_uint4(0, 0, 0, 0);
               occ = 0;
               evict_k = SD_NEVER;
@@ -521,27 +541,23 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
                   cid = A.perm ? (int)A.perm[idx] : idx;
                   const SdChunk ch = A.chunks[cid];
                   const int u = A.ustart[cid];           // warm-up start (sd_prep), 64-byte aligned; < 0: not known
-                  len = A.ctg_len[ch.ctg];
-                  seq = A.bases + A.ctg_off[ch.ctg];
-                  myslots = A.slots + (size_t)cid * 64;
-                  out = A.out + (size_t)cid * A.cap;
                   have_last = false;
                   n_out = 0;
                   if (u >= 0) {
                       ubase = u - k64;
+                      blk64 = (uint32_t)((A.ctg_off[ch.ctg] + u) >> 6) - (uint32_t)(k64 >> 6);
                       endk = (ch.end - u) + k64;
-                      nrun = ch.end == len ? endk + 1 : endk;
-                      recfrom_k = (ch.start - u) + k64;
-                      p = -1; o = 0; vs = 0; rw10 = 0; s_pref = 0;
+                      islast = ch.end == A.ctg_len[ch.ctg];
+                      p = -1; o = 0; vs = 0; rw10 = 0; ltv = 0; ct = 0; s_pref = 0; sl = SD_SLACK_NONE;
                       LN = k64 - 1;
                       pcn = 0x04040404u;
                       for (int i = 0; i < 16; ++i) S.cw[i][lane] = 0;
-                      if (u < len) {
-                          const uint4 *q = reinterpret_cast<const uint4 *>(seq + u);
+                      {
+                          const uint4 *q = reinterpret_cast<const uint4 *>(A.bases + A.ctg_off[ch.ctg] + u);      // u < ch.end <= contig length
                           nb0 = q[0]; nb1 = q[1]; nb2 = q[2]; nb3 = q[3];
                       }
                   } else {
-                      endk = nrun = k64;                 // empty job (the host reruns with the word-count table)
+                      endk = k64;                        // empty job (the host reruns with the word-count table)
                   }
               }
           }
@@ -550,8 +566,8 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
       sd_v16u blk;
       blk.s0 = nb0.x; blk.s1 = nb0.y; blk.s2 = nb0.z; blk.s3 = nb0.w; blk.s4 = nb1.x; blk.s5 = nb1.y; blk.s6 = nb1.z; blk.s7 = nb1.w;
       blk.s8 = nb2.x; blk.s9 = nb2.y; blk.sa = nb2.z; blk.sb = nb2.w; blk.sc = nb3.x; blk.sd = nb3.y; blk.se = nb3.z; blk.sf = nb3.w;
-      if (k64 + 64 < nrun && ubase + k64 + 64 < len) {
-          const uint4 *q = reinterpret_cast<const uint4 *>(seq + ubase + k64 + 64);
+      if (k64 + 64 < SD_NRUN) {              // (at most the block behind the contig's last one: inside the 128 bytes of slack)
+          const uint4 *q = reinterpret_cast<const uint4 *>(A.bases + ((uint64_t)(blk64 + (uint32_t)(k64 >> 6) + 1u) << 6));
           nb0 = q[0]; nb1 = q[1]; nb2 = q[2]; nb3 = q[3];
       }
       // The packed decode below knows letters only.  A byte <= 3 (seq_nt4_table maps 0..3 to themselves) clears the
@@ -636,7 +652,6 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
           }
           const bool isword = f < 64u;
           const unsigned long long wordmask = sd_ballot(f < 64u);
-          int ct = 0;
           if (isword) {
               // shift_window (:66-86) without cv / rv: the two counters are byte fields of LDS dwords, updated by
               // returning atomics (one LDS op each instead of a read and a write)
@@ -647,15 +662,20 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
               const uint32_t old_t = __hip_atomic_fetch_add(&S.cw[f >> 2][lane], 1u << sh_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
               o += pop ? 1 : 0;
               ++p;
+              ltv += T;
               myring[p & 63] = (uint8_t)f;                                                     // :75
               s_pref = myring[o & 63];
               const int cs = (int)((old_s >> sh_s) & 0xFFu) - 1;                               // --cw[s]   (:71)
               ct = (int)((old_t >> sh_t) & 0xFFu);                                             // cw[t]++   (:77), after the pop
               rw10 = __mul24(ct - (pop ? cs : 0), 10) + rw10;
+              sl = __mul24(ct, -10) + sl;      // every examined suffix gains at most ct pairs and one word (see below)
           }
           // v must not hold more than m copies of t.  Only when the window now holds more than m can v,
           // a suffix of it, do so: those lanes get their v start moved by the cooperative pass below.
-          const unsigned long long trim_todo = sd_ballot(ct >= m);                      // ct = 0 < m in lanes without a word
+          const unsigned long long trim_todo = sd_ballot(ct >= m) & wordmask;
+          // v may shrink: find_perfect then examines positions the bound never covered (a lane without a word may drop
+          // its bound needlessly: harmless)
+          sl = ct >= m ? SD_SLACK_NONE : sl;
           // ---- cooperative trim: vs moves just past the (m+1)-th most recent occurrence of t inside v --------
           // (one ballot over the owner's ring: lane j reads ring slot j; about one lane per wave-step needs it
           // in non-repetitive sequence)
@@ -675,15 +695,20 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
                   const int Lc = o_p - first + 1;                                            // 1..64
                   const unsigned long long inv = chron & (Lc >= 64 ? ~0ull : ~0ull << (64 - Lc));
                   if (__popcll(inv) > m) {
-                      const int oldest = __builtin_ctzll(inv);                               // oldest occurrence of t inside v
-                      vs = lane == ol ? o_p - 63 + oldest + 1 : vs;
+                      const int nvs = o_p - 63 + __builtin_ctzll(inv) + 1;                   // just past the oldest occurrence of t inside v
+                      vs = sd_writelane(vs, nvs, ol);
+                      ltv = sd_writelane(ltv, (o_p - nvs + 1) * T, ol);
                   }
               }
           }
           unsigned long long fp_todo;
           {
-              const int first = vs > o ? vs : o;
-              fp_todo = sd_ballot(rw10 > __mul24(p - first, T) + T) & wordmask;         // :149
+              // L = min(p - vs + 1, window size); the window holds W - 2 words whenever that bound matters
+              fp_todo = sd_ballot(rw10 > (ltv < capT ? ltv : capT)) & wordmask;         // :149
+              // find_perfect changes nothing unless some suffix older than v has 10 r > T l.  A call that found none
+              // left the smallest T l - 10 r it saw; since then every such suffix got one word longer per push and
+              // gained at most ct pairs (sl, kept relative to T * p): while that bound is >= 0 the call is skipped.
+              if (fp_todo) fp_todo &= sd_ballot(__mul24(p, T) + sl < 0);
           }
           // ---- cooperative find_perfect (:104-128) ------------------------------------------------------
           // lane <-> window position j = 63 - lane, so that "suffix of the window" = "prefix of the wave" and
@@ -704,7 +729,7 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
                   // lanes holding the same word at a later window position (= lower lanes): one ballot per bit of the
                   // word, kept as two 32-bit halves (per bit: sign-extended bit, compare, two 3-input logic ops)
                   const unsigned long long inb = sd_ballot(inwin);
-                  uint32_t eq_lo = lt_lo & (uint32_t)inb, eq_hi = lt_hi & (uint32_t)(inb >> 32);
+                  uint32_t eq_lo = (uint32_t)inb, eq_hi = (uint32_t)(inb >> 32);
 #pragma unroll
                   for (int bb = 0; bb < 6; ++bb) {
                       const int ext = __builtin_amdgcn_sbfe((int)wj, bb, 1);                     // all ones / zero
@@ -714,11 +739,19 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
                       eq_hi &= ~((uint32_t)ext ^ (uint32_t)(bal >> 32));
                   }
                   // suffix score r_j = inclusive prefix sum
-                  const int r = wave_scan_add(inwin ? __popc(eq_lo) + __popc(eq_hi) : 0);
+                  // (mbcnt: set bits of the mask below this lane)
+                  const int r = wave_scan_add(inwin ? (int)__builtin_amdgcn_mbcnt_hi(eq_hi, __builtin_amdgcn_mbcnt_lo(eq_lo, 0u)) : 0);
                   const int new_l = o_size - j - 1;                                  // :111
                   // :112 (new_l < 64, T < 2^17)
-                  const unsigned long long candmask = sd_ballot(__mul24(r, 10) > __mul24(T, new_l)) & sd_ballot(j <= i0) & inb;
-                  if (candmask == 0) continue;                                       // nothing can be inserted
+                  const int margin = __mul24(T, new_l) - __mul24(r, 10);
+                  const unsigned long long exam = sd_ballot(j <= i0) & inb;          // the positions :107 walks over
+                  const unsigned long long candmask = sd_ballot(margin < 0) & exam;
+                  if (candmask == 0) {                                               // nothing can be inserted: remember by how much
+                      const int mn = rdlane(wave_min_all(((exam >> lane) & 1ull) ? margin : (1 << 29)), 63);
+                      sl = sd_writelane(sl, mn - o_p * T, ol);
+                      continue;
+                  }
+                  if (STATS) ++st_full;
                   const bool cand = (candmask >> lane) & 1ull;
                   int startv;                                                        // :146 for every lane's own state
                   {
@@ -744,6 +777,9 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
                   const uint32_t km = sk > key_e ? sk : key_e;                       // :113-117: entries with start >= i + start
                   const bool ins = cand && key_c >= km;                              // :118
                   if (ins) orow[sidx] = key_c | ((uint32_t)new_l << 24);             // start = i + start, finish = start + l + 3
+                  // The entry is read back by OTHER lanes (the owner in save_masked_regions, lane j' of a later find_perfect):
+                  // the store must have reached L2, where their sc1 loads look, before the wave goes on.
+                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                   const unsigned long long insj = __brevll(sd_ballot(ins));           // bit j <-> window position j
                   if (insj && lane == ol) {
                       const int lowest = o_start + __builtin_ctzll(insj);
@@ -764,6 +800,7 @@ __global__ __launch_bounds__(64, 5) void sdust_w64(SdArgs A)
         const unsigned long long dt = wall_clock64() - st_t0;      // 100 MHz ticks this wave spent in the loop
         atomicAdd(&A.stats[3], dt);
         atomicMax(&A.stats[4], dt);
+        atomicAdd(&A.stats[8], (unsigned long long)st_full);
     }
 }
 
@@ -1088,7 +1125,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
         // per chunk: count (4 B) + ordered offset (4 B) + scan partials; then {total u64, ovf u32}
         uint32_t *d_cnt = (uint32_t *)cn_ws(h, WS_SD_CNT, nc * 8 + ((nc + 4095) / 4096 + 1) * 4);
         unsigned long long *d_tot = (unsigned long long *)cn_ws(h, WS_SD_STATS, 128);   // [0] total [1] overflow | table request [2..6] stats [7] flagged [8] queue
-        unsigned long long *p_tot = (unsigned long long *)cn_pin(h, PIN_SMALL, 64);
+        unsigned long long *p_tot = (unsigned long long *)cn_pin(h, PIN_SMALL, 128);
         if (!d_cnt || !d_tot || !p_tot) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
         uint32_t *d_off = d_cnt + nc, *d_part = d_off + nc;
         const bool want_stats = env_int("CORNETTO_SDUST_STATS", 0) != 0;
@@ -1107,7 +1144,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             const bool use_w64 = W - 2 <= 64 && T >= 5 && T <= 100000 && variant == 0;
             SdArgs A{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, d_out, d_cnt, (uint32_t)cap,
                      want_stats ? d_tot + 2 : nullptr, reinterpret_cast<uint32_t *>(d_tot + 1), d_slots, nullptr, nullptr,
-                     reinterpret_cast<uint32_t *>(d_tot + 8), 0x7fffffff, a->d_wtab, a->d_wtab_base, reinterpret_cast<uint32_t *>(d_tot + 1) + 1};
+                     reinterpret_cast<uint32_t *>(d_tot + 8), a->d_wtab, a->d_wtab_base, reinterpret_cast<uint32_t *>(d_tot + 1) + 1};
             unsigned nb = (unsigned)((nc + 63) / 64);
             if (use_w64) {
                 // warm-up starts and the order of the queue: flag (nc) + rank (nc) + perm (nc) + ustart (nc) + scan partials
@@ -1125,19 +1162,18 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                 }
                 // as many waves as the chip holds at once (LDS-bound: ~19 per CU); each lane works through the queue
                 if (h->sd_slots == 0) {
+                    // The kernel must not spill: builds of it that kept registers in scratch memory gave results that
+                    // changed from run to run on MI355X (ROCm 7.2), builds without scratch never did.
+                    hipFuncAttributes fa;
+                    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&sdust_w64<false>)) != hipSuccess || fa.localSizeBytes != 0)
+                        return cn_fail(h, CORNETTO_E_HIP, "sdust: kernel built with %zu bytes of scratch per lane (register spills): refusing to run it", (size_t)fa.localSizeBytes);
                     int per_cu = 0, cus = 0;
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sdust_w64<false>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 16;
                     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus < 1) cus = 256;
                     h->sd_slots = per_cu * cus;
                     h->sd_cus = cus;
                 }
-                // CORNETTO_SDUST_JOBS = j > 0: a wave retires after j chunks per lane (the grid grows accordingly), so that
-                // work of other streams can move in between; 0: persistent waves
-                const int jobs = env_int("CORNETTO_SDUST_JOBS", 0);
-                if (jobs > 0) {
-                    A.max_jobs = jobs;
-                    nb = (unsigned)((nc + (size_t)64 * jobs - 1) / ((size_t)64 * jobs));
-                } else {
+                {
                     const int per_cu = std::max(1, h->sd_slots / h->sd_cus * h->share / 100);
                     const int waves = env_int("CORNETTO_SDUST_WAVES", per_cu * h->sd_cus);
                     if ((unsigned)waves < nb) nb = (unsigned)waves;
@@ -1151,11 +1187,11 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             }
             // ordered position of every chunk's intervals (chunks are in contig order) + grand total
             CN_TRY(cnscan::exclusive_u32(h, "sdust_scan", d_cnt, (int64_t)nc, 1, d_off, d_part, d_tot));
-            CN_HIP(h, hipMemcpyAsync(p_tot, d_tot, 64, hipMemcpyDeviceToHost, h->stream));
+            CN_HIP(h, hipMemcpyAsync(p_tot, d_tot, 128, hipMemcpyDeviceToHost, h->stream));
             CN_HIP(h, hipStreamSynchronize(h->stream));
             if (want_stats)
-                fprintf(stderr, "[sdust stats] flagged low-complexity %llu; chunks %zu waves %u wave-steps %llu find_perfect calls %llu trims %llu; wave time avg %.1f us max %.1f us\n", p_tot[7], nc, nb,
-                        p_tot[2], p_tot[3], p_tot[4], nb ? (double)p_tot[5] / nb / 100.0 : 0.0, (double)p_tot[6] / 100.0);
+                fprintf(stderr, "[sdust stats] flagged low-complexity %llu; chunks %zu waves %u wave-steps %llu find_perfect calls %llu (%llu with candidates) trims %llu; wave time avg %.1f us max %.1f us\n", p_tot[7], nc, nb,
+                        p_tot[2], p_tot[3], p_tot[10], p_tot[4], nb ? (double)p_tot[5] / nb / 100.0 : 0.0, (double)p_tot[6] / 100.0);
             const uint32_t ovf = (uint32_t)(p_tot[1] & 0xFFFFFFFFull);
             const bool need_wtab = (p_tot[1] >> 32) != 0;
             if (need_wtab) {

@@ -267,6 +267,16 @@ def test_cov_regs_vs_oracle(acc, w, inc):
     cov.close()
 
 
+def test_sdust_repeatable_with_many_small_chunks(acc, golden_dir, monkeypatch):
+    """the chunk queue hands the chunks to different lanes / waves at different times on every run: 24 runs over
+    ~100 k tiny chunks must all give the golden answer (a build of the kernel that spilled registers did not)"""
+    recs = _records(golden_dir, "mix.fa.gz")
+    monkeypatch.setenv("CORNETTO_SDUST_CHUNK", "16")
+    exp = golden(golden_dir, "mix.sdust.exp")
+    for it in range(24):
+        assert gpu_sdust_text(acc, recs, 20, 64) == exp, it
+
+
 def test_sdust_queue_and_order_do_not_change_results(acc, golden_dir, monkeypatch):
     """the chunk queue (persistent waves), its low-complexity-first order and the grid size are scheduling only"""
     recs = _records(golden_dir, "mix.fa.gz")

@@ -507,7 +507,7 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
     uint32_t pcn = 0x04040404u;                      // codes of the previous 4 positions (before u: non-bases, l = 0)
     uint8_t *const myring = &S.ring[lane][0];
 
-    unsigned st_steps = 0, st_fp = 0, st_trim = 0, st_full = 0;
+    unsigned st_steps = 0, st_fp = 0, st_trim = 0, st_full = 0, st_jobs = 0;
     const unsigned long long st_t0 = STATS ? wall_clock64() : 0ull;
     for (int k64 = 0;; k64 += 64) {
       // ---- lanes whose chunk is finished publish it and take the next one from the queue
@@ -561,6 +561,7 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
                   }
               }
           }
+          if (STATS) ++st_jobs;
           if (sd_ballot(!done) == 0) break;
       }
       sd_v16u blk;
@@ -599,6 +600,7 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
                  ((uint32_t)nt4_code((word >> 16) & 0xFFu) << 16) | ((uint32_t)nt4_code(word >> 24) << 24);
         }
         if (sd_any(k4 + 4 > endk)) {                  // end of the sequence / of the chunk inside this group
+            asm volatile("; chunk end" ::);          // (keeps the compiler from doing this arithmetic in every group)
             const int rem = endk - k4 > 0 ? endk - k4 : 0;
             if (rem < 4) cn |= 0x04040404u << (8 * rem);
         }
@@ -655,7 +657,7 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
           if (isword) {
               // shift_window (:66-86) without cv / rv: the two counters are byte fields of LDS dwords, updated by
               // returning atomics (one LDS op each instead of a read and a write)
-              const bool pop = p - o >= CAPW - 1;                                              // size >= W - 2  (:68)
+              const bool pop = p >= CAPW - 1;                  // size >= W - 2 (:68): o = max(0, p - (W - 3)) at all times
               const unsigned s = s_pref;
               const unsigned sh_s = (s & 3u) << 3, sh_t = (f & 3u) << 3;
               const uint32_t old_s = __hip_atomic_fetch_sub(&S.cw[s >> 2][lane], pop ? 1u << sh_s : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -801,6 +803,12 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
         atomicAdd(&A.stats[3], dt);
         atomicMax(&A.stats[4], dt);
         atomicAdd(&A.stats[8], (unsigned long long)st_full);
+        // histogram over the wave's time in the loop (0.5 ms bins): waves, their find_perfect calls with candidates, their end times
+        const unsigned bin = (unsigned)(dt / 50000ull) < 31u ? (unsigned)(dt / 50000ull) : 31u;
+        atomicAdd(&A.stats[14 + 4 * bin], 1ull);
+        atomicAdd(&A.stats[15 + 4 * bin], (unsigned long long)st_full);
+        atomicAdd(&A.stats[16 + 4 * bin], (unsigned long long)st_jobs);
+        atomicAdd(&A.stats[17 + 4 * bin], (unsigned long long)st_fp);
     }
 }
 
@@ -1087,25 +1095,14 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
     // enough that the ~3W-base speculative warm-up stays a few percent.  CORNETTO_SDUST_CHUNK overrides
     // (tests use tiny chunks to stress the speculative start).
     int64_t chunk = env_int("CORNETTO_SDUST_CHUNK", 0);
-    // default: 1536 bases, and a third of that over the last eighth of the input.  The queue hands chunks out in
-    // input order (after the low-complexity ones), so the small ones go last and the lanes run dry within a
-    // third of a chunk of each other instead of a whole one.
-    const bool tiered = chunk <= 0;
     if (chunk <= 0) chunk = 1536;
     chunk = std::max<int64_t>(16, chunk);
-    const int64_t key = tiered ? -chunk : chunk;
+    const int64_t key = chunk;
     if (a->sd_chunk != key) {
         std::vector<SdChunk> chunks;
-        const int64_t tail_from = tiered ? a->total - a->total / 8 : a->total + 1;
-        int64_t before = 0;
-        for (int32_t c = 0; c < a->n; ++c) {
-            for (int64_t s = 0; s < a->len[c];) {
-                const int64_t step = before + s >= tail_from ? chunk / 3 : chunk;
-                chunks.push_back(SdChunk{c, (int32_t)s, (int32_t)std::min<int64_t>(a->len[c], s + step)});
-                s += step;
-            }
-            before += a->len[c];
-        }
+        for (int32_t c = 0; c < a->n; ++c)
+            for (int64_t s = 0; s < a->len[c]; s += chunk)
+                chunks.push_back(SdChunk{c, (int32_t)s, (int32_t)std::min<int64_t>(a->len[c], s + chunk)});
         if (chunks.size() > 0x7fffffffull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "sdust: too many chunks");
         if (a->d_sd_chunks) { (void)hipFree(a->d_sd_chunks); a->d_sd_chunks = nullptr; }
         if (!chunks.empty()) {
@@ -1124,8 +1121,8 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
         const SdChunk *d_chunks = reinterpret_cast<const SdChunk *>(a->d_sd_chunks);
         // per chunk: count (4 B) + ordered offset (4 B) + scan partials; then {total u64, ovf u32}
         uint32_t *d_cnt = (uint32_t *)cn_ws(h, WS_SD_CNT, nc * 8 + ((nc + 4095) / 4096 + 1) * 4);
-        unsigned long long *d_tot = (unsigned long long *)cn_ws(h, WS_SD_STATS, 128);   // [0] total [1] overflow | table request [2..6] stats [7] flagged [8] queue
-        unsigned long long *p_tot = (unsigned long long *)cn_pin(h, PIN_SMALL, 128);
+        unsigned long long *d_tot = (unsigned long long *)cn_ws(h, WS_SD_STATS, 2048);   // [0] total [1] overflow | table request [2..6] stats [7] flagged [8] queue
+        unsigned long long *p_tot = (unsigned long long *)cn_pin(h, PIN_SMALL, 2048);
         if (!d_cnt || !d_tot || !p_tot) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
         uint32_t *d_off = d_cnt + nc, *d_part = d_off + nc;
         const bool want_stats = env_int("CORNETTO_SDUST_STATS", 0) != 0;
@@ -1137,7 +1134,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
         for (int attempt = 0; attempt < 4; ++attempt) {
             d_out = (uint2 *)cn_ws(h, WS_SD_OUT, nc * cap * sizeof(uint2));
             if (!d_out) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation of %zu bytes failed", nc * cap * sizeof(uint2));
-            CN_HIP(h, hipMemsetAsync(d_tot, 0, 128, h->stream));
+            CN_HIP(h, hipMemsetAsync(d_tot, 0, 2048, h->stream));
             uint32_t *d_slots = (uint32_t *)cn_ws(h, WS_SD_OFF, nc * 64 * sizeof(uint32_t));
             if (!d_slots) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
             const int variant = env_int("CORNETTO_SDUST_VARIANT", 0);   // 1 = force the per-lane reference-shaped kernel
@@ -1187,8 +1184,13 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             }
             // ordered position of every chunk's intervals (chunks are in contig order) + grand total
             CN_TRY(cnscan::exclusive_u32(h, "sdust_scan", d_cnt, (int64_t)nc, 1, d_off, d_part, d_tot));
-            CN_HIP(h, hipMemcpyAsync(p_tot, d_tot, 128, hipMemcpyDeviceToHost, h->stream));
+            CN_HIP(h, hipMemcpyAsync(p_tot, d_tot, want_stats ? 2048 : 128, hipMemcpyDeviceToHost, h->stream));
             CN_HIP(h, hipStreamSynchronize(h->stream));
+            if (want_stats)
+                for (int b = 0; b < 32; ++b)
+                    if (p_tot[16 + 4 * b])
+                        fprintf(stderr, "[sdust stats]   waves that ran %4.1f-%4.1f ms: %6llu, job fetches %llu, find_perfect calls %llu (%llu with candidates)\n", b * 0.5, b * 0.5 + 0.5,
+                                p_tot[16 + 4 * b], p_tot[18 + 4 * b], p_tot[19 + 4 * b], p_tot[17 + 4 * b]);
             if (want_stats)
                 fprintf(stderr, "[sdust stats] flagged low-complexity %llu; chunks %zu waves %u wave-steps %llu find_perfect calls %llu (%llu with candidates) trims %llu; wave time avg %.1f us max %.1f us\n", p_tot[7], nc, nb,
                         p_tot[2], p_tot[3], p_tot[10], p_tot[4], nb ? (double)p_tot[5] / nb / 100.0 : 0.0, (double)p_tot[6] / 100.0);

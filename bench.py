@@ -340,13 +340,12 @@ def main():
         dom = "sdust_kernel"
         ach = alg[dom] / (kavg[dom] * 1e-3) / 1e9 if kavg.get(dom, 0) > 0 else 0.0
         # HBM/fabric bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
-        # workload (profiles/README.md: FETCH_SIZE and WRITE_SIZE collected in separate passes; for this
-        # kernel's access pattern - one 64-byte sector per lane - FETCH_SIZE is exact, checked against the known
-        # byte count, so no x2 correction is applied), scaled to the bases of this run
+        # workload (profiles/README.md: FETCH_SIZE and WRITE_SIZE collected in separate passes; FETCH_SIZE doubled as
+        # MI355X_MICROARCH.md prescribes for gfx950: 128-byte requests tallied at 64 bytes), scaled to the bases of this run
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["sdust_w64"]
-            traffic = round((pmc["fetch_bytes_raw"] + pmc["write_bytes"]) * n_bases / pmc.get("bases", 3160108082), 0)
+            traffic = round((pmc["fetch_bytes_corrected_x2"] + pmc["write_bytes"]) * n_bases / pmc.get("bases", 3160108082), 0)
         except Exception:
             pass
         line = {
@@ -361,7 +360,7 @@ def main():
                        else "contig-sharded, %d process(es), 1 GPU each; stages serial on one stream" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "note": "sdust is an integer recurrence (LDS-latency/VALU bound), reported against HBM as the contract asks"},
+                         "note": "sdust is an integer recurrence, VALU-issue bound (SQ_ACTIVE_INST_VALU ~ 0.9-1.0 of the kernel's cycles); reported against HBM as the contract asks"},
             "kernels": kern,
             "stage_wall_ms": {k: round(float(np.mean(v)), 3) for k, v in wall.items()},
             "results_per_rank": {"telomere_runs": counts[0], "telomere_windows": counts[1], "sdust_intervals": counts[2],

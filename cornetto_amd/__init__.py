@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-__all__ = ["lib", "Accel", "AccelError", "HIT_DT", "WIN_DT", "IVL_DT", "REG_DT", "REGREC_DT", "build",
+__all__ = ["lib", "Accel", "AccelError", "HIT_DT", "WIN_DT", "IVL_DT", "TELROW_DT", "khash_str_order", "REG_DT", "REGREC_DT", "build",
            "LIB_PATH", "CLI_PATH"]
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -21,6 +21,7 @@ CLI_PATH = os.path.join(HERE, "cornetto")
 HIT_DT = np.dtype([("ctg", "<i4"), ("strand", "<i4"), ("start", "<i4"), ("end", "<i4")])
 WIN_DT = np.dtype([("ctg", "<i4"), ("start", "<i4"), ("end", "<i4"), ("car", "<i4")])
 IVL_DT = np.dtype([("ctg", "<i4"), ("start", "<i4"), ("finish", "<i4")])
+TELROW_DT = np.dtype([("ctg", "<i4"), ("start", "<i4"), ("end", "<i4"), ("matched", "<i4")])
 REG_DT = np.dtype([("st", "<i4"), ("end", "<i4"), ("depth", "<i4"), ("mq_depth", "<i4")])
 REGREC_DT = np.dtype([("ctg", "<i4"), ("st", "<i4"), ("end", "<i4"), ("depth", "<i4"), ("mq_depth", "<i4")])
 
@@ -72,6 +73,8 @@ def lib():
         "cornetto_free": (None, [vp]),
         "cornetto_accel_last_timing": (C.c_int, [vp, C.POINTER(cp), C.POINTER(C.c_float), C.c_int]),
         "cornetto_accel_set_share": (C.c_int, [vp, C.c_int]),
+        "cornetto_telobreaks": (C.c_int, [vp, vp, C.c_int32, vp, C.c_int64, vp, C.c_int64, C.POINTER(vp), C.POINTER(C.c_int64)]),
+        "cornetto_khash_str_order": (C.c_int32, [C.POINTER(C.c_char_p), C.c_int32, vp, vp]),
         "cornetto_asm_upload": (C.c_int, [vp, vp, vp, i32, pp]),
         "cornetto_asm_wrap": (C.c_int, [vp, vp, vp, vp, i32, pp]),
         "cornetto_asm_free": (None, [vp, vp]),
@@ -240,6 +243,18 @@ class Accel:
         self._chk(self.L.cornetto_sdust_asm(self.h, asm.ptr, T, W, C.byref(p), C.byref(n)))
         return _take(p, n.value, IVL_DT)
 
+    # ---- telobreaks ------------------------------------------------------------------------------
+    def telobreaks(self, ctg_len, sd, tel):
+        """ctg_len: int32 per contig; sd: IVL_DT rows (ctg, start, finish); tel: TELROW_DT rows -> IVL_DT rows
+        {ctg, first - 1 clamped at 0, last} of the low-complexity runs holding a telomere row with its flanks"""
+        ctg_len = np.ascontiguousarray(ctg_len, dtype=np.int32)
+        sd = np.ascontiguousarray(sd, dtype=IVL_DT)
+        tel = np.ascontiguousarray(tel, dtype=TELROW_DT)
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self.L.cornetto_telobreaks(self.h, ctg_len.ctypes.data, len(ctg_len), sd.ctypes.data, len(sd), tel.ctypes.data, len(tel),
+                                             C.byref(p), C.byref(n)))
+        return _take(p, n.value, IVL_DT)
+
     # ---- coverage --------------------------------------------------------------------------------
     def cov_upload(self, depths, mqs):
         d = [np.ascontiguousarray(x, dtype=np.uint16) for x in depths]
@@ -315,3 +330,17 @@ class Accel:
             return _Resident(self, cov, L.cornetto_cov_free, lens), nm, ncl.value
         finally:
             L.cornetto_bgin_close(self.h, bg)
+
+
+def khash_str_order(names):
+    """bucket order of the reference's khash string map after inserting `names` (list of bytes) in order:
+    (slot per name, distinct ids in bucket order).  Host only."""
+    L = lib()
+    n = len(names)
+    arr = (C.c_char_p * max(n, 1))(*names)
+    slot = np.zeros(max(n, 1), np.int32)
+    order = np.zeros(max(n, 1), np.int32)
+    k = L.cornetto_khash_str_order(arr, n, slot.ctypes.data, order.ctypes.data)
+    if k < 0:
+        raise ValueError("cornetto_khash_str_order: bad argument")
+    return slot[:n], order[:k]

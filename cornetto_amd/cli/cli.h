@@ -81,6 +81,7 @@ int boringbits_main(int argc, char *argv[], int8_t boring);
 int bigenough_main(int argc, char *argv[]);
 int find_telomere_main(int argc, char *argv[]);
 int telomere_windows_main(int argc, char *argv[]);
+int telomere_breaks_main(int argc, char *argv[]);
 int sdust_main(int argc, char *argv[]);
 int assbed_main(int argc, char *argv[]);
 int seq_main(int argc, char *argv[]);

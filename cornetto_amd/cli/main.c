@@ -19,6 +19,7 @@ static int print_usage(FILE *fp)
     fprintf(fp, "   telo:\n");
     fprintf(fp, "       telowin         analyse telomere windows in a fasta file\n");
     fprintf(fp, "       telofind        find telomere sequences in a fasta file\n");
+    fprintf(fp, "       telobreaks      find telomere sequences inside low-complexity runs\n");
     fprintf(fp, "       sdust           symmetric DUST (https://github.com/lh3/sdust)\n");
     fprintf(fp, "   misc:\n");
     fprintf(fp, "       fa2bed          create a bed file with assembly contig lengths\n");
@@ -43,6 +44,8 @@ int main(int argc, char *argv[])
         ret = boringbits_main(argc - 1, argv + 1, 0);
     } else if (strcmp(argv[1], "telowin") == 0) {
         ret = telomere_windows_main(argc - 1, argv + 1);
+    } else if (strcmp(argv[1], "telobreaks") == 0) {
+        ret = telomere_breaks_main(argc - 1, argv + 1);
     } else if (strcmp(argv[1], "telofind") == 0) {
         ret = find_telomere_main(argc - 1, argv + 1);
     } else if (strcmp(argv[1], "bigenough") == 0) {

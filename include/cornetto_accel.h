@@ -257,6 +257,32 @@ int cornetto_bgin_done(const cornetto_bgin_t *b);
 int cornetto_bgin_finish(cornetto_accel_t *h, cornetto_bgin_t *b, cornetto_cov_t **cov, int32_t *n_ctg, char ***names,
                          int64_t *n_clamped);
 
+/* ---------------------------------------------------------------------------------------------------
+ * telobreaks — src/telomere_breaks.c:47-172 (the consumer of the sdust BED and the telofind TSV)
+ * ------------------------------------------------------------------------------------------------- */
+
+/* one row of the telofind TSV as telobreaks reads it (:97): contig, start, end, matched length (6th column) */
+typedef struct {
+    int32_t ctg, start, end, matched;
+} cornetto_telrow_t;
+
+/* The bitset stage of telobreaks (:79-148) for contigs given by index (the caller resolves the names; rows of names
+ * that are not in the lens file are dropped, as the reference does at :83,:100: give them ctg = -1).
+ * sd: low-complexity intervals [start, finish), any order, may overlap or touch.  tel: telofind rows; those with
+ * matched < 24 are ignored (MIN_TEL, :10,:98).  out[] = the numbers the reference prints (:140-142): for every maximal
+ * run of the low-complexity bitset that contains a telomere row together with its 100-base flanks (clipped to the
+ * contig): {ctg, first position - 1 clamped at 0, last position}, by contig index, then by position.
+ * The reference prints contigs in khash bucket order: cornetto_khash_str_order().  Coordinates outside the contig are
+ * unchecked heap indices in the reference; here they are CORNETTO_E_FORMAT.  Release out with cornetto_free(). */
+int cornetto_telobreaks(cornetto_accel_t *h, const int32_t *ctg_len, int32_t n_ctg, const cornetto_ivl_t *sd, int64_t n_sd,
+                        const cornetto_telrow_t *tel, int64_t n_tel, cornetto_ivl_t **out, int64_t *n_out);
+
+/* Host helper: the iteration order of the reference's khash string map (klib khash 0.2.8, src/khash.h) after
+ * kh_put() of names[0..n) in that order — the order in which telobreaks prints its contigs (:133).  slot[i] = dense
+ * id of the distinct key of names[i] (ids in order of first appearance); order[k] = id in the k-th occupied bucket.
+ * Returns the number of distinct keys, -1 on a bad argument.  Needs no device. */
+int32_t cornetto_khash_str_order(const char *const *names, int32_t n, int32_t *slot, int32_t *order);
+
 #ifdef __cplusplus
 }
 #endif

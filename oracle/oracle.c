@@ -296,3 +296,142 @@ int orc_bigenough_keep(int32_t covlen, int32_t start, int32_t end, int32_t thres
     int32_t prod = (int32_t)((uint32_t)(end - start) * (uint32_t)threshold);
     return covlen > prod / 100;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * telobreaks — src/telomere_breaks.c
+ * ---------------------------------------------------------------------------------------------- */
+
+static void tb_set(unsigned char *b, int i) { b[i / 8] |= (unsigned char)(1 << (i % 8)); }     /* :33-35 */
+static int tb_get(const unsigned char *b, int i) { return b[i / 8] & (1 << (i % 8)); }           /* :37-39 */
+
+int orc_telobreaks(const int32_t *ctg_len, int32_t n_ctg, const orc_span_t *sd, int64_t n_sd,
+                   const orc_telrow_t *tel, int64_t n_tel, orc_span_t **out, int64_t *n_out)
+{
+    unsigned char **bits = (unsigned char **)calloc((size_t)n_ctg + 1, sizeof(*bits));
+    unsigned char **fin = (unsigned char **)calloc((size_t)n_ctg + 1, sizeof(*fin));
+    orc_span_t *o = NULL;
+    int64_t no = 0, cap = 0;
+    int rc = 0;
+    for (int32_t c = 0; c < n_ctg; ++c) {                                 /* create_scaffold, :25-31 */
+        bits[c] = (unsigned char *)calloc((size_t)ceil(ctg_len[c] / 8.0) + 1, 1);
+        fin[c] = (unsigned char *)calloc((size_t)ceil(ctg_len[c] / 8.0) + 1, 1);
+    }
+    for (int64_t i = 0; i < n_sd && rc == 0; ++i) {                       /* :79-90 */
+        const orc_span_t v = sd[i];
+        if (v.ctg < 0 || v.ctg >= n_ctg) continue;
+        if (v.start < 0 || v.end > ctg_len[v.ctg]) { rc = -1; break; }
+        for (int j = v.start; j < v.end; ++j) tb_set(bits[v.ctg], j);
+    }
+    for (int64_t i = 0; i < n_tel && rc == 0; ++i) {                      /* :95-128 */
+        const orc_telrow_t t = tel[i];
+        if (t.matched < 24) continue;                                     /* MIN_TEL, :10,:98 */
+        if (t.ctg < 0 || t.ctg >= n_ctg) continue;
+        const int length = ctg_len[t.ctg];
+        if (t.start < 0 || t.end > length || t.start >= t.end) { rc = -1; break; }
+        const unsigned char *b = bits[t.ctg];
+        int rStart = t.start - 100 < 0 ? 0 : t.start - 100;               /* :102 */
+        int rEnd = t.end + 100 > length ? length : t.end + 100;          /* :103 */
+        int all_set = 1;
+        for (int j = rStart; j < rEnd; ++j)
+            if (!tb_get(b, j)) { all_set = 0; break; }
+        if (!all_set) continue;
+        rStart = t.start;                                                 /* :114-121 */
+        while (rStart > 0 && tb_get(b, rStart - 1)) rStart--;
+        rEnd = t.end;
+        while (rEnd < length && tb_get(b, rEnd)) rEnd++;
+        for (int j = rStart; j < rEnd; ++j) tb_set(fin[t.ctg], j);
+    }
+    for (int32_t c = 0; c < n_ctg && rc == 0; ++c) {                      /* :133-148, one contig */
+        const int length = ctg_len[c];
+        for (int i = 0; i < length; ++i) {
+            if (tb_get(fin[c], i)) {
+                int end = i;
+                while (end < length && tb_get(fin[c], end)) ++end;
+                i = i - 1 < 0 ? 0 : i - 1;
+                if (no == cap) {
+                    cap = cap ? cap * 2 : 64;
+                    o = (orc_span_t *)realloc(o, (size_t)cap * sizeof(*o));
+                }
+                o[no].ctg = c; o[no].start = i; o[no].end = end - 1;
+                ++no;
+                i = end;
+            }
+        }
+    }
+    for (int32_t c = 0; c < n_ctg; ++c) { free(bits[c]); free(fin[c]); }
+    free(bits); free(fin);
+    if (rc != 0) { free(o); o = NULL; no = 0; }
+    if (!o) o = (orc_span_t *)malloc(sizeof(*o));
+    *out = o;
+    *n_out = no;
+    return rc;
+}
+
+/* ---- khash v0.2.8 string map, insertion only: where the keys end up ------------------------------------- */
+static uint32_t kh_x31(const char *s)                                     /* src/khash.h:395-400 */
+{
+    uint32_t h = (uint32_t)(int)*s;                                       /* char is signed on x86-64 */
+    if (h) for (++s; *s; ++s) h = (h << 5) - h + (uint32_t)(int)*s;
+    return h;
+}
+
+int32_t orc_khash_order(const char *const *names, int32_t n, int32_t *slot, int32_t *order)
+{
+    /* keys[b] = id stored in bucket b, or -1 (empty).  No deletions happen in telobreaks. */
+    uint32_t n_buckets = 0, size = 0, upper = 0;
+    int32_t *keys = NULL, n_ids = 0;
+    const char **id_name = (const char **)malloc(((size_t)n + 1) * sizeof(*id_name));
+    for (int32_t it = 0; it < n; ++it) {
+        if (size >= upper) {                                              /* kh_put, :308-318 (n_occupied == size) */
+            uint32_t want = n_buckets > (size << 1) ? n_buckets - 1 : n_buckets + 1, nb = want;
+            /* kh_resize, :244-305 */
+            --nb; nb |= nb >> 1; nb |= nb >> 2; nb |= nb >> 4; nb |= nb >> 8; nb |= nb >> 16; ++nb;   /* kroundup32 */
+            if (nb < 4) nb = 4;
+            if (!(size >= (uint32_t)(nb * 0.77 + 0.5))) {
+                int32_t *nk = (int32_t *)malloc((size_t)(nb > n_buckets ? nb : n_buckets) * sizeof(*nk));
+                unsigned char *newocc = (unsigned char *)calloc(nb, 1);    /* new_flags */
+                unsigned char *oldocc = (unsigned char *)calloc(n_buckets + 1, 1);
+                for (uint32_t j = 0; j < (nb > n_buckets ? nb : n_buckets); ++j) nk[j] = j < n_buckets ? keys[j] : -1;
+                for (uint32_t j = 0; j < n_buckets; ++j) oldocc[j] = keys[j] >= 0;
+                for (uint32_t j = 0; j != n_buckets; ++j) {
+                    if (!oldocc[j]) continue;
+                    int32_t key = nk[j];
+                    const uint32_t mask = nb - 1;
+                    oldocc[j] = 0;                                        /* __ac_set_isdel_true */
+                    for (;;) {                                            /* kick-out process */
+                        uint32_t i = kh_x31(id_name[key]) & mask, step = 0;
+                        while (newocc[i]) i = (i + (++step)) & mask;
+                        newocc[i] = 1;
+                        if (i < n_buckets && oldocc[i]) {
+                            const int32_t tmp = nk[i]; nk[i] = key; key = tmp;
+                            oldocc[i] = 0;
+                        } else {
+                            nk[i] = key;
+                            break;
+                        }
+                    }
+                }
+                for (uint32_t j = 0; j < nb; ++j) if (!newocc[j]) nk[j] = -1;
+                free(keys); free(newocc); free(oldocc);
+                keys = nk;
+                n_buckets = nb;
+                upper = (uint32_t)(n_buckets * 0.77 + 0.5);
+            }
+        }
+        {                                                                 /* :320-347 */
+            const uint32_t mask = n_buckets - 1;
+            uint32_t i = kh_x31(names[it]) & mask, step = 0;
+            while (keys[i] >= 0 && strcmp(id_name[keys[i]], names[it]) != 0) i = (i + (++step)) & mask;
+            if (keys[i] < 0) {
+                id_name[n_ids] = names[it];
+                keys[i] = n_ids++;
+                ++size;
+            }
+            slot[it] = keys[i];
+        }
+    }
+    int32_t k = 0;
+    for (uint32_t b = 0; b < n_buckets; ++b) if (keys[b] >= 0) order[k++] = keys[b];
+    free(keys); free((void *)id_name);
+    return n_ids;
+}

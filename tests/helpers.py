@@ -144,3 +144,20 @@ def fmt_sdust(name, res):
 def golden(golden_dir, name):
     with open(os.path.join(golden_dir, name), "rb") as f:
         return f.read()
+
+
+def read_telobreaks_inputs(lens_path, sdust_path, telo_path):
+    """the three text inputs of `cornetto telobreaks` as the reference's sscanf calls see them
+    (src/telomere_breaks.c:66,82,97): white-space separated leading fields of every line"""
+    names, lens = [], []
+    for line in open(lens_path, "rb"):
+        f = line.split()
+        if len(f) >= 2:
+            names.append(f[0]); lens.append(int(f[1]))
+    sd = [(f[0], int(f[1]), int(f[2])) for f in (l.split() for l in open(sdust_path, "rb")) if len(f) >= 3]
+    tel = [(f[0], int(f[3]), int(f[4]), int(f[5])) for f in (l.split() for l in open(telo_path, "rb")) if len(f) >= 6]
+    return names, lens, sd, tel
+
+
+def fmt_telobreaks(name, length, first, last):
+    return b"Found telomere positions %d to %d is a telomere in %s of length %d\n" % (first, last, name, length)   # :142

@@ -58,6 +58,10 @@ def lib():
         L.orc_is_fun.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float]
         L.orc_is_fun.restype = C.c_int
         L.orc_bigenough_keep.argtypes = [C.c_int32] * 4
+        L.orc_telobreaks.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.orc_telobreaks.restype = C.c_int
+        L.orc_khash_order.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.c_void_p, C.c_void_p]
+        L.orc_khash_order.restype = C.c_int32
         L.orc_bigenough_keep.restype = C.c_int
         L.orc_free.argtypes = [C.c_void_p]
         L.orc_revcomp.argtypes = [C.c_char_p, C.c_char_p]
@@ -144,3 +148,32 @@ def is_fun(depth, mq, lo, hi, q):
 
 def bigenough_keep(covlen, start, end, T):
     return bool(lib().orc_bigenough_keep(covlen, start, end, T))
+
+
+SPAN_DT = np.dtype([("ctg", "<i4"), ("start", "<i4"), ("end", "<i4")])
+TELROW_DT = np.dtype([("ctg", "<i4"), ("start", "<i4"), ("end", "<i4"), ("matched", "<i4")])
+
+
+def telobreaks(ctg_len, sd, tel):
+    """sd: SPAN_DT array, tel: TELROW_DT array -> SPAN_DT array {ctg, first, last} (None: coordinates outside a contig)"""
+    L = lib()
+    ctg_len = np.ascontiguousarray(ctg_len, dtype=np.int32)
+    sd = np.ascontiguousarray(sd, dtype=SPAN_DT)
+    tel = np.ascontiguousarray(tel, dtype=TELROW_DT)
+    out = C.c_void_p()
+    n = C.c_int64()
+    rc = L.orc_telobreaks(ctg_len.ctypes.data, len(ctg_len), sd.ctypes.data, len(sd), tel.ctypes.data, len(tel), C.byref(out), C.byref(n))
+    res = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_int32)), shape=(max(n.value, 1) * 3,))[: n.value * 3].copy().view(SPAN_DT) if n.value else np.zeros(0, SPAN_DT)
+    L.orc_free(out)
+    return None if rc != 0 else res
+
+
+def khash_order(names):
+    """names: list of bytes -> (slot per name, ids in khash bucket order)"""
+    L = lib()
+    n = len(names)
+    arr = (C.c_char_p * max(n, 1))(*names)
+    slot = np.zeros(max(n, 1), np.int32)
+    order = np.zeros(max(n, 1), np.int32)
+    k = L.orc_khash_order(arr, n, slot.ctypes.data, order.ctypes.data)
+    return slot[:n], order[:k]

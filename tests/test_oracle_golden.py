@@ -226,3 +226,44 @@ def test_sdust_vs_reference_function_random():
         libc.free(r)
         got = ob.sdust(s, T, W)
         assert np.array_equal(got, exp), (it, n, T, W)
+
+
+# ---- telobreaks -------------------------------------------------------------------
+TELOBREAKS_CASES = [("mix.lens", "mix.sdust.exp", "mix.telofind.exp", "mix.breaks.exp"),
+                    ("probe.lens", "probe.sdust.exp", "probe.telofind.exp", "probe.breaks.exp"),
+                    ("tb_many.lens", "tb_many.sdust", "tb_many.telomere", "tb_many.breaks.exp")]
+
+
+def telobreaks_text(golden_dir, lens_f, sd_f, tel_f, breaks_fn, order_fn):
+    """the reference's stdout from array-level telobreaks + khash-order functions (oracle or product)"""
+    from helpers import read_telobreaks_inputs, fmt_telobreaks
+    names, lens, sd, tel = read_telobreaks_inputs(*(os.path.join(golden_dir, f) for f in (lens_f, sd_f, tel_f)))
+    slot, order = order_fn(names)
+    n_ids = int(slot.max()) + 1 if len(slot) else 0
+    id_name, id_len = [None] * n_ids, [0] * n_ids
+    for nm, ln, s in zip(names, lens, slot):
+        if id_name[s] is None:
+            id_name[s] = nm          # kh_put keeps the first key (src/khash.h:345)
+        id_len[s] = ln               # the value is overwritten (src/telomere_breaks.c:69)
+    ids = {nm: i for i, nm in enumerate(id_name)}
+    sd_a = np.array([(ids[n], a, b) for n, a, b in sd if n in ids], dtype=ob.SPAN_DT)
+    tel_a = np.array([(ids[n], a, b, m) for n, a, b, m in tel if n in ids], dtype=ob.TELROW_DT)
+    res = breaks_fn(np.array(id_len, dtype=np.int32), sd_a, tel_a)
+    out = []
+    for cid in order:
+        for r in res[res["ctg"] == cid]:
+            out.append(fmt_telobreaks(id_name[cid], id_len[cid], int(r["start"]), int(r["end"])))
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("lens_f,sd_f,tel_f,exp", TELOBREAKS_CASES)
+def test_oracle_telobreaks_golden(golden_dir, lens_f, sd_f, tel_f, exp):
+    assert telobreaks_text(golden_dir, lens_f, sd_f, tel_f, ob.telobreaks, ob.khash_order) == golden(golden_dir, exp)
+
+
+def test_oracle_khash_order_growth():
+    """bucket order across several table growths (4 -> 1024 buckets), names of mixed shapes"""
+    names = [b"k%d" % (i * 7919 % 1000) for i in range(700)] + [b"k5", b"k12"]
+    slot, order = ob.khash_order(names)
+    assert len(order) == len(set(names)) and sorted(order) == list(range(len(order)))
+    assert slot[700] == slot[names.index(b"k5")]

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--features", type=int, default=1)
     ap.add_argument("--chunk", type=str, default="")
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--read-len", type=int, default=0, help="instead of the assembly: reads of about this length (+-30 %%), --mbases in total")
     ap.add_argument("--simple-cov", type=int, default=0, help="uniform random depth (rocprofv3 --pmc crashes inside torch.poisson)")
     a = ap.parse_args()
     if a.chunk:
@@ -27,6 +28,10 @@ def main():
     import cornetto_amd
     dev = torch.device("cuda", 0)
     lens = bench.contig_lengths(int(a.mbases * 1e6))
+    if a.read_len > 0:
+        rng = np.random.default_rng(7)
+        lens = [int(x) for x in rng.integers(int(a.read_len * 0.7), int(a.read_len * 1.3), size=int(a.mbases * 1e6 / a.read_len))]
+        a.features = 0
     if a.features:
         bases, offs = bench.make_assembly(torch, dev, lens, 1)
     else:
@@ -43,7 +48,10 @@ def main():
     n = sum(lens)
     for rep in range(a.reps):
         if a.stage in ("sdust", "all"):
+            import time
+            t0 = time.perf_counter()
             iv = acc.sdust(asm, 20, 64)
+            print("sdust call %.1f ms;" % ((time.perf_counter() - t0) * 1e3), len(lens), "records;", end=" ")
             print("sdust", a.mbases, "features", a.features, "chunk", a.chunk, [(k, round(v, 3)) for k, v in acc.last_timing()], "ivls", len(iv), flush=True)
         if a.stage in ("telo", "all"):
             h, w = acc.telo_scan(asm, b"TTAGGG", 0.3976)

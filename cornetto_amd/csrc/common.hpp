@@ -78,7 +78,7 @@ enum {   // device workspace slots
     WS_CW_REGS, WS_CW_SEL, WS_CW_CNT, WS_CW_TRES,
     WS_TF_HITS,
     WS_BG_TEXT_A, WS_BG_TEXT_B, WS_BG_TOK_A, WS_BG_TOK_B, WS_BG_CNT_A, WS_BG_CNT_B, WS_BG_SMALL, WS_BG_BRK,
-    WS_TB, WS_TB_SMALL, WS_TB_OUT
+    WS_TB, WS_TB_SMALL, WS_TB_OUT, WS_CW_MERGE, WS_IVL_MERGE
 };
 enum {   // pinned host slots
     PIN_A, PIN_B, PIN_C, PIN_D, PIN_E, PIN_F, PIN_SMALL

@@ -22,6 +22,7 @@
 
 #include "common.hpp"
 #include "scan.hpp"
+#include "ivlmerge.hpp"
 
 namespace {
 
@@ -388,9 +389,10 @@ int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int3
 }
 
 // mode 0: all windows of contig only_ctg into regs_host; mode 1/2: selection into a malloc'd array
+// keep_on_device: *recs is the ordered DEVICE array (workspace WS_CW_SEL, valid until the next call), nothing is copied back
 static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_ctg, int mode, int32_t lo, int32_t hi,
                            float low_mq, int32_t edge, int32_t min_len, cornetto_reg_t *regs_host, cornetto_regrec_t **recs,
-                           int64_t *n_recs)
+                           int64_t *n_recs, bool keep_on_device = false)
 {
     if (!c->d_blk) return cn_fail(h, CORNETTO_E_ARG, "cov: cornetto_cov_prepare() has not been called");
     const int32_t w = c->w, inc = c->inc, q = w / inc, r = w % inc;
@@ -459,22 +461,23 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
         if (attempt == 1 || cnt > 0x7fffffffull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "cov: %llu selected windows", cnt);
         cap = (size_t)cnt;   // exact rerun, never a truncated answer
     }
-    cornetto_regrec_t *o = (cornetto_regrec_t *)cn_result_alloc((cnt ? cnt : 1) * sizeof(cornetto_regrec_t));
+    cornetto_regrec_t *o = keep_on_device ? d_dst : (cornetto_regrec_t *)cn_result_alloc((cnt ? cnt : 1) * sizeof(cornetto_regrec_t));
     if (!o) return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: host allocation failed");
     if (cnt) {
         // tiles are in (contig, window) order: exclusive scan of their counts = final position of each segment
         int rc = cnscan::exclusive_u32(h, "cov_order", reinterpret_cast<const uint32_t *>(d_tres) + 1, (int64_t)nt, 2, d_ooff, d_part, nullptr);
-        if (rc != CORNETTO_OK) { cornetto_free(o); return rc; }
+        if (rc != CORNETTO_OK) { if (!keep_on_device) cornetto_free(o); return rc; }
         const unsigned nb = (unsigned)((nt + 3) / 4);
         hipEvent_t ea = cn_event(h), eb = cn_event(h);
         (void)hipEventRecord(ea, h->stream);
         cov_order<<<dim3(nb), dim3(256), 0, h->stream>>>(d_raw, d_tres, d_ooff, (int64_t)nt, d_dst);
         (void)hipEventRecord(eb, h->stream);
         h->recs.push_back(cornetto_accel::Rec{"cov_order", ea, eb});
-        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(o, d_dst, (size_t)cnt * sizeof(cornetto_regrec_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-            hipStreamSynchronize(h->stream) != hipSuccess) {
+        if (hipGetLastError() != hipSuccess) return cn_fail(h, CORNETTO_E_HIP, "cov_select: ordering failed");
+        if (!keep_on_device && (hipMemcpyAsync(o, d_dst, (size_t)cnt * sizeof(cornetto_regrec_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                                hipStreamSynchronize(h->stream) != hipSuccess)) {
             cornetto_free(o);
-            return cn_fail(h, CORNETTO_E_HIP, "cov_select: ordering / copy back failed");
+            return cn_fail(h, CORNETTO_E_HIP, "cov_select: copy back failed");
         }
     }
     *recs = o;
@@ -507,6 +510,59 @@ int cornetto_cov_select(cornetto_accel_t *h, const cornetto_cov_t *c, int32_t lo
         if (!*recs) return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: host allocation failed");
     }
     return rc;
+}
+
+namespace {
+__global__ void cov_rec_spans(const cornetto_regrec_t *r, int64_t n, cornetto_ivl_t *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = cornetto_ivl_t{r[i].ctg, r[i].st, r[i].end};
+}
+}  // namespace
+
+int cornetto_cov_select_merged(cornetto_accel_t *h, const cornetto_cov_t *c, int32_t lo, int32_t hi, float low_mq, int32_t edge_len,
+                               int32_t min_ctg_len, int boring, int32_t merge_dist, int32_t min_len, cornetto_ivl_t **ivls, int64_t *n_ivls)
+{
+    if (!h || !c || !ivls || !n_ivls || merge_dist < 0) return cn_fail(h, CORNETTO_E_ARG, "cov_select_merged: bad argument");
+    *ivls = nullptr;
+    *n_ivls = 0;
+    CN_HIP(h, hipSetDevice(h->device));
+    cn_timing_begin(h);
+    cornetto_regrec_t *d_recs = nullptr;
+    int64_t n = 0;
+    CN_TRY(cov_run_windows(h, const_cast<cornetto_cov_t *>(c), -1, boring ? 2 : 1, lo, hi, low_mq, edge_len, min_ctg_len, nullptr, &d_recs, &n, true));
+    cornetto_ivl_t *o = nullptr;
+    int64_t n_out = 0;
+    if (n > 0) {
+        // the selected windows are in (contig, start) order already: spans -> merge on the device -> only the merged list comes back
+        uint8_t *ws = (uint8_t *)cn_ws(h, WS_CW_MERGE, cnivl::ws_bytes((size_t)n) + 2 * (size_t)n * sizeof(cornetto_ivl_t));
+        unsigned long long *d_cnt = (unsigned long long *)cn_ws(h, WS_CW_CNT, 16);
+        unsigned long long *p_cnt = (unsigned long long *)cn_pin(h, PIN_SMALL, 64);
+        if (!ws || !d_cnt || !p_cnt) return cn_fail(h, CORNETTO_E_NOMEM, "cov_select_merged: workspace allocation failed");
+        cornetto_ivl_t *d_in = (cornetto_ivl_t *)(ws + cnivl::ws_bytes((size_t)n)), *d_out = d_in + n;
+        CN_LAUNCH(h, "cov_merge", cov_rec_spans<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream>>>(d_recs, n, d_in));
+        CN_TRY(cnivl::merge(h, "cov_merge", d_in, n, merge_dist, ws, d_out, d_cnt + 1));
+        CN_HIP(h, hipMemcpyAsync(p_cnt, d_cnt + 1, 8, hipMemcpyDeviceToHost, h->stream));
+        CN_HIP(h, hipStreamSynchronize(h->stream));
+        const int64_t m = (int64_t)p_cnt[0];
+        o = (cornetto_ivl_t *)cn_result_alloc(((size_t)m ? (size_t)m : 1) * sizeof(cornetto_ivl_t));
+        if (!o) return cn_fail(h, CORNETTO_E_NOMEM, "cov_select_merged: host allocation failed");
+        if (m > 0 && (hipMemcpyAsync(o, d_out, (size_t)m * sizeof(cornetto_ivl_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                      hipStreamSynchronize(h->stream) != hipSuccess)) {
+            cornetto_free(o);
+            return cn_fail(h, CORNETTO_E_HIP, "cov_select_merged: copy back failed");
+        }
+        for (int64_t i = 0; i < m; ++i)                      // awk '($3-$2)>=min_len' of the scripts: the merged list is short
+            if (o[i].finish - o[i].start >= min_len) o[n_out++] = o[i];
+    }
+    cn_timing_end(h);
+    if (!o) {
+        o = (cornetto_ivl_t *)malloc(sizeof(cornetto_ivl_t));
+        if (!o) return cn_fail(h, CORNETTO_E_NOMEM, "cov_select_merged: host allocation failed");
+    }
+    *ivls = o;
+    *n_ivls = n_out;
+    return CORNETTO_OK;
 }
 
 }  // extern "C"

@@ -258,6 +258,37 @@ int cornetto_bgin_finish(cornetto_accel_t *h, cornetto_bgin_t *b, cornetto_cov_t
                          int64_t *n_clamped);
 
 /* ---------------------------------------------------------------------------------------------------
+ * panel interval stage — scripts/create-cornetto.sh:41-66 without bedtools / sort / awk (parity with bedtools itself
+ * is unpinned: see cornetto_amd/csrc/panel.hip)
+ * ------------------------------------------------------------------------------------------------- */
+
+/* cornetto_cov_select() followed, on the device, by `bedtools merge -d merge_dist` and `awk '($3-$2)>=min_len'`
+ * (create-cornetto.sh:44-47: -d 1000, 30000): the selected windows never leave the device, only the merged intervals
+ * {ctg, start, finish} come back (by contig index, by start).  Release with cornetto_free(). */
+int cornetto_cov_select_merged(cornetto_accel_t *h, const cornetto_cov_t *c, int32_t lo, int32_t hi, float low_mq, int32_t edge_len,
+                               int32_t min_ctg_len, int boring, int32_t merge_dist, int32_t min_len, cornetto_ivl_t **ivls,
+                               int64_t *n_ivls);
+
+/* `bedtools merge -d dist` of intervals that are in (contig, start) order (CORNETTO_E_ARG if they are not), on the
+ * device: an interval that starts at most `dist` past the largest finish so far in its contig is merged into it. */
+int cornetto_ivl_merge(cornetto_accel_t *h, const cornetto_ivl_t *in, int64_t n, int32_t dist, cornetto_ivl_t **out, int64_t *n_out);
+
+typedef struct {
+    int32_t min_lowq_len; /* keep hifiasm "low quality" rows of at least this length (8000, :50) */
+    int32_t extend;       /* grow every row that starts beyond this many bases by it on both sides (40000, :53) */
+    int32_t edge_len;     /* add the first / last edge_len bases of every longer contig (200000, :56) */
+    int32_t merge_dist;   /* bedtools merge -d (200000, :59) */
+    int32_t min_ctg_len;  /* contigs shorter than this contribute nothing (800000, :65) */
+} cornetto_panel_opt_t;
+void cornetto_panel_defaults(cornetto_panel_opt_t *opt);
+
+/* Steps 4-9 of create-cornetto.sh (:50-66) on index-based intervals: fun = output of cornetto_cov_select_merged
+ * (ctg = index into ctg_len, the assembly order), lowq = the rows of the hifiasm low-quality BED (any order).
+ * Result: the "boring bits" before bigenough, {ctg, start, finish}, in assembly order; cornetto_free() it.  Host only. */
+int cornetto_panel_boring(const int32_t *ctg_len, int32_t n_ctg, const cornetto_ivl_t *fun, int64_t n_fun, const cornetto_ivl_t *lowq,
+                          int64_t n_lowq, const cornetto_panel_opt_t *opt, cornetto_ivl_t **boring, int64_t *n_boring);
+
+/* ---------------------------------------------------------------------------------------------------
  * telobreaks — src/telomere_breaks.c:47-172 (the consumer of the sdust BED and the telofind TSV)
  * ------------------------------------------------------------------------------------------------- */
 

@@ -435,3 +435,73 @@ int32_t orc_khash_order(const char *const *names, int32_t n, int32_t *slot, int3
     free(keys); free((void *)id_name);
     return n_ids;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * panel interval stage — scripts/create-cornetto.sh:44-66 (PARITY UNPINNED, see oracle.h)
+ * ---------------------------------------------------------------------------------------------- */
+static int span_cmp(const void *a, const void *b)
+{
+    const orc_span_t *x = (const orc_span_t *)a, *y = (const orc_span_t *)b;
+    if (x->ctg != y->ctg) return x->ctg < y->ctg ? -1 : 1;
+    if (x->start != y->start) return x->start < y->start ? -1 : 1;
+    return x->end < y->end ? -1 : (x->end > y->end);
+}
+
+int orc_ivl_merge(const orc_span_t *in, int64_t n, int32_t dist, orc_span_t **out, int64_t *n_out)
+{
+    orc_span_t *v = (orc_span_t *)malloc(((size_t)n + 1) * sizeof(*v));
+    int64_t m = 0;
+    if (n > 0) memcpy(v, in, (size_t)n * sizeof(*v));
+    qsort(v, (size_t)n, sizeof(*v), span_cmp);
+    for (int64_t i = 0; i < n; ++i) {
+        /* bedtools merge: a feature joins the current cluster when it starts at most `dist` behind the cluster's end */
+        if (m > 0 && v[m - 1].ctg == v[i].ctg && (int64_t)v[i].start - (int64_t)v[m - 1].end <= dist) {
+            if (v[i].end > v[m - 1].end) v[m - 1].end = v[i].end;
+        } else {
+            v[m++] = v[i];
+        }
+    }
+    *out = v;
+    *n_out = m;
+    return 0;
+}
+
+int orc_panel_boring(const int32_t *ctg_len, int32_t n_ctg, const orc_span_t *fun, int64_t n_fun, const orc_span_t *lowq, int64_t n_lowq,
+                     int32_t min_lowq_len, int32_t extend, int32_t edge_len, int32_t merge_dist, int32_t min_ctg_len,
+                     orc_span_t **out, int64_t *n_out)
+{
+    orc_span_t *v = (orc_span_t *)malloc(((size_t)n_fun + (size_t)n_lowq + 2 * (size_t)n_ctg + 1) * sizeof(*v));
+    int64_t n = 0;
+    for (int64_t i = 0; i < n_fun; ++i) v[n++] = fun[i];                                   /* 3_tmp.bed */
+    for (int64_t i = 0; i < n_lowq; ++i)                                                   /* :50  awk '($3-$2)>=8000' */
+        if ((int64_t)lowq[i].end - lowq[i].start >= min_lowq_len) v[n++] = lowq[i];
+    for (int64_t i = 0; i < n; ++i)                                                        /* :53  if($2>40000){$2-40000, $3+40000} */
+        if (v[i].start > extend) { v[i].start -= extend; v[i].end += extend; }
+    for (int32_t c = 0; c < n_ctg; ++c)                                                    /* :56  if(($3-$2)>200000) two edge rows */
+        if (ctg_len[c] > edge_len) {
+            v[n].ctg = c; v[n].start = 0; v[n].end = edge_len; ++n;
+            v[n].ctg = c; v[n].start = ctg_len[c] - edge_len; v[n].end = ctg_len[c]; ++n;
+        }
+    orc_span_t *m = NULL;
+    int64_t nm = 0;
+    orc_ivl_merge(v, n, merge_dist, &m, &nm);                                             /* :59 */
+    free(v);
+    /* :62 bedtools subtract -a assembly -b merged; :65-66 minus every contig shorter than min_ctg_len */
+    orc_span_t *o = (orc_span_t *)malloc(((size_t)nm + (size_t)n_ctg + 1) * sizeof(*o));
+    int64_t no = 0;
+    for (int32_t c = 0; c < n_ctg; ++c) {
+        if (ctg_len[c] < min_ctg_len || ctg_len[c] <= 0) continue;
+        int32_t from = 0;                                  /* first base of the contig not yet covered by a merged row */
+        for (int64_t j = 0; j < nm; ++j) {
+            if (m[j].ctg != c) continue;
+            if (m[j].end <= from || m[j].start >= ctg_len[c]) continue;
+            if (m[j].start > from) { o[no].ctg = c; o[no].start = from; o[no].end = m[j].start; ++no; }
+            from = m[j].end;
+        }
+        if (from < ctg_len[c]) { o[no].ctg = c; o[no].start = from; o[no].end = ctg_len[c]; ++no; }
+    }
+    free(m);
+    *out = o;
+    *n_out = no;
+    return 0;
+}

@@ -62,6 +62,10 @@ def lib():
         L.orc_telobreaks.restype = C.c_int
         L.orc_khash_order.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.c_void_p, C.c_void_p]
         L.orc_khash_order.restype = C.c_int32
+        L.orc_ivl_merge.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.orc_ivl_merge.restype = C.c_int
+        L.orc_panel_boring.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64] + [C.c_int32] * 5 + [C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.orc_panel_boring.restype = C.c_int
         L.orc_bigenough_keep.restype = C.c_int
         L.orc_free.argtypes = [C.c_void_p]
         L.orc_revcomp.argtypes = [C.c_char_p, C.c_char_p]
@@ -177,3 +181,29 @@ def khash_order(names):
     order = np.zeros(max(n, 1), np.int32)
     k = L.orc_khash_order(arr, n, slot.ctypes.data, order.ctypes.data)
     return slot[:n], order[:k]
+
+
+def _spans_out(L, out, n):
+    res = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_int32)), shape=(max(n.value, 1) * 3,))[: n.value * 3].copy().view(SPAN_DT) if n.value else np.zeros(0, SPAN_DT)
+    L.orc_free(out)
+    return res
+
+
+def ivl_merge(spans, dist):
+    """sort by (ctg, start) + bedtools merge -d dist"""
+    L = lib()
+    spans = np.ascontiguousarray(spans, dtype=SPAN_DT)
+    out, n = C.c_void_p(), C.c_int64()
+    L.orc_ivl_merge(spans.ctypes.data, len(spans), dist, C.byref(out), C.byref(n))
+    return _spans_out(L, out, n)
+
+
+def panel_boring(ctg_len, fun, lowq, min_lowq_len=8000, extend=40000, edge_len=200000, merge_dist=200000, min_ctg_len=800000):
+    L = lib()
+    ctg_len = np.ascontiguousarray(ctg_len, dtype=np.int32)
+    fun = np.ascontiguousarray(fun, dtype=SPAN_DT)
+    lowq = np.ascontiguousarray(lowq, dtype=SPAN_DT)
+    out, n = C.c_void_p(), C.c_int64()
+    L.orc_panel_boring(ctg_len.ctypes.data, len(ctg_len), fun.ctypes.data, len(fun), lowq.ctypes.data, len(lowq), min_lowq_len, extend, edge_len,
+                       merge_dist, min_ctg_len, C.byref(out), C.byref(n))
+    return _spans_out(L, out, n)

@@ -69,6 +69,14 @@ def main():
             print("cov_prepare", [(k, round(v, 3)) for k, v in acc.last_timing()], flush=True)
             r = acc.cov_select(cov, 12, 75, 0.4, 100000, 1000000, False)
             print("cov_select", [(k, round(v, 3)) for k, v in acc.last_timing()], len(r), flush=True)
+            import time
+            t0 = time.perf_counter()
+            r = acc.cov_select(cov, 12, 75, 0.4, 100000, 1000000, False)
+            t1 = time.perf_counter()
+            m = acc.cov_select_merged(cov, 12, 75, 0.4, 100000, 1000000, False, 1000, 30000)
+            t2 = time.perf_counter()
+            print("cov_select call %.2f ms (%d windows to the host); cov_select_merged call %.2f ms (%d intervals)" % ((t1 - t0) * 1e3, len(r), (t2 - t1) * 1e3, len(m)),
+                  [(k, round(v, 3)) for k, v in acc.last_timing()], flush=True)
 
 
 if __name__ == "__main__":

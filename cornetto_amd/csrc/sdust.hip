@@ -9,8 +9,8 @@
 //    starts 2W bases + (W-2) word emissions before its chunk with an empty state; once W-2 words have been
 //    pushed the window state equals the true one, and every P entry created before that point has been
 //    evicted (its start is < window start) at least 2W-4 bases later — before the chunk begins.  From the
-//    chunk start on, the lane's state IS the sequential state.  The warm-up start is found by scanning
-//    backwards for W-2 word emissions (not bases), so N-dense sequence is handled exactly.
+//    chunk start on, the lane's state IS the sequential state.  The warm-up start is found (sd_prep) by
+//    scanning backwards for W-2 word emissions (not bases), so N-dense sequence is handled exactly.
 //  * Output.  The reference's result list is the canonical union (overlapping or touching intervals
 //    merged, :94-98) of the intervals it saves, in increasing start order.  Each lane records only the
 //    intervals saved at times inside its chunk, merges them locally, and the chunk lists are stitched in
@@ -21,9 +21,10 @@
 //    for every entry (:123 with :111).  So P is a ring of one 32-bit slot (r,l) per start value, and
 //    find_perfect() (:104-128) becomes one backward pass with a running maximum: O(W) instead of O(W*|P|).
 //
-// Per-lane state lives in LDS, laid out lane-minor ([index][lane], 4-byte columns) so that any per-lane
-// index pattern is bank-conflict free: ring of 3-mers (bytes), cw/cv (bytes), P slots (dwords).
-// One wavefront per workgroup; no barriers.  Integer/LDS-latency bound by nature, not HBM bound.
+// Two kernels: sdust_w64 (W - 2 <= 64, T in 5..100000: the production path, described above it) and the older
+// sdust_kernel<RC> for every other parameter pair, which keeps the reference's per-lane loops and all of its state in
+// LDS (lane-minor layout, [index][lane] in 4-byte columns: bank-conflict free for any per-lane index).
+// One wavefront per workgroup; no barriers.  VALU-issue bound by nature, not HBM bound.
 #include <algorithm>
 
 #include "common.hpp"
@@ -313,13 +314,14 @@ __global__ __launch_bounds__(64) void sdust_kernel(SdArgs A)
 //     suffix; pushing word t can only move vs just past the (m+1)-th most recent occurrence of t, which is
 //     looked up — only when cw[t] > m — by ONE ballot over the owner's ring (lane j reads ring slot j).
 //   * find_perfect (:104-128): lane j takes window position j of the owning lane; suffix scores r_j
-//     come from 6 ballots (equal-word mask), a popcount and a suffix-sum scan; the running maximum over
-//     P entries / earlier candidates is a suffix-max scan with exact cross-multiplied ratio compares.
+//     come from 6 ballots (equal-word mask), mbcnt and a suffix-sum scan; the running maximum over P entries /
+//     earlier candidates is a max-scan of exact integer ratio keys (sd_ratio_key).  Calls that provably find
+//     nothing are skipped (the `sl` bound).
 //   * P occupancy is a 64-bit mask per lane (bit = start & 63), so save_masked_regions (:88-102) and the
 //     N flush (:153) are rotates / ctz instead of list walks.
-//     Per-lane LDS state is just the ring and the 64 byte counters (8 KB per wave): 20 waves per CU.
-// Chunks are dealt to lanes strided over the whole grid, so that a long low-complexity array (telomere,
-// satellite) is spread over many waves instead of serialising inside one.
+//     Per-lane LDS state is just the ring and the 64 byte counters (8.4 KB per wave): 19 waves per CU.
+// The waves stay resident and every lane takes chunks from one queue (low-complexity chunks first, one per wave):
+// see "jobs" in the kernel.
 // ---------------------------------------------------------------------------------------------------
 struct SdLds64 {
     uint32_t cw[16][64];       // [3-mer >> 2][lane]: four byte counters (3-mer & 3) = copies of the 3-mer in the window

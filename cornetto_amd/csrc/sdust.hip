@@ -55,6 +55,9 @@ struct SdArgs {
     const uint32_t *perm;        // sdust_w64: queue position -> chunk (low-complexity chunks first), or NULL
     const int32_t *ustart;       // sdust_w64: warm-up start of every chunk (sd_prep)
     uint32_t *queue;             // sdust_w64: next queue position
+    uint32_t *claim;             // sdust_w64: [n_chunks] 0 = free; set by the lane that takes the chunk (from the queue, or by running on into it)
+    int32_t q_len;               // sdust_w64: queue positions (perm entries, 0xFFFFFFFF = hole)
+    int32_t run_on;              // sdust_w64: lanes run on into the next chunk when it is free (CORNETTO_SDUST_RUNON, default 1)
     // bounded warm-up search (sdust_w64): the local backward scan gives up after SD_SCAN_CAP bases; then
     const uint32_t *wtab;        //   exclusive prefix of per-256-base-block word-emission counts, or NULL
     const int64_t *wtab_base;    //   first table entry of each contig
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(64) void sdust_kernel(SdArgs A)
             if (pf > (int)last_f) last_f = (uint32_t)pf;
         } else {
             if (have_last) {
-                if (n_out < A.cap) A.out[(size_t)cid * A.cap + n_out] = make_uint2(last_s, last_f);
+                if (n_out < A.cap) out[n_out] = make_uint2(last_s, last_f);
                 ++n_out;
             }
             have_last = true;
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
     // position ubase + K for it.  Chunks start on 64-step boundaries (u is 64-byte aligned: all lanes stay on
     // the same phase of the 64-byte blocks).
     bool done = false, hasjob = false;
-    int cid = 0, ubase = 0;
+    int cid = 0, cur = 0, ubase = 0;                 // cid .. cur: the chunks of the lane's current run (contiguous, same contig)
     uint32_t blk64 = 0;                              // (contig offset + ubase) / 64: the lane's stream in 64-byte blocks
     // steps >= endk see a non-base: the end of the sequence (:141, flushes P and records it) or the end of the
     // chunk (flushes P without recording: those intervals belong to the next chunk).  Only steps
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
             if (pf > (int)last_f) last_f = (uint32_t)pf;
         } else {
             if (have_last) {
-                if (n_out < A.cap) A.out[(size_t)cid * A.cap + n_out] = make_uint2(last_s, last_f);
+                if (n_out < (uint32_t)(cur - cid + 1) * A.cap) A.out[(size_t)cid * A.cap + n_out] = make_uint2(last_s, last_f);   // the rows of a run are contiguous
                 ++n_out;
             }
             have_last = true;
@@ -506,42 +509,72 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
     // that every 64-byte sector is requested from L2 / the fabric once: with one dword per 4 steps the ~40 k
     // concurrent per-lane streams of an XCD overflowed its 4 MB L2 and each line was re-fetched ~6 times
     // (rocprofv3 FETCH_SIZE, profiles/).  A block never leaves its contig: contigs start 64-byte aligned.
-    uint4 nb0 = make_uint4(0, 0, 0, 0), nb1 = nb0, nb2 = nb0, nb3 = nb0;
+    sd_v16u blk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // the lane's current 64-byte block; each half is refilled half a block ahead
+    int lenk = 0;                                  // contig length as a step (len - ubase): blocks are fetched while the contig goes on
     uint32_t pcn = 0x04040404u;                      // codes of the previous 4 positions (before u: non-bases, l = 0)
     uint8_t *const myring = &S.ring[lane][0];
 
     unsigned st_steps = 0, st_fp = 0, st_trim = 0, st_full = 0, st_jobs = 0;
     const unsigned long long st_t0 = STATS ? wall_clock64() : 0ull;
     for (int k64 = 0;; k64 += 64) {
-      // ---- lanes whose chunk is finished publish it and take the next one from the queue
+      // ---- a lane whose chunk ends inside the coming block runs on into the next chunk of the contig if nobody has
+      // taken it yet: no warm-up, no reset, the records go on in the same (contiguous) rows.  Only when that fails does it
+      // publish and take another chunk from the queue, which hands out every 8th chunk first so that runs have room.
+      auto run_on = [&]() {
+          if (A.run_on && sd_any(hasjob && !islast && endk < k64 + 64)) {
+              while (hasjob && !islast && endk < k64 + 64) {
+                  if (atomicCAS(&A.claim[cur + 1], 0u, 1u) != 0u) break;
+                  ++cur;
+                  const SdChunk nx = A.chunks[cur];
+                  endk += nx.end - nx.start;
+                  islast = nx.end == A.ctg_len[nx.ctg];
+              }
+          }
+      };
+      run_on();
+      // ---- lanes whose run is finished publish it and take the next free chunk from the queue
       const bool need = !done && k64 >= SD_NRUN;
       if (sd_any(need)) {
-          const unsigned long long needmask = sd_ballot(need);
-          int base = 0;
-          if (needmask) {
-              const int first = __builtin_ctzll(needmask);
-              if (lane == first) base = (int)atomicAdd(A.queue, (uint32_t)__popcll(needmask));
+          if (need && hasjob) {
+              if (have_last) {
+                  if (n_out < (uint32_t)(cur - cid + 1) * A.cap) A.out[(size_t)cid * A.cap + n_out] = make_uint2(last_s, last_f);
+                  ++n_out;
+              }
+              A.out_n[cid] = n_out;                    // (the other chunks of the run keep the 0 the host put there)
+              if (n_out > (uint32_t)(cur - cid + 1) * A.cap) atomicMax(A.ovf, n_out);
+          }
+          bool want = need;
+          int got = -1;
+          while (sd_any(want)) {
+              const unsigned long long wmask = sd_ballot(want);
+              const int first = __builtin_ctzll(wmask);
+              int base = 0;
+              if (lane == first) base = (int)atomicAdd(A.queue, (uint32_t)__popcll(wmask));
               base = rdlane(base, first);
+              if (want) {
+                  const int idx = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(wmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wmask, 0u));
+                  if (idx < 0 || idx >= A.q_len) {
+                      want = false;                    // the queue is empty
+                  } else {
+                      const uint32_t c = A.perm ? A.perm[idx] : (uint32_t)idx;
+                      if (c < (uint32_t)A.n_chunks && atomicCAS(&A.claim[c], 0u, 1u) == 0u) {
+                          got = (int)c;
+                          want = false;
+                      }
+                  }
+              }
           }
           if (need) {
-              if (hasjob) {
-                  if (have_last) {
-                      if (n_out < A.cap) A.out[(size_t)cid * A.cap + n_out] = make_uint2(last_s, last_f);
-                      ++n_out;
-                  }
-                  A.out_n[cid] = n_out;
-                  if (n_out > A.cap) atomicMax(A.ovf, n_out);
-              }
-              const int idx = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(needmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needmask, 0u));
-              hasjob = idx >= 0 && idx < A.n_chunks;     // (idx < 0: more than 2^31 fetches, impossible)
+              hasjob = got >= 0;
               done = !hasjob;
               endk = 0;
               islast = false;
-              nb0 = nb1 = nb2 = nb3 = make_uint4(0, 0, 0, 0);
+              blk = sd_v16u{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+              lenk = 0;
               occ = 0;
               evict_k = SD_NEVER;
               if (hasjob) {
-                  cid = A.perm ? (int)A.perm[idx] : idx;
+                  cid = cur = got;
                   const SdChunk ch = A.chunks[cid];
                   const int u = A.ustart[cid];           // warm-up start (sd_prep), 64-byte aligned; < 0: not known
                   have_last = false;
@@ -550,43 +583,50 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
                       ubase = u - k64;
                       blk64 = (uint32_t)((A.ctg_off[ch.ctg] + u) >> 6) - (uint32_t)(k64 >> 6);
                       endk = (ch.end - u) + k64;
-                      islast = ch.end == A.ctg_len[ch.ctg];
+                      islast = (ch.end - u) + k64 == A.ctg_len[ch.ctg] - ubase;
                       p = -1; o = 0; vs = 0; rw10 = 0; ltv = 0; ct = 0; s_pref = 0; sl = SD_SLACK_NONE;
                       LN = k64 - 1;
                       pcn = 0x04040404u;
                       for (int i = 0; i < 16; ++i) S.cw[i][lane] = 0;
+                      lenk = A.ctg_len[ch.ctg] - ubase;
                       {
                           const uint4 *q = reinterpret_cast<const uint4 *>(A.bases + A.ctg_off[ch.ctg] + u);      // u < ch.end <= contig length
-                          nb0 = q[0]; nb1 = q[1]; nb2 = q[2]; nb3 = q[3];
+                          const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                          blk.s0 = q0.x; blk.s1 = q0.y; blk.s2 = q0.z; blk.s3 = q0.w; blk.s4 = q1.x; blk.s5 = q1.y; blk.s6 = q1.z; blk.s7 = q1.w;
+                          blk.s8 = q2.x; blk.s9 = q2.y; blk.sa = q2.z; blk.sb = q2.w; blk.sc = q3.x; blk.sd = q3.y; blk.se = q3.z; blk.sf = q3.w;
                       }
                   } else {
                       endk = k64;                        // empty job (the host reruns with the word-count table)
+                      islast = true;                     // (and never runs on)
                   }
               }
           }
           if (STATS) ++st_jobs;
           if (sd_ballot(!done) == 0) break;
+          run_on();          // a chunk just taken may itself end inside the coming block (contig starts, tiny chunks)
       }
-      sd_v16u blk;
-      blk.s0 = nb0.x; blk.s1 = nb0.y; blk.s2 = nb0.z; blk.s3 = nb0.w; blk.s4 = nb1.x; blk.s5 = nb1.y; blk.s6 = nb1.z; blk.s7 = nb1.w;
-      blk.s8 = nb2.x; blk.s9 = nb2.y; blk.sa = nb2.z; blk.sb = nb2.w; blk.sc = nb3.x; blk.sd = nb3.y; blk.se = nb3.z; blk.sf = nb3.w;
-      if (k64 + 64 < SD_NRUN) {              // (at most the block behind the contig's last one: inside the 128 bytes of slack)
-          const uint4 *q = reinterpret_cast<const uint4 *>(A.bases + ((uint64_t)(blk64 + (uint32_t)(k64 >> 6) + 1u) << 6));
-          nb0 = q[0]; nb1 = q[1]; nb2 = q[2]; nb3 = q[3];
-      }
+      // Bases are consumed one 64-byte block per lane per 64 steps.  The block lives in 16 registers that are read with
+      // a uniform index; each half is refilled as soon as it is dead — words 0-7 at group 8 with the first half of the
+      // NEXT block, words 8-15 after group 15 — i.e. half a block (32 steps) before it is needed, from the same contig
+      // whether or not the lane's own chunk goes on (if it runs on into the next chunk the data is there; if it takes
+      // another chunk, the block is loaded afresh).
       // The packed decode below knows letters only.  A byte <= 3 (seq_nt4_table maps 0..3 to themselves) clears the
-      // top six bits of its byte lane in the AND of the block; letters never do (they all carry 0x40): such a block
+      // top six bits of its byte lane in the AND of the words; letters never do (they all carry 0x40): such a half
       // (and, harmlessly, a few others: zero padding behind a contig, '-' or '*' next to letters) is decoded byte by byte.
-      bool slow;
-      {
-          uint32_t a = blk.s0 & blk.s1 & blk.s2 & blk.s3 & blk.s4 & blk.s5 & blk.s6 & blk.s7 & blk.s8 & blk.s9 & blk.sa & blk.sb & blk.sc & blk.sd & blk.se & blk.sf;
-          a &= 0xFCFCFCFCu;
-          slow = ((a - 0x01010101u) & ~a & 0x80808080u) != 0;
-      }
-      const bool slow_any = sd_any(slow);
+#define SD_HAS_LOW_BYTE(a) ((((a) & 0xFCFCFCFCu) - 0x01010101u) & ~((a) & 0xFCFCFCFCu) & 0x80808080u)
+      const bool more = k64 + 64 < lenk;     // (done lanes and lanes without a chunk: lenk = 0)
+      bool slow_any = sd_any(SD_HAS_LOW_BYTE(blk.s0 & blk.s1 & blk.s2 & blk.s3 & blk.s4 & blk.s5 & blk.s6 & blk.s7) != 0);
 #pragma clang loop unroll(disable)
       for (int g = 0; g < 16; ++g) {
         const int k4 = k64 + 4 * g;
+        if (g == 8) {
+            slow_any = sd_any(SD_HAS_LOW_BYTE(blk.s8 & blk.s9 & blk.sa & blk.sb & blk.sc & blk.sd & blk.se & blk.sf) != 0);
+            if (more) {
+                const uint4 *q = reinterpret_cast<const uint4 *>(A.bases + ((uint64_t)(blk64 + (uint32_t)(k64 >> 6) + 1u) << 6));
+                const uint4 q0 = q[0], q1 = q[1];
+                blk.s0 = q0.x; blk.s1 = q0.y; blk.s2 = q0.z; blk.s3 = q0.w; blk.s4 = q1.x; blk.s5 = q1.y; blk.s6 = q1.z; blk.s7 = q1.w;
+            }
+        }
         const uint32_t word = blk[g];
         // ---- 4 positions -> 4 codes (bits 0-1 base, bit 2 non-base) ------------------------------------
         uint32_t cn;
@@ -798,6 +838,12 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
         }
         if (grp_n && nmask) LN = k4 + ((31 - __builtin_clz(nmask)) >> 3);
       }
+      if (more) {
+          const uint4 *q = reinterpret_cast<const uint4 *>(A.bases + ((uint64_t)(blk64 + (uint32_t)(k64 >> 6) + 1u) << 6));
+          const uint4 q2 = q[2], q3 = q[3];
+          blk.s8 = q2.x; blk.s9 = q2.y; blk.sa = q2.z; blk.sb = q2.w; blk.sc = q3.x; blk.sd = q3.y; blk.se = q3.z; blk.sf = q3.w;
+      }
+#undef SD_HAS_LOW_BYTE
     }
     if (STATS && A.stats && lane == 0) {
         atomicAdd(&A.stats[0], (unsigned long long)st_steps);
@@ -938,8 +984,10 @@ __global__ void sd_prep(SdArgs A, uint32_t *flag, int32_t *ustart)
 }
 
 // Queue order: flagged chunks first, but only one in every S = min(64, chunks / flagged) positions, the rest filled
-// with the other chunks in order: a wave fetches 64 consecutive positions at a time, and 64 lanes inside repeat
-// arrays in ONE wave would serialise (every find_perfect of a wave runs on all of its 64 lanes).
+// with the other chunks: a wave fetches 64 consecutive positions at a time, and 64 lanes inside repeat arrays in ONE
+// wave would serialise (every find_perfect of a wave runs on all of its 64 lanes).  The other chunks come in eight
+// passes over the input — every 8th chunk, then the ones halfway between, ... (bit-reversed phase) — so that a lane has
+// free chunks ahead of it to run on into.  perm has n_chunks + 16 positions, 0xFFFFFFFF where nothing lands.
 __global__ void sd_order(const uint32_t *flag, const uint32_t *rank, const unsigned long long *n_flagged, int32_t n_chunks, uint32_t *perm)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -951,7 +999,10 @@ __global__ void sd_order(const uint32_t *flag, const uint32_t *rank, const unsig
     if (flag[c]) {
         pos = r * S;
     } else {
-        const uint32_t j = (uint32_t)c - r;                  // rank among the others
+        const uint32_t L = (uint32_t)n_chunks - H, stripe = (L + 7u) / 8u;
+        const uint32_t j0 = (uint32_t)c - r;                 // rank among the others, in input order
+        const uint32_t ph = j0 & 7u, rev = ((ph & 1u) << 2) | (ph & 2u) | (ph >> 2);
+        const uint32_t j = rev * stripe + (j0 >> 3);         // its turn: < 8 * stripe <= L + 7
         if (S > 1u && j < H * (S - 1u)) pos = (j / (S - 1u)) * S + 1u + j % (S - 1u);
         else pos = H * S + (j - H * (S - 1u));
     }
@@ -1044,21 +1095,28 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             const bool use_w64 = W - 2 <= 64 && T >= 5 && T <= 100000 && variant == 0;
             SdArgs A{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, d_out, d_cnt, (uint32_t)cap,
                      want_stats ? d_tot + 2 : nullptr, reinterpret_cast<uint32_t *>(d_tot + 1), d_slots, nullptr, nullptr,
-                     reinterpret_cast<uint32_t *>(d_tot + 8), a->d_wtab, a->d_wtab_base, reinterpret_cast<uint32_t *>(d_tot + 1) + 1};
+                     reinterpret_cast<uint32_t *>(d_tot + 8), nullptr, 0, env_int("CORNETTO_SDUST_RUNON", 1), a->d_wtab, a->d_wtab_base, reinterpret_cast<uint32_t *>(d_tot + 1) + 1};
             unsigned nb = (unsigned)((nc + 63) / 64);
             if (use_w64) {
-                // warm-up starts and the order of the queue: flag (nc) + rank (nc) + perm (nc) + ustart (nc) + scan partials
-                uint32_t *d_flag = (uint32_t *)cn_ws(h, WS_SD_PERM, nc * 16 + ((nc + 4095) / 4096 + 1) * 4);
+                // warm-up starts, the order of the queue, the claim flags:
+                // flag (nc) + rank (nc) + ustart (nc) + claim (nc) + perm (nc + 16) + scan partials
+                uint32_t *d_flag = (uint32_t *)cn_ws(h, WS_SD_PERM, (nc * 5 + 16) * 4 + ((nc + 4095) / 4096 + 1) * 4);
                 if (!d_flag) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
-                uint32_t *d_rank = d_flag + nc, *d_perm = d_rank + nc, *d_pp = d_perm + nc + nc;
-                int32_t *d_ustart = reinterpret_cast<int32_t *>(d_perm + nc);
+                uint32_t *d_rank = d_flag + nc, *d_claim = d_rank + nc + nc, *d_perm = d_claim + nc, *d_pp = d_perm + nc + 16;
+                int32_t *d_ustart = reinterpret_cast<int32_t *>(d_rank + nc);
                 const unsigned nbs = (unsigned)((nc + 255) / 256);
+                CN_HIP(h, hipMemsetAsync(d_claim, 0, nc * 4, h->stream));
+                CN_HIP(h, hipMemsetAsync(d_cnt, 0, nc * 4, h->stream));          // chunks a lane runs on into publish nothing of their own
                 CN_LAUNCH(h, "sdust_prep", sd_prep<<<dim3(nbs), dim3(256), 0, h->stream>>>(A, d_flag, d_ustart));
                 A.ustart = d_ustart;
+                A.claim = d_claim;
+                A.q_len = (int32_t)nc;
                 if (env_int("CORNETTO_SDUST_ORDER", 1)) {
+                    CN_HIP(h, hipMemsetAsync(d_perm, 0xFF, (nc + 16) * 4, h->stream));
                     CN_TRY(cnscan::exclusive_u32(h, "sdust_prep", d_flag, (int64_t)nc, 1, d_rank, d_pp, d_tot + 7));
                     CN_LAUNCH(h, "sdust_prep", sd_order<<<dim3(nbs), dim3(256), 0, h->stream>>>(d_flag, d_rank, d_tot + 7, (int32_t)nc, d_perm));
                     A.perm = d_perm;
+                    A.q_len = (int32_t)nc + 16;
                 }
                 // as many waves as the chip holds at once (LDS-bound: ~19 per CU); each lane works through the queue
                 if (h->sd_slots == 0) {

@@ -282,10 +282,13 @@ def test_sdust_queue_and_order_do_not_change_results(acc, golden_dir, monkeypatc
     recs = _records(golden_dir, "mix.fa.gz")
     monkeypatch.setenv("CORNETTO_SDUST_CHUNK", "100")
     exp = golden(golden_dir, "mix.sdust.exp")
-    for waves, order in (("1", "1"), ("2", "0"), ("5", "1"), ("100000", "0")):
+    for waves, order, runon in (("1", "1", "1"), ("2", "0", "1"), ("5", "1", "0"), ("100000", "0", "0"), ("3", "1", "1")):
         monkeypatch.setenv("CORNETTO_SDUST_WAVES", waves)
         monkeypatch.setenv("CORNETTO_SDUST_ORDER", order)
-        assert gpu_sdust_text(acc, recs, 20, 64) == exp, (waves, order)
+        monkeypatch.setenv("CORNETTO_SDUST_RUNON", runon)      # lanes run on into the next chunk while it is free
+        for chunk in ("100", "37", "64"):
+            monkeypatch.setenv("CORNETTO_SDUST_CHUNK", chunk)
+            assert gpu_sdust_text(acc, recs, 20, 64) == exp, (waves, order, runon, chunk)
 
 
 @pytest.mark.parametrize("chunk", ["64", "500", "1536"])

@@ -505,10 +505,9 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
         if (occ) minstart = start + __builtin_ctzll(rotr64(occ, start & 63));
     };
 
-    // Bases are consumed one 64-byte block per lane per 64 steps (4 x dwordx4, fetched a whole block ahead), so
-    // that every 64-byte sector is requested from L2 / the fabric once: with one dword per 4 steps the ~40 k
-    // concurrent per-lane streams of an XCD overflowed its 4 MB L2 and each line was re-fetched ~6 times
-    // (rocprofv3 FETCH_SIZE, profiles/).  A block never leaves its contig: contigs start 64-byte aligned.
+    // Bases are consumed one 64-byte block per lane per 64 steps, in two 32-byte requests (2 x dwordx4 each): with one
+    // dword per 4 steps the ~40 k concurrent per-lane streams of an XCD overflowed its 4 MB L2 and each line was
+    // re-fetched ~6 times (rocprofv3 FETCH_SIZE, profiles/).  A block never leaves its contig: contigs start 64-byte aligned.
     sd_v16u blk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // the lane's current 64-byte block; each half is refilled half a block ahead
     int lenk = 0;                                  // contig length as a step (len - ubase): blocks are fetched while the contig goes on
     uint32_t pcn = 0x04040404u;                      // codes of the previous 4 positions (before u: non-bases, l = 0)

@@ -1044,11 +1044,37 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
     CN_HIP(h, hipSetDevice(h->device));
     cn_timing_begin(h);
 
+    // waves the chip holds at once (LDS-bound: 19 per CU), once per handle
+    const int variant0 = env_int("CORNETTO_SDUST_VARIANT", 0);
+    const bool w64_path = W - 2 <= 64 && T >= 5 && T <= 100000 && variant0 == 0;
+    if (w64_path && h->sd_slots == 0) {
+        // The kernel must not spill: builds of it that kept registers in scratch memory gave results that
+        // changed from run to run on MI355X (ROCm 7.2), builds without scratch never did.
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&sdust_w64<false>)) != hipSuccess || fa.localSizeBytes != 0)
+            return cn_fail(h, CORNETTO_E_HIP, "sdust: kernel built with %zu bytes of scratch per lane (register spills): refusing to run it", (size_t)fa.localSizeBytes);
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sdust_w64<false>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 16;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus < 1) cus = 256;
+        h->sd_slots = per_cu * cus;
+        h->sd_cus = cus;
+    }
+    const int64_t sd_waves = w64_path ? env_int("CORNETTO_SDUST_WAVES", std::max(1, h->sd_slots / h->sd_cus * h->share / 100) * h->sd_cus) : 0;
+
     // chunk = bases per lane.  Small enough that a long low-complexity array is shared by many waves, large
     // enough that the ~3W-base speculative warm-up stays a few percent.  CORNETTO_SDUST_CHUNK overrides
     // (tests use tiny chunks to stress the speculative start).
     int64_t chunk = env_int("CORNETTO_SDUST_CHUNK", 0);
-    if (chunk <= 0) chunk = 1536;
+    if (chunk <= 0) {
+        // about 1536, adjusted so that the chunks come out as a whole number of rounds over the resident lanes: every
+        // lane works through its chunks at the same pace, and 6.6 chunks per lane cost as much time as 7
+        chunk = 1536;
+        const int64_t lanes = sd_waves * 64;
+        if (lanes > 0 && a->total / lanes >= 1536) {
+            const int64_t rounds = a->total / (lanes * 1536);                      // >= 1
+            chunk = std::min<int64_t>(3072, ((a->total + lanes * rounds - 1) / (lanes * rounds) + 63) / 64 * 64);
+        }
+    }
     chunk = std::max<int64_t>(16, chunk);
     const int64_t key = chunk;
     if (a->sd_chunk != key) {
@@ -1090,8 +1116,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             CN_HIP(h, hipMemsetAsync(d_tot, 0, 2048, h->stream));
             uint32_t *d_slots = (uint32_t *)cn_ws(h, WS_SD_OFF, nc * 64 * sizeof(uint32_t));
             if (!d_slots) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
-            const int variant = env_int("CORNETTO_SDUST_VARIANT", 0);   // 1 = force the per-lane reference-shaped kernel
-            const bool use_w64 = W - 2 <= 64 && T >= 5 && T <= 100000 && variant == 0;
+            const bool use_w64 = w64_path;                              // CORNETTO_SDUST_VARIANT=1 forces the per-lane reference-shaped kernel
             SdArgs A{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, d_out, d_cnt, (uint32_t)cap,
                      want_stats ? d_tot + 2 : nullptr, reinterpret_cast<uint32_t *>(d_tot + 1), d_slots, nullptr, nullptr,
                      reinterpret_cast<uint32_t *>(d_tot + 8), nullptr, 0, env_int("CORNETTO_SDUST_RUNON", 1), a->d_wtab, a->d_wtab_base, reinterpret_cast<uint32_t *>(d_tot + 1) + 1};
@@ -1118,23 +1143,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                     A.q_len = (int32_t)nc + 16;
                 }
                 // as many waves as the chip holds at once (LDS-bound: ~19 per CU); each lane works through the queue
-                if (h->sd_slots == 0) {
-                    // The kernel must not spill: builds of it that kept registers in scratch memory gave results that
-                    // changed from run to run on MI355X (ROCm 7.2), builds without scratch never did.
-                    hipFuncAttributes fa;
-                    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&sdust_w64<false>)) != hipSuccess || fa.localSizeBytes != 0)
-                        return cn_fail(h, CORNETTO_E_HIP, "sdust: kernel built with %zu bytes of scratch per lane (register spills): refusing to run it", (size_t)fa.localSizeBytes);
-                    int per_cu = 0, cus = 0;
-                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sdust_w64<false>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 16;
-                    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus < 1) cus = 256;
-                    h->sd_slots = per_cu * cus;
-                    h->sd_cus = cus;
-                }
-                {
-                    const int per_cu = std::max(1, h->sd_slots / h->sd_cus * h->share / 100);
-                    const int waves = env_int("CORNETTO_SDUST_WAVES", per_cu * h->sd_cus);
-                    if ((unsigned)waves < nb) nb = (unsigned)waves;
-                }
+                if ((unsigned)sd_waves < nb) nb = (unsigned)sd_waves;
                 if (want_stats) CN_LAUNCH(h, "sdust_kernel", sdust_w64<true><<<dim3(nb), dim3(64), 0, h->stream>>>(A));
                 else CN_LAUNCH(h, "sdust_kernel", sdust_w64<false><<<dim3(nb), dim3(64), 0, h->stream>>>(A));
             } else if (W - 2 <= 64) {

@@ -605,8 +605,8 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
           run_on();          // a chunk just taken may itself end inside the coming block (contig starts, tiny chunks)
       }
       // Bases are consumed one 64-byte block per lane per 64 steps.  The block lives in 16 registers that are read with
-      // a uniform index; each half is refilled as soon as it is dead — words 0-7 at group 8 with the first half of the
-      // NEXT block, words 8-15 after group 15 — i.e. half a block (32 steps) before it is needed, from the same contig
+      // a uniform index; each half is refilled once it is dead — words 0-7 at group 12 with the first half of the NEXT
+      // block, words 8-15 after group 15 — i.e. 16 and 32 steps before it is needed, from the same contig
       // whether or not the lane's own chunk goes on (if it runs on into the next chunk the data is there; if it takes
       // another chunk, the block is loaded afresh).
       // The packed decode below knows letters only.  A byte <= 3 (seq_nt4_table maps 0..3 to themselves) clears the
@@ -618,8 +618,8 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
 #pragma clang loop unroll(disable)
       for (int g = 0; g < 16; ++g) {
         const int k4 = k64 + 4 * g;
-        if (g == 8) {
-            slow_any = sd_any(SD_HAS_LOW_BYTE(blk.s8 & blk.s9 & blk.sa & blk.sb & blk.sc & blk.sd & blk.se & blk.sf) != 0);
+        if (g == 8) slow_any = sd_any(SD_HAS_LOW_BYTE(blk.s8 & blk.s9 & blk.sa & blk.sb & blk.sc & blk.sd & blk.se & blk.sf) != 0);
+        if (g == 12) {                               // (as late as the latency allows: the other half of the sector follows 16 steps later)
             if (more) {
                 const uint4 *q = reinterpret_cast<const uint4 *>(A.bases + ((uint64_t)(blk64 + (uint32_t)(k64 >> 6) + 1u) << 6));
                 const uint4 q0 = q[0], q1 = q[1];

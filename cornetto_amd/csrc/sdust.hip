@@ -34,6 +34,9 @@
 namespace {
 
 __device__ __forceinline__ int nt4_code(uint32_t c);
+struct SdArgs;
+struct SdChunk;
+__device__ int sd_find_start(const SdArgs &A, const SdChunk ch, const uint8_t *seq);
 
 struct SdChunk {
     int32_t ctg, start, end;
@@ -51,9 +54,8 @@ struct SdArgs {
     uint32_t cap;
     unsigned long long *stats;   // optional [4]: wave steps, cooperative find_perfect calls, cooperative trims, save/evicts
     uint32_t *ovf;               // max over chunks of (intervals produced) when that exceeds cap, else untouched
-    uint32_t *slots;             // sdust_w64: [n_chunks][64] P slots (start & 63 -> ratio key | l << 24), global memory
+    uint32_t *slots;             // sdust_w64: [waves * 64 lanes][64] P slots (start & 63 -> ratio key | l << 24), global memory
     const uint32_t *perm;        // sdust_w64: queue position -> chunk (low-complexity chunks first), or NULL
-    const int32_t *ustart;       // sdust_w64: warm-up start of every chunk (sd_prep)
     uint32_t *queue;             // sdust_w64: next queue position
     uint32_t *claim;             // sdust_w64: [n_chunks] 0 = free; set by the lane that takes the chunk (from the queue, or by running on into it)
     int32_t q_len;               // sdust_w64: queue positions (perm entries, 0xFFFFFFFF = hole)
@@ -491,8 +493,8 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
     };
     // save_masked_regions(start) when it does something: occ != 0 && minstart < start   (:88-102)
     auto save_evict = [&](int start, int nowk) {
-        // P slots of the lane's chunk: one 256-byte row in global memory
-        const uint32_t sl = __hip_atomic_load(&A.slots[(size_t)cid * 64 + (minstart & 63)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // P slots of the lane: one 256-byte row in global memory (only slots whose occupancy bit is set are ever read)
+        const uint32_t sl = __hip_atomic_load(&A.slots[((size_t)blockIdx.x * 64 + lane) * 64 + (minstart & 63)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (nowk >= A.chunks[cid].start - ubase && nowk < SD_NRUN) emit(minstart, minstart + (int)(sl >> 24) + 3);
         const int gone = start - minstart;           // starts minstart .. start-1 leave the window
         if (gone >= 64) {
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
     uint32_t pcn = 0x04040404u;                      // codes of the previous 4 positions (before u: non-bases, l = 0)
     uint8_t *const myring = &S.ring[lane][0];
 
-    unsigned st_steps = 0, st_fp = 0, st_trim = 0, st_full = 0, st_jobs = 0;
+    unsigned st_steps = 0, st_fp = 0, st_trim = 0, st_full = 0, st_jobs = 0, st_iter = 0, st_qt = 0;
     const unsigned long long st_t0 = STATS ? wall_clock64() : 0ull;
     for (int k64 = 0;; k64 += 64) {
       // ---- a lane whose chunk ends inside the coming block runs on into the next chunk of the contig if nobody has
@@ -544,7 +546,9 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
           }
           bool want = need;
           int got = -1;
+          const unsigned long long st_q0 = STATS ? wall_clock64() : 0ull;
           while (sd_any(want)) {
+              if (STATS) ++st_iter;
               const unsigned long long wmask = sd_ballot(want);
               const int first = __builtin_ctzll(wmask);
               int base = 0;
@@ -563,6 +567,7 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
                   }
               }
           }
+          if (STATS) st_qt += (unsigned)(wall_clock64() - st_q0);
           if (need) {
               hasjob = got >= 0;
               done = !hasjob;
@@ -575,7 +580,8 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
               if (hasjob) {
                   cid = cur = got;
                   const SdChunk ch = A.chunks[cid];
-                  const int u = A.ustart[cid];           // warm-up start (sd_prep), 64-byte aligned; < 0: not known
+                  const int u0 = sd_find_start(A, ch, A.bases + A.ctg_off[ch.ctg]);
+                  const int u = u0 < 0 ? -1 : (u0 & ~63);   // starting a little earlier is still exact, and keeps every lane on the same 64-byte phase; < 0: word-count table needed
                   have_last = false;
                   n_out = 0;
                   if (u >= 0) {
@@ -806,8 +812,7 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
                   }
                   const int o_start = rdlane(startv, ol);
                   const unsigned long long o_occ = rdlane64(occ, ol);
-                  const int o_cid = rdlane(cid, ol);
-                  uint32_t *orow = A.slots + (size_t)o_cid * 64;
+                  uint32_t *orow = A.slots + ((size_t)blockIdx.x * 64 + ol) * 64;
                   const int sidx = (o_start + j) & 63;
                   const bool has_e = inwin && ((o_occ >> sidx) & 1ull);
                   const uint32_t e = has_e ? __hip_atomic_load(&orow[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
@@ -852,6 +857,8 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
         atomicAdd(&A.stats[3], dt);
         atomicMax(&A.stats[4], dt);
         atomicAdd(&A.stats[8], (unsigned long long)st_full);
+        atomicAdd(&A.stats[9], (unsigned long long)st_iter);
+        atomicAdd(&A.stats[10], (unsigned long long)st_qt);
         // histogram over the wave's time in the loop (0.5 ms bins): waves, their find_perfect calls with candidates, their end times
         const unsigned bin = (unsigned)(dt / 50000ull) < 31u ? (unsigned)(dt / 50000ull) : 31u;
         atomicAdd(&A.stats[14 + 4 * bin], 1ull);
@@ -869,19 +876,11 @@ __device__ __forceinline__ uint32_t sd_not_acgt(uint32_t word)
     return ((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d;
 }
 
-// ---- per chunk, before the main kernel: (1) where its lane starts, (2) a scheduling hint.
-// (1) Warm-up start: W-2 word emissions before (chunk start - 2W), found by scanning backwards (see the header
-//     comment); the scan gives up after SD_SCAN_CAP bases of N-dense sequence and uses the word-count table, or asks
-//     the host for it.  Rounded down to 64: starting earlier is still exact, and keeps every lane of the main
-//     kernel on the same phase of the 64-byte blocks.
-// (2) The 64 bytes in the middle of the chunk; a sample whose 62 3-mers take few distinct values (random
-//     sequence: ~40 of 64) lies in a repeat array.  The flag only orders the work; results do not depend on it.
-__global__ void sd_prep(SdArgs A, uint32_t *flag, int32_t *ustart)
+// ---- where a lane starts for a chunk: W-2 word emissions before (chunk start - 2W), found by scanning backwards (see
+// the header comment); the common case — the W bases there are plain letters — is checked with 16-byte loads, the scan
+// gives up after SD_SCAN_CAP bases of N-dense sequence and uses the word-count table, or asks the host for it (-1).
+__device__ int sd_find_start(const SdArgs &A, const SdChunk ch, const uint8_t *seq)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= A.n_chunks) return;
-    const SdChunk ch = A.chunks[c];
-    const uint8_t *seq = A.bases + A.ctg_off[ch.ctg];
     const int W = A.W, CAPW = W - 2;
     int u = 0;
     if (ch.start > 0) {
@@ -956,8 +955,18 @@ __global__ void sd_prep(SdArgs A, uint32_t *flag, int32_t *ustart)
             }
         }
     }
-    ustart[c] = u < 0 ? -1 : (u & ~63);
+    return u;
+}
 
+// ---- scheduling hint per chunk, before the main kernel: the 64 bytes in the middle of the chunk; a sample whose 62
+// 3-mers take few distinct values (random sequence: ~40 of 64) lies in a repeat array.  The flag only orders the work;
+// results do not depend on it.
+__global__ void sd_prep(SdArgs A, uint32_t *flag)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= A.n_chunks) return;
+    const SdChunk ch = A.chunks[c];
+    const uint8_t *seq = A.bases + A.ctg_off[ch.ctg];
     // the middle 64 bytes of the chunk
     uint32_t heavy = 0;
     {
@@ -984,10 +993,15 @@ __global__ void sd_prep(SdArgs A, uint32_t *flag, int32_t *ustart)
 
 // Queue order: flagged chunks first, but only one in every S = min(64, chunks / flagged) positions, the rest filled
 // with the other chunks: a wave fetches 64 consecutive positions at a time, and 64 lanes inside repeat arrays in ONE
-// wave would serialise (every find_perfect of a wave runs on all of its 64 lanes).  The other chunks come in eight
-// passes over the input — every 8th chunk, then the ones halfway between, ... (bit-reversed phase) — so that a lane has
-// free chunks ahead of it to run on into.  perm has n_chunks + 16 positions, 0xFFFFFFFF where nothing lands.
-__global__ void sd_order(const uint32_t *flag, const uint32_t *rank, const unsigned long long *n_flagged, int32_t n_chunks, uint32_t *perm)
+// wave would serialise (every find_perfect of a wave runs on all of its 64 lanes).  The other chunks come in P
+// passes over the input — every P-th chunk, then the ones halfway between, ... (phases in bit-reversed order, `turn`) —
+// so that a lane has free chunks ahead of it to run on into.  perm has n_chunks + P + 16 positions, 0xFFFFFFFF where
+// nothing lands.
+struct SdPasses {
+    uint32_t P;
+    uint8_t turn[64];                 // turn[phase] = which pass hands the chunks of that phase out
+};
+__global__ void sd_order(const uint32_t *flag, const uint32_t *rank, const unsigned long long *n_flagged, int32_t n_chunks, uint32_t *perm, SdPasses ps)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
@@ -998,10 +1012,9 @@ __global__ void sd_order(const uint32_t *flag, const uint32_t *rank, const unsig
     if (flag[c]) {
         pos = r * S;
     } else {
-        const uint32_t L = (uint32_t)n_chunks - H, stripe = (L + 7u) / 8u;
+        const uint32_t L = (uint32_t)n_chunks - H, stripe = (L + ps.P - 1u) / ps.P;
         const uint32_t j0 = (uint32_t)c - r;                 // rank among the others, in input order
-        const uint32_t ph = j0 & 7u, rev = ((ph & 1u) << 2) | (ph & 2u) | (ph >> 2);
-        const uint32_t j = rev * stripe + (j0 >> 3);         // its turn: < 8 * stripe <= L + 7
+        const uint32_t j = (uint32_t)ps.turn[j0 % ps.P] * stripe + j0 / ps.P;   // its turn: < P * stripe <= L + P - 1
         if (S > 1u && j < H * (S - 1u)) pos = (j / (S - 1u)) * S + 1u + j % (S - 1u);
         else pos = H * S + (j - H * (S - 1u));
     }
@@ -1114,33 +1127,47 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             d_out = (uint2 *)cn_ws(h, WS_SD_OUT, nc * cap * sizeof(uint2));
             if (!d_out) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation of %zu bytes failed", nc * cap * sizeof(uint2));
             CN_HIP(h, hipMemsetAsync(d_tot, 0, 2048, h->stream));
-            uint32_t *d_slots = (uint32_t *)cn_ws(h, WS_SD_OFF, nc * 64 * sizeof(uint32_t));
+            // P slot rows: one per resident lane (sdust_w64) / unused by the older kernels
+            uint32_t *d_slots = (uint32_t *)cn_ws(h, WS_SD_OFF, (size_t)std::max<int64_t>(sd_waves, 1) * 64 * 64 * sizeof(uint32_t));
             if (!d_slots) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
             const bool use_w64 = w64_path;                              // CORNETTO_SDUST_VARIANT=1 forces the per-lane reference-shaped kernel
             SdArgs A{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, d_out, d_cnt, (uint32_t)cap,
-                     want_stats ? d_tot + 2 : nullptr, reinterpret_cast<uint32_t *>(d_tot + 1), d_slots, nullptr, nullptr,
+                     want_stats ? d_tot + 2 : nullptr, reinterpret_cast<uint32_t *>(d_tot + 1), d_slots, nullptr,
                      reinterpret_cast<uint32_t *>(d_tot + 8), nullptr, 0, env_int("CORNETTO_SDUST_RUNON", 1), a->d_wtab, a->d_wtab_base, reinterpret_cast<uint32_t *>(d_tot + 1) + 1};
             unsigned nb = (unsigned)((nc + 63) / 64);
             if (use_w64) {
                 // warm-up starts, the order of the queue, the claim flags:
-                // flag (nc) + rank (nc) + ustart (nc) + claim (nc) + perm (nc + 16) + scan partials
-                uint32_t *d_flag = (uint32_t *)cn_ws(h, WS_SD_PERM, (nc * 5 + 16) * 4 + ((nc + 4095) / 4096 + 1) * 4);
+                // flag (nc) + rank (nc) + claim (nc) + perm (nc + 80) + scan partials
+                uint32_t *d_flag = (uint32_t *)cn_ws(h, WS_SD_PERM, (nc * 4 + 80) * 4 + ((nc + 4095) / 4096 + 1) * 4);
                 if (!d_flag) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
-                uint32_t *d_rank = d_flag + nc, *d_claim = d_rank + nc + nc, *d_perm = d_claim + nc, *d_pp = d_perm + nc + 16;
-                int32_t *d_ustart = reinterpret_cast<int32_t *>(d_rank + nc);
+                uint32_t *d_rank = d_flag + nc, *d_claim = d_rank + nc, *d_perm = d_claim + nc, *d_pp = d_perm + nc + 80;
                 const unsigned nbs = (unsigned)((nc + 255) / 256);
                 CN_HIP(h, hipMemsetAsync(d_claim, 0, nc * 4, h->stream));
                 CN_HIP(h, hipMemsetAsync(d_cnt, 0, nc * 4, h->stream));          // chunks a lane runs on into publish nothing of their own
-                CN_LAUNCH(h, "sdust_prep", sd_prep<<<dim3(nbs), dim3(256), 0, h->stream>>>(A, d_flag, d_ustart));
-                A.ustart = d_ustart;
                 A.claim = d_claim;
                 A.q_len = (int32_t)nc;
                 if (env_int("CORNETTO_SDUST_ORDER", 1)) {
-                    CN_HIP(h, hipMemsetAsync(d_perm, 0xFF, (nc + 16) * 4, h->stream));
+                    CN_LAUNCH(h, "sdust_prep", sd_prep<<<dim3(nbs), dim3(256), 0, h->stream>>>(A, d_flag));
+                    // passes of the queue over the input: a run can grow to `passes` chunks before it meets a queue start
+                    SdPasses ps;
+                    ps.P = (uint32_t)std::min(64, std::max(1, env_int("CORNETTO_SDUST_PASSES", 8)));
+                    {
+                        int bits = 0;
+                        while ((1u << bits) < ps.P) ++bits;
+                        std::vector<std::pair<uint32_t, uint32_t>> key;      // (bit-reversed phase, phase)
+                        for (uint32_t ph = 0; ph < ps.P; ++ph) {
+                            uint32_t rev = 0;
+                            for (int b = 0; b < bits; ++b) rev |= ((ph >> b) & 1u) << (bits - 1 - b);
+                            key.emplace_back(rev, ph);
+                        }
+                        std::sort(key.begin(), key.end());
+                        for (uint32_t t = 0; t < ps.P; ++t) ps.turn[key[t].second] = (uint8_t)t;
+                    }
+                    CN_HIP(h, hipMemsetAsync(d_perm, 0xFF, (nc + 80) * 4, h->stream));
                     CN_TRY(cnscan::exclusive_u32(h, "sdust_prep", d_flag, (int64_t)nc, 1, d_rank, d_pp, d_tot + 7));
-                    CN_LAUNCH(h, "sdust_prep", sd_order<<<dim3(nbs), dim3(256), 0, h->stream>>>(d_flag, d_rank, d_tot + 7, (int32_t)nc, d_perm));
+                    CN_LAUNCH(h, "sdust_prep", sd_order<<<dim3(nbs), dim3(256), 0, h->stream>>>(d_flag, d_rank, d_tot + 7, (int32_t)nc, d_perm, ps));
                     A.perm = d_perm;
-                    A.q_len = (int32_t)nc + 16;
+                    A.q_len = (int32_t)nc + 80;
                 }
                 // as many waves as the chip holds at once (LDS-bound: ~19 per CU); each lane works through the queue
                 if ((unsigned)sd_waves < nb) nb = (unsigned)sd_waves;
@@ -1161,8 +1188,8 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                         fprintf(stderr, "[sdust stats]   waves that ran %4.1f-%4.1f ms: %6llu, job fetches %llu, find_perfect calls %llu (%llu with candidates)\n", b * 0.5, b * 0.5 + 0.5,
                                 p_tot[16 + 4 * b], p_tot[18 + 4 * b], p_tot[19 + 4 * b], p_tot[17 + 4 * b]);
             if (want_stats)
-                fprintf(stderr, "[sdust stats] flagged low-complexity %llu; chunks %zu waves %u wave-steps %llu find_perfect calls %llu (%llu with candidates) trims %llu; wave time avg %.1f us max %.1f us\n", p_tot[7], nc, nb,
-                        p_tot[2], p_tot[3], p_tot[10], p_tot[4], nb ? (double)p_tot[5] / nb / 100.0 : 0.0, (double)p_tot[6] / 100.0);
+                fprintf(stderr, "[sdust stats] flagged low-complexity %llu; chunks %zu waves %u wave-steps %llu find_perfect calls %llu (%llu with candidates) trims %llu; wave time avg %.1f us max %.1f us; queue: %.1f fetch rounds and %.1f us per wave\n", p_tot[7], nc, nb,
+                        p_tot[2], p_tot[3], p_tot[10], p_tot[4], nb ? (double)p_tot[5] / nb / 100.0 : 0.0, (double)p_tot[6] / 100.0, nb ? (double)p_tot[11] / nb : 0.0, nb ? (double)p_tot[12] / nb / 100.0 : 0.0);
             const uint32_t ovf = (uint32_t)(p_tot[1] & 0xFFFFFFFFull);
             const bool need_wtab = (p_tot[1] >> 32) != 0;
             if (need_wtab) {

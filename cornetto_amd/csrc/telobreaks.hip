@@ -225,20 +225,28 @@ int cornetto_telobreaks(cornetto_accel_t *h, const int32_t *ctg_len, int32_t n_c
         int32_t *d_len = (int32_t *)(d_part + npart);
         cornetto_ivl_t *d_sd = (cornetto_ivl_t *)(d_len + n_ctg + 1);
         cornetto_telrow_t *d_tel = (cornetto_telrow_t *)(d_sd + n_sd);
-        CN_HIP(h, hipMemsetAsync(d_bits, 0, W * 16, h->stream));
-        CN_HIP(h, hipMemsetAsync(d_small, 0, 64, h->stream));
-        CN_HIP(h, hipMemcpyAsync(d_woff, woff.data(), ((size_t)n_ctg + 1) * 8, hipMemcpyHostToDevice, h->stream));
-        CN_HIP(h, hipMemcpyAsync(d_len, ctg_len, (size_t)n_ctg * 4, hipMemcpyHostToDevice, h->stream));
-        CN_HIP(h, hipMemcpyAsync(d_tiles, tiles.data(), nt * sizeof(TbTile), hipMemcpyHostToDevice, h->stream));
-        CN_HIP(h, hipMemcpyAsync(d_sd, sd, (size_t)n_sd * sizeof(cornetto_ivl_t), hipMemcpyHostToDevice, h->stream));
-        CN_HIP(h, hipMemcpyAsync(d_tel, tel, (size_t)n_tel * sizeof(cornetto_telrow_t), hipMemcpyHostToDevice, h->stream));
         TbArgs A{d_len, d_woff, n_ctg, d_bits, d_fin, reinterpret_cast<uint32_t *>(d_small + 2)};
-        CN_LAUNCH(h, "tb_fill", tb_fill<<<dim3((unsigned)((n_sd + 255) / 256)), dim3(256), 0, h->stream>>>(A, d_sd, n_sd));
-        CN_LAUNCH(h, "tb_mark", tb_mark<<<dim3((unsigned)((n_tel + 255) / 256)), dim3(256), 0, h->stream>>>(A, d_tel, n_tel));
-        CN_LAUNCH(h, "tb_count", tb_count<<<dim3((unsigned)nt), dim3(256), 0, h->stream>>>(A, d_tiles, d_ns, d_ne));
-        CN_TRY(cnscan::exclusive_u32(h, "tb_scan", d_ns, (int64_t)nt, 1, d_os, d_part, d_small));
-        CN_TRY(cnscan::exclusive_u32(h, "tb_scan", d_ne, (int64_t)nt, 1, d_oe, d_part, d_small + 1));
-        CN_HIP(h, hipMemcpyAsync(p_small, d_small, 64, hipMemcpyDeviceToHost, h->stream));
+        // (the host arrays below are locals or the caller's: whatever happens, nothing returns before the stream has drained)
+        const int rc_q = [&]() -> int {
+            CN_HIP(h, hipMemsetAsync(d_bits, 0, W * 16, h->stream));
+            CN_HIP(h, hipMemsetAsync(d_small, 0, 64, h->stream));
+            CN_HIP(h, hipMemcpyAsync(d_woff, woff.data(), ((size_t)n_ctg + 1) * 8, hipMemcpyHostToDevice, h->stream));
+            CN_HIP(h, hipMemcpyAsync(d_len, ctg_len, (size_t)n_ctg * 4, hipMemcpyHostToDevice, h->stream));
+            CN_HIP(h, hipMemcpyAsync(d_tiles, tiles.data(), nt * sizeof(TbTile), hipMemcpyHostToDevice, h->stream));
+            CN_HIP(h, hipMemcpyAsync(d_sd, sd, (size_t)n_sd * sizeof(cornetto_ivl_t), hipMemcpyHostToDevice, h->stream));
+            CN_HIP(h, hipMemcpyAsync(d_tel, tel, (size_t)n_tel * sizeof(cornetto_telrow_t), hipMemcpyHostToDevice, h->stream));
+            CN_LAUNCH(h, "tb_fill", tb_fill<<<dim3((unsigned)((n_sd + 255) / 256)), dim3(256), 0, h->stream>>>(A, d_sd, n_sd));
+            CN_LAUNCH(h, "tb_mark", tb_mark<<<dim3((unsigned)((n_tel + 255) / 256)), dim3(256), 0, h->stream>>>(A, d_tel, n_tel));
+            CN_LAUNCH(h, "tb_count", tb_count<<<dim3((unsigned)nt), dim3(256), 0, h->stream>>>(A, d_tiles, d_ns, d_ne));
+            CN_TRY(cnscan::exclusive_u32(h, "tb_scan", d_ns, (int64_t)nt, 1, d_os, d_part, d_small));
+            CN_TRY(cnscan::exclusive_u32(h, "tb_scan", d_ne, (int64_t)nt, 1, d_oe, d_part, d_small + 1));
+            CN_HIP(h, hipMemcpyAsync(p_small, d_small, 64, hipMemcpyDeviceToHost, h->stream));
+            return CORNETTO_OK;
+        }();
+        if (rc_q != CORNETTO_OK) {
+            (void)hipStreamSynchronize(h->stream);
+            return rc_q;
+        }
         CN_HIP(h, hipStreamSynchronize(h->stream));        // (woff / tiles are locals: the copies above are done)
         if (reinterpret_cast<uint32_t *>(p_small + 2)[0] != 0)
             return cn_fail(h, CORNETTO_E_FORMAT, "telobreaks: %s with coordinates outside its contig (the reference indexes its bitset unchecked)",

@@ -60,6 +60,7 @@ struct SdArgs {
     uint32_t *claim;             // sdust_w64: [n_chunks] 0 = free; set by the lane that takes the chunk (from the queue, or by running on into it)
     int32_t q_len;               // sdust_w64: queue positions (perm entries, 0xFFFFFFFF = hole)
     int32_t run_on;              // sdust_w64: lanes run on into the next chunk when it is free (CORNETTO_SDUST_RUNON, default 1)
+    int32_t chunk;               // sdust_w64: bases per chunk (every chunk of a contig but its last)
     // bounded warm-up search (sdust_w64): the local backward scan gives up after SD_SCAN_CAP bases; then
     const uint32_t *wtab;        //   exclusive prefix of per-256-base-block word-emission counts, or NULL
     const int64_t *wtab_base;    //   first table entry of each contig
@@ -521,14 +522,15 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
       // ---- a lane whose chunk ends inside the coming block runs on into the next chunk of the contig if nobody has
       // taken it yet: no warm-up, no reset, the records go on in the same (contiguous) rows.  Only when that fails does it
       // publish and take another chunk from the queue, which hands out every 8th chunk first so that runs have room.
+      // (The next chunk of the contig is [end, min(end + chunk, contig length)): no loads.  The round trip of the claim
+      // stalls this wave only; the SIMD's other waves keep the VALU busy — asking a block ahead changed nothing.)
       auto run_on = [&]() {
           if (A.run_on && sd_any(hasjob && !islast && endk < k64 + 64)) {
               while (hasjob && !islast && endk < k64 + 64) {
                   if (atomicCAS(&A.claim[cur + 1], 0u, 1u) != 0u) break;
                   ++cur;
-                  const SdChunk nx = A.chunks[cur];
-                  endk += nx.end - nx.start;
-                  islast = nx.end == A.ctg_len[nx.ctg];
+                  endk = endk + A.chunk < lenk ? endk + A.chunk : lenk;
+                  islast = endk == lenk;
               }
           }
       };
@@ -1133,7 +1135,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             const bool use_w64 = w64_path;                              // CORNETTO_SDUST_VARIANT=1 forces the per-lane reference-shaped kernel
             SdArgs A{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, d_out, d_cnt, (uint32_t)cap,
                      want_stats ? d_tot + 2 : nullptr, reinterpret_cast<uint32_t *>(d_tot + 1), d_slots, nullptr,
-                     reinterpret_cast<uint32_t *>(d_tot + 8), nullptr, 0, env_int("CORNETTO_SDUST_RUNON", 1), a->d_wtab, a->d_wtab_base, reinterpret_cast<uint32_t *>(d_tot + 1) + 1};
+                     reinterpret_cast<uint32_t *>(d_tot + 8), nullptr, 0, env_int("CORNETTO_SDUST_RUNON", 1), (int32_t)chunk, a->d_wtab, a->d_wtab_base, reinterpret_cast<uint32_t *>(d_tot + 1) + 1};
             unsigned nb = (unsigned)((nc + 63) / 64);
             if (use_w64) {
                 // warm-up starts, the order of the queue, the claim flags:

@@ -14,8 +14,9 @@ Weak scaling: every rank holds its own assembly (config 4 of BASELINE.json: N it
 the only data-path collective is the all-reduce of the 3 x u64 depth totals behind the coverage thresholds.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (sdust_kernel), from HIP events on the
-launch stream; `cpu_baseline` times the CPU oracle ("port": same algorithmic structure as the reference,
-1 core) on a bounded sample of the same workload (N=1 only).
+launch stream; `cpu_baseline` times, on 1 core and on a bounded sample of the same workload (N=1 only), the
+reference's own functions out of oracle/_ref ("reference") where that was built, else the CPU oracle ("port": same
+algorithmic structure as the reference).
 """
 import argparse
 import json
@@ -122,9 +123,114 @@ def make_coverage(torch, dev, lens, offs, seed):
     return depth, mq
 
 
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libcornetto_ref.so")
+
+
+class _RefLib:
+    """The reference's own per-contig functions out of oracle/_ref/libcornetto_ref.so (built from the sources under
+    /root/reference by oracle/ref.mk; git-ignored, travels with the snapshot).  Timed as they are: `find` and
+    `process_scaffold` print their records themselves (find_telomere.c:44, telomere_windows.c:28), so stdout points at
+    /dev/null while they run; `sdust` is sdust.c:162; `get_regs` is boringbits_main.c:322 over the structures of
+    boringbits_main.c:116-130."""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.so = C.CDLL(REF_SO)
+        self.libc = C.CDLL(None)
+        self.libc.free.argtypes = [C.c_void_p]
+        self.so.find.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p]
+        self.so.find.restype = None
+        self.so.process_scaffold.argtypes = [C.c_char_p, C.c_void_p, C.c_int]
+        self.so.process_scaffold.restype = None
+        self.so.sdust.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        self.so.sdust.restype = C.c_void_p
+
+        class CtgDepth(C.Structure):
+            _fields_ = [("ctg_name", C.c_char_p), ("ctg_length", C.c_int), ("c_depth", C.c_int),
+                        ("depth", C.c_void_p), ("mq_depth", C.c_void_p)]
+
+        class AsmDepth(C.Structure):
+            _fields_ = [("num_ctg", C.c_int), ("c_ctg", C.c_int), ("ctg_depth", C.POINTER(CtgDepth)),
+                        ("mean_depth", C.c_int), ("mean_mq_depth", C.c_int)]
+        self.CtgDepth, self.AsmDepth = CtgDepth, AsmDepth
+        self.so.get_regs.argtypes = [C.POINTER(AsmDepth), C.c_int, C.c_int]
+        self.so.get_regs.restype = C.c_void_p
+        self.so.free_asm_reg.argtypes = [C.c_void_p]
+        self.so.free_asm_reg.restype = None
+
+    def quiet(self, fn, *a):
+        """run fn(*a) with file descriptor 1 on /dev/null (the reference functions printf their records)"""
+        sys.stdout.flush()
+        keep = os.dup(1)
+        null = os.open(os.devnull, os.O_WRONLY)
+        try:
+            os.dup2(null, 1)
+            t0 = time.perf_counter()
+            fn(*a)
+            self.libc.fflush(None)
+            return time.perf_counter() - t0
+        finally:
+            os.dup2(keep, 1)
+            os.close(keep)
+            os.close(null)
+
+
+def cpu_baseline_reference(bases, depth, mq, offs, lens, budget_bases):
+    """The reference itself (oracle/_ref) on one host core over the leading contigs of the same workload: the same
+    four stages as the port below.  Contigs are cut at INT_MAX-free sizes by construction (largest 242 Mb)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_bind as ob
+    R = _RefLib()
+    C = R.C
+    t = {"telofind": 0.0, "telowin": 0.0, "sdust": 0.0, "get_regs": 0.0}
+    done, used = 0, 0
+    for off, n in zip(offs, lens):
+        if done >= budget_bases:
+            break
+        n = int(min(n, budget_bases - done))
+        off = int(off)
+        seq = np.ascontiguousarray(np.concatenate([bases[off:off + n].cpu().numpy(), np.zeros(1, np.uint8)]))
+        seq[:n] &= 0xDF                                            # find_telomere.c:76 upper-cases the contig first
+        d = np.ascontiguousarray(depth[off:off + n].cpu().numpy().view(np.uint16))
+        q = np.ascontiguousarray(mq[off:off + n].cpu().numpy().view(np.uint16))
+        t["telofind"] += R.quiet(R.so.find, b"TTAGGG", b"ctg", seq.ctypes.data)
+        hits = ob.telofind(seq[:n], b"TTAGGG")                      # the records `find` just printed (not timed)
+        t0 = time.perf_counter()
+        marks = np.zeros(n, np.uint8)                              # telomere_windows.c:69-79: calloc + mark
+        for st, en in zip(hits["start"].tolist(), hits["end"].tolist()):
+            marks[st:en] = 1
+        t["telowin"] += time.perf_counter() - t0
+        t["telowin"] += R.quiet(R.so.process_scaffold, b"ctg", marks.ctypes.data, n)
+        cnt = C.c_int()
+        t0 = time.perf_counter()
+        r = R.so.sdust(None, seq.ctypes.data, n, 20, 64, C.byref(cnt))
+        t["sdust"] += time.perf_counter() - t0
+        R.libc.free(r)
+        ctg = R.CtgDepth(b"ctg", n, n, d.ctypes.data, q.ctypes.data)
+        asm = R.AsmDepth(1, 1, C.pointer(ctg), 30, 30)
+        t0 = time.perf_counter()
+        regs = R.so.get_regs(C.byref(asm), 2500, 50)
+        t["get_regs"] += time.perf_counter() - t0
+        R.so.free_asm_reg(regs)
+        done += n
+        used += 1
+    total = sum(t.values())
+    return {
+        "value": round(done / total / 1e9, 6), "unit": "Gbases/s", "cores": 1, "kind": "reference",
+        "sample": "first %d bases (%d leading contigs) of the same synthetic assembly and coverage through the "
+                  "reference's own find, process_scaffold, sdust(T=20,W=64) and get_regs(2500,50) "
+                  "(oracle/_ref/libcornetto_ref.so, gcc -O2), each over all of it; %.1f s of CPU" % (done, used, total),
+        "stage_gbases_s": {k: round(done / v / 1e9, 4) for k, v in t.items()},
+    }
+
+
 def cpu_baseline(torch, bases, depth, mq, offs, lens, budget_bases):
-    """CPU oracle ("port" of the reference algorithms, oracle/oracle.c: same algorithmic structure, one
-    thread) on the leading contigs of the same workload, about `budget_bases` bases in total."""
+    """The reference's own functions where oracle/_ref was built ("reference"); otherwise the CPU oracle ("port" of
+    the reference algorithms, oracle/oracle.c: same algorithmic structure, one thread) - on the leading contigs of
+    the same workload, about `budget_bases` bases in total."""
+    if os.path.exists(REF_SO) and os.environ.get("CORNETTO_BENCH_BASELINE", "reference") != "port":
+        return cpu_baseline_reference(bases, depth, mq, offs, lens, budget_bases)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_bind as ob
     ob.lib()

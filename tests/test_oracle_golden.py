@@ -3,6 +3,7 @@
 against the reference's own functions through ctypes.  This is the parity PIN of the oracle."""
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -226,6 +227,24 @@ def test_sdust_vs_reference_function_random():
         libc.free(r)
         got = ob.sdust(s, T, W)
         assert np.array_equal(got, exp), (it, n, T, W)
+
+
+@pytest.mark.skipif(not os.path.exists(REFSO), reason="oracle/_ref not built (no /root/reference here)")
+def test_bench_reference_baseline_runs_and_keeps_stdout(capfd):
+    """bench.py's "reference" cpu_baseline drives find / process_scaffold / sdust / get_regs of the reference's shared
+    object; nothing those functions print may reach stdout (bench.py prints ONE JSON line there)."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    rng = np.random.default_rng(5)
+    n = 300000
+    b = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)].copy()
+    b[:600] = np.frombuffer(b"CCCTAA" * 100, dtype=np.uint8)
+    d = torch.from_numpy(rng.integers(0, 60, n).astype(np.int16))
+    out = bench.cpu_baseline(torch, torch.from_numpy(b), d, d.clone(), [0, 100000], [100000, 200000], n)
+    assert out["kind"] == "reference" and out["cores"] == 1 and out["value"] > 0
+    assert set(out["stage_gbases_s"]) == {"telofind", "telowin", "sdust", "get_regs"}
+    assert capfd.readouterr().out == ""
 
 
 # ---- telobreaks (SURVEY section 8f row 2) -------------------------------------------------------------------

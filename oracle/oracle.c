@@ -505,3 +505,112 @@ int orc_panel_boring(const int32_t *ctg_len, int32_t n_ctg, const orc_span_t *fu
     *n_out = no;
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * FASTA/FASTQ record framing — src/kseq.h (klib kseq as vendored by the reference)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { const uint8_t *t; int64_t n, i; } fxcur_t;
+typedef struct { char *s; int64_t l, m; } fxstr_t;
+
+static void fxs_put(fxstr_t *s, const uint8_t *src, int64_t k)
+{
+    if (s->l + k + 1 > s->m) {
+        s->m = (s->l + k + 1) * 2;
+        s->s = (char *)realloc(s->s, (size_t)s->m);
+    }
+    if (k) memcpy(s->s + s->l, src, (size_t)k);
+    s->l += k;
+    s->s[s->l] = 0;
+}
+
+static int fx_space(int c) { return c == ' ' || (c >= '\t' && c <= '\r'); }   /* isspace() of the C locale */
+
+/* ks_getuntil2, src/kseq.h:93-141, for the two delimiters kseq_read uses: line = 0 white space (KS_SEP_SPACE),
+ * line = 1 newline (KS_SEP_LINE).  Appends; returns -1 when nothing is left at entry (:98), else the length; *dret =
+ * the delimiter met, 0 when the text ended first (:96,:127-130). */
+static int64_t fx_until(fxcur_t *c, int line, fxstr_t *s, int *dret)
+{
+    if (dret) *dret = 0;
+    if (c->i >= c->n) return -1;
+    int64_t j = c->i;
+    if (line) {
+        const uint8_t *nl = (const uint8_t *)memchr(c->t + j, '\n', (size_t)(c->n - j));
+        j = nl ? nl - c->t : c->n;
+    } else {
+        while (j < c->n && !fx_space(c->t[j])) ++j;
+    }
+    fxs_put(s, c->t + c->i, j - c->i);
+    if (j < c->n && dret) *dret = c->t[j];
+    c->i = j < c->n ? j + 1 : c->n;
+    if (line && s->l > 1 && s->s[s->l - 1] == '\r') s->s[--s->l] = 0;      /* :138 */
+    return s->l;
+}
+
+int orc_fastx_parse(const uint8_t *text, int64_t n, orc_fxrec_t **recs, int64_t *n_recs)
+{
+    fxcur_t c = {text, n, 0};
+    fxstr_t name = {0, 0, 0}, com = {0, 0, 0}, seq = {0, 0, 0}, qual = {0, 0, 0};
+    orc_fxrec_t *out = NULL;
+    int64_t cnt = 0, cap = 0;
+    int last = 0, rc = -1;
+    fxs_put(&name, NULL, 0); fxs_put(&com, NULL, 0); fxs_put(&seq, NULL, 0); fxs_put(&qual, NULL, 0);
+    for (;;) {
+        int ch, d;
+        if (last == 0) {                                                        /* :189-193 jump to the next header */
+            while (c.i < c.n && c.t[c.i] != '>' && c.t[c.i] != '@') ++c.i;
+            if (c.i >= c.n) { rc = -1; break; }
+            last = c.t[c.i++];
+        }
+        name.l = com.l = seq.l = qual.l = 0;
+        name.s[0] = com.s[0] = seq.s[0] = qual.s[0] = 0;
+        if (fx_until(&c, 0, &name, &d) < 0) { rc = -1; break; }                 /* :195 */
+        if (d != '\n') fx_until(&c, 1, &com, NULL);                             /* :196 */
+        ch = -1;
+        while (c.i < c.n) {                                                     /* :201-205 */
+            ch = c.t[c.i++];
+            if (ch == '>' || ch == '+' || ch == '@') break;
+            if (ch != '\n') {
+                const uint8_t b = (uint8_t)ch;
+                fxs_put(&seq, &b, 1);
+                fx_until(&c, 1, &seq, NULL);
+            }
+            ch = -1;
+        }
+        last = (ch == '>' || ch == '@') ? ch : last;                            /* :206 */
+        int has_qual = 0;
+        if (ch == '+') {                                                        /* :214-223 */
+            int got_nl = 0;
+            while (c.i < c.n) if (c.t[c.i++] == '\n') { got_nl = 1; break; }
+            if (!got_nl) { rc = -2; break; }
+            while (fx_until(&c, 1, &qual, NULL) >= 0 && qual.l < seq.l) {}
+            last = 0;
+            if (seq.l != qual.l) { rc = -2; break; }
+            has_qual = 1;
+        } else if (ch == -1) {
+            last = 0;      /* end of text: the next call finds no header and returns -1 (no state to keep) */
+        }
+        if (cnt == cap) {
+            cap = cap ? cap * 2 : 64;
+            out = (orc_fxrec_t *)realloc(out, (size_t)cap * sizeof(*out));
+        }
+        orc_fxrec_t *r = &out[cnt++];
+        char *blk = (char *)malloc((size_t)(name.l + com.l + seq.l + qual.l + 4));
+        r->name = blk;                      memcpy(r->name, name.s, (size_t)name.l + 1);
+        r->comment = r->name + name.l + 1;  memcpy(r->comment, com.s, (size_t)com.l + 1);
+        r->seq = r->comment + com.l + 1;    memcpy(r->seq, seq.s, (size_t)seq.l + 1);
+        r->qual = NULL;
+        if (has_qual) { r->qual = r->seq + seq.l + 1; memcpy(r->qual, qual.s, (size_t)qual.l + 1); }
+        r->name_l = name.l; r->comment_l = com.l; r->l = seq.l; r->qual_l = has_qual ? qual.l : 0;
+        if (ch == -1 && c.i >= c.n && last == 0) { rc = -1; break; }
+    }
+    free(name.s); free(com.s); free(seq.s); free(qual.s);
+    *recs = out;
+    *n_recs = cnt;
+    return rc;
+}
+
+void orc_fastx_free(orc_fxrec_t *recs, int64_t n_recs)
+{
+    for (int64_t i = 0; i < n_recs; ++i) free(recs[i].name);
+    free(recs);
+}

@@ -161,3 +161,65 @@ def read_telobreaks_inputs(lens_path, sdust_path, telo_path):
 
 def fmt_telobreaks(name, length, first, last):
     return b"Found telomere positions %d to %d is a telomere in %s of length %d\n" % (first, last, name, length)   # :142
+
+
+def fmt_seq(recs, min_len):
+    """stdout of `cornetto seq -m min_len` for kseq records (name, comment, seq, qual): src/seq.c:120-129"""
+    out = []
+    for name, com, seq, qual in recs:
+        if len(seq) >= min_len:
+            out.append(b"@" + name + (b"\t" + com if com else b"") + b"\n" + seq + b"\n+\n" + (qual if qual is not None else b"(null)") + b"\n")
+    return b"".join(out)
+
+
+def fmt_fa2bed(recs):
+    """stdout of `cornetto fa2bed`: src/assbed.c:99"""
+    return b"".join(b"%s\t0\t%d\n" % (name, len(seq)) for name, com, seq, qual in recs)
+
+
+def tricky_fastx(rng, n_rec, strict=False):
+    """FASTA/FASTQ text exercising the framing rules of kseq: CRLF, comments, empty reads, '@' and '>' inside qualities,
+    multi-line sequences, blank lines, records without qualities, a last line without newline"""
+    alpha = b"ACGTacgtN"
+    qalpha = bytes(range(33, 74))
+    out = []
+    for i in range(n_rec):
+        ln = int(rng.choice([0, 1, 2, 5, 60, 61, 200, 1000])) if rng.random() < 0.4 else int(rng.integers(1, 400))
+        seq = bytes(alpha[k] for k in rng.integers(0, len(alpha), ln))
+        qual = bytes(qalpha[k] for k in rng.integers(0, len(qalpha), ln))
+        eol = b"\r\n" if rng.random() < 0.15 else b"\n"
+        name = b"r%d" % i
+        kind = rng.random()
+        if kind < 0.3:
+            head = name
+        elif kind < 0.6:
+            head = name + b" runid=abc ch=%d" % int(rng.integers(1, 512))
+        elif kind < 0.7:
+            head = name + b"\tcomment with\ttabs "
+        elif kind < 0.8:
+            head = name + b"  two spaces"
+        else:
+            head = name + b" "
+        if strict or rng.random() < 0.75:
+            out.append(b"@" + head + eol + seq + eol + b"+" + (name if rng.random() < 0.2 else b"") + eol + qual + eol)
+        else:
+            v = int(rng.integers(0, 7))
+            if v == 0:      # FASTA record, multi-line
+                out.append(b">" + head + eol + b"".join(seq[k:k + 60] + eol for k in range(0, len(seq), 60)))
+            elif v == 1:    # multi-line FASTQ
+                h = len(seq) // 2
+                out.append(b"@" + head + eol + seq[:h] + eol + seq[h:] + eol + b"+" + eol + qual[:h] + eol + qual[h:] + eol)
+            elif v == 2:    # blank lines around
+                out.append(eol + b"@" + head + eol + seq + eol + eol + b"+" + eol + qual + eol + eol)
+            elif v == 3:    # garbage between records
+                out.append(b"junk line\n@" + head + eol + seq + eol + b"+" + eol + qual + eol)
+            elif v == 4 and ln > 0:    # quality beginning with '@'
+                out.append(b"@" + head + eol + seq + eol + b"+" + eol + b"@" + qual[1:] + eol)
+            elif v == 5 and ln > 0:    # quality beginning with '>' / '+'
+                out.append(b"@" + head + eol + seq + eol + b"+" + eol + (b">" if i & 1 else b"+") + qual[1:] + eol)
+            else:
+                out.append(b"@" + head + eol + seq + eol + b"+" + eol + qual + eol)
+    text = b"".join(out)
+    if text.endswith(b"\n") and rng.random() < 0.3:
+        text = text[:-1]
+    return text

@@ -24,6 +24,11 @@ class Reg(C.Structure):
     _fields_ = [("st", C.c_int32), ("end", C.c_int32), ("depth", C.c_int32), ("mq_depth", C.c_int32)]
 
 
+class FxRec(C.Structure):
+    _fields_ = [("name", C.c_void_p), ("comment", C.c_void_p), ("seq", C.c_void_p), ("qual", C.c_void_p),
+                ("name_l", C.c_int64), ("comment_l", C.c_int64), ("l", C.c_int64), ("qual_l", C.c_int64)]
+
+
 HIT_DT = np.dtype([("start", "<i8"), ("end", "<i8"), ("strand", "<i4"), ("pad", "<i4")])
 WIN_DT = np.dtype([("start", "<i4"), ("end", "<i4"), ("car", "<i4"), ("pad", "<i4")])
 REG_DT = np.dtype([("st", "<i4"), ("end", "<i4"), ("depth", "<i4"), ("mq_depth", "<i4")])
@@ -67,6 +72,10 @@ def lib():
         L.orc_panel_boring.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64] + [C.c_int32] * 5 + [C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.orc_panel_boring.restype = C.c_int
         L.orc_bigenough_keep.restype = C.c_int
+        L.orc_fastx_parse.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.POINTER(FxRec)), C.POINTER(C.c_int64)]
+        L.orc_fastx_parse.restype = C.c_int
+        L.orc_fastx_free.argtypes = [C.POINTER(FxRec), C.c_int64]
+        L.orc_fastx_free.restype = None
         L.orc_free.argtypes = [C.c_void_p]
         L.orc_revcomp.argtypes = [C.c_char_p, C.c_char_p]
         _lib = L
@@ -207,3 +216,18 @@ def panel_boring(ctg_len, fun, lowq, min_lowq_len=8000, extend=40000, edge_len=2
     L.orc_panel_boring(ctg_len.ctypes.data, len(ctg_len), fun.ctypes.data, len(fun), lowq.ctypes.data, len(lowq), min_lowq_len, extend, edge_len,
                        merge_dist, min_ctg_len, C.byref(out), C.byref(n))
     return _spans_out(L, out, n)
+
+
+def fastx_parse(text):
+    """kseq record framing of `text` (bytes) -> (list of (name, comment, seq, qual-or-None) bytes, final status)"""
+    a, p, n = _buf(text)
+    rp = C.POINTER(FxRec)()
+    cnt = C.c_int64()
+    rc = lib().orc_fastx_parse(p, n, C.byref(rp), C.byref(cnt))
+    out = []
+    for i in range(cnt.value):
+        r = rp[i]
+        out.append((C.string_at(r.name, r.name_l), C.string_at(r.comment, r.comment_l), C.string_at(r.seq, r.l),
+                    C.string_at(r.qual, r.qual_l) if r.qual else None))
+    lib().orc_fastx_free(rp, cnt.value)
+    return out, rc

@@ -247,6 +247,57 @@ def test_bench_reference_baseline_runs_and_keeps_stdout(capfd):
     assert capfd.readouterr().out == ""
 
 
+# ---- FASTA/FASTQ record framing ---------------------------------------------------
+def _golden_text(golden_dir, f):
+    import gzip
+    t = open(os.path.join(golden_dir, f), "rb").read()
+    return gzip.decompress(t) if f.endswith(".gz") else t
+
+
+def test_fastx_framing_matches_reference_seq_and_fa2bed_goldens(golden_dir):
+    from helpers import fmt_seq, fmt_fa2bed
+    recs, rc = ob.fastx_parse(_golden_text(golden_dir, "reads.fq"))
+    assert rc == -1 and len(recs) == 40
+    assert fmt_seq(recs, 100) == _golden_text(golden_dir, "reads.m100.seq.exp")
+    assert fmt_seq(recs, 30000) == _golden_text(golden_dir, "reads.default.seq.exp")
+    for f, e in (("reads.fq", "reads.fa2bed.exp"), ("probe.fa", "probe.fa2bed.exp"), ("mix.fa.gz", "mix.fa2bed.exp")):
+        recs, rc = ob.fastx_parse(_golden_text(golden_dir, f))
+        assert fmt_fa2bed(recs) == _golden_text(golden_dir, e), f
+
+
+def test_fastx_framing_status_codes():
+    assert ob.fastx_parse(b"") == ([], -1)
+    assert ob.fastx_parse(b"no header here\n") == ([], -1)
+    assert ob.fastx_parse(b"@r1\nACGT\n+\nIII\n")[1] == -2                  # quality shorter than the read
+    assert ob.fastx_parse(b"@r1\nACGT\n+") == ([], -2)                        # no quality at all
+    recs, rc = ob.fastx_parse(b"@r1 c1\r\nAC\r\n+\r\nII\r\n>f x\nAC\nGT\n\n@r2\n\n+\n\n")
+    assert rc == -1 and recs == [(b"r1", b"c1", b"AC", b"II"), (b"f", b"x", b"ACGT", None), (b"r2", b"", b"", b"")]
+
+
+REFBIN = os.path.join(ROOT, "oracle", "_ref", "cornetto")
+
+
+@pytest.mark.skipif(not os.path.exists(REFBIN), reason="oracle/_ref not built (no /root/reference here)")
+def test_fastx_framing_vs_reference_binary_random(tmp_path):
+    """`fa2bed` prints every record's name and length, `seq -m 0` the four strings; FASTA records and a read whose
+    quality is cut off by the end of the file make `seq` print stale memory, so those texts are
+    compared through fa2bed only."""
+    import subprocess
+    from helpers import fmt_seq, fmt_fa2bed, tricky_fastx
+    rng = np.random.default_rng(3)
+    f = str(tmp_path / "t.fq")
+    n_seq = 0
+    for it in range(150):
+        text = tricky_fastx(rng, int(rng.integers(0, 12)), strict=(it % 3 == 0))
+        open(f, "wb").write(text)
+        recs, rc = ob.fastx_parse(text)
+        assert subprocess.run([REFBIN, "fa2bed", f], capture_output=True).stdout == fmt_fa2bed(recs), it
+        if all(q is not None for _, _, _, q in recs) and not text.endswith(b"+\n") and rc == -1:
+            n_seq += 1
+            assert subprocess.run([REFBIN, "seq", "-m", "0", f], capture_output=True).stdout == fmt_seq(recs, 0), it
+    assert n_seq > 50
+
+
 # ---- telobreaks (SURVEY section 8f row 2) -------------------------------------------------------------------
 TELOBREAKS_CASES = [("mix.lens", "mix.sdust.exp", "mix.telofind.exp", "mix.breaks.exp"),
                     ("probe.lens", "probe.sdust.exp", "probe.telofind.exp", "probe.breaks.exp"),

@@ -22,6 +22,8 @@ HIT_DT = np.dtype([("ctg", "<i4"), ("strand", "<i4"), ("start", "<i4"), ("end", 
 WIN_DT = np.dtype([("ctg", "<i4"), ("start", "<i4"), ("end", "<i4"), ("car", "<i4")])
 IVL_DT = np.dtype([("ctg", "<i4"), ("start", "<i4"), ("finish", "<i4")])
 TELROW_DT = np.dtype([("ctg", "<i4"), ("start", "<i4"), ("end", "<i4"), ("matched", "<i4")])
+FQREC_DT = np.dtype([("head", "<i8"), ("seq", "<i8"), ("qual", "<i8"), ("len", "<i4"), ("name_len", "<i4"),
+                     ("comment_len", "<i4"), ("keep", "<i4")])
 REG_DT = np.dtype([("st", "<i4"), ("end", "<i4"), ("depth", "<i4"), ("mq_depth", "<i4")])
 REGREC_DT = np.dtype([("ctg", "<i4"), ("st", "<i4"), ("end", "<i4"), ("depth", "<i4"), ("mq_depth", "<i4")])
 
@@ -79,6 +81,7 @@ def lib():
         "cornetto_panel_boring": (C.c_int, [vp, C.c_int32, vp, C.c_int64, vp, C.c_int64, vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
         "cornetto_telobreaks": (C.c_int, [vp, vp, C.c_int32, vp, C.c_int64, vp, C.c_int64, C.POINTER(vp), C.POINTER(C.c_int64)]),
         "cornetto_khash_str_order": (C.c_int32, [C.POINTER(C.c_char_p), C.c_int32, vp, vp]),
+        "cornetto_fastq_split": (C.c_int, [vp, vp, i64, C.c_int, i32, pp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), pp]),
         "cornetto_asm_upload": (C.c_int, [vp, vp, vp, i32, pp]),
         "cornetto_asm_wrap": (C.c_int, [vp, vp, vp, vp, i32, pp]),
         "cornetto_asm_free": (None, [vp, vp]),
@@ -215,6 +218,22 @@ class Accel:
         out = C.c_void_p()
         self._chk(self.L.cornetto_asm_wrap(self.h, dev_ptr, offsets.ctypes.data, lens.ctypes.data, len(lens), C.byref(out)))
         return _Resident(self, out, self.L.cornetto_asm_free, lens)
+
+    def fastq_split(self, text, final=True, min_len=0, want_reads=False):
+        """text: bytes-like FASTQ piece (or (address, size) of e.g. pinned memory) -> (records FQREC_DT, consumed bytes,
+        plain flag, resident reads or None): see cornetto_fastq_split() in include/cornetto_accel.h"""
+        if isinstance(text, tuple):
+            addr, n = text
+            keep = None
+        else:
+            keep = np.frombuffer(bytes(text), dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text, dtype=np.uint8)
+            addr, n = keep.ctypes.data, keep.size
+        p, cnt, used, plain, reads = C.c_void_p(), C.c_int64(), C.c_int64(), C.c_int32(), C.c_void_p()
+        self._chk(self.L.cornetto_fastq_split(self.h, addr, n, 1 if final else 0, min_len, C.byref(p), C.byref(cnt), C.byref(used),
+                                              C.byref(plain), C.byref(reads) if want_reads else None))
+        recs = _take(p, cnt.value, FQREC_DT)
+        res = _Resident(self, reads, self.L.cornetto_asm_free, recs["len"][recs["keep"] == 1]) if want_reads else None
+        return recs, used.value, bool(plain.value), res
 
     # ---- telofind / telowin ----------------------------------------------------------------------
     def telofind(self, asm, motif=b"TTAGGG"):

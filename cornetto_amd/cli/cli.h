@@ -59,6 +59,9 @@ typedef struct {
 
 typedef struct cli_fastx cli_fastx_t;
 cli_fastx_t *cli_fastx_open(const char *path); /* "-" = stdin; NULL on failure */
+/* a reader over `n` bytes at `prefix` (borrowed: must outlive the reads of them) followed by the rest of the open
+ * gzFile `gz` (owned: closed by cli_fastx_close) */
+cli_fastx_t *cli_fastx_open_prefixed(void *gz, const void *prefix, size_t n);
 void cli_fastx_close(cli_fastx_t *f);
 /* >= 0: sequence length; -1 end of file; -2 truncated quality string */
 int64_t cli_fastx_read(cli_fastx_t *f, cli_str_t *name, cli_str_t *comment, cli_str_t *seq, cli_str_t *qual);

@@ -5,22 +5,16 @@
 #include <getopt.h>
 #include <stdlib.h>
 #include <string.h>
+#include <zlib.h>
 
 #include "cli.h"
 
 typedef void (*batch_fn)(cornetto_accel_t *h, cli_batch_t *b, void *arg);
 
-static void for_each_batch(const char *path, int must_open, batch_fn fn, void *arg)
+/* read every record of `fx` (closed here), one device pass per batch; `h` may be an open handle (kept open) or NULL */
+static void batches_of(cli_fastx_t *fx, cornetto_accel_t *h_open, batch_fn fn, void *arg)
 {
-    cli_fastx_t *fx = cli_fastx_open(path);
-    if (!fx) {
-        if (must_open) {
-            CLI_ERROR("Failed to open %s : No such file or directory.", path);   /* F_CHK, src/error.h:114-119 */
-            exit(EXIT_FAILURE);
-        }
-        return; /* sdust: the reference has no NULL check (src/sdust/sdust.c:194) and crashes; we just stop */
-    }
-    cornetto_accel_t *h = NULL;
+    cornetto_accel_t *h = h_open;
     cli_str_t name = {0, 0, 0}, comment = {0, 0, 0}, seq = {0, 0, 0}, qual = {0, 0, 0};
     cli_batch_t b;
     memset(&b, 0, sizeof(b));
@@ -43,7 +37,7 @@ static void for_each_batch(const char *path, int must_open, batch_fn fn, void *a
         fn(h, &b, arg);
         cli_batch_clear(&b);
     }
-    if (h) cornetto_accel_close(h);
+    if (h && !h_open) cornetto_accel_close(h);
     free(b.names);
     free(b.seqs);
     free(b.lens);
@@ -52,6 +46,19 @@ static void for_each_batch(const char *path, int must_open, batch_fn fn, void *a
     free(seq.s);
     free(qual.s);
     cli_fastx_close(fx);
+}
+
+static void for_each_batch(const char *path, int must_open, batch_fn fn, void *arg)
+{
+    cli_fastx_t *fx = cli_fastx_open(path);
+    if (!fx) {
+        if (must_open) {
+            CLI_ERROR("Failed to open %s : No such file or directory.", path);   /* F_CHK, src/error.h:114-119 */
+            exit(EXIT_FAILURE);
+        }
+        return; /* sdust: the reference has no NULL check (src/sdust/sdust.c:194) and crashes; we just stop */
+    }
+    batches_of(fx, NULL, fn, arg);
 }
 
 /* ---------------------------------------------------------------- telofind */
@@ -104,6 +111,92 @@ static void sdust_batch(cornetto_accel_t *h, cli_batch_t *b, void *arg)
     cornetto_asm_free(h, a);
 }
 
+/* FASTQ reads (docs/protocol.md:185 pipes `cornetto seq` output here): the file goes to the device in pieces as it is,
+ * cornetto_fastq_split() frames the plain four-line records and lays their bases out for the scan, names are printed
+ * straight from the piece.  Anything else — FASTA, wrapped records, stray lines, the reference's error cases — is read
+ * by the sequential reader from the first byte the device was not sure about, so the output is kseq's either way. */
+static int64_t fastq_piece_bytes(void)
+{
+    const char *e = getenv("CORNETTO_FASTQ_PIECE");
+    int64_t v = e ? atoll(e) : 0;
+    if (v < 64) v = 256LL << 20;
+    if (v > 0xF0000000LL) v = 0xF0000000LL;
+    return v;
+}
+
+static void sdust_stream(const char *path, const sdust_opt_t *o)
+{
+    gzFile fp = strcmp(path, "-") ? gzopen(path, "r") : gzdopen(fileno(stdin), "r");
+    if (!fp) return; /* the reference has no NULL check (src/sdust/sdust.c:194) and crashes; we just stop */
+    gzbuffer(fp, 1 << 18);
+    cornetto_accel_t *h = NULL;
+    char first = 0, *buf = &first;
+    int64_t have = 0, start = 0; /* unread bytes: buf[start .. have) */
+    int eof = 0;
+    const int r0 = gzread(fp, &first, 1);
+    if (r0 == 1) have = 1;
+    else eof = 1;
+    if (have && first == '@') { /* a file that does not begin with '@' is not FASTQ: sequential reader from byte 0 */
+        const int64_t piece = fastq_piece_bytes();
+        h = cli_accel_open();
+        buf = (char *)cornetto_pinned_alloc((size_t)piece);
+        if (!buf) {
+            CLI_ERROR("could not allocate a %lld-byte pinned read buffer", (long long)piece);
+            exit(EXIT_FAILURE);
+        }
+        buf[0] = first;
+        for (;;) {
+            if (start) {
+                memmove(buf, buf + start, (size_t)(have - start));
+                have -= start;
+                start = 0;
+            }
+            while (have < piece && !eof) {
+                const int64_t want = piece - have > (1 << 30) ? (1 << 30) : piece - have;
+                const int r = gzread(fp, buf + have, (unsigned)want);
+                if (r < 0) {
+                    CLI_ERROR("reading %s failed", path);
+                    exit(EXIT_FAILURE);
+                }
+                have += r;
+                if (r < want) eof = 1;
+            }
+            if (have == 0) break;
+            cornetto_fqrec_t *recs = NULL;
+            cornetto_asm_t *reads = NULL;
+            int64_t n = 0, used = 0;
+            int32_t plain = 1;
+            cli_accel_check(h, cornetto_fastq_split(h, buf, have, eof, 0, &recs, &n, &used, &plain, &reads), "framing the FASTQ records");
+            if (n) {
+                cornetto_ivl_t *iv = NULL;
+                int64_t n_iv = 0;
+                cli_accel_check(h, cornetto_sdust_asm(h, reads, o->T, o->W, &iv, &n_iv), "sdust");
+                for (int64_t i = 0; i < n_iv; ++i) { /* src/sdust/sdust.c:201 */
+                    const cornetto_fqrec_t *r = &recs[iv[i].ctg];
+                    fwrite(buf + r->head + 1, 1, (size_t)r->name_len, stdout);
+                    printf("\t%d\t%d\n", iv[i].start, iv[i].finish);
+                }
+                cornetto_free(iv);
+            }
+            cornetto_asm_free(h, reads);
+            cornetto_free(recs);
+            start = used;
+            if (!plain || eof) break;                  /* not plain from buf + start on / the input is finished */
+            if (used == 0 && have == piece) break;     /* one record larger than a piece */
+        }
+    }
+    if (start < have || !eof) { /* the rest (or all of it) through the sequential reader */
+        cli_fastx_t *fx = cli_fastx_open_prefixed(fp, buf + start, (size_t)(have - start));
+        batches_of(fx, h, sdust_batch, (void *)o);
+    } else {
+        gzclose(fp);
+    }
+    if (h) {
+        cornetto_pinned_free(buf);
+        cornetto_accel_close(h);
+    }
+}
+
 int sdust_main(int argc, char *argv[])
 {
     sdust_opt_t o = {64, 20}; /* src/sdust/sdust.c:183 */
@@ -118,7 +211,7 @@ int sdust_main(int argc, char *argv[])
         fprintf(stderr, "Usage: sdust [-w %d] [-t %d] <in.fa>\n", o.W, o.T);
         exit(1);
     }
-    for_each_batch(argv[optind], 0, sdust_batch, &o);
+    sdust_stream(argv[optind], &o);
     return 0;
 }
 

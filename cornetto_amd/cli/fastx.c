@@ -22,6 +22,8 @@ struct cli_fastx {
     unsigned char *buf;
     int begin, end, is_eof;
     int last_char;
+    const unsigned char *pre; /* bytes to be read before the stream's own (cli_fastx_open_prefixed) */
+    size_t pre_left;
 };
 
 cli_fastx_t *cli_fastx_open(const char *path)
@@ -36,6 +38,17 @@ cli_fastx_t *cli_fastx_open(const char *path)
     return f;
 }
 
+cli_fastx_t *cli_fastx_open_prefixed(void *gz, const void *prefix, size_t n)
+{
+    cli_fastx_t *f = (cli_fastx_t *)cli_xmalloc(sizeof(*f));
+    memset(f, 0, sizeof(*f));
+    f->fp = (gzFile)gz;
+    f->buf = (unsigned char *)cli_xmalloc(FX_BUF);
+    f->pre = (const unsigned char *)prefix;
+    f->pre_left = n;
+    return f;
+}
+
 void cli_fastx_close(cli_fastx_t *f)
 {
     if (!f) return;
@@ -46,6 +59,15 @@ void cli_fastx_close(cli_fastx_t *f)
 
 static int fx_fill(cli_fastx_t *f)
 {
+    if (f->pre_left) {
+        const size_t k = f->pre_left < FX_BUF ? f->pre_left : FX_BUF;
+        memcpy(f->buf, f->pre, k);
+        f->pre += k;
+        f->pre_left -= k;
+        f->begin = 0;
+        f->end = (int)k;
+        return 1;
+    }
     if (f->is_eof) return 0;
     f->begin = 0;
     f->end = gzread(f->fp, f->buf, FX_BUF);

@@ -78,8 +78,11 @@ enum {   // device workspace slots
     WS_CW_REGS, WS_CW_SEL, WS_CW_CNT, WS_CW_TRES,
     WS_TF_HITS,
     WS_BG_TEXT_A, WS_BG_TEXT_B, WS_BG_TOK_A, WS_BG_TOK_B, WS_BG_CNT_A, WS_BG_CNT_B, WS_BG_SMALL, WS_BG_BRK,
-    WS_TB, WS_TB_SMALL, WS_TB_OUT, WS_CW_MERGE, WS_IVL_MERGE
+    WS_TB, WS_TB_SMALL, WS_TB_OUT, WS_CW_MERGE, WS_IVL_MERGE,
+    WS_FQ_TEXT, WS_FQ_CNT, WS_FQ_NL, WS_FQ_RECS, WS_FQ_ENDS, WS_FQ_SRC,
+    WS_COUNT
 };
+static_assert(WS_COUNT <= 64, "cornetto_accel::dev has 64 slots");
 enum {   // pinned host slots
     PIN_A, PIN_B, PIN_C, PIN_D, PIN_E, PIN_F, PIN_SMALL
 };
@@ -244,3 +247,7 @@ static inline int64_t cn_align_up(int64_t x, int64_t a) { return (x + a - 1) / a
 // pool of pinned host buffers, so the device-to-host copy runs at full PCIe rate and never page-faults on
 // fresh memory.  Either kind is released with cornetto_free() (runtime.hip).
 void *cn_result_alloc(size_t bytes);
+
+// An assembly object with room for n sequences of the given lengths in the resident layout (every sequence at a
+// multiple of 64, zero-filled, contig table on the device); the caller fills a->owned (runtime.hip).
+int cn_asm_alloc(cornetto_accel_t *h, const int32_t *lens, int32_t n, cornetto_asm_t **out);

@@ -360,3 +360,32 @@ int cornetto_cov_wrap(cornetto_accel_t *h, const void *d_depth, const void *d_mq
 }
 
 }  // extern "C"
+
+int cn_asm_alloc(cornetto_accel_t *h, const int32_t *lens, int32_t n, cornetto_asm_t **out)
+{
+    *out = nullptr;
+    cornetto_asm_t *a = new (std::nothrow) cornetto_asm;
+    if (!a) return cn_fail(h, CORNETTO_E_NOMEM, "asm_alloc: host allocation failed");
+    a->n = n;
+    int64_t pos = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        a->off.push_back(pos);
+        a->len.push_back(lens[i]);
+        a->total += lens[i];
+        pos = cn_align_up(pos + lens[i], 64);
+    }
+    const int64_t bytes = pos + SLACK;
+    if (hipMalloc(&a->owned, (size_t)bytes) != hipSuccess) {
+        delete a;
+        return cn_fail(h, CORNETTO_E_NOMEM, "asm_alloc: hipMalloc of %lld bytes failed", (long long)bytes);
+    }
+    a->d_bases = (const uint8_t *)a->owned;
+    int rc = hipMemsetAsync(a->owned, 0, (size_t)bytes, h->stream) == hipSuccess ? CORNETTO_OK : CORNETTO_E_HIP;
+    if (rc == CORNETTO_OK) rc = asm_finish_table(h, a);
+    if (rc != CORNETTO_OK) {
+        cornetto_asm_free(h, a);
+        return cn_fail(h, rc, "asm_alloc: device set-up failed");
+    }
+    *out = a;
+    return CORNETTO_OK;
+}

@@ -258,6 +258,38 @@ int cornetto_bgin_finish(cornetto_accel_t *h, cornetto_bgin_t *b, cornetto_cov_t
                          int64_t *n_clamped);
 
 /* ---------------------------------------------------------------------------------------------------
+ * FASTQ reads: record framing of `cornetto seq` / `cornetto sdust reads.fastq` on the device
+ * ------------------------------------------------------------------------------------------------- */
+
+/* one plain four-line FASTQ record of the text handed to cornetto_fastq_split(); offsets are into that text */
+typedef struct cornetto_fqrec {
+    int64_t head;        /* the record's '@'; the name follows it */
+    int64_t seq;         /* first base */
+    int64_t qual;        /* first quality value */
+    int32_t len;         /* bases = quality values (kseq_t.seq.l; a trailing '\r' is dropped as src/kseq.h:138 does) */
+    int32_t name_len;    /* kseq_t.name.l: bytes up to the first white space */
+    int32_t comment_len; /* kseq_t.comment.l: the comment starts at head + name_len + 2 */
+    int32_t keep;        /* 1 if len >= min_len (the test of src/seq.c:120) */
+} cornetto_fqrec_t;
+
+/* Frame the FASTQ text `text[0..n)` (host memory, any split point of the file; at most 2^32-256 bytes) the way
+ * kseq_read() does (src/kseq.h:184-224 as called by src/seq.c:116 and src/sdust/sdust.c:196) — for as long as the text
+ * is made of plain records: '@' line, ONE sequence line, '+' line, ONE quality line of the same length.  That is how
+ * basecallers write FASTQ, and for such records the device indexes every line at once instead of walking the bytes.
+ *   recs / n_recs   the leading plain records, in input order (cornetto_free)
+ *   consumed        bytes of `text` those records cover; hand the rest over again in front of the following bytes
+ *   plain           0: what follows at text + consumed is not a plain record (a FASTA record, wrapped sequence or quality,
+ *                   blank or stray lines, a quality of another length, the cut-off end of the input) — continue there
+ *                   with a sequential kseq reader, which also produces the reference's error behaviour;
+ *                   1: only an incomplete record (or nothing) is left, feed more bytes
+ *   final           non-zero when no bytes follow `text` (its last line then need not end in a newline)
+ *   reads           if not NULL: the bases of the records with len >= min_len, resident in HBM in input order, ready for
+ *                   cornetto_sdust_asm() / cornetto_telofind() (cornetto_asm_free) — read i of it is the i-th record
+ *                   with keep == 1 */
+int cornetto_fastq_split(cornetto_accel_t *h, const char *text, int64_t n, int final, int32_t min_len, cornetto_fqrec_t **recs,
+                         int64_t *n_recs, int64_t *consumed, int32_t *plain, cornetto_asm_t **reads);
+
+/* ---------------------------------------------------------------------------------------------------
  * panel interval stage — scripts/create-cornetto.sh:41-66 without bedtools / sort / awk (parity with bedtools itself
  * is unpinned: see cornetto_amd/csrc/panel.hip)
  * ------------------------------------------------------------------------------------------------- */

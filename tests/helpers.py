@@ -177,7 +177,7 @@ def fmt_fa2bed(recs):
     return b"".join(b"%s\t0\t%d\n" % (name, len(seq)) for name, com, seq, qual in recs)
 
 
-def tricky_fastx(rng, n_rec, strict=False):
+def tricky_fastx(rng, n_rec, strict=False, lowc=0.0):
     """FASTA/FASTQ text exercising the framing rules of kseq: CRLF, comments, empty reads, '@' and '>' inside qualities,
     multi-line sequences, blank lines, records without qualities, a last line without newline"""
     alpha = b"ACGTacgtN"
@@ -186,6 +186,11 @@ def tricky_fastx(rng, n_rec, strict=False):
     for i in range(n_rec):
         ln = int(rng.choice([0, 1, 2, 5, 60, 61, 200, 1000])) if rng.random() < 0.4 else int(rng.integers(1, 400))
         seq = bytes(alpha[k] for k in rng.integers(0, len(alpha), ln))
+        if ln >= 40 and rng.random() < lowc:      # a low-complexity stretch, so that sdust has something to report
+            a = int(rng.integers(0, ln - 30))
+            b = int(rng.integers(a + 20, ln + 1))
+            unit = [b"A", b"TA", b"CAG", b"t"][int(rng.integers(0, 4))]
+            seq = seq[:a] + (unit * (b - a))[:b - a] + seq[b:]
         qual = bytes(qalpha[k] for k in rng.integers(0, len(qalpha), ln))
         eol = b"\r\n" if rng.random() < 0.15 else b"\n"
         name = b"r%d" % i

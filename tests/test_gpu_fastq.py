@@ -1,0 +1,240 @@
+"""Device FASTQ record splitter (cornetto_fastq_split) against the oracle's restatement of
+kseq's record framing (oracle.c orc_fastx_parse, itself pinned by the reference's seq / fa2bed outputs)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_bind as ob
+from helpers import tricky_fastx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def acc():
+    import cornetto_amd
+    a = cornetto_amd.Accel(0)
+    yield a
+    a.close()
+
+
+def fields(text, recs):
+    """(name, comment, seq, qual) byte strings of the device's records"""
+    out = []
+    for r in recs:
+        h, nl, cl, L = int(r["head"]), int(r["name_len"]), int(r["comment_len"]), int(r["len"])
+        name = text[h + 1:h + 1 + nl]
+        com = text[h + nl + 2:h + nl + 2 + cl] if cl else b""
+        out.append((name, com, text[int(r["seq"]):int(r["seq"]) + L], text[int(r["qual"]):int(r["qual"]) + L]))
+    return out
+
+
+def check_prefix(acc, text, final=True):
+    """the device's records must be the leading records of kseq's reading, and `plain` must tell whether kseq's next
+    record starts exactly where the device stopped being sure"""
+    recs, used, plain, _ = acc.fastq_split(text, final=final)
+    exp, rc = ob.fastx_parse(text)
+    got = fields(text, recs)
+    assert got == [(n, c, s, q) for n, c, s, q in exp[:len(got)]], (text[:200], got[:3], exp[:3])
+    assert all(q is not None for _, _, _, q in exp[:len(got)])
+    assert 0 <= used <= len(text)
+    if len(got):
+        assert used == int(recs[-1]["qual"]) + len(text[int(recs[-1]["qual"]):].split(b"\n", 1)[0]) + (1 if b"\n" in text[int(recs[-1]["qual"]):] else 0)
+    # the rest, read sequentially, continues the same record list
+    rest, rc2 = ob.fastx_parse(text[used:])
+    assert [(n, c, s, q) for n, c, s, q in exp[len(got):]] == rest and rc2 == rc
+    return recs, used, plain, exp
+
+
+def test_reads_golden_all_plain(acc, golden_dir):
+    text = open(os.path.join(golden_dir, "reads.fq"), "rb").read()
+    recs, used, plain, exp = check_prefix(acc, text)
+    assert len(recs) == len(exp) == 40 and used == len(text) and plain
+
+
+def test_strict_text_is_indexed_completely(acc):
+    rng = np.random.default_rng(11)
+    for it in range(40):
+        text = tricky_fastx(rng, int(rng.integers(1, 60)), strict=True)
+        if not text.endswith(b"\n") and text.endswith(b"+"):
+            text += b"\n"
+        recs, used, plain, exp = check_prefix(acc, text)
+        if text.endswith(b"+\n") or text.endswith(b"+\r\n"):    # empty last read whose (empty) quality line was cut off with the newline
+            continue
+        assert len(recs) == len(exp) and used == len(text) and plain, it
+
+
+def test_irregular_text_stops_at_the_first_irregular_record(acc):
+    rng = np.random.default_rng(12)
+    n_stop = 0
+    for it in range(120):
+        text = tricky_fastx(rng, int(rng.integers(0, 25)), strict=False)
+        recs, used, plain, exp = check_prefix(acc, text)
+        if len(recs) < len(exp):
+            assert not plain
+            n_stop += 1
+    assert n_stop > 30
+
+
+def test_pieces_any_split_point(acc):
+    """feed a text in pieces the way a file reader does: consumed bytes are dropped, the rest is handed over again"""
+    rng = np.random.default_rng(13)
+    text = tricky_fastx(rng, 300, strict=True)
+    if not text.endswith(b"\n"):
+        text += b"\n"
+    exp, rc = ob.fastx_parse(text)
+    for piece in (1 << 20, 4096, 1500, 977):
+        got, pos, pend = [], 0, b""
+        while True:
+            chunk = text[pos:pos + piece]
+            pos += len(chunk)
+            final = pos >= len(text)
+            buf = pend + chunk
+            recs, used, plain, _ = acc.fastq_split(buf, final=final)
+            assert plain
+            got += fields(buf, recs)
+            pend = buf[used:]
+            if final:
+                break
+        assert pend == b"" and got == [(n, c, s, q) for n, c, s, q in exp], piece
+
+
+def test_empty_and_tiny_inputs(acc):
+    for text in (b"", b"\n", b"@", b"@r\n", b"@r\nA\n+\n", b"@r\nA\n+\nI", b"@r\nA\n+\nI\n", b"@r\n\n+\n\n", b"\n\n\n\n"):
+        check_prefix(acc, text)
+    recs, used, plain, _ = acc.fastq_split(b"@r\nA\n+\n", final=False)
+    assert len(recs) == 0 and used == 0 and plain
+
+
+def test_reads_resident_for_sdust(acc, golden_dir):
+    """`seq -m` + per-read sdust without a host-side copy of the reads: same intervals as uploading the kept reads"""
+    text = open(os.path.join(golden_dir, "reads.fq"), "rb").read()
+    for min_len in (0, 100, 5000):
+        recs, used, plain, reads = acc.fastq_split(text, min_len=min_len, want_reads=True)
+        exp, _ = ob.fastx_parse(text)
+        kept = [s for _, _, s, _ in exp if len(s) >= min_len]
+        assert list(recs["keep"]) == [1 if len(s) >= min_len else 0 for _, _, s, _ in exp]
+        assert [int(x) for x in reads.lens] == [len(s) for s in kept]
+        got = acc.sdust(reads, 20, 64)
+        want = []
+        for i, s in enumerate(kept):
+            for v in ob.sdust(np.frombuffer(s, dtype=np.uint8), 20, 64):
+                want.append((i, int(v) >> 32, int(v) & 0xFFFFFFFF))
+        assert [(int(a), int(b), int(c)) for a, b, c in got] == want, min_len
+        reads.close()
+
+
+def test_large_piece_many_reads(acc):
+    """2 M short reads + long reads in one piece: record table against a numpy restatement of the four-line rule"""
+    rng = np.random.default_rng(14)
+    n = 200000
+    lens = np.concatenate([rng.integers(1, 300, n), rng.integers(5000, 20000, 200)])
+    rng.shuffle(lens)
+    parts = []
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for i, L in enumerate(lens.tolist()):
+        parts.append(b"@r%d ch=%d\n" % (i, i % 512))
+        s = alpha[rng.integers(0, 4, L)].tobytes()
+        parts.append(s + b"\n+\n" + b"I" * L + b"\n")
+    text = b"".join(parts)
+    recs, used, plain, reads = acc.fastq_split(text, min_len=250, want_reads=True)
+    assert plain and used == len(text) and len(recs) == len(lens)
+    assert np.array_equal(recs["len"], lens.astype(np.int32))
+    assert np.array_equal(recs["keep"], (lens >= 250).astype(np.int32))
+    idx = rng.integers(0, len(lens), 200)
+    f = fields(text, recs[idx])
+    for k, i in enumerate(idx.tolist()):
+        assert f[k][0] == b"r%d" % i and f[k][1] == b"ch=%d" % (i % 512) and len(f[k][2]) == lens[i] and f[k][3] == b"I" * int(lens[i])
+    # the packed reads are the kept reads: sdust of a few of them equals sdust of the bytes
+    got = acc.sdust(reads, 20, 64)
+    kept = np.flatnonzero(lens >= 250)
+    for j in rng.integers(0, len(kept), 20).tolist():
+        i = int(kept[j])
+        s = np.frombuffer(text[int(recs[i]["seq"]):int(recs[i]["seq"]) + int(lens[i])], dtype=np.uint8)
+        want = [(int(v) >> 32, int(v) & 0xFFFFFFFF) for v in ob.sdust(s, 20, 64)]
+        assert [(int(b), int(c)) for a, b, c in got[got["ctg"] == j]] == want
+    reads.close()
+
+
+# ---- through the CLI: `cornetto sdust reads.fastq` frames the records on the device ---------------------------------
+def run_cli(args, env=None, data=None):
+    import subprocess
+    import cornetto_amd
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([cornetto_amd.CLI_PATH] + args, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+    return p.returncode, p.stdout, p.stderr
+
+
+def sdust_text(text):
+    """stdout of the reference's `sdust` for this FASTA/FASTQ text: kseq records, intervals per record (sdust.c:196-203)"""
+    recs, rc = ob.fastx_parse(text)
+    out = []
+    for name, _, seq, _ in recs:
+        for v in ob.sdust(np.frombuffer(seq, dtype=np.uint8), 20, 64):
+            out.append(b"%s\t%d\t%d\n" % (name, int(v) >> 32, int(v) & 0xFFFFFFFF))
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("piece", [None, "64", "700", "5000", "100000"])
+def test_cli_sdust_reads_golden_any_piece_size(golden_dir, piece):
+    env = {"CORNETTO_FASTQ_PIECE": piece} if piece else None
+    rc, out, err = run_cli(["sdust", os.path.join(golden_dir, "reads.fq")], env=env)
+    assert rc == 0, err.decode()
+    assert out == open(os.path.join(golden_dir, "reads.sdust.exp"), "rb").read()
+
+
+def lowcomplex_fastx(rng, n_rec, strict):
+    return tricky_fastx(rng, n_rec, strict=strict, lowc=0.6)
+
+
+def test_cli_sdust_irregular_fastq_falls_back_mid_file(tmp_path):
+    rng = np.random.default_rng(21)
+    f = str(tmp_path / "t.fq")
+    n_out = 0
+    for it in range(12):
+        # a plain head (so that the device path is taken), then irregular records
+        text = lowcomplex_fastx(rng, 30, True)
+        if not text.endswith(b"\n"):
+            text += b"\n"
+        text += lowcomplex_fastx(rng, 30, False)
+        open(f, "wb").write(text)
+        want = sdust_text(text)
+        n_out += len(want)
+        for piece in ("1500", "4096", None):
+            rc, out, err = run_cli(["sdust", f], env={"CORNETTO_FASTQ_PIECE": piece} if piece else None)
+            assert rc == 0 and out == want, (it, piece, err.decode()[-300:])
+    assert n_out > 1000
+
+
+def test_cli_sdust_fastq_gz_and_stdin(tmp_path, golden_dir):
+    import gzip
+    text = open(os.path.join(golden_dir, "reads.fq"), "rb").read()
+    want = open(os.path.join(golden_dir, "reads.sdust.exp"), "rb").read()
+    gz = str(tmp_path / "reads.fq.gz")
+    with gzip.open(gz, "wb") as fh:
+        fh.write(text)
+    rc, out, err = run_cli(["sdust", gz], env={"CORNETTO_FASTQ_PIECE": "3000"})
+    assert rc == 0 and out == want
+    rc, out, err = run_cli(["sdust", "-"], data=text, env={"CORNETTO_FASTQ_PIECE": "3000"})
+    assert rc == 0 and out == want
+
+
+def test_cli_sdust_record_larger_than_a_piece_and_truncated_quality(tmp_path):
+    rng = np.random.default_rng(22)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    big = alpha[rng.integers(0, 2, 9000)].tobytes()
+    text = b"@a\nACGTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTACGT\n+\n" + b"I" * 45 + b"\n@big x\n" + big + b"\n+\n" + b"#" * 9000 + b"\n" \
+           b"@c\nAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA\n+\n" + b"I" * 45 + b"\n"
+    f = str(tmp_path / "big.fq")
+    open(f, "wb").write(text)
+    for piece in ("256", "4000", None):
+        rc, out, err = run_cli(["sdust", f], env={"CORNETTO_FASTQ_PIECE": piece} if piece else None)
+        assert rc == 0 and out == sdust_text(text), piece
+    # kseq_read returns -2 at a quality string of another length and the reference's loop ends there (sdust.c:196)
+    cut = b"@a\nAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA\n+\n" + b"I" * 45 + b"\n@b\nAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA\n+\nII\n" \
+          b"@c\nAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA\n+\n" + b"I" * 45 + b"\n"
+    open(f, "wb").write(cut)
+    rc, out, err = run_cli(["sdust", f])
+    assert rc == 0 and out == sdust_text(cut) and out.startswith(b"a\t") and b"c\t" not in out

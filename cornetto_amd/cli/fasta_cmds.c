@@ -136,7 +136,8 @@ static void sdust_stream(const char *path, const sdust_opt_t *o)
     const int r0 = gzread(fp, &first, 1);
     if (r0 == 1) have = 1;
     else eof = 1;
-    if (have && first == '@') { /* a file that does not begin with '@' is not FASTQ: sequential reader from byte 0 */
+    const char *how = getenv("CORNETTO_FASTQ_SPLIT"); /* "host": sequential reader only (for comparisons) */
+    if (have && first == '@' && !(how && !strcmp(how, "host"))) { /* a file that does not begin with '@' is not FASTQ: sequential reader from byte 0 */
         const int64_t piece = fastq_piece_bytes();
         h = cli_accel_open();
         buf = (char *)cornetto_pinned_alloc((size_t)piece);

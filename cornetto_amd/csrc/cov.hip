@@ -27,7 +27,8 @@
 namespace {
 
 constexpr int CB_THREADS = 256;
-constexpr int CB_MAX_INC_LDS = 128;   // inc <= this: LDS staging path (256 x inc x 2 B <= 64 KiB)
+constexpr int CB_PARTS = 2;           // a tile goes through LDS in this many parts
+constexpr int CB_MAX_INC_LDS = 128;   // inc <= this: LDS staging path (256 / CB_PARTS x inc x 2 B <= 32 KiB)
 
 struct CbArgs {
     const uint16_t *depth, *mq;
@@ -70,46 +71,54 @@ __global__ __launch_bounds__(CB_THREADS) void cov_blocks(CbArgs A)
     uint32_t fd = 0, fq = 0, hd = 0, hq = 0;
     unsigned long long xd = 0, xq = 0;                  // exact block sums
     if (STAGE) {
-        // One array at a time through the same LDS buffer (256 * inc * 2 bytes): half the footprint, so that twice as
-        // many workgroups fit, also next to another stream's kernel that owns most of the CU's LDS.
+        // One array at a time, and of each array one half of the tile (CB_THREADS / CB_PARTS blocks) at a time, through the
+        // same LDS buffer (256 / CB_PARTS * inc * 2 bytes = 12.8 KB for inc = 50): several workgroups fit into the
+        // LDS that another stream's resident kernel leaves free on a CU, and their phases overlap.
         uint16_t *sv = reinterpret_cast<uint16_t *>(smem);
-        const int nvec = CB_THREADS * inc / 8;          // 16-byte vectors per array (256 * inc * 2 bytes: multiple of 16)
-        const int base = t * inc;
+        constexpr int PB = CB_THREADS / CB_PARTS;       // blocks per part
+        const int nvec = PB * inc / 8;                  // 16-byte vectors per part (PB * inc * 2 bytes: multiple of 16)
+        const int base = (t % PB) * inc;
         const int nval = p0 >= len ? 0 : (int)(len - p0 < inc ? len - p0 : inc);   // elements of my block inside the contig
         const int nh = r < nval ? r : nval;
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
-            const uint4 *g = reinterpret_cast<const uint4 *>((which ? A.mq : A.depth) + off + e0);
-            if (which) __syncthreads();                 // everyone is done reading the first array
-            // eight 16-byte loads in flight per thread before the first LDS store: a single resident workgroup per CU
-            // (all that fits beside another stream's kernel) still keeps 32 KB on the wire
-            for (int v0 = t; v0 < nvec; v0 += 8 * CB_THREADS) {
-                uint4 a[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int v = v0 + k * CB_THREADS;
-                    a[k] = make_uint4(0, 0, 0, 0);
-                    if (v < nvec && e0 + 8LL * v < len) a[k] = g[v];       // vectors at or past the contig end are zeros
+            for (int part = 0; part < CB_PARTS; ++part) {
+                const int64_t pe0 = e0 + (int64_t)part * PB * inc;      // first element of this part within the contig
+                const uint4 *g = reinterpret_cast<const uint4 *>((which ? A.mq : A.depth) + off + pe0);
+                if (which | part) __syncthreads();      // everyone is done reading the previous part
+                // all loads of a thread in flight before the first LDS store
+                constexpr int NV = 4;
+                for (int v0 = t; v0 < nvec; v0 += NV * CB_THREADS) {
+                    uint4 a[NV];
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) {
+                        const int v = v0 + k * CB_THREADS;
+                        a[k] = make_uint4(0, 0, 0, 0);
+                        if (v < nvec && pe0 + 8LL * v < len) a[k] = g[v];     // vectors at or past the contig end are zeros
+                    }
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) {
+                        const int v = v0 + k * CB_THREADS;
+                        if (v < nvec) reinterpret_cast<uint4 *>(sv)[v] = a[k];
+                    }
                 }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int v = v0 + k * CB_THREADS;
-                    if (v < nvec) reinterpret_cast<uint4 *>(sv)[v] = a[k];
+                __syncthreads();
+                if (t / PB == part) {
+                    uint32_t f = 0, hh = 0;
+                    if (nval == inc && (inc & 1) == 0) {
+                        const uint32_t *wd = reinterpret_cast<const uint32_t *>(sv + base);
+                        for (int i = 0; i < inc / 2; ++i) {
+                            const uint32_t a = wd[i];
+                            f += (a & 0xFFFFu) + (a >> 16);
+                        }
+                    } else {
+                        for (int i = 0; i < nval; ++i) f += sv[base + i];
+                    }
+                    for (int i = 0; i < nh; ++i) hh += sv[base + i];
+                    if (which) { fq = f; hq = hh; } else { fd = f; hd = hh; }
                 }
             }
-            __syncthreads();
-            uint32_t f = 0, hh = 0;
-            if (nval == inc && (inc & 1) == 0) {
-                const uint32_t *wd = reinterpret_cast<const uint32_t *>(sv + base);
-                for (int i = 0; i < inc / 2; ++i) {
-                    const uint32_t a = wd[i];
-                    f += (a & 0xFFFFu) + (a >> 16);
-                }
-            } else {
-                for (int i = 0; i < nval; ++i) f += sv[base + i];
-            }
-            for (int i = 0; i < nh; ++i) hh += sv[base + i];
-            if (which) { fq = f; hq = hh; } else { fd = f; hd = hh; }
         }
         xd = fd;
         xq = fq;
@@ -369,7 +378,7 @@ int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int3
     CN_HIP(h, hipMemsetAsync(d_grand, 0, 16, h->stream));
     CbArgs A{c->d_depth, c->d_mq, c->d_off, c->d_len, c->d_cb_tiles, inc, r, d_blk, d_t32, d_t64};
     if (inc <= CB_MAX_INC_LDS) {
-        const size_t lds = (size_t)CB_THREADS * inc * sizeof(uint16_t);
+        const size_t lds = (size_t)CB_THREADS / CB_PARTS * inc * sizeof(uint16_t);
         CN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&cov_blocks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CN_LAUNCH(h, "cov_blocks", cov_blocks<true><<<dim3((unsigned)nt), dim3(CB_THREADS), lds, h->stream>>>(A));
     } else {

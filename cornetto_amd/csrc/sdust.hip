@@ -963,10 +963,15 @@ __device__ int sd_find_start(const SdArgs &A, const SdChunk ch, const uint8_t *s
 // ---- scheduling hint per chunk, before the main kernel: the 64 bytes in the middle of the chunk; a sample whose 62
 // 3-mers take few distinct values (random sequence: ~40 of 64) lies in a repeat array.  The flag only orders the work;
 // results do not depend on it.
-__global__ void sd_prep(SdArgs A, uint32_t *flag)
+// Also resets what the main kernel expects cleared per chunk (claim flag, interval count) and the queue order array
+// (`perm`, n_chunks + 80 positions of "nothing here"): one launch instead of three memsets in front of the scan.
+__global__ void sd_prep(SdArgs A, uint32_t *flag, uint32_t *perm)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < A.n_chunks + 80) perm[c] = 0xFFFFFFFFu;
     if (c >= A.n_chunks) return;
+    A.claim[c] = 0;
+    A.out_n[c] = 0;
     const SdChunk ch = A.chunks[c];
     const uint8_t *seq = A.bases + A.ctg_off[ch.ctg];
     // the middle 64 bytes of the chunk
@@ -1144,12 +1149,14 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                 if (!d_flag) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
                 uint32_t *d_rank = d_flag + nc, *d_claim = d_rank + nc, *d_perm = d_claim + nc, *d_pp = d_perm + nc + 80;
                 const unsigned nbs = (unsigned)((nc + 255) / 256);
-                CN_HIP(h, hipMemsetAsync(d_claim, 0, nc * 4, h->stream));
-                CN_HIP(h, hipMemsetAsync(d_cnt, 0, nc * 4, h->stream));          // chunks a lane runs on into publish nothing of their own
                 A.claim = d_claim;
                 A.q_len = (int32_t)nc;
-                if (env_int("CORNETTO_SDUST_ORDER", 1)) {
-                    CN_LAUNCH(h, "sdust_prep", sd_prep<<<dim3(nbs), dim3(256), 0, h->stream>>>(A, d_flag));
+                if (!env_int("CORNETTO_SDUST_ORDER", 1)) {
+                    CN_HIP(h, hipMemsetAsync(d_claim, 0, nc * 4, h->stream));
+                    CN_HIP(h, hipMemsetAsync(d_cnt, 0, nc * 4, h->stream));      // chunks a lane runs on into publish nothing of their own
+                } else {
+                    const unsigned nbp = (unsigned)((nc + 80 + 255) / 256);
+                    CN_LAUNCH(h, "sdust_prep", sd_prep<<<dim3(nbp), dim3(256), 0, h->stream>>>(A, d_flag, d_perm));
                     // passes of the queue over the input: a run can grow to `passes` chunks before it meets a queue start
                     SdPasses ps;
                     ps.P = (uint32_t)std::min(64, std::max(1, env_int("CORNETTO_SDUST_PASSES", 8)));
@@ -1165,7 +1172,6 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                         std::sort(key.begin(), key.end());
                         for (uint32_t t = 0; t < ps.P; ++t) ps.turn[key[t].second] = (uint8_t)t;
                     }
-                    CN_HIP(h, hipMemsetAsync(d_perm, 0xFF, (nc + 80) * 4, h->stream));
                     CN_TRY(cnscan::exclusive_u32(h, "sdust_prep", d_flag, (int64_t)nc, 1, d_rank, d_pp, d_tot + 7));
                     CN_LAUNCH(h, "sdust_prep", sd_order<<<dim3(nbs), dim3(256), 0, h->stream>>>(d_flag, d_rank, d_tot + 7, (int32_t)nc, d_perm, ps));
                     A.perm = d_perm;

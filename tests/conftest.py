@@ -9,6 +9,15 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+# PyTorch's ROCm wheel carries its own copy of the HIP runtime and loads it by path: a process that has already
+# initialised /opt/rocm's runtime through libcornetto_hip.so then finds "no ROCm-capable device" in torch.  The tests that
+# use torch for device memory import it lazily, so fix the order here: torch's runtime first, the library binds to it.
+try:
+    import torch  # noqa: F401
+except Exception:      # CPU-only tests do not need it
+    torch = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

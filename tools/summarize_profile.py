@@ -24,9 +24,18 @@ def short(name):
     return None
 
 
+def newest(files):
+    """gpurun merges every call's output into the same directory: keep the files of the most recent run only"""
+    import os
+    if not files:
+        return files
+    t = max(os.path.getmtime(f) for f in files)
+    return [f for f in files if t - os.path.getmtime(f) < 60]
+
+
 def stats(src, dst):
     rows = []
-    for f in glob.glob(src + "/**/*_kernel_stats.csv", recursive=True):
+    for f in newest(glob.glob(src + "/**/*_kernel_stats.csv", recursive=True)):
         rows += list(csv.DictReader(open(f)))
     with open(dst, "w", newline="") as fo:
         w = csv.writer(fo)
@@ -45,7 +54,7 @@ def pmc(fetch_dir, write_dir, dst):
     for d, counter in ((fetch_dir, "FETCH_SIZE"), (write_dir, "WRITE_SIZE")):
         agg = collections.defaultdict(float)
         disp = collections.defaultdict(set)
-        for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+        for f in newest(glob.glob(d + "/**/*_counter_collection.csv", recursive=True)):
             for r in csv.DictReader(open(f)):
                 k = short(r["Kernel_Name"])
                 if k and r["Counter_Name"] == counter:

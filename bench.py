@@ -349,10 +349,16 @@ def main():
         for name, ms in acc2.last_timing():
             ktime.setdefault(name, []).append(ms)
 
-    def step(record):
-        box = {}
+    # the sdust side runs on one persistent worker thread (no thread start inside the timed steps)
+    import queue
+    jobs, done = queue.Queue(), queue.Queue()
 
-        def sdust_part():
+    def sdust_worker():
+        while True:
+            record = jobs.get()
+            if record is None:
+                return
+            box = {}
             try:
                 t0 = time.perf_counter()
                 box["ivls"] = acc2.sdust(asm2, 20, 64)
@@ -360,11 +366,14 @@ def main():
                     note2(); lap("sdust", t0)
             except BaseException as e:       # re-raised on the main thread
                 box["err"] = e
+            done.put(box)
 
-        th = None
+    worker = threading.Thread(target=sdust_worker, daemon=True)
+    worker.start()
+
+    def step(record):
         if overlap:
-            th = threading.Thread(target=sdust_part)
-            th.start()
+            jobs.put(record)
         t0 = time.perf_counter()
         hits, wins = acc.telo_scan(asm, b"TTAGGG", thr)
         if record:
@@ -383,10 +392,9 @@ def main():
         recs = acc.cov_select(cov, lo, hi, 0.4, 100000, 1000000, False)
         if record:
             note(); lap("cov_select", t0)
-        if th is not None:
-            th.join()
-        else:
-            sdust_part()
+        if not overlap:
+            jobs.put(record)
+        box = done.get()
         if "err" in box:
             raise box["err"]
         ivls = box["ivls"]
@@ -477,6 +485,8 @@ def main():
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(torch, bases, depth, mq, offs, lens, int(args.cpu_sample_mbases * 1e6))
         print(json.dumps(line), flush=True)
+    jobs.put(None)
+    worker.join()
     asm.close()
     asm2.close()
     cov.close()

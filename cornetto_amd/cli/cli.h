@@ -48,6 +48,11 @@ char *cli_xstrdup(const char *s);
 /* Open the accelerator ($CORNETTO_DEVICE, default 0) or print the reason and exit(EXIT_FAILURE): this
  * build has no CPU path. */
 cornetto_accel_t *cli_accel_open(void);
+/* the same, with the HIP initialisation running on a helper thread between _begin() and _end() (while the input is read);
+ * _cancel() drops it when no device work turned up */
+void cli_accel_open_begin(void);
+cornetto_accel_t *cli_accel_open_end(void);
+void cli_accel_open_cancel(void);
 /* print the handle's last error and exit(EXIT_FAILURE) if rc != 0 */
 void cli_accel_check(cornetto_accel_t *h, int rc, const char *what);
 
@@ -75,6 +80,7 @@ typedef struct {
     int64_t bases;
 } cli_batch_t;
 void cli_batch_push(cli_batch_t *b, const char *name, const char *seq, int64_t len);
+void cli_batch_take(cli_batch_t *b, const char *name, cli_str_t *seq); /* takes seq's buffer over when it is long */
 void cli_batch_clear(cli_batch_t *b);
 int64_t cli_batch_limit(void); /* $CORNETTO_BATCH_BASES, default 4e9 */
 

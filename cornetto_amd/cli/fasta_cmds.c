@@ -20,23 +20,25 @@ static void batches_of(cli_fastx_t *fx, cornetto_accel_t *h_open, batch_fn fn, v
     memset(&b, 0, sizeof(b));
     const int64_t limit = cli_batch_limit();
     int64_t l;
+    if (!h) cli_accel_open_begin();     /* HIP initialises while the records are read */
     while ((l = cli_fastx_read(fx, &name, &comment, &seq, &qual)) >= 0) {
         if (l > 0x7fffffffLL) {
             CLI_ERROR("record %s has %lld bases; the reference's reader is limited to 2^31-1 (src/kseq.h:185)", name.s, (long long)l);
             exit(EXIT_FAILURE);
         }
-        cli_batch_push(&b, name.s, seq.s, l);
+        cli_batch_take(&b, name.s, &seq);
         if (b.bases >= limit) {
-            if (!h) h = cli_accel_open();
+            if (!h) h = cli_accel_open_end();
             fn(h, &b, arg);
             cli_batch_clear(&b);
         }
     }
     if (b.n) {
-        if (!h) h = cli_accel_open();
+        if (!h) h = cli_accel_open_end();
         fn(h, &b, arg);
         cli_batch_clear(&b);
     }
+    if (!h) cli_accel_open_cancel();
     if (h && !h_open) cornetto_accel_close(h);
     free(b.names);
     free(b.seqs);

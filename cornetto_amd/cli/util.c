@@ -70,6 +70,53 @@ cornetto_accel_t *cli_accel_open(void)
     return h;
 }
 
+/* The device is opened on a helper thread while the input is being read (HIP initialisation takes a few hundred
+ * milliseconds); cli_accel_open_end() joins it and behaves like cli_accel_open(). */
+#include <pthread.h>
+static struct {
+    pthread_t th;
+    int started, rc, dev;
+    cornetto_accel_t *h;
+} g_open;
+
+static void *open_thread(void *arg)
+{
+    (void)arg;
+    g_open.rc = cornetto_accel_open(&g_open.h, g_open.dev, NULL);
+    return NULL;
+}
+
+void cli_accel_open_begin(void)
+{
+    if (g_open.started) return;
+    const char *d = getenv("CORNETTO_DEVICE");
+    g_open.dev = d ? atoi(d) : 0;
+    g_open.h = NULL;
+    if (pthread_create(&g_open.th, NULL, open_thread, NULL) == 0) g_open.started = 1;
+}
+
+cornetto_accel_t *cli_accel_open_end(void)
+{
+    if (!g_open.started) return cli_accel_open();
+    pthread_join(g_open.th, NULL);
+    g_open.started = 0;
+    if (g_open.rc != CORNETTO_OK) {
+        CLI_ERROR("cannot open HIP device %d: %s. This build runs the scans on an AMD GPU only; there is no CPU path.",
+                  g_open.dev, cornetto_accel_strerror(g_open.rc));
+        exit(EXIT_FAILURE);
+    }
+    return g_open.h;
+}
+
+/* the helper thread's handle is not needed after all (an input without records) */
+void cli_accel_open_cancel(void)
+{
+    if (!g_open.started) return;
+    pthread_join(g_open.th, NULL);
+    g_open.started = 0;
+    if (g_open.rc == CORNETTO_OK && g_open.h) cornetto_accel_close(g_open.h);
+}
+
 void cli_accel_check(cornetto_accel_t *h, int rc, const char *what)
 {
     if (rc == CORNETTO_OK) return;
@@ -92,6 +139,22 @@ void cli_batch_push(cli_batch_t *b, const char *name, const char *seq, int64_t l
     b->lens[b->n] = len;
     b->bases += len;
     b->n++;
+}
+
+/* like cli_batch_push(), but a long sequence is taken over from the reader's buffer instead of being copied */
+void cli_batch_take(cli_batch_t *b, const char *name, cli_str_t *seq)
+{
+    if (seq->l < (1u << 16) || !seq->s) {
+        cli_batch_push(b, name, seq->s ? seq->s : "", (int64_t)seq->l);
+        return;
+    }
+    cli_batch_push(b, name, "", 0);
+    free(b->seqs[b->n - 1]);
+    b->seqs[b->n - 1] = (uint8_t *)seq->s;
+    b->lens[b->n - 1] = (int64_t)seq->l;
+    b->bases += (int64_t)seq->l;
+    seq->s = NULL;
+    seq->l = seq->m = 0;
 }
 
 void cli_batch_clear(cli_batch_t *b)

@@ -278,6 +278,7 @@ def main():
     ap.add_argument("--cpu-sample-mbases", type=float, default=500.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--sdust-share", type=int, default=75, help="percent of every CU the sdust kernel may occupy while the other stream runs beside it")
+    ap.add_argument("--timing", type=int, default=2, help="HIP events around: 1 the main kernels only (roofline), 2 every launch, 0 none")
     ap.add_argument("--gather", action="store_true", help="N > 1: also gather every result record to rank 0 inside the step (not part of the path: each rank owns the output of its contigs)")
     ap.add_argument("--serial", action="store_true", help="run the stages one after the other on one stream (per-kernel timing without overlap)")
     args = ap.parse_args()
@@ -321,6 +322,7 @@ def main():
     asm = acc.asm_wrap(bases.data_ptr(), offs, np.array(lens, dtype=np.int64))
     cov = acc.cov_wrap(depth.data_ptr(), mq.data_ptr(), offs, np.array(lens, dtype=np.int32))
     thr = acc.telowin_threshold(0.4, 99.9)
+    acc.set_timing(args.timing)
     ktime = {}
 
     def note():
@@ -341,6 +343,7 @@ def main():
     acc2 = cornetto_amd.Accel(local_dev, None)                       # second stream, same device
     asm2 = acc2.asm_wrap(bases.data_ptr(), offs, np.array(lens, dtype=np.int64))
     overlap = not args.serial
+    acc2.set_timing(args.timing)
     if overlap:
         # the sdust waves stay resident until their queue is empty: leave part of every CU to the other stream
         acc2.set_share(args.sdust_share)

@@ -75,6 +75,7 @@ def lib():
         "cornetto_free": (None, [vp]),
         "cornetto_accel_last_timing": (C.c_int, [vp, C.POINTER(cp), C.POINTER(C.c_float), C.c_int]),
         "cornetto_accel_set_share": (C.c_int, [vp, C.c_int]),
+        "cornetto_accel_set_timing": (C.c_int, [vp, C.c_int]),
         "cornetto_cov_select_merged": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_int, C.c_int32, C.c_int32, C.POINTER(vp), C.POINTER(C.c_int64)]),
         "cornetto_ivl_merge": (C.c_int, [vp, vp, C.c_int64, C.c_int32, C.POINTER(vp), C.POINTER(C.c_int64)]),
         "cornetto_panel_defaults": (None, [vp]),
@@ -192,6 +193,9 @@ class Accel:
     def set_share(self, percent):
         """percent of every CU the resident sdust kernel may occupy (another handle computes beside this one)"""
         self._chk(self.L.cornetto_accel_set_share(self.h, int(percent)))
+
+    def set_timing(self, level):
+        self._chk(self.L.cornetto_accel_set_timing(self.h, level))
 
     def last_timing(self):
         """[(kernel name, ms)] of the most recent compute call (HIP events on the handle's stream)"""

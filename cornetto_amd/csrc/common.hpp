@@ -36,6 +36,7 @@ struct cornetto_accel {
     int sd_slots = 0;   // sdust: waves the device holds at once (occupancy query, cached)
     int sd_cus = 0;
     int share = 100;    // percent of every CU the resident sdust kernel may take (cornetto_accel_set_share)
+    int timing = 2;     // event pairs around: 2 every kernel launch, 1 the three streaming / scanning main kernels only, 0 none (cornetto_accel_set_timing)
 };
 
 // device workspace slot `slot` with at least `bytes` bytes (contents undefined); nullptr on failure
@@ -149,15 +150,29 @@ static inline void cn_timing_end(cornetto_accel_t *h)
     h->recs.clear();
 }
 
-// Launch `...` (a kernel<<<>>> expression on h->stream) bracketed by two events recorded under `name`.
+static inline bool cn_timed(const cornetto_accel_t *h, const char *name)
+{
+    if (h->timing >= 2) return true;
+    if (h->timing <= 0) return false;
+    return !strcmp(name, "sdust_kernel") || !strcmp(name, "cov_blocks") || !strcmp(name, "tf_scan");
+}
+
+// Launch `...` (a kernel<<<>>> expression on h->stream) bracketed by two events recorded under `name`.  Every event
+// record is a packet of its own on the queue (tens of microseconds each beside a busy second stream): callers that
+// do not read cornetto_accel_last_timing() switch them off (cornetto_accel_set_timing).
 #define CN_LAUNCH(h, name, ...)                                                                              \
     do {                                                                                                     \
-        cornetto_accel::Rec r_{(name), cn_event(h), cn_event(h)};                                            \
-        CN_HIP(h, hipEventRecord(r_.a, (h)->stream));                                                        \
-        __VA_ARGS__;                                                                                         \
-        CN_HIP(h, hipGetLastError());                                                                        \
-        CN_HIP(h, hipEventRecord(r_.b, (h)->stream));                                                        \
-        (h)->recs.push_back(r_);                                                                             \
+        if (cn_timed((h), (name))) {                                                                         \
+            cornetto_accel::Rec r_{(name), cn_event(h), cn_event(h)};                                        \
+            CN_HIP(h, hipEventRecord(r_.a, (h)->stream));                                                    \
+            __VA_ARGS__;                                                                                     \
+            CN_HIP(h, hipGetLastError());                                                                    \
+            CN_HIP(h, hipEventRecord(r_.b, (h)->stream));                                                    \
+            (h)->recs.push_back(r_);                                                                         \
+        } else {                                                                                             \
+            __VA_ARGS__;                                                                                     \
+            CN_HIP(h, hipGetLastError());                                                                    \
+        }                                                                                                    \
     } while (0)
 
 // ---- RAII device buffer ----------------------------------------------------------------------------

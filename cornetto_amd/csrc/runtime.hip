@@ -134,6 +134,13 @@ int cornetto_accel_set_share(cornetto_accel_t *h, int percent)
     return CORNETTO_OK;
 }
 
+int cornetto_accel_set_timing(cornetto_accel_t *h, int level)
+{
+    if (!h || level < 0 || level > 2) return cn_fail(h, CORNETTO_E_ARG, "set_timing: level must be 0, 1 or 2");
+    h->timing = level;
+    return CORNETTO_OK;
+}
+
 int cornetto_accel_last_timing(const cornetto_accel_t *h, const char **names, float *ms, int cap)
 {
     if (!h) return 0;

@@ -26,6 +26,7 @@
 // LDS (lane-minor layout, [index][lane] in 4-byte columns: bank-conflict free for any per-lane index).
 // One wavefront per workgroup; no barriers.  VALU-issue bound by nature, not HBM bound.
 #include <algorithm>
+#include <ctime>
 
 #include "common.hpp"
 #include "scan.hpp"
@@ -1055,6 +1056,16 @@ extern "C" {
 int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, int32_t W, cornetto_ivl_t **ivls,
                        int64_t *n_ivls)
 {
+    // CORNETTO_SDUST_TRACE=1: host-side time stamps of the call's phases on stderr (development aid)
+    static const bool trace = env_int("CORNETTO_SDUST_TRACE", 0) != 0;
+    struct timespec ts0;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
+    auto stamp = [&](const char *what) {
+        if (!trace) return;
+        struct timespec t;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        fprintf(stderr, "[sdust trace] %-22s %8.3f ms\n", what, (t.tv_sec - ts0.tv_sec) * 1e3 + (t.tv_nsec - ts0.tv_nsec) * 1e-6);
+    };
     if (!h || !a_in || !ivls || !n_ivls) return cn_fail(h, CORNETTO_E_ARG, "sdust: bad argument");
     cornetto_asm_t *a = const_cast<cornetto_asm_t *>(a_in);   // only the cached chunk table is touched
     *ivls = nullptr;
@@ -1188,8 +1199,10 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             }
             // ordered position of every chunk's intervals (chunks are in contig order) + grand total
             CN_TRY(cnscan::exclusive_u32(h, "sdust_scan", d_cnt, (int64_t)nc, 1, d_off, d_part, d_tot));
+            stamp("main kernel queued");
             CN_HIP(h, hipMemcpyAsync(p_tot, d_tot, want_stats ? 2048 : 128, hipMemcpyDeviceToHost, h->stream));
             CN_HIP(h, hipStreamSynchronize(h->stream));
+            stamp("main kernel done");
             if (want_stats)
                 for (int b = 0; b < 32; ++b)
                     if (p_tot[16 + 4 * b])
@@ -1244,6 +1257,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             const unsigned nbg = (unsigned)((nc + 255) / 256);
             CN_LAUNCH(h, "sdust_gather", sdust_gather<<<dim3(nbg), dim3(256), 0, h->stream>>>(d_out, d_cnt, d_off, (uint32_t)cap, d_chunks, (int32_t)nc, d_dst));
             CN_TRY(cnivl::merge(h, "sdust_stitch", d_dst, (int64_t)n, 0, ws, d_st, d_tot + 9));
+            stamp("gather+stitch queued");
             if (hipMemcpyAsync(o, d_st, n * sizeof(cornetto_ivl_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
                 hipMemcpyAsync(p_tot, d_tot + 9, 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
                 hipStreamSynchronize(h->stream) != hipSuccess) {
@@ -1251,6 +1265,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                 return cn_fail(h, CORNETTO_E_HIP, "sdust: stitch / copy back failed");
             }
             n_out = (int64_t)p_tot[0];                 // only the first n_out entries of o are meaningful
+            stamp("results on the host");
         }
     }
     cn_timing_end(h);

@@ -108,6 +108,11 @@ int cornetto_accel_last_timing(const cornetto_accel_t *h, const char **names, fl
  * Scheduling only: results do not depend on it. */
 int cornetto_accel_set_share(cornetto_accel_t *h, int percent);
 
+/* Which kernel launches are bracketed by HIP events for cornetto_accel_last_timing(): 2 (default) every launch, 1 only
+ * the three main kernels (sdust_kernel, cov_blocks, tf_scan), 0 none.  Every event is a packet of its own on the queue;
+ * beside a busy second stream the dozen small launches of a call cost about a millisecond more with level 2. */
+int cornetto_accel_set_timing(cornetto_accel_t *h, int level);
+
 /* ---------------------------------------------------------------------------------------------------
  * sequences in HBM
  * ------------------------------------------------------------------------------------------------- */

@@ -24,6 +24,7 @@ IVL_DT = np.dtype([("ctg", "<i4"), ("start", "<i4"), ("finish", "<i4")])
 TELROW_DT = np.dtype([("ctg", "<i4"), ("start", "<i4"), ("end", "<i4"), ("matched", "<i4")])
 FQREC_DT = np.dtype([("head", "<i8"), ("seq", "<i8"), ("qual", "<i8"), ("len", "<i4"), ("name_len", "<i4"),
                      ("comment_len", "<i4"), ("keep", "<i4")])
+FAREC_DT = np.dtype([("head", "<i8"), ("len", "<i8"), ("name_len", "<i4"), ("pad", "<i4")])
 REG_DT = np.dtype([("st", "<i4"), ("end", "<i4"), ("depth", "<i4"), ("mq_depth", "<i4")])
 REGREC_DT = np.dtype([("ctg", "<i4"), ("st", "<i4"), ("end", "<i4"), ("depth", "<i4"), ("mq_depth", "<i4")])
 
@@ -83,6 +84,7 @@ def lib():
         "cornetto_telobreaks": (C.c_int, [vp, vp, C.c_int32, vp, C.c_int64, vp, C.c_int64, C.POINTER(vp), C.POINTER(C.c_int64)]),
         "cornetto_khash_str_order": (C.c_int32, [C.POINTER(C.c_char_p), C.c_int32, vp, vp]),
         "cornetto_fastq_split": (C.c_int, [vp, vp, i64, C.c_int, i32, pp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), pp]),
+        "cornetto_fasta_split": (C.c_int, [vp, vp, i64, C.c_int, pp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), pp]),
         "cornetto_asm_upload": (C.c_int, [vp, vp, vp, i32, pp]),
         "cornetto_asm_wrap": (C.c_int, [vp, vp, vp, vp, i32, pp]),
         "cornetto_asm_free": (None, [vp, vp]),
@@ -237,6 +239,22 @@ class Accel:
                                               C.byref(plain), C.byref(reads) if want_reads else None))
         recs = _take(p, cnt.value, FQREC_DT)
         res = _Resident(self, reads, self.L.cornetto_asm_free, recs["len"][recs["keep"] == 1]) if want_reads else None
+        return recs, used.value, bool(plain.value), res
+
+    def fasta_split(self, text, final=True, want_seqs=False):
+        """text: bytes-like FASTA piece beginning with '>' (or (address, size)) -> (records FAREC_DT, consumed bytes, plain
+        flag, resident sequences or None): see cornetto_fasta_split() in include/cornetto_accel.h"""
+        if isinstance(text, tuple):
+            addr, n = text
+            keep = None
+        else:
+            keep = np.frombuffer(bytes(text), dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text, dtype=np.uint8)
+            addr, n = keep.ctypes.data, keep.size
+        p, cnt, used, plain, seqs = C.c_void_p(), C.c_int64(), C.c_int64(), C.c_int32(), C.c_void_p()
+        self._chk(self.L.cornetto_fasta_split(self.h, addr, n, 1 if final else 0, C.byref(p), C.byref(cnt), C.byref(used), C.byref(plain),
+                                              C.byref(seqs) if want_seqs else None))
+        recs = _take(p, cnt.value, FAREC_DT)
+        res = _Resident(self, seqs, self.L.cornetto_asm_free, recs["len"]) if want_seqs else None
         return recs, used.value, bool(plain.value), res
 
     # ---- telofind / telowin ----------------------------------------------------------------------

@@ -294,6 +294,22 @@ typedef struct cornetto_fqrec {
 int cornetto_fastq_split(cornetto_accel_t *h, const char *text, int64_t n, int final, int32_t min_len, cornetto_fqrec_t **recs,
                          int64_t *n_recs, int64_t *consumed, int32_t *plain, cornetto_asm_t **reads);
 
+/* one FASTA record of the text handed to cornetto_fasta_split() */
+typedef struct cornetto_farec {
+    int64_t head;        /* the record's '>'; the name follows it */
+    int64_t len;         /* bases (kseq_t.seq.l): the payload of every line up to the next '>' line */
+    int32_t name_len;    /* kseq_t.name.l */
+    int32_t pad;
+} cornetto_farec_t;
+
+/* The same for FASTA text (kseq_read in front of telofind / sdust / fa2bed: src/find_telomere.c:101, src/sdust/sdust.c:196):
+ * `text` must begin with the '>' of a record.  Plain here means that no line begins with '@' or '+' (kseq would read
+ * FASTQ there); sequence lines may be wrapped at any width, empty lines and CRLF are handled as kseq does (:138,:202).
+ * Unless `final`, the last record of the piece is never returned (it may go on in the following bytes): `consumed` stops
+ * at its '>'.  seqs (optional): the sequences of the returned records resident in HBM, newlines removed. */
+int cornetto_fasta_split(cornetto_accel_t *h, const char *text, int64_t n, int final, cornetto_farec_t **recs, int64_t *n_recs,
+                         int64_t *consumed, int32_t *plain, cornetto_asm_t **seqs);
+
 /* ---------------------------------------------------------------------------------------------------
  * panel interval stage — scripts/create-cornetto.sh:41-66 without bedtools / sort / awk (parity with bedtools itself
  * is unpinned: see cornetto_amd/csrc/panel.hip)

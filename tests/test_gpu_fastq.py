@@ -238,3 +238,130 @@ def test_cli_sdust_record_larger_than_a_piece_and_truncated_quality(tmp_path):
     open(f, "wb").write(cut)
     rc, out, err = run_cli(["sdust", f])
     assert rc == 0 and out == sdust_text(cut) and out.startswith(b"a\t") and b"c\t" not in out
+
+
+# ---- FASTA framing on the device (cornetto_fasta_split) -------------------------------------------------------------
+def fasta_text(rng, n_rec, width=None, crlf=False, blank=0.0, lowc=0.3):
+    """FASTA with wrapped lines (width None = one line per record), optional CRLF and blank lines"""
+    alpha = np.frombuffer(b"ACGTacgtN", dtype=np.uint8)
+    eol = b"\r\n" if crlf else b"\n"
+    out = []
+    for i in range(n_rec):
+        L = int(rng.choice([0, 1, 59, 60, 61, 120])) if rng.random() < 0.3 else int(rng.integers(1, 3000))
+        s = alpha[rng.integers(0, len(alpha), L)].tobytes()
+        if L > 100 and rng.random() < lowc:
+            a = int(rng.integers(0, L - 60))
+            s = s[:a] + b"TTAGGG" * 10 + s[a + 60:]
+        head = b">ctg%d" % i + (b" len=%d" % L if rng.random() < 0.5 else b"")
+        out.append(head + eol)
+        w = width or max(L, 1)
+        for k in range(0, L, w):
+            out.append(s[k:k + w] + eol)
+            if rng.random() < blank:
+                out.append(eol)
+        if L == 0 and not crlf and rng.random() < 0.5:      # ("\r" alone under an empty record is a base for kseq: not plain)
+            out.append(eol)
+    return b"".join(out)
+
+
+def check_fasta(acc, text, final=True):
+    recs, used, plain, seqs = acc.fasta_split(text, final=final, want_seqs=True)
+    exp, rc = ob.fastx_parse(text)
+    got = [(text[int(r["head"]) + 1:int(r["head"]) + 1 + int(r["name_len"])], int(r["len"])) for r in recs]
+    assert got == [(n, len(s)) for n, _, s, _ in exp[:len(got)]], (text[:120], got[:3], [(n, len(s)) for n, _, s, _ in exp[:3]])
+    # the resident sequences are the records' sequences: telofind + sdust over them equal the oracle's per record
+    iv = acc.sdust(seqs, 20, 64)
+    want = []
+    for i, (_, _, s, _) in enumerate(exp[:len(got)]):
+        for v in ob.sdust(np.frombuffer(s, dtype=np.uint8), 20, 64):
+            want.append((i, int(v) >> 32, int(v) & 0xFFFFFFFF))
+    assert [(int(a), int(b), int(c)) for a, b, c in iv] == want
+    hits = acc.telofind(seqs, b"TTAGGG")
+    wanth = []
+    for i, (_, _, s, _) in enumerate(exp[:len(got)]):
+        oh = ob.telofind(np.frombuffer(s, dtype=np.uint8), b"TTAGGG")
+        wanth += [(i, int(x["strand"]), int(x["start"]), int(x["end"])) for x in oh]
+    assert [tuple(map(int, x)) for x in hits] == wanth
+    seqs.close()
+    rest, rc2 = ob.fastx_parse(text[used:])
+    assert [(n, s) for n, _, s, _ in exp[len(got):]] == [(n, s) for n, _, s, _ in rest]
+    return recs, used, plain, exp
+
+
+def test_fasta_goldens(acc, golden_dir):
+    import gzip
+    for f in ("probe.fa", "probe_sdust.fa", "probe_selfoverlap.fa"):
+        text = open(os.path.join(golden_dir, f), "rb").read()
+        if text[:1] == b">":
+            check_fasta(acc, text)
+    text = gzip.open(os.path.join(golden_dir, "mix.fa.gz")).read()
+    recs, used, plain, exp = check_fasta(acc, text)
+    assert len(recs) > 0
+
+
+def test_fasta_random_layouts(acc):
+    rng = np.random.default_rng(31)
+    for it in range(40):
+        text = fasta_text(rng, int(rng.integers(1, 30)), width=[None, 60, 80, 7, 1][it % 5], crlf=(it % 3 == 0), blank=0.1 if it % 4 == 0 else 0.0)
+        if it % 7 == 0 and text.endswith(b"\n"):
+            text = text[:-1]
+        recs, used, plain, exp = check_fasta(acc, text)
+        assert plain and used == len(text) and len(recs) == len(exp), it
+
+
+def test_fasta_not_plain_and_pieces(acc):
+    rng = np.random.default_rng(32)
+    text = fasta_text(rng, 10, width=60)
+    # a FASTQ record in the middle: everything before it is FASTA, the device stops at the record the '@' line follows
+    mixed = text + b"@r1\nACGT\n+\nIIII\n" + fasta_text(rng, 3, width=60)
+    recs, used, plain, exp = check_fasta(acc, mixed)
+    assert not plain and len(recs) == 9
+    # "\r"-only first sequence line: kseq keeps it as a base
+    odd = b">a\nACGT\n>b\n\r\nAC\r\n>c\nGG\n"
+    recs, used, plain, exp = check_fasta(acc, odd)
+    assert not plain and len(recs) == 1
+    # does not begin with '>'
+    recs, used, plain, _ = acc.fasta_split(b"\n>a\nACGT\n")
+    assert len(recs) == 0 and used == 0 and not plain
+    # pieces: the last record of a piece that is not the last is left for the next call
+    text = fasta_text(rng, 200, width=80)
+    exp, rc = ob.fastx_parse(text)
+    for piece in (1 << 20, 20000, 9000):
+        got, pos, pend = [], 0, b""
+        while True:
+            chunk = text[pos:pos + piece]
+            pos += len(chunk)
+            final = pos >= len(text)
+            buf = pend + chunk
+            recs, used, plain, _ = acc.fasta_split(buf, final=final)
+            assert plain
+            got += [(buf[int(r["head"]) + 1:int(r["head"]) + 1 + int(r["name_len"])], int(r["len"])) for r in recs]
+            pend = buf[used:]
+            if final:
+                break
+        assert pend == b"" and got == [(n, len(s)) for n, _, s, _ in exp], piece
+
+
+def test_fasta_large_wrapped(acc):
+    """200 Mbases in 80-column lines: lengths and sampled content against numpy"""
+    rng = np.random.default_rng(33)
+    lens = [120_000_001, 60_000_000, 19_999_999, 80, 0, 1]
+    parts, seqs = [], []
+    for i, L in enumerate(lens):
+        s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, L, dtype=np.uint8)]
+        seqs.append(s)
+        k = L // 80 * 80
+        m = np.empty((k // 80, 81), dtype=np.uint8)
+        m[:, :80] = s[:k].reshape(-1, 80)
+        m[:, 80] = 10
+        parts += [b">c%d x\n" % i, m.tobytes(), s[k:].tobytes() + (b"\n" if L > k else b"")]
+    text = b"".join(parts)
+    recs, used, plain, res = acc.fasta_split(text, final=True, want_seqs=True)
+    assert plain and used == len(text) and [int(x) for x in recs["len"]] == lens
+    hits = acc.telofind(res, b"TTAGGG")
+    for i in (0, 2, 3):
+        oh = ob.telofind(seqs[i][:2_000_000], b"TTAGGG")
+        g = hits[(hits["ctg"] == i) & (hits["end"] <= 2_000_000 - 6)]
+        w = oh[oh["end"] <= 2_000_000 - 6]
+        assert [(int(x["strand"]), int(x["start"]), int(x["end"])) for x in g] == [(int(x["strand"]), int(x["start"]), int(x["end"])) for x in w]
+    res.close()

@@ -5,6 +5,7 @@
 #include <getopt.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include "cli.h"
@@ -50,86 +51,89 @@ static void batches_of(cli_fastx_t *fx, cornetto_accel_t *h_open, batch_fn fn, v
     cli_fastx_close(fx);
 }
 
-static void for_each_batch(const char *path, int must_open, batch_fn fn, void *arg)
-{
-    cli_fastx_t *fx = cli_fastx_open(path);
-    if (!fx) {
-        if (must_open) {
-            CLI_ERROR("Failed to open %s : No such file or directory.", path);   /* F_CHK, src/error.h:114-119 */
-            exit(EXIT_FAILURE);
-        }
-        return; /* sdust: the reference has no NULL check (src/sdust/sdust.c:194) and crashes; we just stop */
-    }
-    batches_of(fx, NULL, fn, arg);
-}
+/* ---------------------------------------------------------------- records on the device */
+/* a record as the scans need it: its name (not NUL-terminated when it points into a file piece) and length */
+typedef struct {
+    const char *name;
+    int32_t name_len;
+    int64_t len;
+} cli_recname_t;
+
+/* scan the resident sequences `a` (record i of it = r[i]) and print the sub-command's lines */
+typedef void (*scan_fn)(cornetto_accel_t *h, const cli_recname_t *r, int64_t n, const cornetto_asm_t *a, void *arg);
 
 /* ---------------------------------------------------------------- telofind */
-static void telofind_batch(cornetto_accel_t *h, cli_batch_t *b, void *arg)
+static void telofind_scan(cornetto_accel_t *h, const cli_recname_t *r, int64_t n_rec, const cornetto_asm_t *a, void *arg)
 {
-    const char *motif = (const char *)arg;
-    cornetto_asm_t *a = NULL;
-    cli_accel_check(h, cornetto_asm_upload(h, (const uint8_t *const *)b->seqs, b->lens, b->n, &a), "copying sequences to the GPU");
+    (void)n_rec;
     cornetto_hit_t *hits = NULL;
     int64_t n = 0;
-    cli_accel_check(h, cornetto_telofind(h, a, motif, &hits, &n), "telofind");
-    for (int64_t i = 0; i < n; ++i)   /* src/find_telomere.c:51,56 */
-        printf("%s\t%zu\t%d\t%zu\t%zu\t%zu\n", b->names[hits[i].ctg], (size_t)b->lens[hits[i].ctg], hits[i].strand,
-               (size_t)hits[i].start, (size_t)hits[i].end, (size_t)(hits[i].end - hits[i].start));
+    cli_accel_check(h, cornetto_telofind(h, a, (const char *)arg, &hits, &n), "telofind");
+    for (int64_t i = 0; i < n; ++i) { /* src/find_telomere.c:51,56 */
+        const cli_recname_t *c = &r[hits[i].ctg];
+        fwrite(c->name, 1, (size_t)c->name_len, stdout);
+        printf("\t%zu\t%d\t%zu\t%zu\t%zu\n", (size_t)c->len, hits[i].strand, (size_t)hits[i].start, (size_t)hits[i].end,
+               (size_t)(hits[i].end - hits[i].start));
+    }
     cornetto_free(hits);
-    cornetto_asm_free(h, a);
 }
 
-int find_telomere_main(int argc, char *argv[])
-{
-    if (argc < 2) { /* src/find_telomere.c:84-88 */
-        fprintf(stderr, "Error: invalid number of parameters\n");
-        fprintf(stderr, "Usage: find <input fasta> [optional sequence to search for, default is vertebrate TTAGGG]\n");
-        exit(EXIT_FAILURE);
-    }
-    const char *motif = argc >= 3 ? argv[2] : "TTAGGG";
-    if (motif[0] == 0) {
-        CLI_ERROR("%s", "empty search sequence");
-        exit(EXIT_FAILURE);
-    }
-    for_each_batch(argv[1], 1, telofind_batch, (void *)motif);
-    return EXIT_SUCCESS;
-}
+static void sdust_scan(cornetto_accel_t *h, const cli_recname_t *r, int64_t n_rec, const cornetto_asm_t *a, void *arg);
 
-/* ---------------------------------------------------------------- sdust */
+/* a batch of the sequential reader: upload, then the same scan */
 typedef struct {
-    int W, T;
-} sdust_opt_t;
+    scan_fn scan;
+    void *arg;
+} batch_scan_t;
 
-static void sdust_batch(cornetto_accel_t *h, cli_batch_t *b, void *arg)
+static void scan_batch(cornetto_accel_t *h, cli_batch_t *b, void *arg)
 {
-    const sdust_opt_t *o = (const sdust_opt_t *)arg;
+    const batch_scan_t *bs = (const batch_scan_t *)arg;
     cornetto_asm_t *a = NULL;
     cli_accel_check(h, cornetto_asm_upload(h, (const uint8_t *const *)b->seqs, b->lens, b->n, &a), "copying sequences to the GPU");
-    cornetto_ivl_t *iv = NULL;
-    int64_t n = 0;
-    cli_accel_check(h, cornetto_sdust_asm(h, a, o->T, o->W, &iv, &n), "sdust");
-    for (int64_t i = 0; i < n; ++i) printf("%s\t%d\t%d\n", b->names[iv[i].ctg], iv[i].start, iv[i].finish);   /* :201 */
-    cornetto_free(iv);
+    cli_recname_t *r = (cli_recname_t *)cli_xmalloc(((size_t)b->n + 1) * sizeof(*r));
+    for (int32_t i = 0; i < b->n; ++i) {
+        r[i].name = b->names[i];
+        r[i].name_len = (int32_t)strlen(b->names[i]);
+        r[i].len = b->lens[i];
+    }
+    bs->scan(h, r, b->n, a, bs->arg);
+    free(r);
     cornetto_asm_free(h, a);
 }
 
-/* FASTQ reads (docs/protocol.md:185 pipes `cornetto seq` output here): the file goes to the device in pieces as it is,
- * cornetto_fastq_split() frames the plain four-line records and lays their bases out for the scan, names are printed
- * straight from the piece.  Anything else — FASTA, wrapped records, stray lines, the reference's error cases — is read
- * by the sequential reader from the first byte the device was not sure about, so the output is kseq's either way. */
-static int64_t fastq_piece_bytes(void)
+/* FASTA / FASTQ file -> scans, with the records framed on the device wherever the text is plain (cornetto_fasta_split,
+ * cornetto_fastq_split): the file goes to the device in pieces as it is, names are printed straight from the piece.
+ * Anything else — wrapped FASTQ, stray lines, a FASTQ record inside a FASTA file, the reference's error cases — is read
+ * by the sequential reader (cli/fastx.c) from the first byte the device was not sure about: the output is kseq's either
+ * way.  CORNETTO_FASTQ_PIECE = bytes per piece; CORNETTO_FASTQ_SPLIT=host = sequential reader only. */
+static int64_t piece_bytes(int fasta, const char *path, gzFile fp)
 {
     const char *e = getenv("CORNETTO_FASTQ_PIECE");
     int64_t v = e ? atoll(e) : 0;
-    if (v < 64) v = 256LL << 20;
+    if (v < 64) {
+        v = 256LL << 20;
+        if (fasta) { /* a record must fit into a piece: the whole file at once when its size is known; else grown on demand */
+            struct stat st;
+            v = 64LL << 20;
+            if (strcmp(path, "-") && gzdirect(fp) && stat(path, &st) == 0 && S_ISREG(st.st_mode)) v = (int64_t)st.st_size + 16;
+            if (v > (1LL << 30)) v = 1LL << 30;
+        }
+    }
     if (v > 0xF0000000LL) v = 0xF0000000LL;
     return v;
 }
 
-static void sdust_stream(const char *path, const sdust_opt_t *o)
+static void stream_records(const char *path, int must_open, scan_fn scan, void *arg)
 {
     gzFile fp = strcmp(path, "-") ? gzopen(path, "r") : gzdopen(fileno(stdin), "r");
-    if (!fp) return; /* the reference has no NULL check (src/sdust/sdust.c:194) and crashes; we just stop */
+    if (!fp) {
+        if (must_open) {
+            CLI_ERROR("Failed to open %s : No such file or directory.", path); /* F_CHK, src/error.h:114-119 */
+            exit(EXIT_FAILURE);
+        }
+        return; /* sdust: the reference has no NULL check (src/sdust/sdust.c:194) and crashes; we just stop */
+    }
     gzbuffer(fp, 1 << 18);
     cornetto_accel_t *h = NULL;
     char first = 0, *buf = &first;
@@ -138,12 +142,15 @@ static void sdust_stream(const char *path, const sdust_opt_t *o)
     const int r0 = gzread(fp, &first, 1);
     if (r0 == 1) have = 1;
     else eof = 1;
-    const char *how = getenv("CORNETTO_FASTQ_SPLIT"); /* "host": sequential reader only (for comparisons) */
-    if (have && first == '@' && !(how && !strcmp(how, "host"))) { /* a file that does not begin with '@' is not FASTQ: sequential reader from byte 0 */
-        const int64_t piece = fastq_piece_bytes();
-        h = cli_accel_open();
+    const char *how = getenv("CORNETTO_FASTQ_SPLIT");
+    if (have && (first == '@' || first == '>') && !(how && !strcmp(how, "host"))) {
+        const int fasta = first == '>';
+        int64_t piece = piece_bytes(fasta, path, fp);
+        const int64_t piece_max = getenv("CORNETTO_FASTQ_PIECE") ? piece : 0xF0000000LL;
+        cli_accel_open_begin();
         buf = (char *)cornetto_pinned_alloc((size_t)piece);
         if (!buf) {
+            h = cli_accel_open_end(); /* no usable device: its message and exit(EXIT_FAILURE) */
             CLI_ERROR("could not allocate a %lld-byte pinned read buffer", (long long)piece);
             exit(EXIT_FAILURE);
         }
@@ -165,39 +172,95 @@ static void sdust_stream(const char *path, const sdust_opt_t *o)
                 if (r < want) eof = 1;
             }
             if (have == 0) break;
-            cornetto_fqrec_t *recs = NULL;
-            cornetto_asm_t *reads = NULL;
+            if (!h) h = cli_accel_open_end();
+            cornetto_asm_t *a = NULL;
+            cli_recname_t *r = NULL;
             int64_t n = 0, used = 0;
             int32_t plain = 1;
-            cli_accel_check(h, cornetto_fastq_split(h, buf, have, eof, 0, &recs, &n, &used, &plain, &reads), "framing the FASTQ records");
-            if (n) {
-                cornetto_ivl_t *iv = NULL;
-                int64_t n_iv = 0;
-                cli_accel_check(h, cornetto_sdust_asm(h, reads, o->T, o->W, &iv, &n_iv), "sdust");
-                for (int64_t i = 0; i < n_iv; ++i) { /* src/sdust/sdust.c:201 */
-                    const cornetto_fqrec_t *r = &recs[iv[i].ctg];
-                    fwrite(buf + r->head + 1, 1, (size_t)r->name_len, stdout);
-                    printf("\t%d\t%d\n", iv[i].start, iv[i].finish);
+            if (fasta) {
+                cornetto_farec_t *recs = NULL;
+                cli_accel_check(h, cornetto_fasta_split(h, buf, have, eof, &recs, &n, &used, &plain, &a), "framing the FASTA records");
+                r = (cli_recname_t *)cli_xmalloc(((size_t)n + 1) * sizeof(*r));
+                for (int64_t i = 0; i < n; ++i) {
+                    r[i].name = buf + recs[i].head + 1;
+                    r[i].name_len = recs[i].name_len;
+                    r[i].len = recs[i].len;
                 }
-                cornetto_free(iv);
+                cornetto_free(recs);
+            } else {
+                cornetto_fqrec_t *recs = NULL;
+                cli_accel_check(h, cornetto_fastq_split(h, buf, have, eof, 0, &recs, &n, &used, &plain, &a), "framing the FASTQ records");
+                r = (cli_recname_t *)cli_xmalloc(((size_t)n + 1) * sizeof(*r));
+                for (int64_t i = 0; i < n; ++i) {
+                    r[i].name = buf + recs[i].head + 1;
+                    r[i].name_len = recs[i].name_len;
+                    r[i].len = recs[i].len;
+                }
+                cornetto_free(recs);
             }
-            cornetto_asm_free(h, reads);
-            cornetto_free(recs);
+            if (n) scan(h, r, n, a, arg);
+            free(r);
+            cornetto_asm_free(h, a);
             start = used;
-            if (!plain || eof) break;                  /* not plain from buf + start on / the input is finished */
-            if (used == 0 && have == piece) break;     /* one record larger than a piece */
+            if (!plain || eof) break;              /* not plain from buf + start on / the input is finished */
+            if (used == 0 && have == piece) { /* one record larger than the piece: a larger one, as long as the index allows */
+                if (piece >= piece_max) break;
+                const int64_t bigger = piece * 2 > piece_max ? piece_max : piece * 2;
+                char *nb = (char *)cornetto_pinned_alloc((size_t)bigger);
+                if (!nb) break;
+                memcpy(nb, buf, (size_t)have);
+                cornetto_pinned_free(buf);
+                buf = nb;
+                piece = bigger;
+            }
         }
+        if (!h) h = cli_accel_open_end();
     }
     if (start < have || !eof) { /* the rest (or all of it) through the sequential reader */
+        batch_scan_t bs = {scan, arg};
         cli_fastx_t *fx = cli_fastx_open_prefixed(fp, buf + start, (size_t)(have - start));
-        batches_of(fx, h, sdust_batch, (void *)o);
+        batches_of(fx, h, scan_batch, &bs);
     } else {
         gzclose(fp);
     }
-    if (h) {
-        cornetto_pinned_free(buf);
-        cornetto_accel_close(h);
+    if (buf != &first) cornetto_pinned_free(buf);
+    if (h) cornetto_accel_close(h);
+}
+
+int find_telomere_main(int argc, char *argv[])
+{
+    if (argc < 2) { /* src/find_telomere.c:84-88 */
+        fprintf(stderr, "Error: invalid number of parameters\n");
+        fprintf(stderr, "Usage: find <input fasta> [optional sequence to search for, default is vertebrate TTAGGG]\n");
+        exit(EXIT_FAILURE);
     }
+    const char *motif = argc >= 3 ? argv[2] : "TTAGGG";
+    if (motif[0] == 0) {
+        CLI_ERROR("%s", "empty search sequence");
+        exit(EXIT_FAILURE);
+    }
+    stream_records(argv[1], 1, telofind_scan, (void *)motif);
+    return EXIT_SUCCESS;
+}
+
+/* ---------------------------------------------------------------- sdust */
+typedef struct {
+    int W, T;
+} sdust_opt_t;
+
+static void sdust_scan(cornetto_accel_t *h, const cli_recname_t *r, int64_t n_rec, const cornetto_asm_t *a, void *arg)
+{
+    (void)n_rec;
+    const sdust_opt_t *o = (const sdust_opt_t *)arg;
+    cornetto_ivl_t *iv = NULL;
+    int64_t n = 0;
+    cli_accel_check(h, cornetto_sdust_asm(h, a, o->T, o->W, &iv, &n), "sdust");
+    for (int64_t i = 0; i < n; ++i) { /* src/sdust/sdust.c:201 */
+        const cli_recname_t *c = &r[iv[i].ctg];
+        fwrite(c->name, 1, (size_t)c->name_len, stdout);
+        printf("\t%d\t%d\n", iv[i].start, iv[i].finish);
+    }
+    cornetto_free(iv);
 }
 
 int sdust_main(int argc, char *argv[])
@@ -214,7 +277,7 @@ int sdust_main(int argc, char *argv[])
         fprintf(stderr, "Usage: sdust [-w %d] [-t %d] <in.fa>\n", o.W, o.T);
         exit(1);
     }
-    sdust_stream(argv[optind], &o);
+    stream_records(argv[optind], 0, sdust_scan, &o);
     return 0;
 }
 

@@ -365,3 +365,34 @@ def test_fasta_large_wrapped(acc):
         w = oh[oh["end"] <= 2_000_000 - 6]
         assert [(int(x["strand"]), int(x["start"]), int(x["end"])) for x in g] == [(int(x["strand"]), int(x["start"]), int(x["end"])) for x in w]
     res.close()
+
+
+@pytest.mark.parametrize("piece", [None, "300", "5000", "70000"])
+def test_cli_fasta_goldens_any_piece_size(golden_dir, piece):
+    """telofind / sdust over FASTA framed on the device (tiny pieces: growth is off, so records that do not fit go to the
+    sequential reader) against the reference's stdout"""
+    env = {"CORNETTO_FASTQ_PIECE": piece} if piece else None
+    for args, exp in ((["sdust", "mix.fa.gz"], "mix.sdust.exp"), (["telofind", "mix.fa.gz"], "mix.telofind.exp"),
+                      (["sdust", "probe.fa"], "probe.sdust.exp"), (["telofind", "probe.fa"], "probe.telofind.exp"),
+                      (["telofind", "mix.fa.gz", "TTAGGGTTAGGG"], "mix.k12.telofind.exp"), (["sdust", "-w", "32", "-t", "10", "mix.fa.gz"], "mix.w32t10.sdust.exp")):
+        a = [os.path.join(golden_dir, x) if os.path.exists(os.path.join(golden_dir, x)) else x for x in args]
+        rc, out, err = run_cli(a, env=env)
+        assert rc == 0, err.decode()
+        assert out == open(os.path.join(golden_dir, exp), "rb").read(), (args, piece)
+
+
+def test_cli_fasta_then_fastq_in_one_file_and_stdin(tmp_path):
+    rng = np.random.default_rng(41)
+    text = fasta_text(rng, 12, width=60) + lowcomplex_fastx(rng, 10, True) + b"\n" + fasta_text(rng, 5, width=None, crlf=True)
+    f = str(tmp_path / "mixed.fa")
+    open(f, "wb").write(text)
+    want = sdust_text(text)
+    assert len(want) > 100
+    for piece in ("2000", None):
+        env = {"CORNETTO_FASTQ_PIECE": piece} if piece else None
+        rc, out, err = run_cli(["sdust", f], env=env)
+        assert rc == 0 and out == want, piece
+        rc, out, err = run_cli(["sdust", "-"], data=text, env=env)
+        assert rc == 0 and out == want, piece
+    rc, out, err = run_cli(["sdust", f], env={"CORNETTO_FASTQ_SPLIT": "host"})
+    assert rc == 0 and out == want

@@ -15,4 +15,5 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_ou
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/tools/perf_probe.py all --mbases 3160 --features 0 --reps 1 --simple-cov 1 > $R/gpurun_out/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/tools/perf_probe.py all --mbases 3160 --features 0 --reps 1 --simple-cov 1 > $R/gpurun_out/pmc_write.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_fastq -- python3 $R/tools/perf_fastq.py --mbases 1000 --read-len 10000 --reps 3 > $R/gpurun_out/fastq_prof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_fasta -- python3 $R/tools/perf_fasta.py --width 80 --reps 3 > $R/gpurun_out/fasta_prof.log 2>&1
 tail -2 $R/gpurun_out/bgin_prof.log

@@ -198,7 +198,10 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
     if (have && (first == '@' || first == '>') && !(how && !strcmp(how, "host"))) {
         const int fasta = first == '>';
         int64_t piece = piece_bytes(fasta, path, fp);
-        const int64_t piece_max = getenv("CORNETTO_FASTQ_PIECE") ? piece : 0xF0000000LL;
+        /* a piece size given by hand is kept (tests: records that do not fit go to the sequential reader) unless
+         * CORNETTO_FASTQ_GROW=1 asks for the growth path as well */
+        const char *grow = getenv("CORNETTO_FASTQ_GROW");
+        const int64_t piece_max = getenv("CORNETTO_FASTQ_PIECE") && !(grow && atoi(grow)) ? piece : 0xF0000000LL;
         /* uncompressed regular file: its bytes are the stream's bytes, read them with pread() from here on */
         int raw_fd = -1;
         int64_t raw_off = 1; /* the first byte is in `first` */

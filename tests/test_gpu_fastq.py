@@ -396,3 +396,10 @@ def test_cli_fasta_then_fastq_in_one_file_and_stdin(tmp_path):
         assert rc == 0 and out == want, piece
     rc, out, err = run_cli(["sdust", f], env={"CORNETTO_FASTQ_SPLIT": "host"})
     assert rc == 0 and out == want
+
+
+def test_cli_pieces_grow_until_the_largest_record_fits(golden_dir):
+    env = {"CORNETTO_FASTQ_PIECE": "128", "CORNETTO_FASTQ_GROW": "1"}
+    for args, exp in ((["sdust", "mix.fa.gz"], "mix.sdust.exp"), (["telofind", "probe.fa"], "probe.telofind.exp"), (["sdust", "reads.fq"], "reads.sdust.exp")):
+        rc, out, err = run_cli([args[0], os.path.join(golden_dir, args[1])], env=env)
+        assert rc == 0 and out == open(os.path.join(golden_dir, exp), "rb").read(), args

@@ -414,3 +414,27 @@ def test_bedgraph_ingest_errors(acc, golden_dir):
     assert kind([flat_t], [flat_q]) == (0, -1)
     assert kind([b""], [b""]) == (0, -1)
     assert kind([b"\n\n  \n"], [b""]) == (0, -1)
+
+
+def test_timing_levels(acc):
+    """cornetto_accel_set_timing: which launches carry HIP event pairs (results never depend on it)"""
+    rng = np.random.default_rng(3)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 200000)]
+    asm = acc.asm_upload([seq])
+    try:
+        acc.set_timing(2)
+        ref = acc.sdust(asm, 20, 64)
+        names2 = {n for n, _ in acc.last_timing()}
+        acc.set_timing(1)
+        one = acc.sdust(asm, 20, 64)
+        names1 = {n for n, _ in acc.last_timing()}
+        acc.set_timing(0)
+        zero = acc.sdust(asm, 20, 64)
+        names0 = {n for n, _ in acc.last_timing()}
+    finally:
+        acc.set_timing(2)
+        asm.close()
+    assert np.array_equal(ref, one) and np.array_equal(ref, zero)
+    assert names0 == set() and names1 == {"sdust_kernel"} and "sdust_prep" in names2 and "sdust_kernel" in names2
+    with pytest.raises(Exception):
+        acc.set_timing(3)

@@ -342,18 +342,33 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
     int64_t k = 0;
     for (int32_t i = 0; i < n_ctg; ++i) {
         const char *name = names[i];
+        const size_t name_l = strlen(name);
         const int len = lens[i];
         if (!boring) {
             if (len < opt.min_ctg_len) {
+                cli_out_flush();
                 printf("%s\t%d\t%d\t.\t.\n", name, 0, opt.min_ctg_len); /* :430 prints min_ctg_len, not len */
             } else {
+                cli_out_flush();
                 printf("%s\t%d\t%d\t.\t.\n", name, 0, opt.edge_len);
                 printf("%s\t%d\t%d\t.\t.\n", name, len - opt.edge_len, len);
             }
         }
         for (; k < n_recs && recs[k].ctg == i; ++k)
-            printf("%s\t%d\t%d\t%d\t%d\n", name, recs[k].st, recs[k].end, recs[k].depth, recs[k].mq_depth);
+            { /* name, st, end, depth, mq_depth: :441 / :475 */
+                cli_out_bytes(name, name_l);
+                cli_out_char('\t');
+                cli_out_int(recs[k].st);
+                cli_out_char('\t');
+                cli_out_int(recs[k].end);
+                cli_out_char('\t');
+                cli_out_int(recs[k].depth);
+                cli_out_char('\t');
+                cli_out_int(recs[k].mq_depth);
+                cli_out_char('\n');
+            }
     }
+    cli_out_flush();
     CLI_VERBOSE("Printed the bits in %.2f seconds", cli_realtime() - t0);
     cornetto_free(recs);
     for (int32_t i = 0; i < n_ctg; ++i) free(names[i]);

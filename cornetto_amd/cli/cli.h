@@ -56,6 +56,46 @@ void cli_accel_open_cancel(void);
 /* print the handle's last error and exit(EXIT_FAILURE) if rc != 0 */
 void cli_accel_check(cornetto_accel_t *h, int rc, const char *what);
 
+/* ---- record lines on stdout: a plain buffer + decimal formatter (printf costs ~200 ns per field; the window lists have
+ * millions of lines).  Goes through stdout's FILE, so it may be mixed with printf as long as cli_out_flush() comes first. */
+extern char *cli_out_buf;
+extern size_t cli_out_n;
+#define CLI_OUT_CAP (1u << 22)
+void cli_out_flush(void);
+static inline void cli_out_room(size_t need)
+{
+    if (cli_out_n + need > CLI_OUT_CAP) cli_out_flush();
+}
+static inline void cli_out_bytes(const char *s, size_t n)
+{
+    if (n > CLI_OUT_CAP / 2) {
+        cli_out_flush();
+        fwrite(s, 1, n, stdout);
+        return;
+    }
+    cli_out_room(n);
+    for (size_t i = 0; i < n; ++i) cli_out_buf[cli_out_n + i] = s[i];
+    cli_out_n += n;
+}
+static inline void cli_out_char(char c)
+{
+    cli_out_room(1);
+    cli_out_buf[cli_out_n++] = c;
+}
+static inline void cli_out_int(long long v) /* %lld */
+{
+    char t[24];
+    int k = 0;
+    unsigned long long u = v < 0 ? 0ULL - (unsigned long long)v : (unsigned long long)v;
+    do {
+        t[k++] = (char)('0' + u % 10);
+        u /= 10;
+    } while (u);
+    cli_out_room(24);
+    if (v < 0) cli_out_buf[cli_out_n++] = '-';
+    while (k) cli_out_buf[cli_out_n++] = t[--k];
+}
+
 /* ---- FASTA/FASTQ(+gz) records with the framing rules of klib kseq (src/kseq.h:184-224) ---- */
 typedef struct {
     char *s;

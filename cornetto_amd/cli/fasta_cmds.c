@@ -74,10 +74,20 @@ static void telofind_scan(cornetto_accel_t *h, const cli_recname_t *r, int64_t n
     cli_accel_check(h, cornetto_telofind(h, a, (const char *)arg, &hits, &n), "telofind");
     for (int64_t i = 0; i < n; ++i) { /* src/find_telomere.c:51,56 */
         const cli_recname_t *c = &r[hits[i].ctg];
-        fwrite(c->name, 1, (size_t)c->name_len, stdout);
-        printf("\t%zu\t%d\t%zu\t%zu\t%zu\n", (size_t)c->len, hits[i].strand, (size_t)hits[i].start, (size_t)hits[i].end,
-               (size_t)(hits[i].end - hits[i].start));
+        cli_out_bytes(c->name, (size_t)c->name_len);   /* "%s\t%zu\t%d\t%zu\t%zu\t%zu\n" */
+        cli_out_char('\t');
+        cli_out_int(c->len);
+        cli_out_char('\t');
+        cli_out_int(hits[i].strand);
+        cli_out_char('\t');
+        cli_out_int(hits[i].start);
+        cli_out_char('\t');
+        cli_out_int(hits[i].end);
+        cli_out_char('\t');
+        cli_out_int(hits[i].end - hits[i].start);
+        cli_out_char('\n');
     }
+    cli_out_flush();
     cornetto_free(hits);
 }
 
@@ -330,9 +340,14 @@ static void sdust_scan(cornetto_accel_t *h, const cli_recname_t *r, int64_t n_re
     cli_accel_check(h, cornetto_sdust_asm(h, a, o->T, o->W, &iv, &n), "sdust");
     for (int64_t i = 0; i < n; ++i) { /* src/sdust/sdust.c:201 */
         const cli_recname_t *c = &r[iv[i].ctg];
-        fwrite(c->name, 1, (size_t)c->name_len, stdout);
-        printf("\t%d\t%d\n", iv[i].start, iv[i].finish);
+        cli_out_bytes(c->name, (size_t)c->name_len);   /* "%s\t%d\t%d\n" */
+        cli_out_char('\t');
+        cli_out_int(iv[i].start);
+        cli_out_char('\t');
+        cli_out_int(iv[i].finish);
+        cli_out_char('\n');
     }
+    cli_out_flush();
     cornetto_free(iv);
 }
 

@@ -57,6 +57,16 @@ char *cli_xstrdup(const char *s)
     return d;
 }
 
+static char out_storage[CLI_OUT_CAP + 64];
+char *cli_out_buf = out_storage;
+size_t cli_out_n = 0;
+
+void cli_out_flush(void)
+{
+    if (cli_out_n) fwrite(cli_out_buf, 1, cli_out_n, stdout);
+    cli_out_n = 0;
+}
+
 cornetto_accel_t *cli_accel_open(void)
 {
     const char *d = getenv("CORNETTO_DEVICE");

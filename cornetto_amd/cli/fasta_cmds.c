@@ -186,8 +186,15 @@ static int64_t pread_parallel(int fd, char *dst, int64_t want, int64_t off)
     return total;
 }
 
+#define TRACE(what)                                                                                      \
+    do {                                                                                                 \
+        if (trace) fprintf(stderr, "[cli trace] %-28s %8.1f ms\n", (what), (cli_realtime() - t_begin) * 1e3); \
+    } while (0)
+
 static void stream_records(const char *path, int must_open, scan_fn scan, void *arg)
 {
+    const int trace = getenv("CORNETTO_CLI_TRACE") != NULL;
+    const double t_begin = cli_realtime();
     gzFile fp = strcmp(path, "-") ? gzopen(path, "r") : gzdopen(fileno(stdin), "r");
     if (!fp) {
         if (must_open) {
@@ -227,6 +234,7 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
             exit(EXIT_FAILURE);
         }
         buf[0] = first;
+        TRACE("pinned piece allocated");
         for (;;) {
             if (start) {
                 memmove(buf, buf + start, (size_t)(have - start));
@@ -251,7 +259,9 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
                 if (r < want) eof = 1;
             }
             if (have == 0) break;
+            TRACE("piece read");
             if (!h) h = cli_accel_open_end();
+            TRACE("device open");
             cornetto_asm_t *a = NULL;
             cli_recname_t *r = NULL;
             int64_t n = 0, used = 0;
@@ -277,7 +287,9 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
                 }
                 cornetto_free(recs);
             }
+            TRACE("records framed");
             if (n) scan(h, r, n, a, arg);
+            TRACE("scanned and printed");
             free(r);
             cornetto_asm_free(h, a);
             start = used;
@@ -306,8 +318,10 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
     } else {
         gzclose(fp);
     }
-    if (buf != &first) cornetto_pinned_free(buf);
-    if (h) cornetto_accel_close(h);
+    /* the pinned piece and the device handle are left to the end of the process (main.c leaves with _exit right after
+     * the sub-command): unpinning a 1 GB piece and closing the handle take about 0.1 s */
+    (void)h;
+    TRACE("done");
 }
 
 int find_telomere_main(int argc, char *argv[])

@@ -4,6 +4,7 @@
  * telobreaks) are named in the usage text as not built here and exit with status 1. */
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "cli.h"
 
@@ -70,5 +71,8 @@ int main(int argc, char *argv[])
     for (int i = 0; i < argc; ++i) fprintf(stderr, " %s", argv[i]);
     fprintf(stderr, "\n[%s] Real time: %.3f sec; CPU time: %.3f sec; Peak RAM: %.3f GB\n\n", __func__,
             cli_realtime() - realtime0, cli_cputime(), cli_peakrss() / 1024.0 / 1024.0 / 1024.0);
-    return ret;
+    /* everything is printed: leave without the orderly teardown of the HIP runtime and of gigabytes of pinned memory
+     * (0.1-0.2 s that the kernel does faster) */
+    fflush(NULL);
+    _exit(ret);
 }

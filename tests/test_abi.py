@@ -50,3 +50,17 @@ def test_pure_host_helpers(lib):
     assert lib.cornetto_cov_threshold(1.6, 22) == 35
     assert abs(lib.cornetto_telowin_threshold(0.4, 99.9) - 0.397606) < 1e-6
     assert lib.cornetto_accel_strerror(-5) == b"parameter outside the supported range"
+
+
+def test_documents_name_only_declared_entry_points():
+    """every cornetto_*() call INTEGRATION.md / DESIGN.md / README.md show is an entry point of the header, and the
+    header cites a reference location (file:line) for the units it replaces"""
+    names = set(declared_symbols())
+    for doc in ("INTEGRATION.md", "DESIGN.md", "README.md"):
+        text = open(os.path.join(ROOT, doc)).read()
+        for n in set(re.findall(r"\b(cornetto_[a-z0-9_]+)\s*\(", text)):
+            if n.endswith("_t") or n in ("cornetto_amd",):
+                continue
+            assert n in names, (doc, n)
+    hdr = open(os.path.join(ROOT, "include", "cornetto_accel.h")).read()
+    assert len(re.findall(r"src/[a-z_/]+\.[ch]:\d+", hdr)) >= 25

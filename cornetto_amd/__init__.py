@@ -94,6 +94,9 @@ def lib():
         "cornetto_telo_scan": (C.c_int, [vp, vp, cp, C.c_double, pp, C.POINTER(i64), pp, C.POINTER(i64)]),
         "cornetto_sdust_asm": (C.c_int, [vp, vp, i32, i32, pp, C.POINTER(i64)]),
         "cornetto_sdust": (C.POINTER(C.c_uint64), [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+        "cornetto_sdust_buf_init": (vp, [vp]),
+        "cornetto_sdust_buf_destroy": (None, [vp]),
+        "cornetto_sdust_core": (C.POINTER(C.c_uint64), [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), vp]),
         "cornetto_cov_upload": (C.c_int, [vp, vp, vp, vp, i32, pp]),
         "cornetto_cov_wrap": (C.c_int, [vp, vp, vp, vp, vp, i32, pp]),
         "cornetto_cov_free": (None, [vp, vp]),

@@ -2,6 +2,7 @@
  * only).  Reference: src/find_telomere.c:83-111, src/sdust/sdust.c:179-207, src/assbed.c:50-107,
  * src/seq.c:53-138.  Records are read into a batch (whole assembly, or $CORNETTO_BATCH_BASES bases of
  * reads at a time), scanned by ONE device pass per batch, and printed in input order. */
+#include <errno.h>
 #include <getopt.h>
 #include <stdlib.h>
 #include <fcntl.h>
@@ -144,21 +145,25 @@ typedef struct {
     int fd;
     char *dst;
     int64_t off, want, got;
+    int failed; /* a pread() returned < 0 (EIO, ESTALE ...): not an end of file */
 } pread_job_t;
 
 static void *pread_thread(void *p)
 {
     pread_job_t *j = (pread_job_t *)p;
     j->got = 0;
+    j->failed = 0;
     while (j->got < j->want) {
         const ssize_t r = pread(j->fd, j->dst + j->got, (size_t)(j->want - j->got), (off_t)(j->off + j->got));
-        if (r <= 0) break;
+        if (r < 0 && errno == EINTR) continue;
+        if (r < 0) j->failed = 1;
+        if (r <= 0) break; /* r == 0: end of the file */
         j->got += r;
     }
     return NULL;
 }
 
-/* bytes read at file offset `off` (short only at the end of the file or on an error) */
+/* bytes read at file offset `off` (short only at the end of the file); -1 when a read failed */
 static int64_t pread_parallel(int fd, char *dst, int64_t want, int64_t off)
 {
     pread_job_t job[READ_THREADS];
@@ -181,6 +186,7 @@ static int64_t pread_parallel(int fd, char *dst, int64_t want, int64_t off)
     for (int i = 0; i < nj; ++i) {
         if (started[i]) pthread_join(th[i], NULL);
         if (open_end) total += job[i].got;
+        if (open_end && job[i].failed) return -1; /* an error inside the bytes that count, not behind the end of the file */
         if (job[i].got < job[i].want) open_end = 0;
     }
     return total;
@@ -244,6 +250,10 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
             if (raw_fd >= 0 && have < piece && !eof) {
                 const int64_t want = piece - have;
                 const int64_t r = pread_parallel(raw_fd, buf + have, want, raw_off);
+                if (r < 0) {
+                    CLI_ERROR("reading %s failed", path);
+                    exit(EXIT_FAILURE);
+                }
                 have += r;
                 raw_off += r;
                 if (r < want) eof = 1;

@@ -229,12 +229,13 @@ __global__ __launch_bounds__(256) void bg_records(BgArgs A)
 __global__ void bg_layout(const uint16_t *src, const int64_t *src_off, const int64_t *dst_off, const int32_t *len, int32_t n_ctg,
                           uint16_t *dst)
 {
-    const int c = blockIdx.y;
-    if (c >= n_ctg) return;
-    const int64_t n = len[c];
-    const uint16_t *s = src + src_off[c];
-    uint16_t *d = dst + dst_off[c];
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = s[i];
+    // grid.y is limited to 65535: contigs are taken with a grid stride (read-level coverage sets have more)
+    for (int c = blockIdx.y; c < n_ctg; c += gridDim.y) {
+        const int64_t n = len[c];
+        const uint16_t *s = src + src_off[c];
+        uint16_t *d = dst + dst_off[c];
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = s[i];
+    }
 }
 
 }  // namespace
@@ -521,8 +522,8 @@ int cornetto_bgin_finish(cornetto_accel_t *h, cornetto_bgin_t *b, cornetto_cov_t
         if (e == hipSuccess) e = hipMemcpyAsync(c->d_len, c->len.data(), (size_t)nc * 4, hipMemcpyHostToDevice, h->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d_src, src_off.data(), (size_t)nc * 8, hipMemcpyHostToDevice, h->stream);
         if (e == hipSuccess) {
-            bg_layout<<<dim3(64, (unsigned)nc), dim3(256), 0, h->stream>>>(b->d_a, d_src, c->d_off, c->d_len, nc, (uint16_t *)c->owned_d);
-            bg_layout<<<dim3(64, (unsigned)nc), dim3(256), 0, h->stream>>>(b->d_b, d_src, c->d_off, c->d_len, nc, (uint16_t *)c->owned_q);
+            bg_layout<<<dim3(64, (unsigned)std::min<int32_t>(nc, 32768)), dim3(256), 0, h->stream>>>(b->d_a, d_src, c->d_off, c->d_len, nc, (uint16_t *)c->owned_d);
+            bg_layout<<<dim3(64, (unsigned)std::min<int32_t>(nc, 32768)), dim3(256), 0, h->stream>>>(b->d_b, d_src, c->d_off, c->d_len, nc, (uint16_t *)c->owned_q);
             e = hipGetLastError();
         }
     }

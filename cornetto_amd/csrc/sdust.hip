@@ -1278,13 +1278,32 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
     return CORNETTO_OK;
 }
 
-// process-wide handle for the sdust() drop-in
+// process-wide handle for the sdust() / sdust_core() drop-ins
 static cornetto_accel_t *g_handle = nullptr;
 
-uint64_t *cornetto_sdust(void *km, const uint8_t *seq, int l_seq, int T, int W, int *n)
+// = sdust_buf_t (src/sdust/sdust.c:54-59) as far as a caller can see it: the owner of the result array of sdust_core()
+struct cornetto_sdust_buf {
+    uint64_t *res;      // plain malloc / realloc memory (sdust() hands it to a caller who free()s it)
+    int64_t cap;        // entries allocated
+};
+
+cornetto_sdust_buf_t *cornetto_sdust_buf_init(void *km)
+{
+    if (km) return nullptr;                       // kalloc pools are not supported (the reference passes 0: src/sdust/sdust.c:199)
+    return (cornetto_sdust_buf_t *)calloc(1, sizeof(cornetto_sdust_buf));
+}
+
+void cornetto_sdust_buf_destroy(cornetto_sdust_buf_t *buf)
+{
+    if (!buf) return;
+    free(buf->res);
+    free(buf);
+}
+
+const uint64_t *cornetto_sdust_core(const uint8_t *seq, int l_seq, int T, int W, int *n, cornetto_sdust_buf_t *buf)
 {
     if (n) *n = -1;
-    if (km || !seq || !n) return nullptr;
+    if (!seq || !n || !buf) return nullptr;
     if (!g_handle) {
         const char *d = getenv("CORNETTO_DEVICE");
         if (cornetto_accel_open(&g_handle, d ? atoi(d) : 0, nullptr) != CORNETTO_OK) return nullptr;
@@ -1298,13 +1317,30 @@ uint64_t *cornetto_sdust(void *km, const uint8_t *seq, int l_seq, int T, int W, 
     int rc = cornetto_sdust_asm(g_handle, a, T, W, &iv, &ni);
     cornetto_asm_free(g_handle, a);
     if (rc != CORNETTO_OK) return nullptr;
-    uint64_t *r = (uint64_t *)malloc((ni ? ni : 1) * sizeof(uint64_t));
-    if (r) {
-        for (int64_t i = 0; i < ni; ++i) r[i] = (uint64_t)(uint32_t)iv[i].start << 32 | (uint32_t)iv[i].finish;
-        *n = (int)ni;
+    if (ni > buf->cap || !buf->res) {
+        const int64_t cap = ni > 16 ? ni : 16;
+        uint64_t *r = (uint64_t *)realloc(buf->res, (size_t)cap * sizeof(uint64_t));
+        if (!r) { cornetto_free(iv); return nullptr; }
+        buf->res = r;
+        buf->cap = cap;
     }
-    free(iv);
-    return r;
+    for (int64_t i = 0; i < ni; ++i) buf->res[i] = (uint64_t)(uint32_t)iv[i].start << 32 | (uint32_t)iv[i].finish;   // :91
+    cornetto_free(iv);            // library memory (pinned pool for large results): never free()
+    *n = (int)ni;
+    return buf->res;
+}
+
+uint64_t *cornetto_sdust(void *km, const uint8_t *seq, int l_seq, int T, int W, int *n)
+{
+    // src/sdust/sdust.c:162-171: a fresh buf, sdust_core, the result array detached from the buf and handed to the caller
+    if (n) *n = -1;
+    if (km || !seq || !n) return nullptr;
+    cornetto_sdust_buf_t *buf = cornetto_sdust_buf_init(nullptr);
+    if (!buf) return nullptr;
+    uint64_t *ret = const_cast<uint64_t *>(cornetto_sdust_core(seq, l_seq, T, W, n, buf));
+    buf->res = nullptr;
+    cornetto_sdust_buf_destroy(buf);
+    return ret;
 }
 
 }  // extern "C"

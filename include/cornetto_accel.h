@@ -172,6 +172,15 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a, int32_t T, 
  * sets *n = -1 when the device path is unavailable. */
 uint64_t *cornetto_sdust(void *km, const uint8_t *seq, int l_seq, int T, int W, int *n);
 
+/* Drop-ins for the buffered interface of src/sdust/sdust.h:16-21 (`sdust_buf_init`, `sdust_buf_destroy`, `sdust_core`):
+ * the result array belongs to the buf, is valid until the next cornetto_sdust_core() on that buf or its destruction, and
+ * must not be freed by the caller.  km must be NULL.  Same process-wide handle as cornetto_sdust(); NULL and *n = -1
+ * when the device path is unavailable. */
+typedef struct cornetto_sdust_buf cornetto_sdust_buf_t;
+cornetto_sdust_buf_t *cornetto_sdust_buf_init(void *km);
+void cornetto_sdust_buf_destroy(cornetto_sdust_buf_t *buf);
+const uint64_t *cornetto_sdust_core(const uint8_t *seq, int l_seq, int T, int W, int *n, cornetto_sdust_buf_t *buf);
+
 /* ---------------------------------------------------------------------------------------------------
  * (no)boringbits window stage
  * ------------------------------------------------------------------------------------------------- */

@@ -124,11 +124,20 @@ def test_sdust_golden(acc, golden_dir, monkeypatch, fa, T, W, exp, chunk):
     assert gpu_sdust_text(acc, _records(golden_dir, fa), T, W) == golden(golden_dir, exp)
 
 
+def _libc_free():
+    import ctypes as C
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free.restype = None
+    return libc.free
+
+
 def test_sdust_dropin_signature(golden_dir):
-    """cornetto_sdust(): same arguments and ownership as sdust() of src/sdust/sdust.h:19"""
+    """cornetto_sdust(): same arguments and ownership as sdust() of src/sdust/sdust.h:19 (the caller free()s)"""
     import ctypes as C
     import cornetto_amd
     L = cornetto_amd.lib()
+    free = _libc_free()
     recs = _records(golden_dir, "probe_sdust.fa")
     out = []
     for name, _c, seq, _q in recs:
@@ -137,8 +146,83 @@ def test_sdust_dropin_signature(golden_dir):
         r = L.cornetto_sdust(None, C.cast(buf, C.c_void_p), -1, 20, 64, C.byref(n))
         assert n.value >= 0
         out.append(fmt_sdust(name, np.array([r[i] for i in range(n.value)], dtype=np.uint64)))
-        L.cornetto_free(r)
+        free(C.cast(r, C.c_void_p))
     assert b"".join(out) == golden(golden_dir, "probe_sdust.sdust.exp")
+
+
+def _low_complexity_rich(n, seed):
+    """n random bases with a short tandem repeat every ~700 bases: > 1 interval per kb"""
+    rng = np.random.default_rng(seed)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].copy()
+    units = [b"A", b"AT", b"CATTC", b"AAAG", b"TTAGGG", b"GGAAT"]
+    for k, p in enumerate(range(300, n - 400, 700)):
+        u = units[k % len(units)]
+        rep = np.frombuffer(u * (120 // len(u) + 1), dtype=np.uint8)[:60 + (k % 7) * 10]
+        seq[p:p + len(rep)] = rep
+    return seq
+
+
+def _tiled_low_complexity(block, reps, seed):
+    """`reps` copies of one low-complexity-rich block and the intervals the oracle gives for it.  sdust is local (its state
+    is the last W-2 words), and the block borders lie in random sequence, so the intervals of every copy after the first
+    are those of the second copy shifted — the reference itself needs ~1.6 us per base on such input (find_perfect walks P),
+    the oracle is therefore run over two copies only (and that is checked on three)."""
+    one = _low_complexity_rich(block, seed)
+    two = ob.sdust(np.concatenate([one, one]), 20, 64)
+    st, fi = (two >> np.uint64(32)).astype(np.int64), (two & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    assert not np.any((st < block) & (fi > block))                       # nothing straddles the border
+    first = two[st < block]
+    second_s, second_f = st[st >= block] - block, fi[st >= block] - block
+    parts = [first]
+    for k in range(1, reps):
+        parts.append(((second_s + k * block).astype(np.uint64) << np.uint64(32)) | (second_f + k * block).astype(np.uint64))
+    return np.tile(one, reps), np.concatenate(parts)
+
+
+def test_tiled_expectation_holds_on_three_copies():
+    seq, exp = _tiled_low_complexity(300_000, 3, 5)
+    assert np.array_equal(ob.sdust(seq, 20, 64), exp)
+
+
+def test_sdust_dropin_large_result_is_libc_freeable():
+    """One 100 Mb low-complexity-rich sequence through the per-record call shape of src/sdust/sdust.c:199: the interval
+    list (> 1 MiB: the library's pinned result pool inside) comes back as plain malloc memory the caller free()s, and
+    equals the oracle's."""
+    import ctypes as C
+    import cornetto_amd
+    L = cornetto_amd.lib()
+    free = _libc_free()
+    seq, exp = _tiled_low_complexity(2_000_000, 50, 11)
+    n_bases = len(seq)
+    assert len(exp) >= 90_000                      # >= 1 MiB of cornetto_ivl_t before the conversion
+    for _ in range(2):                             # twice: the pool entry of the first call must have been returned
+        n = C.c_int()
+        r = L.cornetto_sdust(None, seq.ctypes.data_as(C.c_void_p), n_bases, 20, 64, C.byref(n))
+        assert n.value == len(exp)
+        got = np.ctypeslib.as_array(r, shape=(n.value,)).copy()
+        free(C.cast(r, C.c_void_p))
+        assert np.array_equal(got, exp)
+
+
+def test_sdust_core_buffered_interface(golden_dir):
+    """cornetto_sdust_buf_init / cornetto_sdust_core / cornetto_sdust_buf_destroy: src/sdust/sdust.h:16-21 — the result
+    belongs to the buf and stays valid until the next call on it"""
+    import ctypes as C
+    import cornetto_amd
+    L = cornetto_amd.lib()
+    recs = _records(golden_dir, "mix.fa.gz")
+    buf = L.cornetto_sdust_buf_init(None)
+    assert buf
+    assert not L.cornetto_sdust_buf_init(C.c_void_p(1))          # kalloc pools: not supported, like km != NULL in cornetto_sdust
+    out = []
+    for name, _c, seq, _q in recs:
+        n = C.c_int()
+        arr = np.frombuffer(seq, dtype=np.uint8)
+        r = L.cornetto_sdust_core(arr.ctypes.data_as(C.c_void_p), len(seq), 20, 64, C.byref(n), buf)
+        assert n.value >= 0 and r
+        out.append(fmt_sdust(name, np.array([r[i] for i in range(n.value)], dtype=np.uint64)))
+    L.cornetto_sdust_buf_destroy(buf)
+    assert b"".join(out) == golden(golden_dir, "mix.sdust.exp")
 
 
 def _rand_seqs(rng, n_seq, kind):

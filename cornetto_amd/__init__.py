@@ -77,6 +77,7 @@ def lib():
         "cornetto_accel_last_timing": (C.c_int, [vp, C.POINTER(cp), C.POINTER(C.c_float), C.c_int]),
         "cornetto_accel_set_share": (C.c_int, [vp, C.c_int]),
         "cornetto_accel_set_timing": (C.c_int, [vp, C.c_int]),
+        "cornetto_accel_sdust_stats": (C.c_int, [vp, C.c_int, vp, C.c_int]),
         "cornetto_cov_select_merged": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_int, C.c_int32, C.c_int32, C.POINTER(vp), C.POINTER(C.c_int64)]),
         "cornetto_ivl_merge": (C.c_int, [vp, vp, C.c_int64, C.c_int32, C.POINTER(vp), C.POINTER(C.c_int64)]),
         "cornetto_panel_defaults": (None, [vp]),
@@ -290,6 +291,28 @@ class Accel:
         p, n = C.c_void_p(), C.c_int64()
         self._chk(self.L.cornetto_sdust_asm(self.h, asm.ptr, T, W, C.byref(p), C.byref(n)))
         return _take(p, n.value, IVL_DT)
+
+    def sdust_stats(self, asm, T=20, W=64):
+        """one extra sdust pass with the counting build of the kernel -> its counters as a dict (see
+        cornetto_accel_sdust_stats() in include/cornetto_accel.h); None for parameters the production kernel does not take"""
+        self.L.cornetto_accel_sdust_stats(self.h, 1, None, 0)
+        try:
+            self.sdust(asm, T, W)
+        finally:
+            out = np.zeros(256, dtype=np.uint64)
+            n = self.L.cornetto_accel_sdust_stats(self.h, 0, out.ctypes.data, 256)
+        s = [int(x) for x in out[:n]]
+        waves = s[254]
+        if not waves or not s[2]:
+            return None
+        hist = []
+        for b in range(32):
+            w = s[16 + 4 * b]
+            if w:
+                hist.append({"ms": [b * 0.5, b * 0.5 + 0.5], "waves": w, "jobs": s[18 + 4 * b], "find_perfect": s[19 + 4 * b], "find_perfect_with_candidates": s[17 + 4 * b]})
+        return {"waves": waves, "chunks": s[255], "chunks_sampled_low_complexity": s[7], "wave_steps": s[2], "find_perfect_calls": s[3],
+                "find_perfect_with_candidates": s[10], "trims": s[4], "wave_ms_avg": round(s[5] / waves / 1e5, 3), "wave_ms_max": round(s[6] / 1e5, 3),
+                "queue_fetch_rounds_per_wave": round(s[11] / waves, 1), "wave_time_histogram": hist}
 
     # ---- panel interval stage ---------------------------------------------------------------------
     def cov_select_merged(self, cov, lo, hi, low_mq, edge_len, min_ctg_len, boring, merge_dist=1000, min_len=30000):

@@ -36,6 +36,8 @@ struct cornetto_accel {
     int sd_slots = 0;   // sdust: waves the device holds at once (occupancy query, cached)
     int sd_cus = 0;
     int share = 100;    // percent of every CU the resident sdust kernel may take (cornetto_accel_set_share)
+    int sd_stats = 0;   // sdust: run the statistics build of the kernel (cornetto_accel_sdust_stats)
+    unsigned long long sd_last[256] = {0};   // its counters from the most recent such run
     int timing = 2;     // event pairs around: 2 every kernel launch, 1 the three streaming / scanning main kernels only, 0 none (cornetto_accel_set_timing)
 };
 

@@ -1135,7 +1135,8 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
         unsigned long long *p_tot = (unsigned long long *)cn_pin(h, PIN_SMALL, 2048);
         if (!d_cnt || !d_tot || !p_tot) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
         uint32_t *d_off = d_cnt + nc, *d_part = d_off + nc;
-        const bool want_stats = env_int("CORNETTO_SDUST_STATS", 0) != 0;
+        const bool env_stats = env_int("CORNETTO_SDUST_STATS", 0) != 0;
+        const bool want_stats = env_stats || h->sd_stats != 0;
         size_t cap = (size_t)std::max<int64_t>(16, chunk / 32);
         cap = (size_t)env_int("CORNETTO_SDUST_CAP", (int)cap);
         if (h->dev[WS_SD_OUT].bytes / (nc * sizeof(uint2)) > cap) cap = h->dev[WS_SD_OUT].bytes / (nc * sizeof(uint2));
@@ -1203,12 +1204,17 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             CN_HIP(h, hipMemcpyAsync(p_tot, d_tot, want_stats ? 2048 : 128, hipMemcpyDeviceToHost, h->stream));
             CN_HIP(h, hipStreamSynchronize(h->stream));
             stamp("main kernel done");
-            if (want_stats)
+            if (want_stats) {
+                memcpy(h->sd_last, p_tot, 2048);
+                h->sd_last[254] = nb;
+                h->sd_last[255] = nc;
+            }
+            if (env_stats)
                 for (int b = 0; b < 32; ++b)
                     if (p_tot[16 + 4 * b])
                         fprintf(stderr, "[sdust stats]   waves that ran %4.1f-%4.1f ms: %6llu, job fetches %llu, find_perfect calls %llu (%llu with candidates)\n", b * 0.5, b * 0.5 + 0.5,
                                 p_tot[16 + 4 * b], p_tot[18 + 4 * b], p_tot[19 + 4 * b], p_tot[17 + 4 * b]);
-            if (want_stats)
+            if (env_stats)
                 fprintf(stderr, "[sdust stats] flagged low-complexity %llu; chunks %zu waves %u wave-steps %llu find_perfect calls %llu (%llu with candidates) trims %llu; wave time avg %.1f us max %.1f us; queue: %.1f fetch rounds and %.1f us per wave\n", p_tot[7], nc, nb,
                         p_tot[2], p_tot[3], p_tot[10], p_tot[4], nb ? (double)p_tot[5] / nb / 100.0 : 0.0, (double)p_tot[6] / 100.0, nb ? (double)p_tot[11] / nb : 0.0, nb ? (double)p_tot[12] / nb / 100.0 : 0.0);
             const uint32_t ovf = (uint32_t)(p_tot[1] & 0xFFFFFFFFull);
@@ -1276,6 +1282,16 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
     *ivls = o;
     *n_ivls = n_out;
     return CORNETTO_OK;
+}
+
+int cornetto_accel_sdust_stats(cornetto_accel_t *h, int enable, uint64_t *out, int cap)
+{
+    if (!h) return CORNETTO_E_ARG;
+    h->sd_stats = enable ? 1 : 0;
+    int n = 0;
+    if (out)
+        for (; n < cap && n < 256; ++n) out[n] = h->sd_last[n];
+    return n;
 }
 
 // process-wide handle for the sdust() / sdust_core() drop-ins

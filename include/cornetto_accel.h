@@ -108,6 +108,15 @@ int cornetto_accel_last_timing(const cornetto_accel_t *h, const char **names, fl
  * Scheduling only: results do not depend on it. */
 int cornetto_accel_set_share(cornetto_accel_t *h, int percent);
 
+/* Statistics of the production sdust kernel (development / bench aid).  `enable` != 0 makes the following
+ * cornetto_sdust_asm() calls on this handle run the counting build of the kernel (a few percent slower); `out`, if not
+ * NULL, receives up to `cap` (<= 256) counters of the most recent such call: [2] wave steps, [3] find_perfect calls,
+ * [4] trims, [5] sum and [6] maximum over the waves of their run time in 10 ns ticks, [7] chunks sampled as low-complexity,
+ * [10] find_perfect calls with candidates, [11] queue fetch rounds, [12] ticks spent fetching, [16 + 4b ...] per 0.5 ms bin b
+ * of wave run time: waves, find_perfect calls with candidates, jobs, find_perfect calls; [254] waves launched, [255] chunks.
+ * Returns the number of counters copied.  Results of sdust do not depend on it. */
+int cornetto_accel_sdust_stats(cornetto_accel_t *h, int enable, uint64_t *out, int cap);
+
 /* Which kernel launches are bracketed by HIP events for cornetto_accel_last_timing(): 2 (default) every launch, 1 only
  * the three main kernels (sdust_kernel, cov_blocks, tf_scan), 0 none.  Every event is a packet of its own on the queue;
  * beside a busy second stream the dozen small launches of a call cost about a millisecond more with level 2. */

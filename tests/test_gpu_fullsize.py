@@ -1,14 +1,15 @@
-"""GPU, at the bench workload's scale (the synthetic HG002-like assembly of bench.py, 1 Gbp here so that the
-test stays under a minute): size-independent properties + oracle spot checks on slices.
+"""GPU, at the bench workload's scale (the synthetic HG002-like assembly of bench.py).
 
-  * sdust: the result is canonical (sorted, disjoint, non-adjacent per contig) and identical for different
-    chunk sizes / chunk-to-lane mappings (the speculative decomposition must not show in the output);
-    small contigs are compared with the oracle in full;
-  * telofind: runs are sorted and disjoint per contig and strand, every planted telomere array is found with
-    its exact extent, small contigs equal the oracle;
-  * coverage windows: device totals equal the exact sums, all windows of small contigs equal the oracle."""
+  * 1 Gbp, EVERY contig against the CPU oracle (all four stages, record for record); the oracle runs on a thread per
+    contig (ctypes releases the GIL);
+  * sdust: canonical form and independence of the chunk decomposition;
+  * a 4.5 Gbp layout whose contigs lie beyond byte offsets 2^31 and 2^32 (u16 coverage: element offsets beyond 2^31),
+    oracle on the contigs that straddle those borders and on the last one;
+  * a satellite-dense assembly (bench.py --profile satellite) against the oracle.
+"""
 import os
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import pytest
@@ -18,35 +19,91 @@ import oracle_bind as ob
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+THREADS = max(1, min(16, (os.cpu_count() or 2) - 1))
 
 
-@pytest.fixture(scope="module")
-def world():
+def _make(lens, seed, profile="uniform", coverage=True):
     import torch
     import bench
     import cornetto_amd
     dev = torch.device("cuda", 0)
-    lens = bench.contig_lengths(1_000_000_000)
-    bases, offs = bench.make_assembly(torch, dev, lens, 7)
-    depth, mq = bench.make_coverage(torch, dev, lens, offs, 7)
+    bases, offs = bench.make_assembly(torch, dev, lens, seed, profile)
+    depth = mq = None
+    if coverage:
+        depth, mq = bench.make_coverage(torch, dev, lens, offs, seed)
     torch.cuda.synchronize()
     acc = cornetto_amd.Accel(0)
     asm = acc.asm_wrap(bases.data_ptr(), offs, np.array(lens, dtype=np.int64))
-    cov = acc.cov_wrap(depth.data_ptr(), mq.data_ptr(), offs, np.array(lens, dtype=np.int32))
-    yield dict(torch=torch, acc=acc, asm=asm, cov=cov, lens=lens, offs=offs, bases=bases, depth=depth, mq=mq)
-    asm.close()
-    cov.close()
-    acc.close()
+    cov = acc.cov_wrap(depth.data_ptr(), mq.data_ptr(), offs, np.array(lens, dtype=np.int32)) if coverage else None
+    return dict(torch=torch, acc=acc, asm=asm, cov=cov, lens=lens, offs=offs, bases=bases, depth=depth, mq=mq)
 
 
-def _small_contigs(lens, limit=400_000, n=6):
-    idx = [i for i, x in enumerate(lens) if x <= limit]
-    return idx[-n:]
+def _close(w):
+    w["asm"].close()
+    if w["cov"] is not None:
+        w["cov"].close()
+    w["acc"].close()
+
+
+@pytest.fixture(scope="module")
+def world():
+    import bench
+    w = _make(bench.contig_lengths(1_000_000_000), 7)
+    yield w
+    _close(w)
+
+
+def _oracle_contig(w, ci, thr, stages):
+    """the oracle's records of contig ci: dict stage -> array"""
+    off, n = int(w["offs"][ci]), int(w["lens"][ci])
+    out = {}
+    seq = w["bases"][off:off + n].cpu().numpy()
+    if "telo" in stages:
+        oh = ob.telofind(seq, b"TTAGGG")
+        out["hits"] = [(int(x["strand"]), int(x["start"]), int(x["end"])) for x in oh]
+        out["wins"] = [(int(x["start"]), int(x["end"]), int(x["car"])) for x in ob.telowin(oh, n, thr)]
+    if "sdust" in stages:
+        out["sdust"] = np.asarray(ob.sdust(seq, 20, 64), dtype=np.uint64)
+    if "cov" in stages:
+        d = w["depth"][off:off + n].cpu().numpy().view(np.uint16)
+        q = w["mq"][off:off + n].cpu().numpy().view(np.uint16)
+        out["regs"] = ob.get_regs(d, q, 2500, 50)
+    return out
+
+
+def _compare_contigs(w, contigs, hits, wins, ivls, thr, stages=("telo", "sdust", "cov")):
+    acc, cov = w["acc"], w["cov"]
+    ob.lib()
+    with ThreadPoolExecutor(THREADS) as ex:
+        futs = {ci: ex.submit(_oracle_contig, w, ci, thr, stages) for ci in contigs}
+        for ci in contigs:
+            exp = futs[ci].result()
+            if "telo" in stages:
+                a, b = np.searchsorted(hits["ctg"], ci, "left"), np.searchsorted(hits["ctg"], ci, "right")
+                assert [(int(x["strand"]), int(x["start"]), int(x["end"])) for x in hits[a:b]] == exp["hits"], ci
+                a, b = np.searchsorted(wins["ctg"], ci, "left"), np.searchsorted(wins["ctg"], ci, "right")
+                assert [(int(x["start"]), int(x["end"]), int(x["car"])) for x in wins[a:b]] == exp["wins"], ci
+            if "sdust" in stages:
+                a, b = np.searchsorted(ivls["ctg"], ci, "left"), np.searchsorted(ivls["ctg"], ci, "right")
+                got = (ivls["start"][a:b].astype(np.uint64) << np.uint64(32)) | ivls["finish"][a:b].astype(np.uint32).astype(np.uint64)
+                assert np.array_equal(got, exp["sdust"]), ci
+            if "cov" in stages:
+                got = acc.cov_regs(cov, ci)
+                assert np.array_equal(got, exp["regs"].astype(got.dtype)), ci
+
+
+def test_every_contig_equals_the_oracle_at_1gbp(world):
+    acc, asm, cov, lens = world["acc"], world["asm"], world["cov"], world["lens"]
+    thr = acc.telowin_threshold(0.4, 99.9)
+    hits, wins = acc.telo_scan(asm, b"TTAGGG", thr)
+    ivls = acc.sdust(asm, 20, 64)
+    acc.cov_prepare(cov, 2500, 50)
+    assert len(hits) > 100000 and len(ivls) > 10000
+    _compare_contigs(world, list(range(len(lens))), hits, wins, ivls, thr)
 
 
 def test_sdust_decomposition_invariance_and_canonical_form(world, monkeypatch):
-    acc, asm, lens = world["acc"], world["asm"], world["lens"]
-    monkeypatch.setenv("CORNETTO_SDUST_CHUNK", "1536")
+    acc, asm = world["acc"], world["asm"]
     a = acc.sdust(asm, 20, 64).copy()
     monkeypatch.setenv("CORNETTO_SDUST_CHUNK", "4096")
     b = acc.sdust(asm, 20, 64).copy()
@@ -61,20 +118,12 @@ def test_sdust_decomposition_invariance_and_canonical_form(world, monkeypatch):
     assert np.all(np.diff(a["ctg"]) >= 0)
     assert np.all(a["start"][1:][same] > a["finish"][:-1][same])
     assert np.all(a["finish"] > a["start"])
-    # oracle on whole small contigs
-    for ci in _small_contigs(lens):
-        off = int(world["offs"][ci])
-        seq = world["bases"][off:off + lens[ci]].cpu().numpy()
-        exp = [(int(r) >> 32, int(r) & 0xFFFFFFFF) for r in ob.sdust(seq, 20, 64)]
-        got = [(int(x["start"]), int(x["finish"])) for x in a[a["ctg"] == ci]]
-        assert got == exp, ci
 
 
 def test_telofind_properties_and_planted_arrays(world):
     acc, asm, lens = world["acc"], world["asm"], world["lens"]
     thr = acc.telowin_threshold(0.4, 99.9)
     hits, wins = acc.telo_scan(asm, b"TTAGGG", thr)
-    assert len(hits) > 100000
     key = hits["ctg"].astype(np.int64) * 2 + hits["strand"]
     assert np.all(np.diff(key) >= 0)                                    # contig, then strand 0 before strand 1
     same = key[1:] == key[:-1]
@@ -90,19 +139,9 @@ def test_telofind_properties_and_planted_arrays(world):
         assert (n - 9000, n) in {(int(x["start"]), int(x["end"])) for x in fwd}, ci       # TTAGGG x 1500 at the end
         w = wins[wins["ctg"] == ci]
         assert len(w) > 0 and int(w["start"][0]) == 0
-    for ci in _small_contigs(lens):
-        off = int(world["offs"][ci])
-        seq = world["bases"][off:off + lens[ci]].cpu().numpy()
-        oh = ob.telofind(seq, b"TTAGGG")
-        exp = [(int(x["strand"]), int(x["start"]), int(x["end"])) for x in oh]
-        got = [(int(x["strand"]), int(x["start"]), int(x["end"])) for x in hits[hits["ctg"] == ci]]
-        assert got == exp, ci
-        ew = [(int(x["start"]), int(x["end"]), int(x["car"])) for x in ob.telowin(oh, lens[ci], thr)]
-        gw = [(int(x["start"]), int(x["end"]), int(x["car"])) for x in wins[wins["ctg"] == ci]]
-        assert gw == ew, ci
 
 
-def test_coverage_totals_and_windows(world):
+def test_coverage_totals_and_selection(world):
     acc, cov, lens, torch = world["acc"], world["cov"], world["lens"], world["torch"]
     sd, sq, n = acc.cov_prepare(cov, 2500, 50)
     tot_d = tot_q = 0
@@ -110,19 +149,58 @@ def test_coverage_totals_and_windows(world):
         tot_d += int(world["depth"][int(off):int(off) + ln].to(torch.int64).sum().item())
         tot_q += int(world["mq"][int(off):int(off) + ln].to(torch.int64).sum().item())
     assert (sd, sq, n) == (tot_d, tot_q, sum(lens))
-    for ci in _small_contigs(lens):
-        off = int(world["offs"][ci])
-        d = world["depth"][off:off + lens[ci]].cpu().numpy().view(np.uint16)
-        q = world["mq"][off:off + lens[ci]].cpu().numpy().view(np.uint16)
-        got = acc.cov_regs(cov, ci)
-        exp = ob.get_regs(d, q, 2500, 50)
-        assert np.array_equal(got, exp.astype(got.dtype)), ci
     mean = int(np.floor(sd / n + 0.5))
     lo, hi = acc.cov_threshold(0.4, mean), acc.cov_threshold(2.5, mean)
     recs = acc.cov_select(cov, lo, hi, 0.4, 100000, 1000000, False)
     assert len(recs) > 100000
     key = recs["ctg"].astype(np.int64) * (1 << 32) + recs["st"]
     assert np.all(np.diff(key) > 0)                                      # print order: contig, then window
-    assert np.all(recs["st"] % 50 == 0)
-    fun = (recs["depth"] < lo) | (recs["depth"] > hi) | (recs["mq_depth"] / np.maximum(recs["depth"], 1e-300) < np.float32(0.4))
-    assert np.all(fun | (recs["depth"] == 0))
+    # the selection = print_fun_bits' predicate (src/boringbits_main.c:439-440) over all windows of a contig
+    for ci in (0, len(lens) // 2, len(lens) - 1):
+        regs = acc.cov_regs(cov, ci)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            flag = (regs["depth"] < lo) | (regs["depth"] > hi) | (regs["mq_depth"].astype(np.float64) / regs["depth"].astype(np.float64) < np.float64(np.float32(0.4)))
+        exp = regs[flag] if lens[ci] >= 1000000 else regs[:0]
+        got = recs[recs["ctg"] == ci]
+        assert len(got) == len(exp), ci
+        for k in ("st", "end", "depth", "mq_depth"):
+            assert np.array_equal(got[k], exp[k]), (ci, k)
+
+
+def test_offsets_beyond_2_pow_32():
+    """20 contigs of ~225 Mb = 4.5 Gbp: contig 9 straddles byte offset 2^31 of the bases, contig 19 byte offset 2^32;
+    the u16 coverage arrays pass element offset 2^31 in contig 9 (byte offset 2^32) — the bench workload (3.16 Gbp) crosses
+    the same borders"""
+    lens = [225_000_000 + 1009 * i for i in range(20)]
+    w = _make(lens, 3)
+    try:
+        offs = w["offs"]
+        assert offs[9] < 2 ** 31 < offs[9] + lens[9] and offs[19] < 2 ** 32 < offs[19] + lens[19]
+        acc, asm, cov = w["acc"], w["asm"], w["cov"]
+        thr = acc.telowin_threshold(0.4, 99.9)
+        hits, wins = acc.telo_scan(asm, b"TTAGGG", thr)
+        ivls = acc.sdust(asm, 20, 64)
+        sd, sq, n = acc.cov_prepare(cov, 2500, 50)
+        assert n == sum(lens)
+        _compare_contigs(w, [9, 10, 19], hits, wins, ivls, thr)
+    finally:
+        _close(w)
+        del w
+
+
+def test_satellite_dense_assembly_equals_the_oracle():
+    """bench.py --profile satellite at 30 Mb: (CATTC)n / (GGAAT)n arrays over > 3 % of the bases, microsatellites,
+    poly-A runs — thousands of consecutive low-complexity chunks for the sdust queue"""
+    import bench
+    lens = bench.contig_lengths(30_000_000)
+    w = _make(lens, 5, "satellite", coverage=False)
+    try:
+        acc, asm = w["acc"], w["asm"]
+        thr = acc.telowin_threshold(0.4, 99.9)
+        hits, wins = acc.telo_scan(asm, b"TTAGGG", thr)
+        ivls = acc.sdust(asm, 20, 64)
+        masked = int((ivls["finish"].astype(np.int64) - ivls["start"]).sum())
+        assert masked > 0.03 * sum(lens)
+        _compare_contigs(w, list(range(len(lens))), hits, wins, ivls, thr, stages=("telo", "sdust"))
+    finally:
+        _close(w)

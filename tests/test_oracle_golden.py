@@ -229,22 +229,89 @@ def test_sdust_vs_reference_function_random():
         assert np.array_equal(got, exp), (it, n, T, W)
 
 
-@pytest.mark.skipif(not os.path.exists(REFSO), reason="oracle/_ref not built (no /root/reference here)")
-def test_bench_reference_baseline_runs_and_keeps_stdout(capfd):
-    """bench.py's "reference" cpu_baseline drives find / process_scaffold / sdust / get_regs of the reference's shared
-    object; nothing those functions print may reach stdout (bench.py prints ONE JSON line there)."""
+def _bench_cpu_leg(kind, monkeypatch):
     import torch
     sys.path.insert(0, ROOT)
     import bench
+    monkeypatch.setenv("CORNETTO_BENCH_BASELINE", kind)
     rng = np.random.default_rng(5)
-    n = 300000
+    lens = [100000, 200000, 50000]
+    offs = [0, 100032, 300032]
+    n = 350100
     b = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)].copy()
     b[:600] = np.frombuffer(b"CCCTAA" * 100, dtype=np.uint8)
+    b[100032 + 5000:100032 + 6200] = np.frombuffer(b"TTAGGG" * 200, dtype=np.uint8)
+    b[100032 + 9000:100032 + 9300] = np.frombuffer(b"ttaggg" * 50, dtype=np.uint8)
+    b[100032 + 20000:100032 + 20090] = np.frombuffer(b"AC" * 45, dtype=np.uint8)
     d = torch.from_numpy(rng.integers(0, 60, n).astype(np.int16))
-    out = bench.cpu_baseline(torch, torch.from_numpy(b), d, d.clone(), [0, 100000], [100000, 200000], n)
-    assert out["kind"] == "reference" and out["cores"] == 1 and out["value"] > 0
-    assert set(out["stage_gbases_s"]) == {"telofind", "telowin", "sdust", "get_regs"}
+    q = (d // 2).clone()
+    base, results = bench.cpu_reference_leg(torch.from_numpy(b), d, q, offs, lens, [0, 1, 2], 310000)
+    return bench, base, results, lens
+
+
+def _as_gpu_records(results):
+    """the CPU leg's own results laid out like the four GPU record arrays (for the parity checker's self-test)"""
+    HIT = np.dtype([("ctg", "<i4"), ("strand", "<i4"), ("start", "<i4"), ("end", "<i4")])
+    WIN = np.dtype([("ctg", "<i4"), ("start", "<i4"), ("end", "<i4"), ("car", "<i4")])
+    IVL = np.dtype([("ctg", "<i4"), ("start", "<i4"), ("finish", "<i4")])
+    REC = np.dtype([("ctg", "<i4"), ("st", "<i4"), ("end", "<i4"), ("depth", "<i4"), ("mq_depth", "<i4")])
+    hits, wins, ivls, recs = [], [], [], []
+    lo, hi, q = 30, 30, 0.4
+    for r in results:
+        li = r["local"]
+        hits += [(li, int(a), int(b), int(c)) for a, b, c in r["hits"]]
+        for ln in r["wins_text"].splitlines():
+            f = ln.split(b"\t")
+            st, en = int(f[3]), int(f[4])
+            marks = np.zeros(r["len"], np.uint8)
+            for _s, a, b in r["hits"]:
+                marks[a:b] = 1
+            wins.append((li, st, en, int(marks[st:en].sum())))
+        ivls += [(li, int(x) >> 32, int(x) & 0xFFFFFFFF) for x in r["sdust"]]
+        for st, en, dp, mq in r["regs"]:
+            flagged = dp < lo or dp > hi or (dp != 0 and mq / dp < np.float64(np.float32(q))) or (dp == 0 and False)
+            if flagged:
+                recs.append((li, st, en, dp, mq))
+    return (np.array(hits, dtype=HIT), np.array(wins, dtype=WIN), np.array(ivls, dtype=IVL), np.array(recs, dtype=REC)), (lo, hi, q)
+
+
+@pytest.mark.parametrize("kind", ["reference", "port"])
+def test_bench_cpu_leg_and_parity_checker(capfd, monkeypatch, kind):
+    """bench.py's CPU leg ("reference": find / process_scaffold / sdust / get_regs of the reference's shared object; "port":
+    the oracle) keeps what it computes for the parity check; nothing those functions print may reach stdout (bench.py
+    prints ONE JSON line there); the checker accepts matching records and names the first difference otherwise."""
+    if kind == "reference" and not os.path.exists(REFSO):
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    bench, base, results, lens = _bench_cpu_leg(kind, monkeypatch)
+    assert base["kind"] == kind and base["cores"] == 1 and base["value"] > 0 and base["host_cores"] >= 1 and base["host_cpu"]
+    assert set(base["stage_gbases_s"]) == {"telofind", "telowin", "sdust", "get_regs"}
     assert capfd.readouterr().out == ""
+    assert [r["local"] for r in results] == [0, 1] and all(r["whole"] for r in results)      # whole leading contigs within the budget
+    assert len(results[1]["hits"]) >= 2 and len(results[1]["sdust"]) >= 1 and results[1]["wins_text"].count(b"\n") >= 1
+    gpu, (lo, hi, q) = _as_gpu_records(results)
+    par = bench.check_parity(results, gpu, lo, hi, q, 60000, lens)
+    assert par["ok"], par
+    assert par["checked_bases"] == 300000 and par["contigs"] == 2 and par["sdust_intervals"] == sum(len(r["sdust"]) for r in results)
+    assert par["cov_windows_selected"] == len(gpu[3]) > 0
+    # a single changed record of any stage is found
+    for k in range(4):
+        bad = [a.copy() for a in gpu]
+        field = ("end", "car", "finish", "depth")[k]
+        bad[k][field][-1] += 1
+        assert not bench.check_parity(results, bad, lo, hi, q, 60000, lens)["ok"], k
+    short = [gpu[0], gpu[1], gpu[2][:-1], gpu[3]]
+    assert "sdust" in bench.check_parity(results, short, lo, hi, q, 60000, lens)["first_mismatch"]
+
+
+def test_reference_and_port_cpu_legs_agree(monkeypatch):
+    if not os.path.exists(REFSO):
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    _b, _base, ref, _l = _bench_cpu_leg("reference", monkeypatch)
+    _b, _base, port, _l = _bench_cpu_leg("port", monkeypatch)
+    for a, b in zip(ref, port):
+        assert np.array_equal(a["hits"], b["hits"]) and np.array_equal(a["sdust"], b["sdust"]) and np.array_equal(a["regs"], b["regs"])
+        # the reference's process_scaffold runs with its built-in 0.4, the port with the adjusted threshold: a superset
+        assert set(a["wins_text"].splitlines()) <= set(b["wins_text"].splitlines())
 
 
 # ---- FASTA/FASTQ record framing (SURVEY section 8f row 4) ---------------------------------------------------

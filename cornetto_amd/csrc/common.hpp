@@ -17,6 +17,8 @@ struct cornetto_accel {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t stream2 = nullptr;     // sdust: the dense kernel runs here, beside the main kernel on `stream`
+    hipEvent_t ev1 = nullptr, ev2 = nullptr;
     char err[512] = {0};
     // event timing of the kernels of the current / most recent compute call
     struct Rec {

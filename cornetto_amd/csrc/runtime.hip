@@ -83,6 +83,9 @@ void cornetto_accel_close(cornetto_accel_t *h)
         if (w.p) (void)hipFree(w.p);
     for (auto &w : h->pin)
         if (w.p) (void)hipHostFree(w.p);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev2) (void)hipEventDestroy(h->ev2);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }

@@ -435,6 +435,188 @@ __device__ __forceinline__ unsigned long long sd_ballot(bool x) { return __built
 __device__ __forceinline__ bool sd_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0; }
 constexpr int SD_NEVER = 0x7fffffff;
 
+// ---------------------------------------------------------------------------------------------------
+// sdust_dense: the kernel for chunks that lie INSIDE a repeat array (sd_prep's sample of the chunk: few distinct 3-mers).
+// There find_perfect runs, and inserts, at every base; done wave-cooperatively for one lane at a time (sdust_w64) that
+// costs a wave ~150 instructions per base, and a 5 Mb satellite array is 3 000 consecutive such chunks.  Here the 64
+// lanes of a wave each take one such chunk and every lane walks its own window (the reference's loop, :104-128): all
+// lanes need it at every step, so nothing diverges, ~15 instructions per base and lane.
+//
+// What makes the walk simple (tools/sim/sdust_trigger_sim.c checks it on millions of steps for many (T, W)):
+//   With m = floor(T / 5), v (:79-85) is the longest suffix of the window in which no 3-mer occurs more than m times.  A
+//   suffix of q words inside v has score r <= q (m - 1) / 2 (and <= q (q - 1) / 2), hence 10 r <= T (q - 1): it is never a
+//   candidate of :112.  And a candidate of q > L words gives 10 rw >= 10 r > T (q - 1) >= T L: the gate of :149 holds by
+//   itself.  So find_perfect over EVERY suffix of the window, at every word, without the gate, is the same function, and
+//   v, L, rv, cv, rw, cw need not exist: the walk starts at the newest word with r = 0.
+// The walk needs, for the word at each window position, the number of equal words behind it (newer): r(suffix) is the sum
+// of those over the suffix.  Every 3-mer has a push counter G (never decremented, mod 256); a ring slot keeps the word and
+// the value of its counter right after its own push: equal newer words = G[word] now - that value.  No counts to build
+// up and take down again per walk, no read-modify-write chains: the walk only READS the ring, G and the P slots, eight
+// positions at a time (independent LDS reads, one wait per batch).
+// P is the slot ring + occupancy mask of sdust_w64 (slot = r | l << 16, compared by cross-multiplication as in :115,118).
+// All state in LDS, lane-minor ([index][lane]: bank-conflict free for any per-lane index).
+// ---------------------------------------------------------------------------------------------------
+struct SdDenseLds {
+    uint16_t ring[64][64];     // [word index & 63][lane]: word | (G[word] after its push) << 8
+    uint8_t G[16][64][4];      // [word >> 2][lane][word & 3]: pushes of the word so far (mod 256)
+    uint32_t slot[64][64];     // [start & 63][lane]
+};
+
+__global__ __launch_bounds__(64) void sdust_dense(SdArgs A, const uint32_t *list, const unsigned long long *n_list)
+{
+    __shared__ SdDenseLds S;
+    const int lane = threadIdx.x;
+    const int T = A.T, W = A.W, CAPW = W - 2;
+    const int H = (int)*n_list;
+    for (int job = blockIdx.x; job * 64 < H; job += gridDim.x) {
+        for (int i = 0; i < 16; ++i) *reinterpret_cast<uint32_t *>(S.G[i][lane]) = 0;
+        const bool have = job * 64 + lane < H;
+        const int cid = have ? (int)list[job * 64 + lane] : 0;
+        const SdChunk ch = have ? A.chunks[cid] : SdChunk{0, 0, 0};
+        const int len = have ? A.ctg_len[ch.ctg] : 0;
+        const uint8_t *seq = A.bases + A.ctg_off[ch.ctg];
+        int u = have ? sd_find_start(A, ch, seq) : 0;
+        const bool live = have && u >= 0;             // u < 0: the word-count table is needed, the host reruns with it
+        if (u < 0) u = 0;
+        const int stop = !live ? u : (ch.end == len ? len + 1 : ch.end);   // the last chunk also runs the sentinel step i == len
+        const int rec_from = ch.start;
+
+        int l = 0, p = -1;                            // p: index of the newest word (count of pushes - 1); the window is words max(0, p - (W-3)) .. p
+        unsigned t = 0;
+        unsigned long long occ = 0;
+        int minstart = 0;
+        bool have_last = false;
+        uint32_t last_s = 0, last_f = 0, n_out = 0;
+        uint2 *out = A.out + (size_t)cid * A.cap;
+
+        auto emit = [&](int ps, int pf) {      // :93-99 on the lane-local list
+            if (have_last && ps <= (int)last_f) {
+                if (pf > (int)last_f) last_f = (uint32_t)pf;
+            } else {
+                if (have_last) {
+                    if (n_out < A.cap) out[n_out] = make_uint2(last_s, last_f);
+                    ++n_out;
+                }
+                have_last = true;
+                last_s = (uint32_t)ps;
+                last_f = (uint32_t)pf;
+            }
+        };
+        // save_masked_regions(start) when it does something: occ != 0 && minstart < start   (:88-102)
+        auto save_evict = [&](int start, int now) {
+            const uint32_t sl = S.slot[minstart & 63][lane];
+            if (now >= rec_from) emit(minstart, minstart + (int)(sl >> 16) + 3);
+            const int gone = start - minstart;           // starts minstart .. start-1 leave the window
+            if (gone >= 64) {
+                occ = 0;
+            } else {
+                unsigned long long r = rotr64(occ, minstart & 63);   // bit 0 <-> minstart
+                r &= ~0ull << gone;
+                occ = rotl64(r, minstart & 63);
+            }
+            if (occ) minstart = start + __builtin_ctzll(rotr64(occ, start & 63));
+        };
+
+        uint32_t word = 0;
+        if (live && u < len) word = *reinterpret_cast<const uint32_t *>(seq + (u & ~3)) >> (8 * (u & 3));
+        int i = u;
+        while (sd_any(live && i < stop)) {
+            const bool on = live && i < stop;
+            bool isword = false;
+            int start = 0;
+            if (on) {
+                if ((i & 3) == 0 && i != u && i < len) word = *reinterpret_cast<const uint32_t *>(seq + i);
+                const int b = i < len ? nt4_code(word & 0xFFu) : 4;
+                word >>= 8;
+                if (b < 4) {
+                    ++l;
+                    t = (t << 2 | (unsigned)b) & 63u;                           // :144
+                    if (l >= 3) {
+                        isword = true;
+                        start = (l - W > 0 ? l - W : 0) + (i + 1 - l);           // :146
+                        if (occ != 0 && minstart < start) save_evict(start, i);  // :147
+                        // shift_window (:66-86): the oldest word just falls out of the index range; push t
+                        ++p;
+                        const unsigned g = (unsigned)(S.G[t >> 2][lane][t & 3] + 1) & 0xFFu;
+                        S.G[t >> 2][lane][t & 3] = (uint8_t)g;
+                        S.ring[p & 63][lane] = (uint16_t)(t | (g << 8));
+                    }
+                } else {
+                    int st = (l - W + 1 > 0 ? l - W + 1 : 0) + (i + 1 - l);      // :152
+                    while (occ) {                                                // :153
+                        if (minstart >= st) st = minstart + 1;
+                        save_evict(st, i);
+                        ++st;
+                    }
+                    l = 0;
+                    t = 0;                                                       // :154 — window and counters kept
+                }
+            }
+            // ---- find_perfect (:104-128) over every suffix of the window, newest word first; branch-free per position
+            // (selects instead of jumps: all lanes do the same thing).  The occupancy mask is rotated so that the slot of the
+            // newest window position is bit 63 and the position `new_l` words back is bit 63 - new_l: constant masks per position.
+            if (sd_any(isword)) {
+                const int size = p + 1 < CAPW ? p + 1 : CAPW;
+                const int base = start + size - 1;                               // start value of the newest window position
+                const int rot = (63 - base) & 63;
+                const unsigned long long occr = rotl64(occ, rot);
+                uint32_t occ_hi = (uint32_t)(occr >> 32), occ_lo = (uint32_t)occr;
+                int r = 0, max_r = 0, max_l = 0;
+                const uint32_t p63 = (uint32_t)p & 63u, b63 = (uint32_t)base & 63u;
+                for (int kb = 0; kb < CAPW; kb += 8) {
+                    uint32_t e[8], gv[8], sl[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) e[j] = S.ring[(p63 - (uint32_t)(kb + j)) & 63u][lane];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const unsigned w = e[j] & 63u;
+                        gv[j] = S.G[w >> 2][lane][w & 3];
+                        sl[j] = S.slot[(b63 - (uint32_t)(kb + j)) & 63u][lane];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int new_l = kb + j;                                // words in the suffix - 1 (:111)
+                        if (new_l >= CAPW) continue;                             // (compile-time: the last batch is shorter)
+                        const bool livej = isword & (new_l < size);
+                        const int c = (int)((gv[j] - (e[j] >> 8)) & 0xFFu);       // equal words behind this one
+                        r += livej ? c : 0;
+                        const uint32_t bit = 1u << (31 - (new_l & 31));
+                        const uint32_t half = new_l < 32 ? occ_hi : occ_lo;
+                        const bool has_e = livej & ((half & bit) != 0);
+                        const int pr = (int)(sl[j] & 0xFFFFu), pl = (int)(sl[j] >> 16);
+                        // :113-117: entries with start >= i + start
+                        const bool fold = has_e & ((max_r == 0) | (__mul24(pr, max_l) > __mul24(max_r, pl)));
+                        max_r = fold ? pr : max_r;
+                        max_l = fold ? pl : max_l;
+                        // :112, :118
+                        const bool ins = livej & (__mul24(r, 10) > T * new_l) & ((max_r == 0) | (__mul24(r, max_l) >= __mul24(max_r, new_l)));
+                        max_r = ins ? r : max_r;
+                        max_l = ins ? new_l : max_l;
+                        if (new_l < 32) occ_hi |= ins ? bit : 0u;
+                        else occ_lo |= ins ? bit : 0u;
+                        if (ins) S.slot[(b63 - (uint32_t)new_l) & 63u][lane] = (uint32_t)r | ((uint32_t)new_l << 16);
+                    }
+                }
+                if (isword) {
+                    const unsigned long long o2 = ((unsigned long long)occ_hi << 32) | occ_lo;
+                    occ = rotr64(o2, rot);
+                    if (o2) minstart = base - 63 + __builtin_ctzll(o2);         // the lowest start that has an entry
+                }
+            }
+            ++i;
+        }
+        if (have) {
+            if (have_last) {
+                if (n_out < A.cap) out[n_out] = make_uint2(last_s, last_f);
+                ++n_out;
+            }
+            A.out_n[cid] = n_out;
+            if (n_out > A.cap) atomicMax(A.ovf, n_out);
+        }
+    }
+}
+
+
 // Requires 1 <= m = 2T/10 and T <= 100000 (24-bit products exact); other thresholds take the legacy kernel.
 template <bool STATS>
 __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
@@ -495,7 +677,11 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
     };
     // save_masked_regions(start) when it does something: occ != 0 && minstart < start   (:88-102)
     auto save_evict = [&](int start, int nowk) {
-        // P slots of the lane: one 256-byte row in global memory (only slots whose occupancy bit is set are ever read)
+        // P slots of the lane: one 256-byte row in global memory (only slots whose occupancy bit is set are ever read).
+        // A slot may have been written by ANOTHER lane of this wave (find_perfect below): every store of the wave has to be
+        // acknowledged by L2, where the sc1 loads look, before a slot is read — waited for here, in front of the load, so
+        // that the store itself does not hold the wave up.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t sl = __hip_atomic_load(&A.slots[((size_t)blockIdx.x * 64 + lane) * 64 + (minstart & 63)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (nowk >= A.chunks[cid].start - ubase && nowk < SD_NRUN) emit(minstart, minstart + (int)(sl >> 24) + 3);
         const int gone = start - minstart;           // starts minstart .. start-1 leave the window
@@ -818,6 +1004,7 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
                   uint32_t *orow = A.slots + ((size_t)blockIdx.x * 64 + ol) * 64;
                   const int sidx = (o_start + j) & 63;
                   const bool has_e = inwin && ((o_occ >> sidx) & 1ull);
+                  if (o_occ) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (see save_evict)
                   const uint32_t e = has_e ? __hip_atomic_load(&orow[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                   // Ratios r / l are compared through key = floor(r * 2^13 / l) (sd_ratio_key): exact for l <= 64.  All that
                   // :113-118 need of P is, for every start, the best ratio among the entries with a start at or after it.
@@ -831,8 +1018,8 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
                   const bool ins = cand && key_c >= km;                              // :118
                   if (ins) orow[sidx] = key_c | ((uint32_t)new_l << 24);             // start = i + start, finish = start + l + 3
                   // The entry is read back by OTHER lanes (the owner in save_masked_regions, lane j' of a later find_perfect):
-                  // the store must have reached L2, where their sc1 loads look, before the wave goes on.
-                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                  // the store must have reached L2, where their sc1 loads look, before any of them reads — they wait (vmcnt(0)) in
+                  // front of their loads.
                   const unsigned long long insj = __brevll(sd_ballot(ins));           // bit j <-> window position j
                   if (insj && lane == ol) {
                       const int lowest = o_start + __builtin_ctzll(insj);
@@ -1009,11 +1196,25 @@ struct SdPasses {
     uint32_t P;
     uint8_t turn[64];                 // turn[phase] = which pass hands the chunks of that phase out
 };
-__global__ void sd_order(const uint32_t *flag, const uint32_t *rank, const unsigned long long *n_flagged, int32_t n_chunks, uint32_t *perm, SdPasses ps)
+__global__ void sd_order(const uint32_t *flag, const uint32_t *rank, const unsigned long long *n_flagged, int32_t n_chunks, uint32_t *perm, SdPasses ps,
+                         uint32_t *dense_list, uint32_t *claim)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
-    const uint32_t H = (uint32_t)*n_flagged, r = rank[c];
+    uint32_t H = (uint32_t)*n_flagged;
+    const uint32_t r = rank[c];
+    if (dense_list) {
+        // the flagged chunks go to sdust_dense: they get no queue position and count as taken (nobody runs on into them)
+        if (flag[c]) {
+            dense_list[r] = (uint32_t)c;
+            claim[c] = 1u;
+            return;
+        }
+        const uint32_t L = (uint32_t)n_chunks - H, stripe = (L + ps.P - 1u) / ps.P;
+        const uint32_t j0 = (uint32_t)c - r;                 // rank among the others, in input order
+        perm[(uint32_t)ps.turn[j0 % ps.P] * stripe + j0 / ps.P] = (uint32_t)c;
+        return;
+    }
     uint32_t S = H ? (uint32_t)n_chunks / H : 64u;
     S = S > 64u ? 64u : (S < 1u ? 1u : S);
     uint32_t pos;
@@ -1154,12 +1355,13 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                      want_stats ? d_tot + 2 : nullptr, reinterpret_cast<uint32_t *>(d_tot + 1), d_slots, nullptr,
                      reinterpret_cast<uint32_t *>(d_tot + 8), nullptr, 0, env_int("CORNETTO_SDUST_RUNON", 1), (int32_t)chunk, a->d_wtab, a->d_wtab_base, reinterpret_cast<uint32_t *>(d_tot + 1) + 1};
             unsigned nb = (unsigned)((nc + 63) / 64);
+            bool dense_pending = false;
             if (use_w64) {
                 // warm-up starts, the order of the queue, the claim flags:
-                // flag (nc) + rank (nc) + claim (nc) + perm (nc + 80) + scan partials
-                uint32_t *d_flag = (uint32_t *)cn_ws(h, WS_SD_PERM, (nc * 4 + 80) * 4 + ((nc + 4095) / 4096 + 1) * 4);
+                // flag (nc) + rank (nc) + claim (nc) + perm (nc + 80) + dense list (nc) + scan partials
+                uint32_t *d_flag = (uint32_t *)cn_ws(h, WS_SD_PERM, (nc * 5 + 80) * 4 + ((nc + 4095) / 4096 + 1) * 4);
                 if (!d_flag) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
-                uint32_t *d_rank = d_flag + nc, *d_claim = d_rank + nc, *d_perm = d_claim + nc, *d_pp = d_perm + nc + 80;
+                uint32_t *d_rank = d_flag + nc, *d_claim = d_rank + nc, *d_perm = d_claim + nc, *d_list = d_perm + nc + 80, *d_pp = d_list + nc;
                 const unsigned nbs = (unsigned)((nc + 255) / 256);
                 A.claim = d_claim;
                 A.q_len = (int32_t)nc;
@@ -1167,6 +1369,9 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                     CN_HIP(h, hipMemsetAsync(d_claim, 0, nc * 4, h->stream));
                     CN_HIP(h, hipMemsetAsync(d_cnt, 0, nc * 4, h->stream));      // chunks a lane runs on into publish nothing of their own
                 } else {
+                    // CORNETTO_SDUST_DENSE: 1 (default) the chunks inside repeat arrays go to sdust_dense when there are enough of
+                    // them to pay for it, 2 always (tests), 0 never (they stay in the main kernel's queue, first, one per wave)
+                    const int dense_mode = env_int("CORNETTO_SDUST_DENSE", 1);
                     const unsigned nbp = (unsigned)((nc + 80 + 255) / 256);
                     CN_LAUNCH(h, "sdust_prep", sd_prep<<<dim3(nbp), dim3(256), 0, h->stream>>>(A, d_flag, d_perm));
                     // passes of the queue over the input: a run can grow to `passes` chunks before it meets a queue start
@@ -1185,9 +1390,46 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                         for (uint32_t t = 0; t < ps.P; ++t) ps.turn[key[t].second] = (uint8_t)t;
                     }
                     CN_TRY(cnscan::exclusive_u32(h, "sdust_prep", d_flag, (int64_t)nc, 1, d_rank, d_pp, d_tot + 7));
-                    CN_LAUNCH(h, "sdust_prep", sd_order<<<dim3(nbs), dim3(256), 0, h->stream>>>(d_flag, d_rank, d_tot + 7, (int32_t)nc, d_perm, ps));
+                    // The number of flagged chunks comes back to the host: it decides whether the dense kernel is worth its
+                    // latency (one job = one chunk = several milliseconds for a wave), and the dense blocks (28 KB of LDS each)
+                    // must be resident BEFORE the main kernel takes every wave slot of the chip, or they would wait for its
+                    // last wave; launched from here, a few microseconds ahead of it, they are.
+                    unsigned long long n_dense = 0;
+                    if (dense_mode) {
+                        CN_HIP(h, hipMemcpyAsync(p_tot + 200, d_tot + 7, 8, hipMemcpyDeviceToHost, h->stream));
+                        CN_HIP(h, hipStreamSynchronize(h->stream));
+                        n_dense = p_tot[200];
+                        if (dense_mode == 1 && n_dense < std::max<unsigned long long>(1024, nc / 256)) n_dense = 0;
+                    }
+                    CN_LAUNCH(h, "sdust_prep", sd_order<<<dim3(nbs), dim3(256), 0, h->stream>>>(d_flag, d_rank, d_tot + 7, (int32_t)nc, d_perm, ps,
+                                                                                           n_dense ? d_list : nullptr, d_claim));
                     A.perm = d_perm;
                     A.q_len = (int32_t)nc + 80;
+                    if (n_dense > 0) {
+                        if (!h->stream2) {
+                            CN_HIP(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+                            CN_HIP(h, hipEventCreateWithFlags(&h->ev2, hipEventDisableTiming));
+                            CN_HIP(h, hipEventCreateWithFlags(&h->ev1, hipEventDisableTiming));
+                        }
+                        CN_HIP(h, hipEventRecord(h->ev1, h->stream));                  // the dense list is complete
+                        CN_HIP(h, hipStreamWaitEvent(h->stream2, h->ev1, 0));
+                        const unsigned nbd = (unsigned)std::min<unsigned long long>((n_dense + 63) / 64, 8ull * (unsigned)std::max(h->sd_cus, 1));
+                        const bool timed = cn_timed(h, "sdust_dense");
+                        cornetto_accel::Rec rd{"sdust_dense", nullptr, nullptr};
+                        if (timed) {
+                            rd.a = cn_event(h);
+                            rd.b = cn_event(h);
+                            CN_HIP(h, hipEventRecord(rd.a, h->stream2));
+                        }
+                        sdust_dense<<<dim3(nbd), dim3(64), 0, h->stream2>>>(A, d_list, d_tot + 7);
+                        CN_HIP(h, hipGetLastError());
+                        if (timed) {
+                            CN_HIP(h, hipEventRecord(rd.b, h->stream2));
+                            h->recs.push_back(rd);
+                        }
+                        CN_HIP(h, hipEventRecord(h->ev2, h->stream2));
+                        dense_pending = true;
+                    }
                 }
                 // as many waves as the chip holds at once (LDS-bound: ~19 per CU); each lane works through the queue
                 if ((unsigned)sd_waves < nb) nb = (unsigned)sd_waves;
@@ -1198,6 +1440,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             } else {
                 CN_LAUNCH(h, "sdust_kernel", sdust_kernel<256><<<dim3(nb), dim3(64), 0, h->stream>>>(A));
             }
+            if (dense_pending) CN_HIP(h, hipStreamWaitEvent(h->stream, h->ev2, 0));
             // ordered position of every chunk's intervals (chunks are in contig order) + grand total
             CN_TRY(cnscan::exclusive_u32(h, "sdust_scan", d_cnt, (int64_t)nc, 1, d_off, d_part, d_tot));
             stamp("main kernel queued");

@@ -116,11 +116,15 @@ SDUST_CASES = [
 ]
 
 
+@pytest.mark.parametrize("dense", ["2", "0"])
 @pytest.mark.parametrize("chunk", ["0", "16", "100", "1000", "4096"])
 @pytest.mark.parametrize("fa,T,W,exp", SDUST_CASES)
-def test_sdust_golden(acc, golden_dir, monkeypatch, fa, T, W, exp, chunk):
-    """chunk = bases per lane (0 = default heuristic); tiny chunks stress the speculative warm-up"""
+def test_sdust_golden(acc, golden_dir, monkeypatch, fa, T, W, exp, chunk, dense):
+    """chunk = bases per lane (0 = default heuristic); tiny chunks stress the speculative warm-up.  dense = 2: the chunks
+    sampled as low-complexity always go to the per-lane kernel (sdust_dense) beside the main one (the default, 1, does that
+    only when there are many of them), 0: everything to the main kernel"""
     monkeypatch.setenv("CORNETTO_SDUST_CHUNK", chunk)
+    monkeypatch.setenv("CORNETTO_SDUST_DENSE", dense)
     assert gpu_sdust_text(acc, _records(golden_dir, fa), T, W) == golden(golden_dir, exp)
 
 

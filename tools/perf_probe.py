@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--features", type=int, default=1)
     ap.add_argument("--chunk", type=str, default="")
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--profile", default="uniform", help="bench.make_assembly profile: uniform | satellite")
     ap.add_argument("--read-len", type=int, default=0, help="instead of the assembly: reads of about this length (+-30 %%), --mbases in total")
     ap.add_argument("--simple-cov", type=int, default=0, help="uniform random depth (rocprofv3 --pmc crashes inside torch.poisson)")
     a = ap.parse_args()
@@ -33,7 +34,7 @@ def main():
         lens = [int(x) for x in rng.integers(int(a.read_len * 0.7), int(a.read_len * 1.3), size=int(a.mbases * 1e6 / a.read_len))]
         a.features = 0
     if a.features:
-        bases, offs = bench.make_assembly(torch, dev, lens, 1)
+        bases, offs = bench.make_assembly(torch, dev, lens, 0xC0FFEE if a.profile != "uniform" else 1, a.profile)
     else:
         offs, pos = [], 0
         for n in lens:
@@ -52,7 +53,7 @@ def main():
             t0 = time.perf_counter()
             iv = acc.sdust(asm, 20, 64)
             print("sdust call %.1f ms;" % ((time.perf_counter() - t0) * 1e3), len(lens), "records;", end=" ")
-            print("sdust", a.mbases, "features", a.features, "chunk", a.chunk, [(k, round(v, 3)) for k, v in acc.last_timing()], "ivls", len(iv), flush=True)
+            print("sdust", a.mbases, "features", a.features, "chunk", a.chunk, [(k, round(v, 3)) for k, v in acc.last_timing()], "ivls", len(iv), "digest", bench.digest([iv]), flush=True)
         if a.stage in ("telo", "all"):
             h, w = acc.telo_scan(asm, b"TTAGGG", 0.3976)
             print("telo", [(k, round(v, 3)) for k, v in acc.last_timing()], len(h), len(w), flush=True)

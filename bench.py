@@ -570,10 +570,14 @@ class Rank:
         if record:
             self._lap("cov_prepare", t0)
         t0 = time.perf_counter()
-        recs = acc.cov_select(self.cov, self.lo, self.hi, 0.4, 100000, 1000000, False)
+        # the selected windows in packed form (8 B per window + the first record of every contig: include/cornetto_accel.h)
+        recs_pk, ctg_first = acc.cov_select_packed(self.cov, self.lo, self.hi, 0.4, 100000, 1000000, False)
         if record:
             self._note(acc)
             self._lap("cov_select", t0)
+        recs = recs_pk
+        if keep or self.args.gather:                  # rows with their contig and end, as cornetto_cov_select() returns them
+            recs = acc.unpack_regs(recs_pk, ctg_first, self.lens_own, 2500)
         if not self.overlap:
             self.jobs.put(record)
         box = self.done.get()

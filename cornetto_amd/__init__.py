@@ -27,6 +27,7 @@ FQREC_DT = np.dtype([("head", "<i8"), ("seq", "<i8"), ("qual", "<i8"), ("len", "
 FAREC_DT = np.dtype([("head", "<i8"), ("len", "<i8"), ("name_len", "<i4"), ("pad", "<i4")])
 REG_DT = np.dtype([("st", "<i4"), ("end", "<i4"), ("depth", "<i4"), ("mq_depth", "<i4")])
 REGREC_DT = np.dtype([("ctg", "<i4"), ("st", "<i4"), ("end", "<i4"), ("depth", "<i4"), ("mq_depth", "<i4")])
+REGPK_DT = np.dtype([("st", "<i4"), ("depth", "<u2"), ("mq_depth", "<u2")])
 
 
 class BgErr(C.Structure):
@@ -106,6 +107,7 @@ def lib():
         "cornetto_cov_regs": (C.c_int, [vp, vp, i32, vp]),
         "cornetto_cov_threshold": (i32, [C.c_float, i32]),
         "cornetto_cov_select": (C.c_int, [vp, vp, i32, i32, C.c_float, i32, i32, C.c_int, pp, C.POINTER(i64)]),
+        "cornetto_cov_select_packed": (C.c_int, [vp, vp, i32, i32, C.c_float, i32, i32, C.c_int, pp, C.POINTER(i64), pp]),
         "cornetto_cov_n": (i32, [vp]),
         "cornetto_cov_lens": (C.POINTER(i32), [vp]),
         "cornetto_pinned_alloc": (vp, [C.c_size_t]),
@@ -379,6 +381,27 @@ class Accel:
         self._chk(self.L.cornetto_cov_select(self.h, cov.ptr, lo, hi, low_mq, edge_len, min_ctg_len, int(boring),
                                              C.byref(p), C.byref(n)))
         return _take(p, n.value, REGREC_DT)
+
+    def cov_select_packed(self, cov, lo, hi, low_mq, edge_len, min_ctg_len, boring):
+        """-> (REGPK_DT records {st, depth, mq_depth}, int64 ctg_first[n + 1]): the windows of contig i are
+        recs[ctg_first[i]:ctg_first[i + 1]], end = min(st + w, len)"""
+        p, n, cf = C.c_void_p(), C.c_int64(), C.c_void_p()
+        self._chk(self.L.cornetto_cov_select_packed(self.h, cov.ptr, lo, hi, low_mq, edge_len, min_ctg_len, int(boring),
+                                                    C.byref(p), C.byref(n), C.byref(cf)))
+        return _take(p, n.value, REGPK_DT), _take(cf, len(cov.lens) + 1, np.dtype("<i8"))
+
+    @staticmethod
+    def unpack_regs(recs, ctg_first, lens, w):
+        """packed selection -> REGREC_DT rows (ctg, st, end, depth, mq_depth)"""
+        out = np.zeros(len(recs), dtype=REGREC_DT)
+        counts = np.diff(np.asarray(ctg_first, dtype=np.int64))
+        ctg = np.repeat(np.arange(len(counts), dtype=np.int32), counts)
+        out["ctg"] = ctg
+        out["st"] = recs["st"]
+        out["end"] = np.minimum(recs["st"].astype(np.int64) + w, np.asarray(lens, dtype=np.int64)[ctg]).astype(np.int32)
+        out["depth"] = recs["depth"]
+        out["mq_depth"] = recs["mq_depth"]
+        return out
 
     # ---- bedgraph ingest ---------------------------------------------------------------------------
     def bedgraph_ingest(self, tot_pieces, mq_pieces):

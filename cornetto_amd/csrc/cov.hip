@@ -213,6 +213,7 @@ struct CwArgs {
     double low_mq;
     cornetto_reg_t *regs;
     cornetto_regrec_t *sel;    // selected windows, tile by tile (one reservation per tile)
+    cornetto_regpk_t *pk;      // ... or, if not NULL, their packed form (cornetto_cov_select_packed)
     unsigned long long *counter;
     uint32_t cap;
     uint2 *tile_res;           // per tile {base, count}
@@ -284,20 +285,23 @@ __global__ __launch_bounds__(256) void cov_windows(CwArgs A)
     __syncthreads();
     if (sel) {
         const unsigned long long idx = sbase + pre + __popcll(bal & ((1ull << lane) - 1ull));
-        if (idx < A.cap) A.sel[idx] = cornetto_regrec_t{ctg, st, end, depth, mq};
+        if (idx < A.cap) {
+            if (A.pk) A.pk[idx] = cornetto_regpk_t{st, (uint16_t)depth, (uint16_t)mq};   // means of uint16 values: they fit
+            else A.sel[idx] = cornetto_regrec_t{ctg, st, end, depth, mq};
+        }
     }
 }
 
-// tile segments (reservation order) -> (contig, window) order: one wavefront per tile
-__global__ __launch_bounds__(256) void cov_order(const cornetto_regrec_t *raw, const uint2 *tres, const uint32_t *ooff, int64_t n_tiles,
-                                                 cornetto_regrec_t *dst)
+// tile segments (reservation order) -> (contig, window) order: one wavefront per tile; INTS = 4-byte words per record
+template <int INTS>
+__global__ __launch_bounds__(256) void cov_order(const int32_t *raw, const uint2 *tres, const uint32_t *ooff, int64_t n_tiles, int32_t *dst)
 {
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= n_tiles) return;
     const uint2 r = tres[t];
-    const int32_t *src = reinterpret_cast<const int32_t *>(raw + r.x);
-    int32_t *d = reinterpret_cast<int32_t *>(dst + ooff[t]);
-    const uint32_t nint = r.y * 5u;
+    const int32_t *src = raw + (size_t)r.x * INTS;
+    int32_t *d = dst + (size_t)ooff[t] * INTS;
+    const uint32_t nint = r.y * (uint32_t)INTS;
     for (uint32_t i = threadIdx.x & 63; i < nint; i += 64) d[i] = src[i];
 }
 
@@ -401,8 +405,10 @@ int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int3
 // keep_on_device: *recs is the ordered DEVICE array (workspace WS_CW_SEL, valid until the next call), nothing is copied back
 static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_ctg, int mode, int32_t lo, int32_t hi,
                            float low_mq, int32_t edge, int32_t min_len, cornetto_reg_t *regs_host, cornetto_regrec_t **recs,
-                           int64_t *n_recs, bool keep_on_device = false)
+                           int64_t *n_recs, bool keep_on_device = false, cornetto_regpk_t **pk_out = nullptr, int64_t **ctg_first = nullptr)
 {
+    const bool packed = pk_out != nullptr;
+    const size_t rec_bytes = packed ? sizeof(cornetto_regpk_t) : sizeof(cornetto_regrec_t);
     if (!c->d_blk) return cn_fail(h, CORNETTO_E_ARG, "cov: cornetto_cov_prepare() has not been called");
     const int32_t w = c->w, inc = c->inc, q = w / inc, r = w % inc;
     if (c->cw_mode != mode || c->cw_min_len != min_len || c->cw_only != only_ctg) {   // window tiles, cached
@@ -451,15 +457,16 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
     }
     // raw (reservation order) and ordered copies share one workspace: [cap] + [cap]
     size_t cap = std::max<size_t>(1 << 16, nt * 256 / 8);
-    cap = std::max(cap, h->dev[WS_CW_SEL].bytes / (2 * sizeof(cornetto_regrec_t)));   // keep what an earlier call grew to
+    cap = std::max(cap, h->dev[WS_CW_SEL].bytes / (2 * rec_bytes));   // keep what an earlier call grew to
     unsigned long long cnt = 0;
     cornetto_regrec_t *d_raw = nullptr, *d_dst = nullptr;
     for (int attempt = 0; attempt < 2; ++attempt) {
         cap = std::min<size_t>(cap, 0x7fffffff);
-        d_raw = (cornetto_regrec_t *)cn_ws(h, WS_CW_SEL, 2 * cap * sizeof(cornetto_regrec_t));
-        if (!d_raw) return cn_fail(h, CORNETTO_E_NOMEM, "cov: workspace allocation of %zu bytes failed", 2 * cap * sizeof(cornetto_regrec_t));
-        d_dst = d_raw + cap;
+        d_raw = (cornetto_regrec_t *)cn_ws(h, WS_CW_SEL, 2 * cap * rec_bytes);
+        if (!d_raw) return cn_fail(h, CORNETTO_E_NOMEM, "cov: workspace allocation of %zu bytes failed", 2 * cap * rec_bytes);
+        d_dst = reinterpret_cast<cornetto_regrec_t *>(reinterpret_cast<uint8_t *>(d_raw) + cap * rec_bytes);
         A.sel = d_raw;
+        A.pk = packed ? reinterpret_cast<cornetto_regpk_t *>(d_raw) : nullptr;
         A.cap = (uint32_t)cap;
         CN_HIP(h, hipMemsetAsync(d_cnt, 0, 8, h->stream));
         CN_LAUNCH(h, "cov_windows", cov_windows<<<dim3((unsigned)nt), dim3(256), 0, h->stream>>>(A));
@@ -470,7 +477,7 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
         if (attempt == 1 || cnt > 0x7fffffffull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "cov: %llu selected windows", cnt);
         cap = (size_t)cnt;   // exact rerun, never a truncated answer
     }
-    cornetto_regrec_t *o = keep_on_device ? d_dst : (cornetto_regrec_t *)cn_result_alloc((cnt ? cnt : 1) * sizeof(cornetto_regrec_t));
+    cornetto_regrec_t *o = keep_on_device ? d_dst : (cornetto_regrec_t *)cn_result_alloc((cnt ? cnt : 1) * rec_bytes);
     if (!o) return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: host allocation failed");
     if (cnt) {
         // tiles are in (contig, window) order: exclusive scan of their counts = final position of each segment
@@ -479,17 +486,38 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
         const unsigned nb = (unsigned)((nt + 3) / 4);
         hipEvent_t ea = cn_event(h), eb = cn_event(h);
         (void)hipEventRecord(ea, h->stream);
-        cov_order<<<dim3(nb), dim3(256), 0, h->stream>>>(d_raw, d_tres, d_ooff, (int64_t)nt, d_dst);
+        if (packed) cov_order<2><<<dim3(nb), dim3(256), 0, h->stream>>>(reinterpret_cast<const int32_t *>(d_raw), d_tres, d_ooff, (int64_t)nt, reinterpret_cast<int32_t *>(d_dst));
+        else cov_order<5><<<dim3(nb), dim3(256), 0, h->stream>>>(reinterpret_cast<const int32_t *>(d_raw), d_tres, d_ooff, (int64_t)nt, reinterpret_cast<int32_t *>(d_dst));
         (void)hipEventRecord(eb, h->stream);
         h->recs.push_back(cornetto_accel::Rec{"cov_order", ea, eb});
         if (hipGetLastError() != hipSuccess) return cn_fail(h, CORNETTO_E_HIP, "cov_select: ordering failed");
-        if (!keep_on_device && (hipMemcpyAsync(o, d_dst, (size_t)cnt * sizeof(cornetto_regrec_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        // packed: the first record of every contig = the ordered offset of its first tile (1 MB beside the records)
+        std::vector<uint32_t> ooff;
+        if (packed) ooff.resize(nt);
+        if (!keep_on_device && (hipMemcpyAsync(o, d_dst, (size_t)cnt * rec_bytes, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                                (packed && hipMemcpyAsync(ooff.data(), d_ooff, nt * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess) ||
                                 hipStreamSynchronize(h->stream) != hipSuccess)) {
             cornetto_free(o);
             return cn_fail(h, CORNETTO_E_HIP, "cov_select: copy back failed");
         }
+        if (packed) {
+            int64_t *cf = (int64_t *)malloc(((size_t)c->n + 1) * sizeof(int64_t));
+            if (!cf) { cornetto_free(o); return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: host allocation failed"); }
+            size_t ti = 0;
+            for (int32_t i = 0; i < c->n; ++i) {                 // tiles are in contig order; contigs without tiles have no records
+                while (ti < nt && c->cw_tiles[ti].x < i) ++ti;
+                cf[i] = ti < nt ? (int64_t)ooff[ti] : (int64_t)cnt;
+            }
+            cf[c->n] = (int64_t)cnt;
+            *ctg_first = cf;
+        }
+    } else if (packed) {
+        int64_t *cf = (int64_t *)calloc((size_t)c->n + 1, sizeof(int64_t));
+        if (!cf) { if (!keep_on_device) cornetto_free(o); return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: host allocation failed"); }
+        *ctg_first = cf;
     }
-    *recs = o;
+    if (packed) *pk_out = reinterpret_cast<cornetto_regpk_t *>(o);
+    else *recs = o;
     *n_recs = (int64_t)cnt;
     return CORNETTO_OK;
 }
@@ -517,6 +545,26 @@ int cornetto_cov_select(cornetto_accel_t *h, const cornetto_cov_t *c, int32_t lo
     if (rc == CORNETTO_OK && !*recs) {   // nothing to scan (no contig qualifies): an empty, freeable result
         *recs = (cornetto_regrec_t *)malloc(sizeof(cornetto_regrec_t));
         if (!*recs) return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: host allocation failed");
+    }
+    return rc;
+}
+
+int cornetto_cov_select_packed(cornetto_accel_t *h, const cornetto_cov_t *c, int32_t lo, int32_t hi, float low_mq, int32_t edge_len,
+                               int32_t min_ctg_len, int boring, cornetto_regpk_t **recs, int64_t *n_recs, int64_t **ctg_first)
+{
+    if (!h || !c || !recs || !n_recs || !ctg_first) return cn_fail(h, CORNETTO_E_ARG, "cov_select_packed: bad argument");
+    *recs = nullptr;
+    *n_recs = 0;
+    *ctg_first = nullptr;
+    CN_HIP(h, hipSetDevice(h->device));
+    cn_timing_begin(h);
+    int rc = cov_run_windows(h, const_cast<cornetto_cov_t *>(c), -1, boring ? 2 : 1, lo, hi, low_mq, edge_len, min_ctg_len, nullptr, nullptr, n_recs, false,
+                             recs, ctg_first);
+    cn_timing_end(h);
+    if (rc == CORNETTO_OK && !*recs) {   // nothing to scan (no contig qualifies): empty, freeable results
+        *recs = (cornetto_regpk_t *)malloc(sizeof(cornetto_regpk_t));
+        if (!*ctg_first) *ctg_first = (int64_t *)calloc((size_t)c->n + 1, sizeof(int64_t));
+        if (!*recs || !*ctg_first) return cn_fail(h, CORNETTO_E_NOMEM, "cov_select_packed: host allocation failed");
     }
     return rc;
 }

@@ -462,14 +462,17 @@ struct SdDenseLds {
     uint32_t slot[64][64];     // [start & 63][lane]
 };
 
-__global__ __launch_bounds__(64) void sdust_dense(SdArgs A, const uint32_t *list, const unsigned long long *n_list)
+__global__ __launch_bounds__(64) void sdust_dense(SdArgs A, const uint32_t *list, const unsigned long long *n_list, uint32_t *started)
 {
     __shared__ SdDenseLds S;
     const int lane = threadIdx.x;
+    // the host launches the main kernel once this one is on the chip (its blocks need 28 KB of LDS each: see the launch)
+    if (started && blockIdx.x == 0 && lane == 0) __hip_atomic_store(started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const int T = A.T, W = A.W, CAPW = W - 2;
     const int H = (int)*n_list;
     for (int job = blockIdx.x; job * 64 < H; job += gridDim.x) {
         for (int i = 0; i < 16; ++i) *reinterpret_cast<uint32_t *>(S.G[i][lane]) = 0;
+        for (int i = 0; i < 64; ++i) S.slot[i][lane] = 0;
         const bool have = job * 64 + lane < H;
         const int cid = have ? (int)list[job * 64 + lane] : 0;
         const SdChunk ch = have ? A.chunks[cid] : SdChunk{0, 0, 0};
@@ -502,15 +505,21 @@ __global__ __launch_bounds__(64) void sdust_dense(SdArgs A, const uint32_t *list
                 last_f = (uint32_t)pf;
             }
         };
-        // save_masked_regions(start) when it does something: occ != 0 && minstart < start   (:88-102)
+        // save_masked_regions(start) when it does something: occ != 0 && minstart < start   (:88-102).  Slots that hold no
+        // entry are kept at zero (r = 0: "nothing here" for the walk below), so the slots of the entries that leave are cleared.
         auto save_evict = [&](int start, int now) {
             const uint32_t sl = S.slot[minstart & 63][lane];
             if (now >= rec_from) emit(minstart, minstart + (int)(sl >> 16) + 3);
             const int gone = start - minstart;           // starts minstart .. start-1 leave the window
+            unsigned long long r = rotr64(occ, minstart & 63);   // bit 0 <-> minstart
+            unsigned long long out_m = gone >= 64 ? r : r & ~(~0ull << gone);
+            while (out_m) {
+                S.slot[(minstart + __builtin_ctzll(out_m)) & 63][lane] = 0;
+                out_m &= out_m - 1;
+            }
             if (gone >= 64) {
                 occ = 0;
             } else {
-                unsigned long long r = rotr64(occ, minstart & 63);   // bit 0 <-> minstart
                 r &= ~0ull << gone;
                 occ = rotl64(r, minstart & 63);
             }
@@ -553,16 +562,16 @@ __global__ __launch_bounds__(64) void sdust_dense(SdArgs A, const uint32_t *list
                 }
             }
             // ---- find_perfect (:104-128) over every suffix of the window, newest word first; branch-free per position
-            // (selects instead of jumps: all lanes do the same thing).  The occupancy mask is rotated so that the slot of the
-            // newest window position is bit 63 and the position `new_l` words back is bit 63 - new_l: constant masks per position.
+            // (selects instead of jumps: all lanes do the same thing).  The running maximum (max_r, max_l) starts at (0, 1):
+            // "r max_l >= max_r l" and "pr max_l > max_r pl" are then what :115,:118 test with max_r == 0, and an empty slot
+            // (r = 0, l = 0) never wins.
             if (sd_any(isword)) {
                 const int size = p + 1 < CAPW ? p + 1 : CAPW;
+                const int limit = isword ? size : 0;                             // positions new_l < limit exist
                 const int base = start + size - 1;                               // start value of the newest window position
-                const int rot = (63 - base) & 63;
-                const unsigned long long occr = rotl64(occ, rot);
-                uint32_t occ_hi = (uint32_t)(occr >> 32), occ_lo = (uint32_t)occr;
-                int r = 0, max_r = 0, max_l = 0;
+                int r = 0, max_r = 0, max_l = 1, lowest = -1;                    // lowest: largest new_l inserted
                 const uint32_t p63 = (uint32_t)p & 63u, b63 = (uint32_t)base & 63u;
+                unsigned long long newbits = 0;                                  // bit new_l: inserted there
                 for (int kb = 0; kb < CAPW; kb += 8) {
                     uint32_t e[8], gv[8], sl[8];
 #pragma unroll
@@ -573,34 +582,33 @@ __global__ __launch_bounds__(64) void sdust_dense(SdArgs A, const uint32_t *list
                         gv[j] = S.G[w >> 2][lane][w & 3];
                         sl[j] = S.slot[(b63 - (uint32_t)(kb + j)) & 63u][lane];
                     }
+                    uint32_t nb8 = 0;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int new_l = kb + j;                                // words in the suffix - 1 (:111)
                         if (new_l >= CAPW) continue;                             // (compile-time: the last batch is shorter)
-                        const bool livej = isword & (new_l < size);
+                        const bool livej = new_l < limit;
                         const int c = (int)((gv[j] - (e[j] >> 8)) & 0xFFu);       // equal words behind this one
                         r += livej ? c : 0;
-                        const uint32_t bit = 1u << (31 - (new_l & 31));
-                        const uint32_t half = new_l < 32 ? occ_hi : occ_lo;
-                        const bool has_e = livej & ((half & bit) != 0);
                         const int pr = (int)(sl[j] & 0xFFFFu), pl = (int)(sl[j] >> 16);
-                        // :113-117: entries with start >= i + start
-                        const bool fold = has_e & ((max_r == 0) | (__mul24(pr, max_l) > __mul24(max_r, pl)));
+                        const bool fold = __mul24(pr, max_l) > __mul24(max_r, pl);               // :113-117: entries with start >= i + start
                         max_r = fold ? pr : max_r;
                         max_l = fold ? pl : max_l;
-                        // :112, :118
-                        const bool ins = livej & (__mul24(r, 10) > T * new_l) & ((max_r == 0) | (__mul24(r, max_l) >= __mul24(max_r, new_l)));
+                        const bool ins = livej & (__mul24(r, 10) > T * new_l) & (__mul24(r, max_l) >= __mul24(max_r, new_l));   // :112, :118
                         max_r = ins ? r : max_r;
                         max_l = ins ? new_l : max_l;
-                        if (new_l < 32) occ_hi |= ins ? bit : 0u;
-                        else occ_lo |= ins ? bit : 0u;
+                        nb8 |= ins ? 1u << j : 0u;
                         if (ins) S.slot[(b63 - (uint32_t)new_l) & 63u][lane] = (uint32_t)r | ((uint32_t)new_l << 16);
                     }
+                    newbits |= (unsigned long long)nb8 << kb;
                 }
-                if (isword) {
-                    const unsigned long long o2 = ((unsigned long long)occ_hi << 32) | occ_lo;
-                    occ = rotr64(o2, rot);
-                    if (o2) minstart = base - 63 + __builtin_ctzll(o2);         // the lowest start that has an entry
+                if (newbits) {
+                    // position new_l <-> start value base - new_l <-> occupancy bit (base - new_l) & 63
+                    const unsigned long long rev = __brevll(newbits);            // bit 63 - new_l
+                    const bool was_empty = occ == 0;
+                    occ |= rotr64(rev, (63 - base) & 63);
+                    lowest = base - (63 - __builtin_clzll(newbits));
+                    if (was_empty || lowest < minstart) minstart = lowest;
                 }
             }
             ++i;
@@ -1407,7 +1415,10 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                     A.q_len = (int32_t)nc + 80;
                     if (n_dense > 0) {
                         if (!h->stream2) {
-                            CN_HIP(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+                            // (highest priority: where both kernels have workgroups waiting, the dense ones are placed first)
+                            int pr_least = 0, pr_greatest = 0;
+                            (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+                            CN_HIP(h, hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, pr_greatest));
                             CN_HIP(h, hipEventCreateWithFlags(&h->ev2, hipEventDisableTiming));
                             CN_HIP(h, hipEventCreateWithFlags(&h->ev1, hipEventDisableTiming));
                         }
@@ -1421,8 +1432,20 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                             rd.b = cn_event(h);
                             CN_HIP(h, hipEventRecord(rd.a, h->stream2));
                         }
-                        sdust_dense<<<dim3(nbd), dim3(64), 0, h->stream2>>>(A, d_list, d_tot + 7);
+                        volatile uint32_t *started = reinterpret_cast<volatile uint32_t *>(p_tot + 201);
+                        *started = 0;
+                        sdust_dense<<<dim3(nbd), dim3(64), 0, h->stream2>>>(A, d_list, d_tot + 7, const_cast<uint32_t *>(started));
                         CN_HIP(h, hipGetLastError());
+                        {
+                            // wait (bounded: 2 ms) until its first block runs: the main kernel, launched next, fills every
+                            // wave slot that is left and would otherwise keep the dense blocks waiting for its last wave
+                            struct timespec w0, w1;
+                            clock_gettime(CLOCK_MONOTONIC, &w0);
+                            while (*started == 0) {
+                                clock_gettime(CLOCK_MONOTONIC, &w1);
+                                if ((w1.tv_sec - w0.tv_sec) * 1000000000L + (w1.tv_nsec - w0.tv_nsec) > 2000000L) break;
+                            }
+                        }
                         if (timed) {
                             CN_HIP(h, hipEventRecord(rd.b, h->stream2));
                             h->recs.push_back(rd);

@@ -236,6 +236,19 @@ int cornetto_cov_select(cornetto_accel_t *h, const cornetto_cov_t *c, int32_t lo
                         int32_t edge_len, int32_t min_ctg_len, int boring, cornetto_regrec_t **recs,
                         int64_t *n_recs);
 
+/* The same selection in packed form, for callers that take millions of windows per call (the whole-assembly panel: 7.5 M
+ * windows of a 3 Gbp assembly are 150 MB as cornetto_regrec_t, 60 MB packed): 8 bytes per window, the contig given by
+ * position — the windows of contig i are recs[ctg_first[i] .. ctg_first[i + 1]) (ctg_first has n + 1 entries) — and
+ * end = min(st + window_size, length of the contig) (src/boringbits_main.c:348-351).  depth and mq_depth are means of uint16
+ * values (:354-361), so they fit.  Release recs and ctg_first with cornetto_free(). */
+typedef struct {
+    int32_t st;
+    uint16_t depth, mq_depth;
+} cornetto_regpk_t;
+int cornetto_cov_select_packed(cornetto_accel_t *h, const cornetto_cov_t *c, int32_t lo, int32_t hi, float low_mq,
+                               int32_t edge_len, int32_t min_ctg_len, int boring, cornetto_regpk_t **recs, int64_t *n_recs,
+                               int64_t **ctg_first);
+
 /* ---------------------------------------------------------------------------------------------------
  * bedgraph ingest on the device (the text parse of get_depths(), src/boringbits_main.c:204-287)
  * ------------------------------------------------------------------------------------------------- */

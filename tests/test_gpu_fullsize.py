@@ -153,6 +153,14 @@ def test_coverage_totals_and_selection(world):
     lo, hi = acc.cov_threshold(0.4, mean), acc.cov_threshold(2.5, mean)
     recs = acc.cov_select(cov, lo, hi, 0.4, 100000, 1000000, False)
     assert len(recs) > 100000
+    # the packed form of the same selection (8 B per window, contig by position)
+    pk, first = acc.cov_select_packed(cov, lo, hi, 0.4, 100000, 1000000, False)
+    assert len(first) == len(lens) + 1 and first[0] == 0 and first[-1] == len(pk) == len(recs)
+    assert np.array_equal(acc.unpack_regs(pk, first, lens, 2500), recs)
+    for boring in (True,):
+        a = acc.cov_select(cov, lo, hi, 0.4, 100000, 1000000, boring)
+        pk, first = acc.cov_select_packed(cov, lo, hi, 0.4, 100000, 1000000, boring)
+        assert np.array_equal(acc.unpack_regs(pk, first, lens, 2500), a)
     key = recs["ctg"].astype(np.int64) * (1 << 32) + recs["st"]
     assert np.all(np.diff(key) > 0)                                      # print order: contig, then window
     # the selection = print_fun_bits' predicate (src/boringbits_main.c:439-440) over all windows of a contig

@@ -82,6 +82,7 @@ def lib():
         "cornetto_cov_select_merged": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_int, C.c_int32, C.c_int32, C.POINTER(vp), C.POINTER(C.c_int64)]),
         "cornetto_ivl_merge": (C.c_int, [vp, vp, C.c_int64, C.c_int32, C.POINTER(vp), C.POINTER(C.c_int64)]),
         "cornetto_panel_defaults": (None, [vp]),
+        "cornetto_panel_defaults_recreate": (None, [vp]),
         "cornetto_panel_boring": (C.c_int, [vp, C.c_int32, vp, C.c_int64, vp, C.c_int64, vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
         "cornetto_telobreaks": (C.c_int, [vp, vp, C.c_int32, vp, C.c_int64, vp, C.c_int64, C.POINTER(vp), C.POINTER(C.c_int64)]),
         "cornetto_khash_str_order": (C.c_int32, [C.POINTER(C.c_char_p), C.c_int32, vp, vp]),
@@ -455,14 +456,19 @@ def khash_str_order(names):
 
 
 class PanelOpt(C.Structure):
-    _fields_ = [("min_lowq_len", C.c_int32), ("extend", C.c_int32), ("edge_len", C.c_int32), ("merge_dist", C.c_int32), ("min_ctg_len", C.c_int32)]
+    _fields_ = [("min_lowq_len", C.c_int32), ("extend", C.c_int32), ("edge_len", C.c_int32), ("merge_dist", C.c_int32), ("min_ctg_len", C.c_int32),
+                ("extend_right", C.c_int32), ("extend_gate", C.c_int32)]
 
 
-def panel_boring(ctg_len, fun, lowq, **kw):
-    """steps 4-9 of scripts/create-cornetto.sh on index-based intervals (host only); kw overrides PanelOpt fields"""
+def panel_boring(ctg_len, fun, lowq, recreate=False, **kw):
+    """steps 4-9 of scripts/create-cornetto.sh (recreate=True: the constants of scripts/recreate-cornetto.sh) on index-based
+    intervals (host only); kw overrides PanelOpt fields — `extend` alone sets all three of extend / extend_right / extend_gate"""
     L = lib()
     opt = PanelOpt()
-    L.cornetto_panel_defaults(C.byref(opt))
+    (L.cornetto_panel_defaults_recreate if recreate else L.cornetto_panel_defaults)(C.byref(opt))
+    if "extend" in kw:
+        kw.setdefault("extend_right", kw["extend"])
+        kw.setdefault("extend_gate", kw["extend"])
     for k, v in kw.items():
         setattr(opt, k, v)
     ctg_len = np.ascontiguousarray(ctg_len, dtype=np.int32)

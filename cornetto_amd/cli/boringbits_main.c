@@ -44,7 +44,7 @@ typedef struct {
     char **name;
     int32_t *len, n, cap;
 } pn_asm_t;
-static int pn_par[7] = {1000, 30000, 8000, 40000, 200000, 200000, 800000};   /* create-cornetto.sh:44,47,50,53,56,59,65 */
+static int pn_par[9] = {1000, 30000, 8000, 40000, 200000, 200000, 800000, -1, -1};   /* create-cornetto.sh:44,47,50,53,56,59,65; extend-right, extend-gate (-1: as extend) */
 
 static int32_t pn_find(const pn_asm_t *a, const int32_t *slots, uint32_t n_slots, const char *name)
 {
@@ -128,6 +128,8 @@ static void panel_print(const char *asm_bed, const char *lowq_bed, char **cov_na
     cornetto_panel_opt_t po;
     cornetto_panel_defaults(&po);
     po.min_lowq_len = pn_par[2]; po.extend = pn_par[3]; po.edge_len = pn_par[4]; po.merge_dist = pn_par[5]; po.min_ctg_len = pn_par[6];
+    po.extend_right = pn_par[7] >= 0 ? pn_par[7] : pn_par[3]; /* the two constants recreate-cornetto.sh:38 adds; default: symmetric */
+    po.extend_gate = pn_par[8] >= 0 ? pn_par[8] : pn_par[3];
     cornetto_ivl_t *out = NULL;
     int64_t n_out = 0;
     if (cornetto_panel_boring(a.len, a.n, fv, nf, lq, nl, &po, &out, &n_out) != CORNETTO_OK) {
@@ -198,8 +200,10 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
         } else if (c == 0 && li == 19) {
             lowq_bed = optarg;
         } else if (c == 0 && li == 20) { /* the seven constants of create-cornetto.sh:44-65, in the order they appear */
-            if (sscanf(optarg, "%d,%d,%d,%d,%d,%d,%d", &pn_par[0], &pn_par[1], &pn_par[2], &pn_par[3], &pn_par[4], &pn_par[5], &pn_par[6]) != 7) {
-                CLI_ERROR("%s", "--panel-params wants seven integers: merge-d,min-fun-len,min-lowq-len,extend,edge-len,merge-d2,min-ctg-len");
+            const int got = sscanf(optarg, "%d,%d,%d,%d,%d,%d,%d,%d,%d", &pn_par[0], &pn_par[1], &pn_par[2], &pn_par[3], &pn_par[4], &pn_par[5], &pn_par[6],
+                                   &pn_par[7], &pn_par[8]);
+            if (got != 7 && got != 9) {
+                CLI_ERROR("%s", "--panel-params wants seven integers: merge-d,min-fun-len,min-lowq-len,extend,edge-len,merge-d2,min-ctg-len (or nine: ...,extend-right,extend-gate)");
                 exit(EXIT_FAILURE);
             }
         } else if (c == 0 && li == 9) { /* --accel: the seam the reference left (src/boringbits_main.c:627-632) */

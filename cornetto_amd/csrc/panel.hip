@@ -64,6 +64,20 @@ void cornetto_panel_defaults(cornetto_panel_opt_t *o)
     o->edge_len = 200000;       /* :56 */
     o->merge_dist = 200000;     /* :59 */
     o->min_ctg_len = 800000;    /* :65 */
+    o->extend_right = 40000;    /* :53 */
+    o->extend_gate = 40000;     /* :53 */
+}
+
+void cornetto_panel_defaults_recreate(cornetto_panel_opt_t *o)
+{
+    if (!o) return;
+    o->min_lowq_len = 7500;     /* recreate-cornetto.sh:35 */
+    o->extend = 40000;          /* :38  print $2-40000 */
+    o->extend_right = 50000;    /* :38  $3+50000 */
+    o->extend_gate = 50000;     /* :38  if ($2 > 50000) */
+    o->edge_len = 200000;       /* :41 */
+    o->merge_dist = 200000;     /* :44 */
+    o->min_ctg_len = 1000000;   /* :50 */
 }
 
 int cornetto_panel_boring(const int32_t *ctg_len, int32_t n_ctg, const cornetto_ivl_t *fun, int64_t n_fun, const cornetto_ivl_t *lowq,
@@ -74,16 +88,17 @@ int cornetto_panel_boring(const int32_t *ctg_len, int32_t n_ctg, const cornetto_
     *boring = nullptr;
     *n_boring = 0;
     std::vector<cornetto_ivl_t> v;
-    // :50-53  lowQ rows of at least min_lowq_len join the merged fun windows; every row with start > extend grows by
-    // `extend` on both sides (rows that start within the first `extend` bases are left as they are, as the awk does)
+    // :50-53  lowQ rows of at least min_lowq_len join the merged fun windows; every row with start > extend_gate grows by
+    // `extend` to the left and `extend_right` to the right (rows that start within the first extend_gate bases are left as
+    // they are, as the awk does; recreate-cornetto.sh:38 uses 50000 / 40000 / 50000)
     for (int64_t i = 0; i < n_fun; ++i)
         if (fun[i].ctg >= 0 && fun[i].ctg < n_ctg) v.push_back(fun[i]);
     for (int64_t i = 0; i < n_lowq; ++i)
         if (lowq[i].ctg >= 0 && lowq[i].ctg < n_ctg && (int64_t)lowq[i].finish - lowq[i].start >= opt->min_lowq_len) v.push_back(lowq[i]);
     for (cornetto_ivl_t &x : v)
-        if (x.start > opt->extend) {
+        if (x.start > opt->extend_gate) {
             x.start -= opt->extend;
-            x.finish = (int32_t)std::min<int64_t>((int64_t)x.finish + opt->extend, INT32_MAX);
+            x.finish = (int32_t)std::min<int64_t>((int64_t)x.finish + opt->extend_right, INT32_MAX);
         }
     // :56  contigs longer than edge_len: their first and last edge_len bases
     for (int32_t c = 0; c < n_ctg; ++c)

@@ -1332,6 +1332,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
         }
         a->sd_chunk = key;
         a->sd_n_chunks = (int64_t)chunks.size();
+        a->sd_flagged = -1;
     }
     const size_t nc = (size_t)a->sd_n_chunks;
     cornetto_ivl_t *o = nullptr;
@@ -1404,9 +1405,13 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                     // last wave; launched from here, a few microseconds ahead of it, they are.
                     unsigned long long n_dense = 0;
                     if (dense_mode) {
-                        CN_HIP(h, hipMemcpyAsync(p_tot + 200, d_tot + 7, 8, hipMemcpyDeviceToHost, h->stream));
-                        CN_HIP(h, hipStreamSynchronize(h->stream));
-                        n_dense = p_tot[200];
+                        // (the count is a property of the assembly and the chunk size: asked for once per resident assembly)
+                        if (a->sd_flagged < 0) {
+                            CN_HIP(h, hipMemcpyAsync(p_tot + 200, d_tot + 7, 8, hipMemcpyDeviceToHost, h->stream));
+                            CN_HIP(h, hipStreamSynchronize(h->stream));
+                            a->sd_flagged = (int64_t)p_tot[200];
+                        }
+                        n_dense = (unsigned long long)a->sd_flagged;
                         if (dense_mode == 1 && n_dense < std::max<unsigned long long>(1024, nc / 256)) n_dense = 0;
                     }
                     CN_LAUNCH(h, "sdust_prep", sd_order<<<dim3(nbs), dim3(256), 0, h->stream>>>(d_flag, d_rank, d_tot + 7, (int32_t)nc, d_perm, ps,

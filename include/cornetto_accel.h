@@ -358,13 +358,16 @@ int cornetto_cov_select_merged(cornetto_accel_t *h, const cornetto_cov_t *c, int
 int cornetto_ivl_merge(cornetto_accel_t *h, const cornetto_ivl_t *in, int64_t n, int32_t dist, cornetto_ivl_t **out, int64_t *n_out);
 
 typedef struct {
-    int32_t min_lowq_len; /* keep hifiasm "low quality" rows of at least this length (8000, :50) */
-    int32_t extend;       /* grow every row that starts beyond this many bases by it on both sides (40000, :53) */
+    int32_t min_lowq_len; /* keep hifiasm "low quality" rows of at least this length (8000, create-cornetto.sh:50; 7500, recreate-cornetto.sh:35) */
+    int32_t extend;       /* rows that start beyond extend_gate grow by this many bases to the LEFT (40000, :53; 40000, recreate :38) */
     int32_t edge_len;     /* add the first / last edge_len bases of every longer contig (200000, :56) */
     int32_t merge_dist;   /* bedtools merge -d (200000, :59) */
-    int32_t min_ctg_len;  /* contigs shorter than this contribute nothing (800000, :65) */
+    int32_t min_ctg_len;  /* contigs shorter than this contribute nothing (800000, :65; 1000000, recreate :47) */
+    int32_t extend_right; /* ... and by this many to the RIGHT (40000, :53; 50000, recreate :38) */
+    int32_t extend_gate;  /* the awk's `if ($2 > gate)` (40000, :53; 50000, recreate :38) */
 } cornetto_panel_opt_t;
-void cornetto_panel_defaults(cornetto_panel_opt_t *opt);
+void cornetto_panel_defaults(cornetto_panel_opt_t *opt);          /* scripts/create-cornetto.sh */
+void cornetto_panel_defaults_recreate(cornetto_panel_opt_t *opt); /* scripts/recreate-cornetto.sh:34-49 (no coverage stage: n_fun = 0) */
 
 /* Steps 4-9 of create-cornetto.sh (:50-66) on index-based intervals: fun = output of cornetto_cov_select_merged
  * (ctg = index into ctg_len, the assembly order), lowq = the rows of the hifiasm low-quality BED (any order).

@@ -468,15 +468,15 @@ int orc_ivl_merge(const orc_span_t *in, int64_t n, int32_t dist, orc_span_t **ou
 
 int orc_panel_boring(const int32_t *ctg_len, int32_t n_ctg, const orc_span_t *fun, int64_t n_fun, const orc_span_t *lowq, int64_t n_lowq,
                      int32_t min_lowq_len, int32_t extend, int32_t edge_len, int32_t merge_dist, int32_t min_ctg_len,
-                     orc_span_t **out, int64_t *n_out)
+                     int32_t extend_right, int32_t extend_gate, orc_span_t **out, int64_t *n_out)
 {
     orc_span_t *v = (orc_span_t *)malloc(((size_t)n_fun + (size_t)n_lowq + 2 * (size_t)n_ctg + 1) * sizeof(*v));
     int64_t n = 0;
     for (int64_t i = 0; i < n_fun; ++i) v[n++] = fun[i];                                   /* 3_tmp.bed */
     for (int64_t i = 0; i < n_lowq; ++i)                                                   /* :50  awk '($3-$2)>=8000' */
         if ((int64_t)lowq[i].end - lowq[i].start >= min_lowq_len) v[n++] = lowq[i];
-    for (int64_t i = 0; i < n; ++i)                                                        /* :53  if($2>40000){$2-40000, $3+40000} */
-        if (v[i].start > extend) { v[i].start -= extend; v[i].end += extend; }
+    for (int64_t i = 0; i < n; ++i)                                                        /* :53  if($2>40000){$2-40000, $3+40000}; recreate :38 if($2>50000){$2-40000, $3+50000} */
+        if (v[i].start > extend_gate) { v[i].start -= extend; v[i].end += extend_right; }
     for (int32_t c = 0; c < n_ctg; ++c)                                                    /* :56  if(($3-$2)>200000) two edge rows */
         if (ctg_len[c] > edge_len) {
             v[n].ctg = c; v[n].start = 0; v[n].end = edge_len; ++n;

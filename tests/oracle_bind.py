@@ -69,7 +69,7 @@ def lib():
         L.orc_khash_order.restype = C.c_int32
         L.orc_ivl_merge.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.orc_ivl_merge.restype = C.c_int
-        L.orc_panel_boring.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64] + [C.c_int32] * 5 + [C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.orc_panel_boring.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64] + [C.c_int32] * 7 + [C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.orc_panel_boring.restype = C.c_int
         L.orc_bigenough_keep.restype = C.c_int
         L.orc_fastx_parse.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.POINTER(FxRec)), C.POINTER(C.c_int64)]
@@ -207,14 +207,17 @@ def ivl_merge(spans, dist):
     return _spans_out(L, out, n)
 
 
-def panel_boring(ctg_len, fun, lowq, min_lowq_len=8000, extend=40000, edge_len=200000, merge_dist=200000, min_ctg_len=800000):
+def panel_boring(ctg_len, fun, lowq, min_lowq_len=8000, extend=40000, edge_len=200000, merge_dist=200000, min_ctg_len=800000,
+                 extend_right=None, extend_gate=None):
+    extend_right = extend if extend_right is None else extend_right
+    extend_gate = extend if extend_gate is None else extend_gate
     L = lib()
     ctg_len = np.ascontiguousarray(ctg_len, dtype=np.int32)
     fun = np.ascontiguousarray(fun, dtype=SPAN_DT)
     lowq = np.ascontiguousarray(lowq, dtype=SPAN_DT)
     out, n = C.c_void_p(), C.c_int64()
     L.orc_panel_boring(ctg_len.ctypes.data, len(ctg_len), fun.ctypes.data, len(fun), lowq.ctypes.data, len(lowq), min_lowq_len, extend, edge_len,
-                       merge_dist, min_ctg_len, C.byref(out), C.byref(n))
+                       merge_dist, min_ctg_len, extend_right, extend_gate, C.byref(out), C.byref(n))
     return _spans_out(L, out, n)
 
 

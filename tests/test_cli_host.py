@@ -1,5 +1,8 @@
 """CPU: the host-only parts of the `cornetto` CLI (dispatcher, fa2bed, seq, bigenough, depth stub, usage and
-exit codes) against golden stdout of the unmodified reference.  No GPU needed: none of these touch HIP."""
+exit codes, the text parsers in front of the device calls) against golden stdout of the unmodified reference.  No GPU
+needed: none of these touch HIP.  Every test runs twice: with the product binary and with the sanitized build of the same
+host C (`make -C cornetto_amd asan=1`: AddressSanitizer + UndefinedBehaviorSanitizer, the reference's own switch,
+Makefile:32-35 / test/test.sh:16-22) — a sanitizer report fails the test."""
 import os
 import subprocess
 
@@ -11,15 +14,27 @@ from helpers import golden
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def cli():
+ASAN_PATH = cornetto_amd.CLI_PATH + "_asan"
+
+
+@pytest.fixture(scope="module", params=["product", "asan"])
+def cli(request):
     if not os.path.exists(cornetto_amd.CLI_PATH):
         cornetto_amd.build()
-    return cornetto_amd.CLI_PATH
+    if request.param == "product":
+        return cornetto_amd.CLI_PATH
+    subprocess.check_call(["make", "-C", os.path.dirname(cornetto_amd.CLI_PATH), "-s", "asan=1"])
+    return ASAN_PATH
 
 
-def run(cli, args, cwd=None):
-    p = subprocess.run([cli] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=cwd)
+def run(cli, args, cwd=None, stdin=None):
+    # leaks are reported without changing the exit code: a leak on a path that ends in success fails the test; a run that
+    # ends in exit(EXIT_FAILURE) leaves with its buffers allocated, as the reference does (src/error.h:97-103)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:exitcode=99", LSAN_OPTIONS="exitcode=0", UBSAN_OPTIONS="print_stacktrace=1")
+    p = subprocess.run([cli] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=cwd, env=env, input=stdin)
+    tail = p.stderr.decode(errors="replace")[-3000:]
+    assert b"ERROR: AddressSanitizer" not in p.stderr and b"runtime error:" not in p.stderr and p.returncode != 99, tail
+    assert p.returncode != 0 or b"LeakSanitizer" not in p.stderr, tail
     return p.returncode, p.stdout, p.stderr
 
 
@@ -112,3 +127,32 @@ def test_missing_input_file_exit_codes(cli):
     assert run(cli, ["telofind", "/nonexistent.fa"])[0] == 1
     assert run(cli, ["telowin", "/nonexistent.tsv", "99.9"])[0] == 1
     assert run(cli, ["noboringbits", "/nonexistent.bg", "-q", "/nonexistent2.bg"])[0] == 1
+
+
+def test_text_parsers_in_front_of_the_device_calls(cli, golden_dir, tmp_path):
+    """telowin / telobreaks / (no)boringbits parse their text on the host before anything touches the device: without a GPU
+    the run ends with the device error (exit 1) — after the parsers have seen the whole input, malformed lines included"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: these paths are covered by tests/test_gpu_cli.py")
+    for tsv in ("probe.telomere", "mix.telofind.exp"):
+        rc, out, err = run(cli, ["telowin", os.path.join(golden_dir, tsv), "99.9", "0.4"])
+        assert rc == 1 and out == b""
+    bad = tmp_path / "bad.telomere"
+    bad.write_bytes(b"c1\t100\t0\t0\t12\n" + b"x" * 5000 + b"\n\nc2 7\n")
+    assert run(cli, ["telowin", str(bad), "99.9"])[0] == 1
+    empty = tmp_path / "empty.telomere"
+    empty.write_bytes(b"")
+    rc, out, err = run(cli, ["telowin", str(empty), "99.9"])
+    assert rc == 0 and out == b""                                   # no contig, nothing to scan: src/telomere_windows.c:65-84
+    args = [os.path.join(golden_dir, f) for f in ("tb_many.lens", "tb_many.sdust", "tb_many.telomere")]
+    assert run(cli, ["telobreaks"] + args)[0] == 1
+    rc, out, err = run(cli, ["noboringbits", os.path.join(golden_dir, "cov-total.bg.gz"), "-q", os.path.join(golden_dir, "cov-mq20.bg.gz")])
+    assert rc == 1
+    for sub in ("sdust", "telofind"):
+        assert run(cli, [sub, os.path.join(golden_dir, "mix.fa.gz")])[0] == 1
+        assert run(cli, [sub, "-"], stdin=b">a\nACGT\n")[0] == 1
+    rc, out, err = run(cli, ["seq", "-m", "3", "-"], stdin=b"@r c\nACGT\n+\nIIII\n@t\nAC\n+\nII\n@cut\nACGT\n+\nII")
+    assert out == b"@r\tc\nACGT\n+\nIIII\n"
+    rc, out, err = run(cli, ["fa2bed", "-"], stdin=b">a b c\r\nAC\r\nGT\r\n>e\n\n>f\nA")
+    assert rc == 0 and out == b"a\t0\t4\ne\t0\t0\nf\t0\t1\n"

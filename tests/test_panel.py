@@ -56,6 +56,81 @@ def test_panel_boring_random_vs_oracle(seed):
     assert all(0 <= r["start"] < r["finish"] <= lens[r["ctg"]] for r in got)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_panel_boring_asymmetric_extend_vs_oracle(seed):
+    """the three constants of scripts/recreate-cornetto.sh:38 — `if ($2 > 50000) {$2 - 40000, $3 + 50000}` — are separate options"""
+    rng = np.random.default_rng(100 + seed)
+    n_ctg = 12
+    lens = rng.integers(200_000, 4_000_000, size=n_ctg).astype(np.int32)
+    lowq = np.array([(int(c), int(a), int(a + l)) for c, a, l in zip(rng.integers(0, n_ctg, 60), rng.integers(0, 190_000, 60), rng.integers(100, 30_000, 60))],
+                    cornetto_amd.IVL_DT)
+    fun = np.zeros(0, cornetto_amd.IVL_DT)
+    kw = dict(extend=int(rng.integers(0, 60000)), extend_right=int(rng.integers(0, 90000)), extend_gate=int(rng.integers(0, 120000)))
+    got = cornetto_amd.panel_boring(lens, fun, lowq, **kw)
+    exp = ob.panel_boring(lens, _p2o(fun), _p2o(lowq), **kw)
+    assert np.array_equal(_p2o(got), exp)
+
+
+def test_panel_recreate_script_constants_hand_worked():
+    """scripts/recreate-cornetto.sh:34-49, no coverage stage.  One 3 Mb contig: a lowQ row 60000-67500 (7 500 long: kept, starts
+    beyond 50 000: becomes 20000-117500), one 50000-58000 (starts AT 50 000, not beyond: unchanged), one 1500000-1507499 (7 499:
+    dropped); edges 0-200000 and 2800000-3000000; merge -d 200000 folds the two rows into the left edge; left over: 200000-2800000.
+    A 999 999-base contig is shorter than 1 Mb: nothing."""
+    lens = [3_000_000, 999_999]
+    lowq = np.array([(0, 60_000, 67_500), (0, 50_000, 58_000), (0, 1_500_000, 1_507_499), (1, 400_000, 500_000)], cornetto_amd.IVL_DT)
+    got = cornetto_amd.panel_boring(lens, np.zeros(0, cornetto_amd.IVL_DT), lowq, recreate=True)
+    assert [tuple(int(x) for x in r) for r in got] == [(0, 200_000, 2_800_000)]
+    exp = ob.panel_boring(lens, np.zeros(0, ob.SPAN_DT), _p2o(lowq), 7500, 40000, 200000, 200000, 1000000, 50000, 50000)
+    assert np.array_equal(_p2o(got), exp)
+    # with the row moved one base further it is extended: 50001 - 40000 = 10001 .. 58001 + 50000
+    lowq[1] = (0, 50_001, 58_001)
+    lowq2 = np.array([(0, 900_000, 910_000)], cornetto_amd.IVL_DT)
+    got = cornetto_amd.panel_boring(lens, np.zeros(0, cornetto_amd.IVL_DT), np.concatenate([lowq, lowq2]), recreate=True)
+    # 860000-960000 is more than 200 kb from the left block (ends 200000) and from the right edge: it stays a block of its own
+    assert [tuple(int(x) for x in r) for r in got] == [(0, 200_000, 860_000), (0, 960_000, 2_800_000)]
+
+
+def _bed(golden_dir, name):
+    import os
+    rows = [l.split("\t") for l in open(os.path.join(golden_dir, "bedtools", name)).read().splitlines() if l]
+    return [(r[0], int(r[1]), int(r[2])) for r in rows]
+
+
+def test_bedtools_manual_merge_examples(golden_dir):
+    """tests/golden/bedtools/: the worked examples of the bedtools manual for `merge` (restated from the manual, not bedtools
+    output: see the README there) through the oracle; the device merge runs the same cases in the GPU test below"""
+    for fin, fexp, d in (("merge_default.in.bed", "merge_default.exp.bed", 0), ("merge_d1000.in.bed", "merge_d1000.exp.bed", 1000)):
+        rows = _bed(golden_dir, fin)
+        spans = np.array([(0, a, b) for _n, a, b in rows], ob.SPAN_DT)
+        got = ob.ivl_merge(spans, d)
+        assert [(int(r["start"]), int(r["end"])) for r in got] == [(a, b) for _n, a, b in _bed(golden_dir, fexp)], fin
+    # derived from the manual's wording ("maximum distance between features allowed for features to be merged"):
+    spans = np.array([(0, 100, 200), (0, 200 + 7, 300), (0, 300 + 8, 400)], ob.SPAN_DT)     # gap == d merges, gap == d + 1 does not
+    assert [(int(r["start"]), int(r["end"])) for r in ob.ivl_merge(spans, 7)] == [(100, 300), (308, 400)]
+
+
+def test_bedtools_manual_subtract_example(golden_dir):
+    """`bedtools subtract -a A -b B` (manual, default behaviour): chr1 10-20 is covered by B 0-30 and disappears, chr1 100-200
+    keeps 100-180.  The panel stage only ever subtracts from whole contigs (create-cornetto.sh:62,66): the example is run with
+    each A row as a contig of its own whose coordinates start at the row's start."""
+    a, b, exp = (_bed(golden_dir, "subtract_default.%s.bed" % k) for k in ("a", "b", "exp"))
+    out = []
+    for name, a0, a1 in a:
+        # B clipped to the A row and shifted so that the row is the contig [0, a1 - a0)
+        inside = [(0, max(b0, a0) - a0, min(b1, a1) - a0) for n, b0, b1 in b if n == name and min(b1, a1) > max(b0, a0)]
+        got = ob.panel_boring([a1 - a0], np.array(inside, ob.SPAN_DT).reshape(-1), np.zeros(0, ob.SPAN_DT), 1, 0, 1 << 30, 0, 0, 0, 1 << 30)
+        prod = cornetto_amd.panel_boring([a1 - a0], _o2p(np.array(inside, ob.SPAN_DT).reshape(-1)), np.zeros(0, cornetto_amd.IVL_DT),
+                                         min_lowq_len=1, extend=0, extend_right=0, extend_gate=1 << 30, edge_len=1 << 30, merge_dist=0, min_ctg_len=0)
+        assert np.array_equal(_p2o(prod), got)
+        out += [(name, int(r["start"]) + a0, int(r["end"]) + a0) for r in got]
+    assert out == exp
+    # derived: several B per A, a B inside A, a book-ended B
+    lens = [1000]
+    bs = np.array([(0, 0, 30), (0, 180, 300), (0, 300, 310), (0, 500, 600)], ob.SPAN_DT)
+    got = ob.panel_boring(lens, bs, np.zeros(0, ob.SPAN_DT), 1, 0, 1 << 30, 0, 0, 0, 1 << 30)
+    assert [(int(r["start"]), int(r["end"])) for r in got] == [(30, 180), (310, 500), (600, 1000)]
+
+
 @pytest.fixture(scope="module")
 def acc():
     a = cornetto_amd.Accel(0)
@@ -77,6 +152,16 @@ def test_ivl_merge_vs_oracle(acc, seed, n, dist):
         iv["finish"][n // 2] = iv["start"][n // 2] + 4_000_000            # one interval that swallows many
     got = acc.ivl_merge(iv, dist)
     assert np.array_equal(_p2o(got), ob.ivl_merge(_p2o(iv), dist))
+
+
+@pytest.mark.gpu
+def test_device_merge_on_the_bedtools_manual_examples(acc, golden_dir):
+    for fin, fexp, d in (("merge_default.in.bed", "merge_default.exp.bed", 0), ("merge_d1000.in.bed", "merge_d1000.exp.bed", 1000)):
+        rows = _bed(golden_dir, fin)
+        got = acc.ivl_merge(np.array([(0, a, b) for _n, a, b in rows], cornetto_amd.IVL_DT), d)
+        assert [(int(r["start"]), int(r["finish"])) for r in got] == [(a, b) for _n, a, b in _bed(golden_dir, fexp)], fin
+    got = acc.ivl_merge(np.array([(0, 100, 200), (0, 207, 300), (0, 308, 400)], cornetto_amd.IVL_DT), 7)
+    assert [(int(r["start"]), int(r["finish"])) for r in got] == [(100, 300), (308, 400)]
 
 
 @pytest.mark.gpu

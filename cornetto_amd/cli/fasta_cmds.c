@@ -66,6 +66,9 @@ typedef struct {
 /* scan the resident sequences `a` (record i of it = r[i]) and print the sub-command's lines */
 typedef void (*scan_fn)(cornetto_accel_t *h, const cli_recname_t *r, int64_t n, const cornetto_asm_t *a, void *arg);
 
+static void print_hit(const char *name, size_t name_len, int64_t len, const cornetto_hit_t *h);
+static void print_ivl(const char *name, size_t name_len, const cornetto_ivl_t *v);
+
 /* ---------------------------------------------------------------- telofind */
 static void telofind_scan(cornetto_accel_t *h, const cli_recname_t *r, int64_t n_rec, const cornetto_asm_t *a, void *arg)
 {
@@ -73,26 +76,228 @@ static void telofind_scan(cornetto_accel_t *h, const cli_recname_t *r, int64_t n
     cornetto_hit_t *hits = NULL;
     int64_t n = 0;
     cli_accel_check(h, cornetto_telofind(h, a, (const char *)arg, &hits, &n), "telofind");
-    for (int64_t i = 0; i < n; ++i) { /* src/find_telomere.c:51,56 */
-        const cli_recname_t *c = &r[hits[i].ctg];
-        cli_out_bytes(c->name, (size_t)c->name_len);   /* "%s\t%zu\t%d\t%zu\t%zu\t%zu\n" */
-        cli_out_char('\t');
-        cli_out_int(c->len);
-        cli_out_char('\t');
-        cli_out_int(hits[i].strand);
-        cli_out_char('\t');
-        cli_out_int(hits[i].start);
-        cli_out_char('\t');
-        cli_out_int(hits[i].end);
-        cli_out_char('\t');
-        cli_out_int(hits[i].end - hits[i].start);
-        cli_out_char('\n');
-    }
+    for (int64_t i = 0; i < n; ++i) print_hit(r[hits[i].ctg].name, (size_t)r[hits[i].ctg].name_len, r[hits[i].ctg].len, &hits[i]);
     cli_out_flush();
     cornetto_free(hits);
 }
 
 static void sdust_scan(cornetto_accel_t *h, const cli_recname_t *r, int64_t n_rec, const cornetto_asm_t *a, void *arg);
+
+/* ---------------------------------------------------------------- several GPUs of one node
+ * CORNETTO_DEVICES=0,1,2,...  (two or more ordinals; a device may be named twice): every scan is independent per record
+ * (src/find_telomere.c:101-105, src/sdust/sdust.c:196-203), so the records of a batch are dealt to the devices —
+ * longest first, each to the device with the least bases so far (LPT) — and every device gets one host thread with its
+ * own handle: upload, scan, results.  Printing happens after the join, record by record in INPUT order (each device's
+ * results come back ordered by its local record index, and a device's records keep their input order, so one cursor per
+ * device suffices): the output is byte for byte that of one device.  Nothing is exchanged between the devices. */
+#define CLI_MAX_DEV 64
+typedef struct {
+    int kind;                    /* 0 telofind, 1 sdust */
+    const char *motif;
+    int T, W;
+} multi_what_t;
+
+typedef struct {
+    int dev;
+    cornetto_accel_t *h;         /* opened by the worker on its first batch, kept for the next ones */
+    const multi_what_t *what;
+    const cli_batch_t *b;
+    int32_t *mine, n_mine;       /* batch indices of the records of this device, ascending */
+    cornetto_hit_t *hits;
+    cornetto_ivl_t *ivls;
+    int64_t n_res;
+    int rc;
+    char err[600];
+} multi_dev_t;
+
+static void *multi_worker(void *p)
+{
+    multi_dev_t *d = (multi_dev_t *)p;
+    d->rc = CORNETTO_OK;
+    d->hits = NULL;
+    d->ivls = NULL;
+    d->n_res = 0;
+    d->err[0] = 0;
+    if (!d->h) {
+        d->rc = cornetto_accel_open(&d->h, d->dev, NULL);
+        if (d->rc != CORNETTO_OK) {
+            snprintf(d->err, sizeof(d->err), "cannot open HIP device %d: %s", d->dev, cornetto_accel_strerror(d->rc));
+            return NULL;
+        }
+    }
+    if (d->n_mine == 0) return NULL;
+    const uint8_t **seqs = (const uint8_t **)cli_xmalloc((size_t)d->n_mine * sizeof(*seqs));
+    int64_t *lens = (int64_t *)cli_xmalloc((size_t)d->n_mine * sizeof(*lens));
+    for (int32_t i = 0; i < d->n_mine; ++i) {
+        seqs[i] = d->b->seqs[d->mine[i]];
+        lens[i] = d->b->lens[d->mine[i]];
+    }
+    cornetto_asm_t *a = NULL;
+    d->rc = cornetto_asm_upload(d->h, seqs, lens, d->n_mine, &a);
+    if (d->rc == CORNETTO_OK) {
+        if (d->what->kind == 0) d->rc = cornetto_telofind(d->h, a, d->what->motif, &d->hits, &d->n_res);
+        else d->rc = cornetto_sdust_asm(d->h, a, d->what->T, d->what->W, &d->ivls, &d->n_res);
+    }
+    if (d->rc != CORNETTO_OK)
+        snprintf(d->err, sizeof(d->err), "device %d: %s (%s)", d->dev, cornetto_accel_last_error(d->h), cornetto_accel_strerror(d->rc));
+    if (a) cornetto_asm_free(d->h, a);
+    free(seqs);
+    free(lens);
+    return NULL;
+}
+
+static void print_hit(const char *name, size_t name_len, int64_t len, const cornetto_hit_t *h)
+{
+    cli_out_bytes(name, name_len);   /* "%s\t%zu\t%d\t%zu\t%zu\t%zu\n": src/find_telomere.c:51,56 */
+    cli_out_char('\t');
+    cli_out_int(len);
+    cli_out_char('\t');
+    cli_out_int(h->strand);
+    cli_out_char('\t');
+    cli_out_int(h->start);
+    cli_out_char('\t');
+    cli_out_int(h->end);
+    cli_out_char('\t');
+    cli_out_int(h->end - h->start);
+    cli_out_char('\n');
+}
+
+static void print_ivl(const char *name, size_t name_len, const cornetto_ivl_t *v)
+{
+    cli_out_bytes(name, name_len);   /* "%s\t%d\t%d\n": src/sdust/sdust.c:201 */
+    cli_out_char('\t');
+    cli_out_int(v->start);
+    cli_out_char('\t');
+    cli_out_int(v->finish);
+    cli_out_char('\n');
+}
+
+/* the ordinals of $CORNETTO_DEVICES; 0 when it is not set (one device: $CORNETTO_DEVICE) */
+static int cli_device_list(int *devs)
+{
+    const char *s = getenv("CORNETTO_DEVICES");
+    int n = 0;
+    if (!s || !*s) return 0;
+    while (*s) {
+        char *end = NULL;
+        const long v = strtol(s, &end, 10);
+        if (end == s || v < 0 || n == CLI_MAX_DEV) {
+            CLI_ERROR("CORNETTO_DEVICES=%s: a comma-separated list of at most %d device ordinals is expected", getenv("CORNETTO_DEVICES"), CLI_MAX_DEV);
+            exit(EXIT_FAILURE);
+        }
+        devs[n++] = (int)v;
+        s = end;
+        while (*s == ',' || *s == ' ') ++s;
+    }
+    return n;
+}
+
+static void multi_batch(multi_dev_t *dv, int n_dev, const cli_batch_t *b)
+{
+    /* LPT: records by descending length (ties: input order), each to the least loaded device */
+    int32_t *order = (int32_t *)cli_xmalloc(((size_t)b->n + 1) * sizeof(*order));
+    for (int32_t i = 0; i < b->n; ++i) order[i] = i;
+    for (int32_t i = 1; i < b->n; ++i) { /* batches hold a few hundred contigs — or many short reads, nearly sorted runs: insertion sort by length */
+        const int32_t x = order[i];
+        int32_t j = i;
+        while (j > 0 && b->lens[order[j - 1]] < b->lens[x]) { order[j] = order[j - 1]; --j; }
+        order[j] = x;
+    }
+    int64_t load[CLI_MAX_DEV];
+    int32_t *owner = (int32_t *)cli_xmalloc(((size_t)b->n + 1) * sizeof(*owner));
+    for (int d = 0; d < n_dev; ++d) { load[d] = 0; dv[d].n_mine = 0; dv[d].b = b; }
+    for (int32_t k = 0; k < b->n; ++k) {
+        int best = 0;
+        for (int d = 1; d < n_dev; ++d)
+            if (load[d] < load[best]) best = d;
+        owner[order[k]] = best;
+        load[best] += b->lens[order[k]] + 1; /* (+1: empty records are spread as well) */
+    }
+    for (int d = 0; d < n_dev; ++d) dv[d].mine = (int32_t *)cli_xmalloc(((size_t)b->n + 1) * sizeof(int32_t));
+    for (int32_t i = 0; i < b->n; ++i) dv[owner[i]].mine[dv[owner[i]].n_mine++] = i; /* ascending = input order */
+    pthread_t th[CLI_MAX_DEV];
+    int started[CLI_MAX_DEV];
+    for (int d = 0; d < n_dev; ++d) started[d] = d > 0 && pthread_create(&th[d], NULL, multi_worker, &dv[d]) == 0;
+    for (int d = 0; d < n_dev; ++d)
+        if (!started[d]) multi_worker(&dv[d]);
+    for (int d = 0; d < n_dev; ++d)
+        if (started[d]) pthread_join(th[d], NULL);
+    for (int d = 0; d < n_dev; ++d)
+        if (dv[d].rc != CORNETTO_OK) {
+            CLI_ERROR("%s", dv[d].err);
+            exit(EXIT_FAILURE);
+        }
+    /* input order: record i is local record `local[owner]` of its device; its results are the next ones of that device */
+    int64_t cur[CLI_MAX_DEV];
+    int32_t local[CLI_MAX_DEV];
+    for (int d = 0; d < n_dev; ++d) { cur[d] = 0; local[d] = 0; }
+    for (int32_t i = 0; i < b->n; ++i) {
+        multi_dev_t *d = &dv[owner[i]];
+        const int32_t li = local[owner[i]]++;
+        int64_t *c = &cur[owner[i]];
+        const size_t nl = strlen(b->names[i]);
+        if (d->what->kind == 0)
+            for (; *c < d->n_res && d->hits[*c].ctg == li; ++*c) print_hit(b->names[i], nl, b->lens[i], &d->hits[*c]);
+        else
+            for (; *c < d->n_res && d->ivls[*c].ctg == li; ++*c) print_ivl(b->names[i], nl, &d->ivls[*c]);
+    }
+    cli_out_flush();
+    for (int d = 0; d < n_dev; ++d) {
+        cornetto_free(dv[d].hits);
+        cornetto_free(dv[d].ivls);
+        free(dv[d].mine);
+        dv[d].hits = NULL;
+        dv[d].ivls = NULL;
+    }
+    free(order);
+    free(owner);
+}
+
+/* the whole sub-command over several devices: the sequential reader fills batches, every batch is dealt out */
+static void multi_stream(const char *path, int must_open, const multi_what_t *what, const int *devs, int n_dev)
+{
+    cli_fastx_t *fx = cli_fastx_open(path);
+    if (!fx) {
+        if (must_open) {
+            CLI_ERROR("Failed to open %s : No such file or directory.", path); /* F_CHK, src/error.h:114-119 */
+            exit(EXIT_FAILURE);
+        }
+        return;
+    }
+    multi_dev_t dv[CLI_MAX_DEV];
+    memset(dv, 0, sizeof(dv));
+    for (int d = 0; d < n_dev; ++d) { dv[d].dev = devs[d]; dv[d].what = what; }
+    cli_str_t name = {0, 0, 0}, comment = {0, 0, 0}, seq = {0, 0, 0}, qual = {0, 0, 0};
+    cli_batch_t b;
+    memset(&b, 0, sizeof(b));
+    const int64_t limit = cli_batch_limit();
+    int64_t l;
+    while ((l = cli_fastx_read(fx, &name, &comment, &seq, &qual)) >= 0) {
+        if (l > 0x7fffffffLL) {
+            CLI_ERROR("record %s has %lld bases; the reference's reader is limited to 2^31-1 (src/kseq.h:185)", name.s, (long long)l);
+            exit(EXIT_FAILURE);
+        }
+        cli_batch_take(&b, name.s, &seq);
+        if (b.bases >= limit) {
+            multi_batch(dv, n_dev, &b);
+            cli_batch_clear(&b);
+        }
+    }
+    if (b.n) {
+        multi_batch(dv, n_dev, &b);
+        cli_batch_clear(&b);
+    }
+    for (int d = 0; d < n_dev; ++d)
+        if (dv[d].h) cornetto_accel_close(dv[d].h);
+    free(b.names);
+    free(b.seqs);
+    free(b.lens);
+    free(name.s);
+    free(comment.s);
+    free(seq.s);
+    free(qual.s);
+    cli_fastx_close(fx);
+}
 
 /* a batch of the sequential reader: upload, then the same scan */
 typedef struct {
@@ -346,6 +551,18 @@ int find_telomere_main(int argc, char *argv[])
         CLI_ERROR("%s", "empty search sequence");
         exit(EXIT_FAILURE);
     }
+    int devs[CLI_MAX_DEV];
+    const int n_dev = cli_device_list(devs);
+    if (n_dev >= 2) {
+        const multi_what_t what = {0, motif, 0, 0};
+        multi_stream(argv[1], 1, &what, devs, n_dev);
+        return EXIT_SUCCESS;
+    }
+    if (n_dev == 1) {
+        char one[32];
+        snprintf(one, sizeof(one), "%d", devs[0]);
+        setenv("CORNETTO_DEVICE", one, 1);
+    }
     stream_records(argv[1], 1, telofind_scan, (void *)motif);
     return EXIT_SUCCESS;
 }
@@ -362,15 +579,7 @@ static void sdust_scan(cornetto_accel_t *h, const cli_recname_t *r, int64_t n_re
     cornetto_ivl_t *iv = NULL;
     int64_t n = 0;
     cli_accel_check(h, cornetto_sdust_asm(h, a, o->T, o->W, &iv, &n), "sdust");
-    for (int64_t i = 0; i < n; ++i) { /* src/sdust/sdust.c:201 */
-        const cli_recname_t *c = &r[iv[i].ctg];
-        cli_out_bytes(c->name, (size_t)c->name_len);   /* "%s\t%d\t%d\n" */
-        cli_out_char('\t');
-        cli_out_int(iv[i].start);
-        cli_out_char('\t');
-        cli_out_int(iv[i].finish);
-        cli_out_char('\n');
-    }
+    for (int64_t i = 0; i < n; ++i) print_ivl(r[iv[i].ctg].name, (size_t)r[iv[i].ctg].name_len, &iv[i]);
     cli_out_flush();
     cornetto_free(iv);
 }
@@ -388,6 +597,18 @@ int sdust_main(int argc, char *argv[])
     if (optind == argc) {
         fprintf(stderr, "Usage: sdust [-w %d] [-t %d] <in.fa>\n", o.W, o.T);
         exit(1);
+    }
+    int devs[CLI_MAX_DEV];
+    const int n_dev = cli_device_list(devs);
+    if (n_dev >= 2) {
+        const multi_what_t what = {1, NULL, o.T, o.W};
+        multi_stream(argv[optind], 0, &what, devs, n_dev);
+        return 0;
+    }
+    if (n_dev == 1) {
+        char one[32];
+        snprintf(one, sizeof(one), "%d", devs[0]);
+        setenv("CORNETTO_DEVICE", one, 1);
     }
     stream_records(argv[optind], 0, sdust_scan, &o);
     return 0;

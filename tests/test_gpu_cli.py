@@ -127,3 +127,35 @@ def test_panel_streamed_in_small_pieces(cli, golden_dir, plain, piece):
     rc, out, err = run(cli, args, env={"CORNETTO_BG_PIECE": piece})
     assert rc == 0, err.decode()
     assert out == golden(golden_dir, "bg.fun_t2.exp")
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+@pytest.mark.parametrize("batch", ["", "200000"])
+@pytest.mark.parametrize("args,exp", [
+    (["telofind", "mix.fa.gz"], "mix.telofind.exp"),
+    (["telofind", "mix.fa.gz", "AAAA"], "mix.AAAA.telofind.exp"),
+    (["sdust", "mix.fa.gz"], "mix.sdust.exp"),
+    (["sdust", "-w", "32", "-t", "10", "mix.fa.gz"], "mix.w32t10.sdust.exp"),
+    (["sdust", "reads.fq"], "reads.sdust.exp"),
+    (["telofind", "probe.fa"], "probe.telofind.exp"),
+])
+def test_several_devices_print_the_output_of_one(cli, golden_dir, args, exp, devices, batch):
+    """CORNETTO_DEVICES: the records of a batch are dealt to one host thread + handle per listed device (LPT by length) and
+    printed in input order after the join — here the same GPU several times, which exercises everything but the peer GPUs;
+    small batches make several rounds of it"""
+    a = [os.path.join(golden_dir, x) if os.path.exists(os.path.join(golden_dir, x)) else x for x in args]
+    env = {"CORNETTO_DEVICES": devices}
+    if batch:
+        env["CORNETTO_BATCH_BASES"] = batch
+    rc, out, err = run(cli, a, env)
+    assert rc == 0, err[-500:]
+    assert out == golden(golden_dir, exp)
+
+
+def test_device_list_errors(cli, golden_dir):
+    rc, out, err = run(cli, ["sdust", os.path.join(golden_dir, "probe.fa")], {"CORNETTO_DEVICES": "0,banana"})
+    assert rc == 1 and out == b"" and b"CORNETTO_DEVICES" in err
+    rc, out, err = run(cli, ["sdust", os.path.join(golden_dir, "probe.fa")], {"CORNETTO_DEVICES": "0,63"})
+    assert rc == 1 and out == b"" and b"cannot open HIP device 63" in err
+    rc, out, err = run(cli, ["sdust", os.path.join(golden_dir, "probe.fa")], {"CORNETTO_DEVICES": "0"})       # one device: the usual path
+    assert rc == 0 and out == golden(golden_dir, "probe.sdust.exp")

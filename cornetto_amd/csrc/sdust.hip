@@ -1279,7 +1279,8 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
     cornetto_asm_t *a = const_cast<cornetto_asm_t *>(a_in);   // only the cached chunk table is touched
     *ivls = nullptr;
     *n_ivls = 0;
-    if (W < 3 || W > 258) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "sdust: -w %d outside 3..258 (the reference crashes below 3)", W);
+    // (W - 2 words in the window; the older kernel keeps its 3-mer counters in bytes: at most 255 copies, W <= 257)
+    if (W < 3 || W > 257) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "sdust: -w %d outside 3..257 (the reference crashes below 3)", W);
     if (T < 0 || T > (1 << 20)) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "sdust: -t %d outside 0..2^20", T);
     CN_HIP(h, hipSetDevice(h->device));
     cn_timing_begin(h);

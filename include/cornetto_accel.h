@@ -36,7 +36,7 @@ enum {
     CORNETTO_E_HIP = -2,      /* a HIP call or kernel failed; see cornetto_accel_last_error() */
     CORNETTO_E_ARG = -3,      /* invalid argument (NULL, negative length, misaligned device offset, ...) */
     CORNETTO_E_NOMEM = -4,    /* host or device allocation failed */
-    CORNETTO_E_UNSUPPORTED = -5, /* parameter outside the implemented range (motif > 32, W > 256, ...) */
+    CORNETTO_E_UNSUPPORTED = -5, /* parameter outside the implemented range (motif > 32, W > 257, ...) */
     CORNETTO_E_FORMAT = -6       /* malformed input text; see cornetto_bgin_error() */
 };
 
@@ -169,7 +169,7 @@ int cornetto_telo_scan(cornetto_accel_t *h, const cornetto_asm_t *a, const char 
  * ------------------------------------------------------------------------------------------------- */
 
 /* symmetric DUST over every contig of `a`; replaces sdust() called per record at src/sdust/sdust.c:199
- * (sdust_core :130-160).  3 <= W <= 256, T >= 1.  Intervals by contig, then by start; per contig they are
+ * (sdust_core :130-160).  3 <= W <= 257 (CORNETTO_E_UNSUPPORTED beyond), T >= 0.  Intervals by contig, then by start; per contig they are
  * exactly the reference's (start<<32|finish) list, including intervals that run past the contig end
  * after an N run. */
 int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a, int32_t T, int32_t W,

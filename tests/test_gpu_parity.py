@@ -254,7 +254,7 @@ def _rand_seqs(rng, n_seq, kind):
 
 
 @pytest.mark.parametrize("T,W,chunk", [(20, 64, "37"), (20, 64, "512"), (10, 32, "64"), (5, 64, "200"), (30, 16, "16"),
-                                       (25, 100, "300"), (20, 8, "50"), (20, 258, "700"), (1, 3, "40")])
+                                       (25, 100, "300"), (20, 8, "50"), (20, 257, "700"), (1, 3, "40")])
 def test_sdust_random_vs_oracle(acc, monkeypatch, T, W, chunk):
     monkeypatch.setenv("CORNETTO_SDUST_CHUNK", chunk)
     # a small grid: every lane takes many chunks from the queue, of unequal lengths, one after the other
@@ -271,6 +271,24 @@ def test_sdust_random_vs_oracle(acc, monkeypatch, T, W, chunk):
             r = int(r)
             exp.append((ci, r >> 32, r & 0xFFFFFFFF))
     assert got == exp
+
+
+def test_sdust_largest_window_on_homopolymers(acc):
+    """W = 257: the window holds 255 words and a homopolymer fills it with 255 copies of one 3-mer — the most the byte
+    counters of the older kernel hold; W = 258 is refused instead of wrapping them"""
+    import cornetto_amd
+    rng = np.random.default_rng(3)
+    s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=6000)].copy()
+    s[1000:1700] = ord("A")
+    s[3000:3300] = np.frombuffer(b"AC" * 150, dtype=np.uint8)
+    s[4000:4258] = ord("T")
+    asm = acc.asm_upload([s])
+    for T in (20, 100):
+        iv = acc.sdust(asm, T, 257)
+        assert [(int(x["start"]), int(x["finish"])) for x in iv] == [(int(r) >> 32, int(r) & 0xFFFFFFFF) for r in ob.sdust(s, T, 257)]
+    with pytest.raises(cornetto_amd.AccelError):
+        acc.sdust(asm, 20, 258)
+    asm.close()
 
 
 def test_telofind_random_vs_oracle(acc):

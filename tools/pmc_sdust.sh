@@ -51,12 +51,12 @@ if w.get("SQ_BUSY_CYCLES") and w.get("SQ_ACTIVE_INST_VALU"):
 json.dump(out, open("gpurun_out/%s_sq_sdust.json" % tag, "w"), indent=1)
 print(json.dumps(out["per_wave_step"]), steps)
 # ---- traffic, with the calibration of FETCH_SIZE on this access pattern
-cal = counters("gpurun_out/pmc_%s_calib/**/*_counter_collection.csv" % tag, ["calib_coalesced", "calib_laneILi2", "calib_laneILi4"])
+cal = counters("gpurun_out/pmc_%s_calib/**/*_counter_collection.csv" % tag, ["calib_coalesced", "calib_lane<2>", "calib_lane<4>"])
 log = open("gpurun_out/pmc_%s_calib.log" % tag).read()
 b_co = int(re.search(r"calib_coalesced (\d+)", log).group(1)) if "calib_coalesced" in log else 0
 b_ln = int(re.search(r"each calib_lane (\d+)", log).group(1)) if "each calib_lane" in log else 0
 calib = {}
-for k, b in (("calib_coalesced", b_co), ("calib_laneILi2", b_ln), ("calib_laneILi4", b_ln)):
+for k, b in (("calib_coalesced", b_co), ("calib_lane<2>", b_ln), ("calib_lane<4>", b_ln)):
     v = cal.get((k, "FETCH_SIZE"))
     if v and b:
         calib[k] = {"bytes_read": b, "FETCH_SIZE_KiB": v, "bytes_per_counted_byte": round(b / (v * 1024), 4)}
@@ -71,11 +71,11 @@ import bench
 bases = sum(bench.contig_lengths(int(mb * 1e6)))
 tr = {"workload": out["workload"], "bases": bases, "calibration": calib,
       "calibration_note": "tools/ubench/fetch_calib: 4 GiB read exactly once per kernel; bytes_per_counted_byte = true bytes / (FETCH_SIZE x 1024). "
-                          "calib_laneILi2 is the access pattern of sdust_w64 (every lane its own region, 32 bytes per request group)"}
+                          "calib_lane<2> is the access pattern of sdust_w64 (every lane its own region, 32 bytes per request group)"}
 f = fe.get(("sdust_w64", "FETCH_SIZE"))
 wv = wr.get(("sdust_w64", "WRITE_SIZE"))
 if f is not None and wv is not None:
-    scale = calib.get("calib_laneILi2", {}).get("bytes_per_counted_byte", 2.0)
+    scale = calib.get("calib_lane<2>", {}).get("bytes_per_counted_byte", 2.0)
     tr["sdust_w64"] = {"bases": bases, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": wv, "fetch_scale_used": scale,
                        "fetch_bytes": f * 1024 * scale, "write_bytes": wv * 1024, "hbm_bytes": f * 1024 * scale + wv * 1024,
                        "bytes_per_base": round((f * 1024 * scale + wv * 1024) / bases, 4)}

@@ -61,7 +61,7 @@ struct SdArgs {
     uint32_t *claim;             // sdust_w64: [n_chunks] 0 = free; set by the lane that takes the chunk (from the queue, or by running on into it)
     int32_t q_len;               // sdust_w64: queue positions (perm entries, 0xFFFFFFFF = hole)
     int32_t run_on;              // sdust_w64: lanes run on into the next chunk when it is free (CORNETTO_SDUST_RUNON, default 1)
-    int32_t chunk;               // sdust_w64: bases per chunk (every chunk of a contig but its last)
+    int32_t chunk;               // sdust_w64: bases per chunk of the main part (every such chunk of a contig but its last)
     // bounded warm-up search (sdust_w64): the local backward scan gives up after SD_SCAN_CAP bases; then
     const uint32_t *wtab;        //   exclusive prefix of per-256-base-block word-emission counts, or NULL
     const int64_t *wtab_base;    //   first table entry of each contig
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
               while (hasjob && !islast && endk < k64 + 64) {
                   if (atomicCAS(&A.claim[cur + 1], 0u, 1u) != 0u) break;
                   ++cur;
-                  endk = endk + A.chunk < lenk ? endk + A.chunk : lenk;
+                  endk = A.chunks[cur].end - ubase;          // (chunks differ in size: the last part of the queue is made of short ones)
                   islast = endk == lenk;
               }
           }
@@ -1160,11 +1160,11 @@ __device__ int sd_find_start(const SdArgs &A, const SdChunk ch, const uint8_t *s
 // 3-mers take few distinct values (random sequence: ~40 of 64) lies in a repeat array.  The flag only orders the work;
 // results do not depend on it.
 // Also resets what the main kernel expects cleared per chunk (claim flag, interval count) and the queue order array
-// (`perm`, n_chunks + 80 positions of "nothing here"): one launch instead of three memsets in front of the scan.
+// (`perm`, n_chunks + 160 positions of "nothing here"): one launch instead of three memsets in front of the scan.
 __global__ void sd_prep(SdArgs A, uint32_t *flag, uint32_t *perm)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < A.n_chunks + 80) perm[c] = 0xFFFFFFFFu;
+    if (c < A.n_chunks + 160) perm[c] = 0xFFFFFFFFu;
     if (c >= A.n_chunks) return;
     A.claim[c] = 0;
     A.out_n[c] = 0;
@@ -1205,12 +1205,20 @@ struct SdPasses {
     uint8_t turn[64];                 // turn[phase] = which pass hands the chunks of that phase out
 };
 __global__ void sd_order(const uint32_t *flag, const uint32_t *rank, const unsigned long long *n_flagged, int32_t n_chunks, uint32_t *perm, SdPasses ps,
-                         uint32_t *dense_list, uint32_t *claim)
+                         uint32_t *dense_list, uint32_t *claim, int32_t tail0)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     uint32_t H = (uint32_t)*n_flagged;
     const uint32_t r = rank[c];
+    // the others, in input order: main part [0, Lm), then the part made of short chunks [Lm, L); each is handed out in P
+    // passes of its own (every P-th chunk first ...), the short ones after all of the main part
+    const uint32_t L = (uint32_t)n_chunks - H;
+    const uint32_t Lm = tail0 < n_chunks ? (uint32_t)tail0 - rank[tail0] : L;
+    const uint32_t j0 = (uint32_t)c - r;                     // rank among the others
+    const uint32_t stripe_m = (Lm + ps.P - 1u) / ps.P, stripe_t = (L - Lm + ps.P - 1u) / ps.P;
+    const uint32_t j = j0 < Lm ? (uint32_t)ps.turn[j0 % ps.P] * stripe_m + j0 / ps.P                       // < P * stripe_m <= Lm + P - 1
+                               : ps.P * stripe_m + (uint32_t)ps.turn[(j0 - Lm) % ps.P] * stripe_t + (j0 - Lm) / ps.P;
     if (dense_list) {
         // the flagged chunks go to sdust_dense: they get no queue position and count as taken (nobody runs on into them)
         if (flag[c]) {
@@ -1218,9 +1226,7 @@ __global__ void sd_order(const uint32_t *flag, const uint32_t *rank, const unsig
             claim[c] = 1u;
             return;
         }
-        const uint32_t L = (uint32_t)n_chunks - H, stripe = (L + ps.P - 1u) / ps.P;
-        const uint32_t j0 = (uint32_t)c - r;                 // rank among the others, in input order
-        perm[(uint32_t)ps.turn[j0 % ps.P] * stripe + j0 / ps.P] = (uint32_t)c;
+        perm[j] = (uint32_t)c;
         return;
     }
     uint32_t S = H ? (uint32_t)n_chunks / H : 64u;
@@ -1229,9 +1235,6 @@ __global__ void sd_order(const uint32_t *flag, const uint32_t *rank, const unsig
     if (flag[c]) {
         pos = r * S;
     } else {
-        const uint32_t L = (uint32_t)n_chunks - H, stripe = (L + ps.P - 1u) / ps.P;
-        const uint32_t j0 = (uint32_t)c - r;                 // rank among the others, in input order
-        const uint32_t j = (uint32_t)ps.turn[j0 % ps.P] * stripe + j0 / ps.P;   // its turn: < P * stripe <= L + P - 1
         if (S > 1u && j < H * (S - 1u)) pos = (j / (S - 1u)) * S + 1u + j % (S - 1u);
         else pos = H * S + (j - H * (S - 1u));
     }
@@ -1317,12 +1320,30 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
         }
     }
     chunk = std::max<int64_t>(16, chunk);
-    const int64_t key = chunk;
+    // The last part of the work is cut into shorter chunks (handed out last): when the queue runs dry every wave still has to
+    // finish the chunks its lanes hold, and a wave-step costs the same with 3 busy lanes as with 64 — the shorter the last
+    // chunks, the shorter that drain.  CORNETTO_SDUST_TAIL = percent of the bases (default 20), CORNETTO_SDUST_TAILDIV = how
+    // many times shorter (default 4).  Results do not depend on the decomposition.
+    const int tail_pct = std::min(90, std::max(0, env_int("CORNETTO_SDUST_TAIL", w64_path && env_int("CORNETTO_SDUST_CHUNK", 0) <= 0 ? 20 : 0)));
+    const int tail_div = std::min(16, std::max(1, env_int("CORNETTO_SDUST_TAILDIV", 4)));
+    const int64_t small = std::max<int64_t>(64, (chunk / tail_div + 63) / 64 * 64);
+    const int64_t tail_from = tail_pct > 0 && tail_div > 1 ? a->total - a->total * tail_pct / 100 : a->total + 1;   // in bases, assembly order
+    const int64_t key = chunk + (int64_t)tail_pct * (1ll << 40) + (int64_t)tail_div * (1ll << 48);
     if (a->sd_chunk != key) {
         std::vector<SdChunk> chunks;
-        for (int32_t c = 0; c < a->n; ++c)
-            for (int64_t s = 0; s < a->len[c]; s += chunk)
-                chunks.push_back(SdChunk{c, (int32_t)s, (int32_t)std::min<int64_t>(a->len[c], s + chunk)});
+        int64_t seen = 0;
+        a->sd_tail0 = -1;
+        for (int32_t c = 0; c < a->n; ++c) {
+            for (int64_t s = 0; s < a->len[c];) {
+                const bool tail = seen + s >= tail_from;
+                if (tail && a->sd_tail0 < 0) a->sd_tail0 = (int64_t)chunks.size();
+                const int64_t sz = tail ? small : chunk;
+                chunks.push_back(SdChunk{c, (int32_t)s, (int32_t)std::min<int64_t>(a->len[c], s + sz)});
+                s += sz;
+            }
+            seen += a->len[c];
+        }
+        if (a->sd_tail0 < 0) a->sd_tail0 = (int64_t)chunks.size();
         if (chunks.size() > 0x7fffffffull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "sdust: too many chunks");
         if (a->d_sd_chunks) { (void)hipFree(a->d_sd_chunks); a->d_sd_chunks = nullptr; }
         if (!chunks.empty()) {
@@ -1369,9 +1390,9 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             if (use_w64) {
                 // warm-up starts, the order of the queue, the claim flags:
                 // flag (nc) + rank (nc) + claim (nc) + perm (nc + 80) + dense list (nc) + scan partials
-                uint32_t *d_flag = (uint32_t *)cn_ws(h, WS_SD_PERM, (nc * 5 + 80) * 4 + ((nc + 4095) / 4096 + 1) * 4);
+                uint32_t *d_flag = (uint32_t *)cn_ws(h, WS_SD_PERM, (nc * 5 + 160) * 4 + ((nc + 4095) / 4096 + 1) * 4);
                 if (!d_flag) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
-                uint32_t *d_rank = d_flag + nc, *d_claim = d_rank + nc, *d_perm = d_claim + nc, *d_list = d_perm + nc + 80, *d_pp = d_list + nc;
+                uint32_t *d_rank = d_flag + nc, *d_claim = d_rank + nc, *d_perm = d_claim + nc, *d_list = d_perm + nc + 160, *d_pp = d_list + nc;
                 const unsigned nbs = (unsigned)((nc + 255) / 256);
                 A.claim = d_claim;
                 A.q_len = (int32_t)nc;
@@ -1382,7 +1403,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                     // CORNETTO_SDUST_DENSE: 1 (default) the chunks inside repeat arrays go to sdust_dense when there are enough of
                     // them to pay for it, 2 always (tests), 0 never (they stay in the main kernel's queue, first, one per wave)
                     const int dense_mode = env_int("CORNETTO_SDUST_DENSE", 1);
-                    const unsigned nbp = (unsigned)((nc + 80 + 255) / 256);
+                    const unsigned nbp = (unsigned)((nc + 160 + 255) / 256);
                     CN_LAUNCH(h, "sdust_prep", sd_prep<<<dim3(nbp), dim3(256), 0, h->stream>>>(A, d_flag, d_perm));
                     // passes of the queue over the input: a run can grow to `passes` chunks before it meets a queue start
                     SdPasses ps;
@@ -1416,9 +1437,9 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                         if (dense_mode == 1 && n_dense < std::max<unsigned long long>(1024, nc / 256)) n_dense = 0;
                     }
                     CN_LAUNCH(h, "sdust_prep", sd_order<<<dim3(nbs), dim3(256), 0, h->stream>>>(d_flag, d_rank, d_tot + 7, (int32_t)nc, d_perm, ps,
-                                                                                           n_dense ? d_list : nullptr, d_claim));
+                                                                                           n_dense ? d_list : nullptr, d_claim, (int32_t)a->sd_tail0));
                     A.perm = d_perm;
-                    A.q_len = (int32_t)nc + 80;
+                    A.q_len = (int32_t)nc + 160;
                     if (n_dense > 0) {
                         if (!h->stream2) {
                             // (highest priority: where both kernels have workgroups waiting, the dense ones are placed first)

@@ -1216,9 +1216,10 @@ __global__ void sd_order(const uint32_t *flag, const uint32_t *rank, const unsig
     const uint32_t L = (uint32_t)n_chunks - H;
     const uint32_t Lm = tail0 < n_chunks ? (uint32_t)tail0 - rank[tail0] : L;
     const uint32_t j0 = (uint32_t)c - r;                     // rank among the others
-    const uint32_t stripe_m = (Lm + ps.P - 1u) / ps.P, stripe_t = (L - Lm + ps.P - 1u) / ps.P;
+    // (the short chunks in ONE pass, in input order: a run must not grow over several of them again)
+    const uint32_t stripe_m = (Lm + ps.P - 1u) / ps.P;
     const uint32_t j = j0 < Lm ? (uint32_t)ps.turn[j0 % ps.P] * stripe_m + j0 / ps.P                       // < P * stripe_m <= Lm + P - 1
-                               : ps.P * stripe_m + (uint32_t)ps.turn[(j0 - Lm) % ps.P] * stripe_t + (j0 - Lm) / ps.P;
+                               : ps.P * stripe_m + (j0 - Lm);
     if (dense_list) {
         // the flagged chunks go to sdust_dense: they get no queue position and count as taken (nobody runs on into them)
         if (flag[c]) {
@@ -1320,11 +1321,13 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
         }
     }
     chunk = std::max<int64_t>(16, chunk);
-    // The last part of the work is cut into shorter chunks (handed out last): when the queue runs dry every wave still has to
-    // finish the chunks its lanes hold, and a wave-step costs the same with 3 busy lanes as with 64 — the shorter the last
-    // chunks, the shorter that drain.  CORNETTO_SDUST_TAIL = percent of the bases (default 20), CORNETTO_SDUST_TAILDIV = how
-    // many times shorter (default 4).  Results do not depend on the decomposition.
-    const int tail_pct = std::min(90, std::max(0, env_int("CORNETTO_SDUST_TAIL", w64_path && env_int("CORNETTO_SDUST_CHUNK", 0) <= 0 ? 20 : 0)));
+    // Optionally the last part of the work is cut into shorter chunks, handed out last and in one pass: when the queue runs
+    // dry every wave still has to finish the chunks its lanes hold, and a wave-step costs the same with 3 busy lanes as with
+    // 64.  Measured on the 3.16 Gbp assembly (tools/perf_probe.py, 5 launches each): 0 % 8.5-9.1 ms, 10 % / 4x 8.5-8.8,
+    // 20 % / 4x 8.7-9.1, 20 % / 2x 8.5-9.0, 30 % / 4x 8.9-9.2 — the extra warm-ups cost what the shorter drain saves, so it is
+    // OFF by default.  CORNETTO_SDUST_TAIL = percent of the bases, CORNETTO_SDUST_TAILDIV = how many times shorter (4).
+    // Results do not depend on the decomposition.
+    const int tail_pct = std::min(90, std::max(0, env_int("CORNETTO_SDUST_TAIL", 0)));
     const int tail_div = std::min(16, std::max(1, env_int("CORNETTO_SDUST_TAILDIV", 4)));
     const int64_t small = std::max<int64_t>(64, (chunk / tail_div + 63) / 64 * 64);
     const int64_t tail_from = tail_pct > 0 && tail_div > 1 ? a->total - a->total * tail_pct / 100 : a->total + 1;   // in bases, assembly order

@@ -395,6 +395,13 @@ def test_sdust_queue_and_order_do_not_change_results(acc, golden_dir, monkeypatc
         for chunk in ("100", "37", "64"):
             monkeypatch.setenv("CORNETTO_SDUST_CHUNK", chunk)
             assert gpu_sdust_text(acc, recs, 20, 64) == exp, (waves, order, runon, chunk)
+    # a table of two chunk sizes: the last 35 % of the bases in chunks 2 / 4 times shorter, handed out last
+    monkeypatch.setenv("CORNETTO_SDUST_CHUNK", "512")
+    for tail, div, dense in (("35", "4", "2"), ("35", "2", "0"), ("90", "3", "2"), ("5", "16", "1")):
+        monkeypatch.setenv("CORNETTO_SDUST_TAIL", tail)
+        monkeypatch.setenv("CORNETTO_SDUST_TAILDIV", div)
+        monkeypatch.setenv("CORNETTO_SDUST_DENSE", dense)
+        assert gpu_sdust_text(acc, recs, 20, 64) == exp, (tail, div, dense)
 
 
 @pytest.mark.parametrize("chunk", ["64", "500", "1536"])

@@ -1293,11 +1293,21 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
     const int variant0 = env_int("CORNETTO_SDUST_VARIANT", 0);
     const bool w64_path = W - 2 <= 64 && T >= 5 && T <= 100000 && variant0 == 0;
     if (w64_path && h->sd_slots == 0) {
-        // The kernel must not spill: builds of it that kept registers in scratch memory gave results that
-        // changed from run to run on MI355X (ROCm 7.2), builds without scratch never did.
-        hipFuncAttributes fa;
-        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&sdust_w64<false>)) != hipSuccess || fa.localSizeBytes != 0)
-            return cn_fail(h, CORNETTO_E_HIP, "sdust: kernel built with %zu bytes of scratch per lane (register spills): refusing to run it", (size_t)fa.localSizeBytes);
+        // The kernel must not spill: round-1 builds of it that kept registers in scratch memory gave results that changed from
+        // run to run on MI355X (ROCm 7.2), builds without scratch never did (20 bench steps over 3.16 Gbp digest identically:
+        // bench.py "determinism").  The cause could not be isolated since: hipcc 7.2 no longer produces a spilling build of this
+        // kernel even when asked for 8 waves per SIMD or 48 registers ("failed to meet occupancy target": it keeps 89 VGPRs), so
+        // there is nothing to test.  What was tightened meanwhile: the P-slot hand-off between lanes waits for the wave's
+        // outstanding stores in front of EVERY slot load.  The guard covers both instantiations that can be launched;
+        // CORNETTO_SDUST_ALLOW_SCRATCH=1 lifts it.
+        for (int inst = 0; inst < 2; ++inst) {
+            hipFuncAttributes fa;
+            const void *fn = inst ? reinterpret_cast<const void *>(&sdust_w64<true>) : reinterpret_cast<const void *>(&sdust_w64<false>);
+            if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return cn_fail(h, CORNETTO_E_HIP, "sdust: hipFuncGetAttributes failed");
+            if (fa.localSizeBytes != 0 && !env_int("CORNETTO_SDUST_ALLOW_SCRATCH", 0))
+                return cn_fail(h, CORNETTO_E_HIP, "sdust: kernel%s built with %zu bytes of scratch per lane (register spills): refusing to run it",
+                               inst ? " (statistics build)" : "", (size_t)fa.localSizeBytes);
+        }
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sdust_w64<false>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 16;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus < 1) cus = 256;

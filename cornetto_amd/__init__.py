@@ -103,6 +103,7 @@ def lib():
         "cornetto_cov_upload": (C.c_int, [vp, vp, vp, vp, i32, pp]),
         "cornetto_cov_wrap": (C.c_int, [vp, vp, vp, vp, vp, i32, pp]),
         "cornetto_cov_free": (None, [vp, vp]),
+        "cornetto_cov_shard": (C.c_int, [vp, vp, vp, vp, i32, pp]),
         "cornetto_n_reg": (i32, [i32, i32, i32]),
         "cornetto_cov_prepare": (C.c_int, [vp, vp, i32, i32, C.POINTER(C.c_uint64)]),
         "cornetto_cov_regs": (C.c_int, [vp, vp, i32, vp]),
@@ -361,6 +362,13 @@ class Accel:
         out = C.c_void_p()
         self._chk(self.L.cornetto_cov_wrap(self.h, d_depth, d_mq, offsets.ctypes.data, lens.ctypes.data, len(lens), C.byref(out)))
         return _Resident(self, out, self.L.cornetto_cov_free, lens)
+
+    def cov_shard(self, src_acc, cov, ctgs):
+        """contigs `ctgs` of `cov` (resident on src_acc's device) as a new coverage object on this handle's device"""
+        ctgs = np.ascontiguousarray(ctgs, dtype=np.int32)
+        out = C.c_void_p()
+        self._chk(self.L.cornetto_cov_shard(src_acc.h, cov.ptr, self.h, ctgs.ctypes.data, len(ctgs), C.byref(out)))
+        return _Resident(self, out, self.L.cornetto_cov_free, [cov.lens[i] for i in ctgs])
 
     def cov_prepare(self, cov, w=2500, inc=50):
         sums = (C.c_uint64 * 3)()

@@ -14,6 +14,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <pthread.h>
+
 #include "cli.h"
 
 typedef struct {
@@ -141,6 +143,141 @@ static void panel_print(const char *asm_bed, const char *lowq_bed, char **cov_na
     free(line);
 }
 
+/* ---------------- several GPUs (CORNETTO_DEVICES): the window stage sharded by contig ----------------
+ * get_regs() is independent per contig (src/boringbits_main.c:331); the thresholds depend on the assembly-wide mean
+ * (:283-294 -> :518-519).  The text is parsed on the first device; its contigs are then dealt to the devices (longest first,
+ * each to the least loaded: LPT) and copied there (cornetto_cov_shard: xGMI peer copies); every device gets one host thread
+ * with its own handle: block sums + totals of its share, the host adds the 3 x u64 totals up, then the classification with
+ * the common thresholds.  The selected windows come back per device and are put together in contig order: the printing
+ * below is the same as with one device. */
+typedef struct {
+    int dev;
+    cornetto_accel_t *h, *h_src;
+    const cornetto_cov_t *src;
+    cornetto_cov_t *part;
+    int32_t *ctgs, n;
+    int phase;
+    uint64_t sums[3];
+    const optp_t *opt;
+    int32_t lo, hi;
+    int8_t boring;
+    cornetto_regrec_t *recs;
+    int64_t n_recs;
+    int rc;
+    char err[600];
+} bb_dev_t;
+
+static void *bb_worker(void *p)
+{
+    bb_dev_t *d = (bb_dev_t *)p;
+    d->rc = CORNETTO_OK;
+    if (d->phase == 0) {
+        if (!d->h) {
+            d->rc = cornetto_accel_open(&d->h, d->dev, NULL);
+            if (d->rc != CORNETTO_OK) {
+                snprintf(d->err, sizeof(d->err), "cannot open HIP device %d: %s", d->dev, cornetto_accel_strerror(d->rc));
+                return NULL;
+            }
+        }
+        d->rc = cornetto_cov_shard(d->h_src, d->src, d->h, d->ctgs, d->n, &d->part);
+        if (d->rc == CORNETTO_OK && d->n > 0) d->rc = cornetto_cov_prepare(d->h, d->part, d->opt->window_size, d->opt->window_inc, d->sums);
+    } else if (d->n > 0) {
+        d->rc = cornetto_cov_select(d->h, d->part, d->lo, d->hi, d->opt->low_mq_cov_thresh, d->opt->edge_len, d->opt->min_ctg_len, d->boring, &d->recs, &d->n_recs);
+    }
+    if (d->rc != CORNETTO_OK && !d->err[0])
+        snprintf(d->err, sizeof(d->err), "device %d: %s (%s)", d->dev, cornetto_accel_last_error(d->h), cornetto_accel_strerror(d->rc));
+    return NULL;
+}
+
+static void bb_run(bb_dev_t *dv, int n_dev, int phase)
+{
+    pthread_t th[CLI_MAX_DEV];
+    int started[CLI_MAX_DEV];
+    for (int d = 0; d < n_dev; ++d) dv[d].phase = phase;
+    for (int d = 0; d < n_dev; ++d) started[d] = d > 0 && pthread_create(&th[d], NULL, bb_worker, &dv[d]) == 0;
+    for (int d = 0; d < n_dev; ++d)
+        if (!started[d]) bb_worker(&dv[d]);
+    for (int d = 0; d < n_dev; ++d)
+        if (started[d]) pthread_join(th[d], NULL);
+    for (int d = 0; d < n_dev; ++d)
+        if (dv[d].rc != CORNETTO_OK) {
+            CLI_ERROR("%s", dv[d].err);
+            exit(EXIT_FAILURE);
+        }
+}
+
+/* -> the selected windows of all contigs in contig order (cornetto_free), and the three totals */
+static void bb_multi(cornetto_accel_t *h0, const cornetto_cov_t *cov, int32_t n_ctg, const int32_t *lens, const int *devs, int n_dev, const optp_t *opt,
+                     int8_t boring, uint64_t sums[3], int32_t *mean_depth, int32_t *mean_mq, cornetto_regrec_t **recs, int64_t *n_recs)
+{
+    bb_dev_t dv[CLI_MAX_DEV];
+    memset(dv, 0, sizeof(dv));
+    int32_t *order = (int32_t *)cli_xmalloc(((size_t)n_ctg + 1) * sizeof(int32_t));
+    int32_t *owner = (int32_t *)cli_xmalloc(((size_t)n_ctg + 1) * sizeof(int32_t));
+    for (int32_t i = 0; i < n_ctg; ++i) order[i] = i;
+    for (int32_t i = 1; i < n_ctg; ++i) { /* by descending length, ties in input order */
+        const int32_t x = order[i];
+        int32_t j = i;
+        while (j > 0 && lens[order[j - 1]] < lens[x]) { order[j] = order[j - 1]; --j; }
+        order[j] = x;
+    }
+    int64_t load[CLI_MAX_DEV];
+    for (int d = 0; d < n_dev; ++d) {
+        load[d] = 0;
+        dv[d].dev = devs[d];
+        dv[d].h = d == 0 ? h0 : NULL;
+        dv[d].h_src = h0;
+        dv[d].src = cov;
+        dv[d].opt = opt;
+        dv[d].boring = boring;
+        dv[d].ctgs = (int32_t *)cli_xmalloc(((size_t)n_ctg + 1) * sizeof(int32_t));
+    }
+    for (int32_t k = 0; k < n_ctg; ++k) {
+        int best = 0;
+        for (int d = 1; d < n_dev; ++d)
+            if (load[d] < load[best]) best = d;
+        owner[order[k]] = best;
+        load[best] += (int64_t)lens[order[k]] + 1;
+    }
+    for (int32_t i = 0; i < n_ctg; ++i) dv[owner[i]].ctgs[dv[owner[i]].n++] = i; /* ascending: a device's contigs keep their input order */
+    bb_run(dv, n_dev, 0);
+    sums[0] = sums[1] = sums[2] = 0;
+    for (int d = 0; d < n_dev; ++d)
+        for (int k = 0; k < 3; ++k) sums[k] += dv[d].sums[k];            /* the one exchange: 3 x u64 per device */
+    *mean_depth = (int32_t)round((double)sums[0] / (double)sums[2]);     /* :293 */
+    *mean_mq = (int32_t)round((double)sums[1] / (double)sums[2]);        /* :294 */
+    for (int d = 0; d < n_dev; ++d) {
+        dv[d].lo = cornetto_cov_threshold(opt->low_cov_thresh, *mean_depth);   /* :518 */
+        dv[d].hi = cornetto_cov_threshold(opt->high_cov_thresh, *mean_depth);  /* :519 */
+    }
+    bb_run(dv, n_dev, 1);
+    int64_t total = 0;
+    for (int d = 0; d < n_dev; ++d) total += dv[d].n_recs;
+    cornetto_regrec_t *all = (cornetto_regrec_t *)cli_xmalloc(((size_t)total + 1) * sizeof(*all));
+    int64_t cur[CLI_MAX_DEV], at = 0;
+    int32_t local[CLI_MAX_DEV];
+    for (int d = 0; d < n_dev; ++d) { cur[d] = 0; local[d] = 0; }
+    for (int32_t i = 0; i < n_ctg; ++i) {
+        bb_dev_t *d = &dv[owner[i]];
+        const int32_t li = local[owner[i]]++;
+        int64_t *c = &cur[owner[i]];
+        for (; *c < d->n_recs && d->recs[*c].ctg == li; ++*c) {
+            all[at] = d->recs[*c];
+            all[at++].ctg = i;
+        }
+    }
+    for (int d = 0; d < n_dev; ++d) {
+        cornetto_free(dv[d].recs);
+        if (dv[d].part) cornetto_cov_free(dv[d].h, dv[d].part);
+        if (d > 0 && dv[d].h) cornetto_accel_close(dv[d].h);
+        free(dv[d].ctgs);
+    }
+    free(order);
+    free(owner);
+    *recs = all;
+    *n_recs = at;
+}
+
 int boringbits_main(int argc, char *argv[], int8_t boring)
 {
     static const struct option lo[] = {
@@ -241,6 +378,13 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
         CLI_ERROR("Failed to open %s : No such file or directory.", covmq);
         exit(EXIT_FAILURE);
     }
+    int devs[CLI_MAX_DEV];
+    const int n_dev = cli_device_list(devs);
+    if (n_dev >= 1) { /* the text is parsed on the first listed device */
+        char one[32];
+        snprintf(one, sizeof(one), "%d", devs[0]);
+        setenv("CORNETTO_DEVICE", one, 1);
+    }
     cornetto_accel_t *h = cli_accel_open();
     cornetto_bgin_t *bg = NULL;
     cli_accel_check(h, cornetto_bgin_open(h, &bg), "bedgraph ingest");
@@ -300,7 +444,14 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
     cornetto_regrec_t *recs = NULL;
     cornetto_ivl_t *fun = NULL;
     int64_t n_recs = 0, n_fun = 0;
-    if (n_ctg > 0) {
+    int recs_are_malloced = 0;
+    if (n_ctg > 0 && n_dev >= 2 && !panel_bed) {
+        t0 = cli_realtime();
+        uint64_t sums[3];
+        bb_multi(h, cov, n_ctg, lens, devs, n_dev, &opt, boring, sums, &mean_depth, &mean_mq, &recs, &n_recs);
+        recs_are_malloced = 1;
+        CLI_VERBOSE("Found regions on %d devices in %.2f seconds", n_dev, cli_realtime() - t0);
+    } else if (n_ctg > 0) {
         t0 = cli_realtime();
         uint64_t sums[3];
         cli_accel_check(h, cornetto_cov_prepare(h, cov, opt.window_size, opt.window_inc, sums), "window block sums");
@@ -374,7 +525,8 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
     }
     cli_out_flush();
     CLI_VERBOSE("Printed the bits in %.2f seconds", cli_realtime() - t0);
-    cornetto_free(recs);
+    if (recs_are_malloced) free(recs);
+    else cornetto_free(recs);
     for (int32_t i = 0; i < n_ctg; ++i) free(names[i]);
     free(names);
     cornetto_cov_free(h, cov);

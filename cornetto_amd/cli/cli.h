@@ -111,6 +111,10 @@ void cli_fastx_close(cli_fastx_t *f);
 /* >= 0: sequence length; -1 end of file; -2 truncated quality string */
 int64_t cli_fastx_read(cli_fastx_t *f, cli_str_t *name, cli_str_t *comment, cli_str_t *seq, cli_str_t *qual);
 
+/* $CORNETTO_DEVICES: ordinals of the GPUs to spread the contigs over (at most CLI_MAX_DEV); returns how many, 0 if unset */
+#define CLI_MAX_DEV 64
+int cli_device_list(int *devs);
+
 /* a batch of records held in memory for one device pass */
 typedef struct {
     char **names;

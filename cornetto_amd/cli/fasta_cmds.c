@@ -90,7 +90,6 @@ static void sdust_scan(cornetto_accel_t *h, const cli_recname_t *r, int64_t n_re
  * own handle: upload, scan, results.  Printing happens after the join, record by record in INPUT order (each device's
  * results come back ordered by its local record index, and a device's records keep their input order, so one cursor per
  * device suffices): the output is byte for byte that of one device.  Nothing is exchanged between the devices. */
-#define CLI_MAX_DEV 64
 typedef struct {
     int kind;                    /* 0 telofind, 1 sdust */
     const char *motif;
@@ -170,26 +169,6 @@ static void print_ivl(const char *name, size_t name_len, const cornetto_ivl_t *v
     cli_out_char('\t');
     cli_out_int(v->finish);
     cli_out_char('\n');
-}
-
-/* the ordinals of $CORNETTO_DEVICES; 0 when it is not set (one device: $CORNETTO_DEVICE) */
-static int cli_device_list(int *devs)
-{
-    const char *s = getenv("CORNETTO_DEVICES");
-    int n = 0;
-    if (!s || !*s) return 0;
-    while (*s) {
-        char *end = NULL;
-        const long v = strtol(s, &end, 10);
-        if (end == s || v < 0 || n == CLI_MAX_DEV) {
-            CLI_ERROR("CORNETTO_DEVICES=%s: a comma-separated list of at most %d device ordinals is expected", getenv("CORNETTO_DEVICES"), CLI_MAX_DEV);
-            exit(EXIT_FAILURE);
-        }
-        devs[n++] = (int)v;
-        s = end;
-        while (*s == ',' || *s == ' ') ++s;
-    }
-    return n;
 }
 
 static void multi_batch(multi_dev_t *dv, int n_dev, const cli_batch_t *b)

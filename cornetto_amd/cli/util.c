@@ -183,3 +183,24 @@ int64_t cli_batch_limit(void)
     int64_t v = s ? atoll(s) : 0;
     return v > 0 ? v : 4000000000LL;
 }
+
+/* the ordinals of $CORNETTO_DEVICES ("0,1,2": several GPUs of one node, a device may be named twice); 0 when it is not set
+ * (one device: $CORNETTO_DEVICE) */
+int cli_device_list(int *devs)
+{
+    const char *s = getenv("CORNETTO_DEVICES");
+    int n = 0;
+    if (!s || !*s) return 0;
+    while (*s) {
+        char *end = NULL;
+        const long v = strtol(s, &end, 10);
+        if (end == s || v < 0 || n == CLI_MAX_DEV) {
+            CLI_ERROR("CORNETTO_DEVICES=%s: a comma-separated list of at most %d device ordinals is expected", getenv("CORNETTO_DEVICES"), CLI_MAX_DEV);
+            exit(EXIT_FAILURE);
+        }
+        devs[n++] = (int)v;
+        s = end;
+        while (*s == ',' || *s == ' ') ++s;
+    }
+    return n;
+}

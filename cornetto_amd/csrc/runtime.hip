@@ -339,6 +339,54 @@ int cornetto_cov_upload(cornetto_accel_t *h, const uint16_t *const *depth, const
     return CORNETTO_OK;
 }
 
+int cornetto_cov_shard(cornetto_accel_t *h_src, const cornetto_cov_t *src, cornetto_accel_t *h_dst, const int32_t *ctgs, int32_t n, cornetto_cov_t **out)
+{
+    if (!h_src || !h_dst || !src || !out || n < 0 || (n > 0 && !ctgs)) return cn_fail(h_dst, CORNETTO_E_ARG, "cov_shard: bad argument");
+    *out = nullptr;
+    for (int32_t i = 0; i < n; ++i)
+        if (ctgs[i] < 0 || ctgs[i] >= src->n) return cn_fail(h_dst, CORNETTO_E_ARG, "cov_shard: contig index %d outside 0..%d", ctgs[i], src->n - 1);
+    CN_HIP(h_dst, hipSetDevice(h_dst->device));
+    cornetto_cov_t *c = new (std::nothrow) cornetto_cov;
+    if (!c) return cn_fail(h_dst, CORNETTO_E_NOMEM, "cov_shard: host allocation failed");
+    c->n = n;
+    int64_t pos = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        c->off.push_back(pos);
+        c->len.push_back(src->len[ctgs[i]]);
+        c->total += src->len[ctgs[i]];
+        pos = cn_align_up(pos + src->len[ctgs[i]], 64);
+    }
+    const size_t bytes = (size_t)(pos + SLACK) * sizeof(uint16_t);
+    if (hipMalloc(&c->owned_d, bytes) != hipSuccess || hipMalloc(&c->owned_q, bytes) != hipSuccess) {
+        cornetto_cov_free(h_dst, c);
+        return cn_fail(h_dst, CORNETTO_E_NOMEM, "cov_shard: hipMalloc of 2 x %zu bytes failed", bytes);
+    }
+    c->d_depth = (const uint16_t *)c->owned_d;
+    c->d_mq = (const uint16_t *)c->owned_q;
+    int rc = CORNETTO_OK;
+    // everything the source handle queued (the ingest) has to be done before the peer copies read it
+    if (hipSetDevice(h_src->device) != hipSuccess || hipStreamSynchronize(h_src->stream) != hipSuccess) rc = CORNETTO_E_HIP;
+    if (hipSetDevice(h_dst->device) != hipSuccess) rc = CORNETTO_E_HIP;
+    if (rc == CORNETTO_OK && (hipMemsetAsync(c->owned_d, 0, bytes, h_dst->stream) != hipSuccess || hipMemsetAsync(c->owned_q, 0, bytes, h_dst->stream) != hipSuccess))
+        rc = CORNETTO_E_HIP;
+    for (int32_t i = 0; i < n && rc == CORNETTO_OK; ++i) {
+        const size_t nb = (size_t)src->len[ctgs[i]] * sizeof(uint16_t);
+        if (nb == 0) continue;
+        // xGMI peer copy (staged through the host by the runtime where peer access is not available); the same device is a plain copy
+        if (hipMemcpyPeerAsync((uint16_t *)c->owned_d + c->off[i], h_dst->device, src->d_depth + src->off[ctgs[i]], h_src->device, nb, h_dst->stream) != hipSuccess ||
+            hipMemcpyPeerAsync((uint16_t *)c->owned_q + c->off[i], h_dst->device, src->d_mq + src->off[ctgs[i]], h_src->device, nb, h_dst->stream) != hipSuccess)
+            rc = CORNETTO_E_HIP;
+    }
+    if (rc == CORNETTO_OK) rc = cov_finish_table(h_dst, c);
+    if (rc == CORNETTO_OK && hipStreamSynchronize(h_dst->stream) != hipSuccess) rc = CORNETTO_E_HIP;
+    if (rc != CORNETTO_OK) {
+        cornetto_cov_free(h_dst, c);
+        return cn_fail(h_dst, rc, "cov_shard: copy between devices failed");
+    }
+    *out = c;
+    return CORNETTO_OK;
+}
+
 int cornetto_cov_wrap(cornetto_accel_t *h, const void *d_depth, const void *d_mq_depth, const int64_t *offsets,
                       const int32_t *lens, int32_t n, cornetto_cov_t **out)
 {

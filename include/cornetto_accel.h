@@ -205,6 +205,13 @@ int cornetto_cov_wrap(cornetto_accel_t *h, const void *d_depth, const void *d_mq
                       const int32_t *lens, int32_t n, cornetto_cov_t **out);
 void cornetto_cov_free(cornetto_accel_t *h, cornetto_cov_t *c);
 
+/* Several GPUs: copy contigs ctgs[0..n) (indices into `src`, any order) of a coverage object that is resident on the device of
+ * h_src into a new object on the device of h_dst (the same device is allowed).  get_regs() is independent per contig
+ * (src/boringbits_main.c:331); the one quantity that spans contigs is the assembly-wide mean behind the thresholds
+ * (:283-294 -> :518-519): every device runs cornetto_cov_prepare() on its share, the caller adds the sums[] up. */
+int cornetto_cov_shard(cornetto_accel_t *h_src, const cornetto_cov_t *src, cornetto_accel_t *h_dst, const int32_t *ctgs, int32_t n,
+                       cornetto_cov_t **out);
+
 /* number of contigs and their lengths (owned by the object) */
 int32_t cornetto_cov_n(const cornetto_cov_t *c);
 const int32_t *cornetto_cov_lens(const cornetto_cov_t *c);

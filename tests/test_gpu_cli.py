@@ -101,6 +101,19 @@ def test_panel(cli, golden_dir, plain, args, exp):
     assert out == golden(golden_dir, exp)
 
 
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0,0"])
+@pytest.mark.parametrize("args,exp", PANEL)
+def test_panel_window_stage_over_several_devices(cli, golden_dir, plain, args, exp, devices):
+    """CORNETTO_DEVICES: the contigs are dealt to the devices after the ingest (cornetto_cov_shard), every device sums and
+    classifies its share, the host adds the three totals up for the common thresholds — same bytes as one device (here the
+    same GPU several times; more devices than contigs leaves some without work)"""
+    a = [plain["cov-total.bg"] if x == "T" else plain["cov-mq20.bg"] if x == "Q" else x for x in args]
+    rc, out, err = run(cli, a, {"CORNETTO_DEVICES": devices})
+    assert rc == 0, err.decode()
+    assert out == golden(golden_dir, exp)
+    assert err.count(b"Average depth:") == 1
+
+
 def test_panel_malformed_inputs_exit_1(cli, plain, tmp_path):
     tot = open(plain["cov-total.bg"], "rb").read().splitlines(True)
     mq = open(plain["cov-mq20.bg"], "rb").read().splitlines(True)

@@ -175,6 +175,28 @@ def test_coverage_totals_and_selection(world):
             assert np.array_equal(got[k], exp[k]), (ci, k)
 
 
+def test_cov_shard_sums_and_windows(world):
+    """cornetto_cov_shard: two shares of the contigs on two handles; the totals add up to the whole and every contig's windows
+    are the ones the whole object gives"""
+    import cornetto_amd
+    acc, cov, lens = world["acc"], world["cov"], world["lens"]
+    whole = acc.cov_prepare(cov, 2500, 50)
+    acc2 = cornetto_amd.Accel(0)
+    try:
+        a_idx = list(range(0, len(lens), 2))[::-1]           # any order
+        b_idx = list(range(1, len(lens), 2))
+        pa, pb = acc2.cov_shard(acc, cov, a_idx), acc.cov_shard(acc, cov, b_idx)
+        sa, sb = acc2.cov_prepare(pa, 2500, 50), acc.cov_prepare(pb, 2500, 50)
+        assert tuple(x + y for x, y in zip(sa, sb)) == whole
+        acc.cov_prepare(cov, 2500, 50)
+        for k in (0, len(a_idx) // 2, len(a_idx) - 1):
+            assert np.array_equal(acc2.cov_regs(pa, k), acc.cov_regs(cov, a_idx[k]))
+        pa.close()
+        pb.close()
+    finally:
+        acc2.close()
+
+
 def test_offsets_beyond_2_pow_32():
     """20 contigs of ~225 Mb = 4.5 Gbp: contig 9 straddles byte offset 2^31 of the bases, contig 19 byte offset 2^32;
     the u16 coverage arrays pass element offset 2^31 in contig 9 (byte offset 2^32) — the bench workload (3.16 Gbp) crosses

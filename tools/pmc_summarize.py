@@ -10,7 +10,7 @@ def counters(pattern, want):
             for w in want:
                 if w in r["Kernel_Name"]:
                     agg[(w, r["Counter_Name"])] += float(r["Counter_Value"])
-                    n[(w, r["Counter_Name"])].add(r["Dispatch_Id"])
+                    n[(w, r["Counter_Name"])].add((f, r["Dispatch_Id"]))
     return {k: v / max(1, len(n[k])) for k, v in agg.items()}          # per launch
 sq = counters("gpurun_out/pmc_%s_s*/**/*_counter_collection.csv" % tag, ["sdust_w64", "sdust_dense"])
 stats = open("gpurun_out/%s_stats.txt" % tag).read()

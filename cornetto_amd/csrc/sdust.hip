@@ -311,6 +311,215 @@ __global__ __launch_bounds__(64) void sdust_kernel(SdArgs A)
 #undef SLOT
 }
 
+// The same kernel for windows of 256 to 1024 words (258 <= W <= 1026; the reference takes any -w): the state of a lane — ring,
+// 32-bit counters, P slots — lives in global memory, laid out [index][lane of the grid] so that the 64 lanes of a wave touch
+// consecutive words.  Correct, not fast: nobody masks with such windows routinely.  Slots hold r (< 2^20) | l << 20.
+__global__ __launch_bounds__(64) void sdust_kernel_g(SdArgs A, uint8_t *g_ring, uint32_t *g_cw, uint32_t *g_cv, uint32_t *g_slot, int RC)
+{
+    __shared__ uint8_t s_lut[256];
+    const int lane = threadIdx.x;
+    const int MASK = RC - 1;
+    const size_t NL = (size_t)gridDim.x * 64, gl = (size_t)blockIdx.x * 64 + lane;
+
+    // seq_nt4_table (src/sdust/sdust.c:23-40): A/a C/c G/g T/t -> 0..3, bytes 0..3 -> themselves, else 4
+    for (int c = lane; c < 256; c += 64) {
+        uint8_t v = 4;
+        if (c < 4) v = (uint8_t)c;
+        else if (c == 'A' || c == 'a') v = 0;
+        else if (c == 'C' || c == 'c') v = 1;
+        else if (c == 'G' || c == 'g') v = 2;
+        else if (c == 'T' || c == 't') v = 3;
+        s_lut[c] = v;
+    }
+    for (int i = 0; i < 64; ++i) {
+        g_cw[(size_t)i * NL + gl] = 0;
+        g_cv[(size_t)i * NL + gl] = 0;
+    }
+    for (int i = 0; i < RC; ++i) g_slot[(size_t)i * NL + gl] = 0;
+    __syncthreads();
+
+    const int cid = blockIdx.x * 64 + lane;
+    if (cid >= A.n_chunks) return;
+    const SdChunk ch = A.chunks[cid];
+    const int len = A.ctg_len[ch.ctg];
+    const uint8_t *seq = A.bases + A.ctg_off[ch.ctg];
+    const int T = A.T, W = A.W, CAPW = W - 2;
+
+#define RING(i) g_ring[(size_t)((i) & MASK) * NL + gl]
+#define CW(t) g_cw[(size_t)(t) * NL + gl]
+#define CV(t) g_cv[(size_t)(t) * NL + gl]
+#define SLOT(s) g_slot[(size_t)((s) & MASK) * NL + gl]
+
+    // ---- where to start: W-2 word emissions before (chunk start - 2W) ------------------------------
+    int u = 0;
+    if (ch.start > 0) {
+        int y = ch.start - 2 * W;
+        if (y > 2) {
+            int need = CAPW, run = 0, p = y - 1;
+            // walking down, `run` = number of consecutive ACGT bases at [p, p+run); a word ends at q
+            // (bases q-2..q) for every q with a run of >= 3 ending there
+            for (; p >= 0; --p) {
+                if (s_lut[seq[p]] < 4) {
+                    if (++run >= 3 && --need == 0) break;
+                } else {
+                    run = 0;
+                }
+            }
+            u = p > 0 ? p : 0;
+        }
+    }
+
+    // ---- sequential state ------------------------------------------------------------------------
+    int l = 0, front = 0, size = 0, L = 0, rw = 0, rv = 0;
+    unsigned t = 0;
+    int nP = 0, minstart = 0;
+    bool have_last = false;
+    uint32_t last_s = 0, last_f = 0, n_out = 0;
+    uint2 *out = A.out + (size_t)cid * A.cap;
+    const int rec_from = ch.start;
+
+    auto emit = [&](int ps, int pf) {      // :93-99 on the lane-local list
+        if (have_last && ps <= (int)last_f) {
+            if (pf > (int)last_f) last_f = (uint32_t)pf;
+        } else {
+            if (have_last) {
+                if (n_out < A.cap) out[n_out] = make_uint2(last_s, last_f);
+                ++n_out;
+            }
+            have_last = true;
+            last_s = (uint32_t)ps;
+            last_f = (uint32_t)pf;
+        }
+    };
+    // save_masked_regions(start) (:88-102) when it is not a no-op: nP > 0 && minstart < start
+    auto save_evict = [&](int start, int now) {
+        const uint32_t sl = SLOT(minstart);
+        if (now >= rec_from) emit(minstart, minstart + (int)(sl >> 20) + 3);
+        int q = minstart;
+        const int qend = start - minstart > RC ? minstart + RC : start;
+        for (; q < qend && nP > 0; ++q)
+            if (SLOT(q)) {
+                SLOT(q) = 0;
+                --nP;
+            }
+        if (nP > 0) {
+            q = start;
+            for (int g = 0; g < RC && SLOT(q) == 0; ++g) ++q;   // bounded: a live entry lies within RC of start
+            minstart = q;
+        }
+    };
+
+    const int stop = (ch.end == len) ? len + 1 : ch.end;   // the last chunk also runs the sentinel step i == len
+    uint32_t word = 0;
+    if (u < len) word = *reinterpret_cast<const uint32_t *>(seq + (u & ~3)) >> (8 * (u & 3));
+    for (int i = u; i < stop; ++i) {
+        if ((i & 3) == 0 && i != u && i < len) word = *reinterpret_cast<const uint32_t *>(seq + i);
+        const int b = i < len ? s_lut[word & 0xFFu] : 4;
+        word >>= 8;
+        if (b < 4) {
+            ++l;
+            t = (t << 2 | (unsigned)b) & 63u;                           // :144
+            if (l >= 3) {
+                const int start = (l - W > 0 ? l - W : 0) + (i + 1 - l);   // :146
+                if (nP > 0 && minstart < start) save_evict(start, i);  // :147
+                // shift_window (:66-86)
+                if (size >= CAPW) {
+                    const int s = RING(front);
+                    front = (front + 1) & MASK;
+                    --size;
+                    const int c = CW(s) - 1;
+                    CW(s) = (uint32_t)c;
+                    rw -= c;
+                    if (L > size) {
+                        --L;
+                        const int d = CV(s) - 1;
+                        CV(s) = (uint32_t)d;
+                        rv -= d;
+                    }
+                }
+                RING(front + size) = (uint8_t)t;
+                ++size;
+                ++L;
+                {
+                    const int c = CW(t);
+                    CW(t) = (uint32_t)(c + 1);
+                    rw += c;
+                    const int d = CV(t);
+                    CV(t) = (uint32_t)(d + 1);
+                    rv += d;
+                    if ((d + 1) * 10 > T << 1) {                        // :79
+                        int s;
+                        do {
+                            s = RING(front + size - L);
+                            const int e = CV(s) - 1;
+                            CV(s) = (uint32_t)e;
+                            rv -= e;
+                            --L;
+                        } while (s != (int)t && L > 0);
+                    }
+                }
+                if (rw * 10 > L * T) {                                  // :149 -> find_perfect (:104-128)
+                    int r = rv, max_r = 0, max_l = 0, fold = size;
+                    const int i0 = size - L - 1;
+                    for (int k = i0; k >= 0; --k) {
+                        const int tt = RING(front + k);
+                        const int c = CV(tt);
+                        CV(tt) = (uint32_t)(c + 1);
+                        r += c;
+                        const int new_l = size - k - 1;
+                        if (r * 10 > T * new_l) {                       // :112
+                            while (fold > k) {                          // :113-117 as a running maximum
+                                --fold;
+                                const uint32_t sl = SLOT(start + fold);
+                                if (sl) {
+                                    const int pr = (int)(sl & 0xFFFFFu), pl = (int)(sl >> 20);
+                                    if (max_r == 0 || pr * max_l > max_r * pl) {
+                                        max_r = pr;
+                                        max_l = pl;
+                                    }
+                                }
+                            }
+                            if (max_r == 0 || r * max_l >= max_r * new_l) {   // :118
+                                max_r = r;
+                                max_l = new_l;
+                                const int ps = start + k;
+                                if (SLOT(ps) == 0) {
+                                    if (nP == 0 || ps < minstart) minstart = ps;
+                                    ++nP;
+                                }
+                                SLOT(ps) = (uint32_t)r | ((uint32_t)new_l << 20);
+                            }
+                        }
+                    }
+                    for (int k = 0; k <= i0; ++k) {                     // undo the in-place use of cv as c[]
+                        const int tt = RING(front + k);
+                        CV(tt) = CV(tt) - 1;
+                    }
+                }
+            }
+        } else {
+            int start = (l - W + 1 > 0 ? l - W + 1 : 0) + (i + 1 - l);  // :152
+            while (nP > 0) {                                            // :153
+                if (minstart >= start) start = minstart + 1;
+                save_evict(start, i);
+                ++start;
+            }
+            l = 0;
+            t = 0;                                                      // :154 — window and counters kept
+        }
+    }
+    if (have_last) {
+        if (n_out < A.cap) out[n_out] = make_uint2(last_s, last_f);
+        ++n_out;
+    }
+    A.out_n[cid] = n_out;
+    if (n_out > A.cap) atomicMax(A.ovf, n_out);
+#undef RING
+#undef CW
+#undef CV
+#undef SLOT
+}
+
 
 // ---------------------------------------------------------------------------------------------------
 // sdust_w64: the production kernel for W - 2 <= 64 (default W = 64).  Same recurrence, but every
@@ -1283,8 +1492,9 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
     cornetto_asm_t *a = const_cast<cornetto_asm_t *>(a_in);   // only the cached chunk table is touched
     *ivls = nullptr;
     *n_ivls = 0;
-    // (W - 2 words in the window; the older kernel keeps its 3-mer counters in bytes: at most 255 copies, W <= 257)
-    if (W < 3 || W > 257) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "sdust: -w %d outside 3..257 (the reference crashes below 3)", W);
+    // (W - 2 words in the window.  Up to 64: sdust_w64; up to 255: the older kernel with byte counters in LDS; up to 1024: the
+    // same with its state in global memory.  Beyond, the reference's own 32-bit products r * l (:115,:118) overflow.)
+    if (W < 3 || W > 1026) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "sdust: -w %d outside 3..1026 (the reference crashes below 3)", W);
     if (T < 0 || T > (1 << 20)) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "sdust: -t %d outside 0..2^20", T);
     CN_HIP(h, hipSetDevice(h->device));
     cn_timing_begin(h);
@@ -1331,6 +1541,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
         }
     }
     chunk = std::max<int64_t>(16, chunk);
+    if (W > 257 && env_int("CORNETTO_SDUST_CHUNK", 0) <= 0) chunk = std::max<int64_t>(chunk, 32 * (int64_t)W);   // (warm-up: 3 W bases per chunk)
     // Optionally the last part of the work is cut into shorter chunks, handed out last and in one pass: when the queue runs
     // dry every wave still has to finish the chunks its lanes hold, and a wave-step costs the same with 3 busy lanes as with
     // 64.  Measured on the 3.16 Gbp assembly (tools/perf_probe.py, 5 launches each): 0 % 8.5-9.1 ms, 10 % / 4x 8.5-8.8,
@@ -1500,8 +1711,17 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                 else CN_LAUNCH(h, "sdust_kernel", sdust_w64<false><<<dim3(nb), dim3(64), 0, h->stream>>>(A));
             } else if (W - 2 <= 64) {
                 CN_LAUNCH(h, "sdust_kernel", sdust_kernel<64><<<dim3(nb), dim3(64), 0, h->stream>>>(A));
-            } else {
+            } else if (W - 2 <= 255) {
                 CN_LAUNCH(h, "sdust_kernel", sdust_kernel<256><<<dim3(nb), dim3(64), 0, h->stream>>>(A));
+            } else {
+                int rc = 512;
+                while (rc < W - 2) rc <<= 1;
+                const size_t NL = (size_t)nb * 64;
+                uint8_t *g = (uint8_t *)cn_ws(h, WS_SD_OFF, NL * ((size_t)rc * 5 + 512) + 64);
+                if (!g) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation of %zu bytes failed", NL * ((size_t)rc * 5 + 512));
+                uint32_t *g_cw = reinterpret_cast<uint32_t *>(g), *g_cv = g_cw + 64 * NL, *g_slot = g_cv + 64 * NL;
+                uint8_t *g_ring = reinterpret_cast<uint8_t *>(g_slot + (size_t)rc * NL);
+                CN_LAUNCH(h, "sdust_kernel", sdust_kernel_g<<<dim3(nb), dim3(64), 0, h->stream>>>(A, g_ring, g_cw, g_cv, g_slot, rc));
             }
             if (dense_pending) CN_HIP(h, hipStreamWaitEvent(h->stream, h->ev2, 0));
             // ordered position of every chunk's intervals (chunks are in contig order) + grand total

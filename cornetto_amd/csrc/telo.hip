@@ -41,6 +41,7 @@ struct TfArgs {
     const int32_t *ctg_len;
     const int2 *tiles;   // {ctg, first position}
     const uint2 *lut;    // [256] {fwd mask, rev mask}
+    const uint8_t *mot;  // tf_scan<-1> (motifs longer than 32 bytes): the motif, then its reverse complement, k bytes each
     int32_t k;
     int32_t bordered;    // 0: heads/tails + bitmap; 1: all matches (lists 0 and 2)
     int32_t mode;        // 0: count only; 1: write at tile_off (dense lists); 2: write into fixed rows of TF_ROW
@@ -84,8 +85,29 @@ __global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
     __syncthreads();
 
     unsigned long long Mf = 0, Mr = 0;
+    if constexpr (H < 0) {
+        // motifs longer than 32 bytes (not a telomere unit; the reference takes any string): every start position compared
+        // byte by byte with the motif and with its reverse complement, the sequence upper-cased as src/find_telomere.c:76-81
+        // does ('a'..'z' only), stopping at the first difference of both
+        if (s0 >= 0 && s0 < len) {
+            const uint8_t *seq = A.bases + off;
+            const int k = A.k;
+            for (int b = 0; b < TF_SEG && s0 + b + k <= len; ++b) {
+                bool mf = true, mr = true;
+                for (int j = 0; j < k && (mf || mr); ++j) {
+                    uint8_t u = seq[s0 + b + j];
+                    u = (u >= 'a' && u <= 'z') ? (uint8_t)(u - 32) : u;
+                    mf = mf && u == A.mot[j];
+                    mr = mr && u == A.mot[k + j];
+                }
+                Mf |= (unsigned long long)mf << b;
+                Mr |= (unsigned long long)mr << b;
+            }
+        }
+    } else
     if (s0 >= 0 && s0 < len) {
-        constexpr int NW = (TF_SEG + H + 3) / 4;      // dwords touched
+        constexpr int HH = H < 0 ? 0 : H;
+        constexpr int NW = (TF_SEG + HH + 3) / 4;      // dwords touched
         constexpr int NV = (NW + 3) / 4;              // 16-byte loads
         uint32_t w[NV * 4];
         const uint4 *src = reinterpret_cast<const uint4 *>(A.bases + off + s0);
@@ -94,16 +116,16 @@ __global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
             uint4 v = src[i];
             w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
         }
-        constexpr uint32_t INJ = 1u << (31 - H);
+        constexpr uint32_t INJ = 1u << (31 - HH);
         uint32_t Sf = 0, Sr = 0, Af = 0, Bf = 0, Ar = 0, Br = 0;
 #pragma unroll
-        for (int e = 0; e < TF_SEG + H; ++e) {
+        for (int e = 0; e < TF_SEG + HH; ++e) {
             const uint32_t c = (w[e >> 2] >> (8 * (e & 3))) & 0xFFu;
             const uint2 L = lut[c];
             Sf = ((Sf << 1) | INJ) & L.x;
             Sr = ((Sr << 1) | INJ) & L.y;
-            if (e >= H) {                             // bit 31 of S = "a match starts at e - H"
-                if (e - H < 32) {
+            if (e >= HH) {                             // bit 31 of S = "a match starts at e - H"
+                if (e - HH < 32) {
                     Af = __builtin_amdgcn_alignbit(Af, Sf, 31);
                     Ar = __builtin_amdgcn_alignbit(Ar, Sr, 31);
                 } else {
@@ -489,20 +511,21 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
     const std::string motif(motif_c);
     const int k = (int)motif.size();
     if (k < 1) return cn_fail(h, CORNETTO_E_ARG, "telofind: empty motif (the reference never terminates on it)");
-    if (k > MAX_MOTIF) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "telofind: motif of %d bytes; at most %d are supported", k, MAX_MOTIF);
+    if (k > (1 << 20)) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "telofind: motif of %d bytes; at most %d are supported", k, 1 << 20);
+    const bool long_motif = k > MAX_MOTIF;   // beyond the 32-bit automaton: compared byte by byte (tf_scan<-1>), runs by the sequential rule
     CN_HIP(h, hipSetDevice(h->device));
     if (hits) { *hits = nullptr; *n_hits = 0; }
     if (bitmap_valid) *bitmap_valid = false;
 
     const std::string rc = revcomp(motif);
-    const bool bordered = has_border(motif) || has_border(rc);
-    const int H = k <= 8 ? 7 : (k <= 16 ? 15 : 31);
+    const bool bordered = long_motif || has_border(motif) || has_border(rc);
+    const int H = long_motif ? 0 : (k <= 8 ? 7 : (k <= 16 ? 15 : 31));
     // shift-and tables: motif position j -> bit (31 - H + j); positions k..H are wildcards
     std::vector<uint2> lut(256);
     for (int c = 0; c < 256; ++c) {
         uint32_t f = 0, r = 0;
         const uint8_t u = c_toupper((uint8_t)c);      // src/find_telomere.c:76-81: sequence upper-cased, motif not
-        for (int j = 0; j <= H; ++j) {
+        for (int j = 0; j <= H && !long_motif; ++j) {
             const uint32_t bit = 1u << (31 - H + j);
             if (j >= k) { f |= bit; r |= bit; continue; }
             if (u == (uint8_t)motif[j]) f |= bit;
@@ -534,7 +557,8 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
     int64_t n_out = 0;
     if (nt > 0) {
         const size_t np = (nt + 4095) / 4096 + 1;
-        uint2 *d_lut = (uint2 *)cn_ws(h, WS_TF_LUT, 256 * sizeof(uint2));
+        uint2 *d_lut = (uint2 *)cn_ws(h, WS_TF_LUT, 256 * sizeof(uint2) + 2 * (size_t)k + 16);
+        uint8_t *d_mot = reinterpret_cast<uint8_t *>(d_lut + 256);
         // small device block: totals[4] u64, ovf u32, err u32
         unsigned long long *d_cnt = (unsigned long long *)cn_ws(h, WS_TF_CNT, 64);
         uint4 *d_tc = (uint4 *)cn_ws(h, WS_TF_TC, nt * sizeof(uint4));
@@ -545,6 +569,8 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
         uint32_t *d_offq[4] = {d_off, d_off + nt, d_off + 2 * nt, d_off + 3 * nt}, *d_part = d_off + 4 * nt;
         uint32_t *d_ovf = reinterpret_cast<uint32_t *>(d_cnt + 4), *d_err = d_ovf + 1;
         CN_HIP(h, hipMemcpyAsync(d_lut, lut.data(), 256 * sizeof(uint2), hipMemcpyHostToDevice, h->stream));
+        const std::string both = motif + rc;          // (pageable host memory: the copy has left it when the call returns)
+        if (d_lut && long_motif) CN_HIP(h, hipMemcpyAsync(d_mot, both.data(), 2 * (size_t)k, hipMemcpyHostToDevice, h->stream));
         CN_HIP(h, hipMemsetAsync(d_cnt, 0, 64, h->stream));
         const bool want_bitmap = want_bitmap_req && !bordered;
         unsigned long long *d_bitmap = nullptr;
@@ -559,13 +585,14 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
             if (bitmap_out) *bitmap_out = d_bitmap;
         }
         auto launch = [&](const TfArgs &A) -> int {
-            if (H == 7) CN_LAUNCH(h, "tf_scan", tf_scan<7><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
+            if (long_motif) CN_LAUNCH(h, "tf_scan", tf_scan<-1><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
+            else if (H == 7) CN_LAUNCH(h, "tf_scan", tf_scan<7><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
             else if (H == 15) CN_LAUNCH(h, "tf_scan", tf_scan<15><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
             else CN_LAUNCH(h, "tf_scan", tf_scan<31><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
             return CORNETTO_OK;
         };
         TfArgs A{};
-        A.bases = a->d_bases; A.ctg_off = a->d_off; A.ctg_len = a->d_len; A.tiles = a->d_tf_tiles; A.lut = d_lut; A.k = k;
+        A.bases = a->d_bases; A.ctg_off = a->d_off; A.ctg_len = a->d_len; A.tiles = a->d_tf_tiles; A.lut = d_lut; A.k = k; A.mot = d_mot;
         A.bordered = bordered ? 1 : 0; A.bitmap = want_bitmap ? d_bitmap : nullptr; A.tile_cnt = d_tc; A.ovf = d_ovf;
         // pass 1: single pass into fixed rows (unbordered motif, hits wanted), or counts only
         const bool rows_mode = hits && !bordered;

@@ -36,7 +36,7 @@ enum {
     CORNETTO_E_HIP = -2,      /* a HIP call or kernel failed; see cornetto_accel_last_error() */
     CORNETTO_E_ARG = -3,      /* invalid argument (NULL, negative length, misaligned device offset, ...) */
     CORNETTO_E_NOMEM = -4,    /* host or device allocation failed */
-    CORNETTO_E_UNSUPPORTED = -5, /* parameter outside the implemented range (motif > 32, W > 257, ...) */
+    CORNETTO_E_UNSUPPORTED = -5, /* parameter outside the implemented range (sdust W > 1026, T > 2^20, ...) */
     CORNETTO_E_FORMAT = -6       /* malformed input text; see cornetto_bgin_error() */
 };
 
@@ -143,7 +143,8 @@ void cornetto_asm_free(cornetto_accel_t *h, cornetto_asm_t *a);
  * ------------------------------------------------------------------------------------------------- */
 
 /* telofind over every contig of `a`: replaces disambiguate()+find() (src/find_telomere.c:76-81,44-74)
- * called per record at :103-104.  motif: 1..32 bytes, compared as the reference does (sequence
+ * called per record at :103-104.  motif: any length from 1 byte (up to 32 bytes: the fast path; longer ones are compared
+ * byte by byte), compared as the reference does (sequence
  * upper-cased, motif not).  hits come out in the reference's print order: by contig, all strand-0 runs by
  * position, then all strand-1 runs. */
 int cornetto_telofind(cornetto_accel_t *h, const cornetto_asm_t *a, const char *motif,
@@ -169,7 +170,7 @@ int cornetto_telo_scan(cornetto_accel_t *h, const cornetto_asm_t *a, const char 
  * ------------------------------------------------------------------------------------------------- */
 
 /* symmetric DUST over every contig of `a`; replaces sdust() called per record at src/sdust/sdust.c:199
- * (sdust_core :130-160).  3 <= W <= 257 (CORNETTO_E_UNSUPPORTED beyond), T >= 0.  Intervals by contig, then by start; per contig they are
+ * (sdust_core :130-160).  3 <= W <= 1026 (CORNETTO_E_UNSUPPORTED beyond: there the reference's own int products overflow), T >= 0.  Intervals by contig, then by start; per contig they are
  * exactly the reference's (start<<32|finish) list, including intervals that run past the contig end
  * after an N run. */
 int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a, int32_t T, int32_t W,

@@ -204,6 +204,8 @@ def main():
     assert open("mix.telofind.exp", "rb").read() == open(os.path.join(tmp, "mix.gz.telofind"), "rb").read()
     run(["telofind", mix, "ttaggg"], "mix.lower_motif.telofind.exp")
     run(["telofind", mix, "TTAGGGTTAGGG"], "mix.k12.telofind.exp")
+    run(["telofind", mix, "TTAGGG" * 6], "mix.k36.telofind.exp")            # longer than the 32-byte automaton of the device path
+    run(["telofind", mix, "GGGTTA" * 11 + "G"], "mix.k67.telofind.exp")
     run(["telofind", mix, "AAAA"], "mix.AAAA.telofind.exp")
     run(["telofind", mix, "GNG"], "mix.GNG.telofind.exp")
     run(["telowin", "mix.telofind.exp", "99.9", "0.4"], "mix.telowin.exp")

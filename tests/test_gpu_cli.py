@@ -42,6 +42,8 @@ def plain(golden_dir, tmp_path_factory):
     (["telofind", "mix.fa.gz"], "mix.telofind.exp"),
     (["telofind", "mix.fa.gz", "ttaggg"], "mix.lower_motif.telofind.exp"),
     (["telofind", "mix.fa.gz", "TTAGGGTTAGGG"], "mix.k12.telofind.exp"),
+    (["telofind", "mix.fa.gz", "TTAGGG" * 6], "mix.k36.telofind.exp"),
+    (["telofind", "mix.fa.gz", "GGGTTA" * 11 + "G"], "mix.k67.telofind.exp"),
     (["telofind", "mix.fa.gz", "AAAA"], "mix.AAAA.telofind.exp"),
     (["telofind", "mix.fa.gz", "GNG"], "mix.GNG.telofind.exp"),
     (["telofind", "probe_selfoverlap.fa", "ACACA"], "probe_selfoverlap.ACACA.telofind.exp"),

@@ -43,6 +43,8 @@ def gpu_telofind_text(acc, recs, motif):
     ("mix.fa.gz", b"TTAGGG", "mix.telofind.exp"),
     ("mix.fa.gz", b"ttaggg", "mix.lower_motif.telofind.exp"),
     ("mix.fa.gz", b"TTAGGGTTAGGG", "mix.k12.telofind.exp"),
+    ("mix.fa.gz", b"TTAGGG" * 6, "mix.k36.telofind.exp"),
+    ("mix.fa.gz", b"GGGTTA" * 11 + b"G", "mix.k67.telofind.exp"),
     ("mix.fa.gz", b"AAAA", "mix.AAAA.telofind.exp"),
     ("mix.fa.gz", b"GNG", "mix.GNG.telofind.exp"),
 ])
@@ -275,7 +277,7 @@ def test_sdust_random_vs_oracle(acc, monkeypatch, T, W, chunk):
 
 def test_sdust_largest_window_on_homopolymers(acc):
     """W = 257: the window holds 255 words and a homopolymer fills it with 255 copies of one 3-mer — the most the byte
-    counters of the older kernel hold; W = 258 is refused instead of wrapping them"""
+    counters of the older kernel hold; from W = 258 on another kernel (32-bit counters, state in global memory) takes over"""
     import cornetto_amd
     rng = np.random.default_rng(3)
     s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=6000)].copy()
@@ -286,14 +288,23 @@ def test_sdust_largest_window_on_homopolymers(acc):
     for T in (20, 100):
         iv = acc.sdust(asm, T, 257)
         assert [(int(x["start"]), int(x["finish"])) for x in iv] == [(int(r) >> 32, int(r) & 0xFFFFFFFF) for r in ob.sdust(s, T, 257)]
+    # wider windows: the kernel that keeps its state in global memory (258 <= W <= 1026)
+    big = np.concatenate([s, s[::-1], np.frombuffer(b"ACG" * 700, dtype=np.uint8), s])
+    asm2 = acc.asm_upload([big, s[:50], np.zeros(0, np.uint8)])
+    for T, W in ((20, 258), (20, 400), (35, 1026), (200, 700)):
+        iv = acc.sdust(asm2, T, W)
+        exp = [(ci, int(r) >> 32, int(r) & 0xFFFFFFFF) for ci, q in enumerate((big, s[:50], np.zeros(0, np.uint8))) for r in ob.sdust(q, T, W)]
+        assert [(int(x["ctg"]), int(x["start"]), int(x["finish"])) for x in iv] == exp, (T, W)
     with pytest.raises(cornetto_amd.AccelError):
-        acc.sdust(asm, 20, 258)
+        acc.sdust(asm, 20, 1027)
+    asm2.close()
     asm.close()
 
 
 def test_telofind_random_vs_oracle(acc):
     rng = np.random.default_rng(99)
-    for motif in (b"TTAGGG", b"CCCTAA", b"TTTAGGG", b"AC", b"A", b"ACGTACGTACGTACGTACGTACGTACGTACGT", b"TTAGGGTTAGGGTTAGG"):
+    for motif in (b"TTAGGG", b"CCCTAA", b"TTTAGGG", b"AC", b"A", b"ACGTACGTACGTACGTACGTACGTACGTACGT", b"TTAGGGTTAGGGTTAGG",
+                  b"ACGTTGCAAGGCTTAGGCATCGATTAGCCATGGACA", b"AC" * 20, b"TTAGGG" * 11 + b"TTA", b"G" * 33):
         seqs = []
         for _ in range(40):
             n = int(rng.integers(0, 40000))

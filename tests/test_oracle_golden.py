@@ -29,6 +29,8 @@ def _telofind_text(path, motif=b"TTAGGG"):
     ("mix.fa.gz", b"TTAGGG", "mix.telofind.exp"),
     ("mix.fa.gz", b"ttaggg", "mix.lower_motif.telofind.exp"),
     ("mix.fa.gz", b"TTAGGGTTAGGG", "mix.k12.telofind.exp"),
+    ("mix.fa.gz", b"TTAGGG" * 6, "mix.k36.telofind.exp"),
+    ("mix.fa.gz", b"GGGTTA" * 11 + b"G", "mix.k67.telofind.exp"),
     ("mix.fa.gz", b"AAAA", "mix.AAAA.telofind.exp"),
     ("mix.fa.gz", b"GNG", "mix.GNG.telofind.exp"),
 ])

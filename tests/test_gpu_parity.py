@@ -290,9 +290,9 @@ def test_sdust_largest_window_on_homopolymers(acc):
         assert [(int(x["start"]), int(x["finish"])) for x in iv] == [(int(r) >> 32, int(r) & 0xFFFFFFFF) for r in ob.sdust(s, T, 257)]
     # wider windows: the kernel that keeps its state in global memory (258 <= W <= 1026); small inputs: it walks a window of up
     # to 1024 words out of global memory at every candidate step
-    big = np.concatenate([s[900:1800], s[3000:3400], np.frombuffer(b"ACG" * 300, dtype=np.uint8), s[:300]])
+    big = np.concatenate([s[900:1150], s[3000:3100], np.frombuffer(b"ACG" * 60, dtype=np.uint8), s[:120]])
     asm2 = acc.asm_upload([big, s[:50], np.zeros(0, np.uint8)])
-    for T, W in ((20, 258), (35, 1026)):
+    for T, W in ((20, 258), (35, 530), (20, 1026)):
         iv = acc.sdust(asm2, T, W)
         exp = [(ci, int(r) >> 32, int(r) & 0xFFFFFFFF) for ci, q in enumerate((big, s[:50], np.zeros(0, np.uint8))) for r in ob.sdust(q, T, W)]
         assert [(int(x["ctg"]), int(x["start"]), int(x["finish"])) for x in iv] == exp, (T, W)

@@ -671,14 +671,14 @@ struct SdDenseLds {
     uint32_t slot[64][64];     // [start & 63][lane]
 };
 
-__global__ __launch_bounds__(64) void sdust_dense(SdArgs A, const uint32_t *list, const unsigned long long *n_list, uint32_t *started)
+__global__ __launch_bounds__(64) void sdust_dense(SdArgs A, const uint32_t *list, int n_list, uint32_t *started)
 {
     __shared__ SdDenseLds S;
     const int lane = threadIdx.x;
     // the host launches the main kernel once this one is on the chip (its blocks need 28 KB of LDS each: see the launch)
     if (started && blockIdx.x == 0 && lane == 0) __hip_atomic_store(started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const int T = A.T, W = A.W, CAPW = W - 2;
-    const int H = (int)*n_list;
+    const int H = n_list;
     for (int job = blockIdx.x; job * 64 < H; job += gridDim.x) {
         for (int i = 0; i < 16; ++i) *reinterpret_cast<uint32_t *>(S.G[i][lane]) = 0;
         for (int i = 0; i < 64; ++i) S.slot[i][lane] = 0;
@@ -1627,41 +1627,54 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                     // CORNETTO_SDUST_DENSE: 1 (default) the chunks inside repeat arrays go to sdust_dense when there are enough of
                     // them to pay for it, 2 always (tests), 0 never (they stay in the main kernel's queue, first, one per wave)
                     const int dense_mode = env_int("CORNETTO_SDUST_DENSE", 1);
-                    const unsigned nbp = (unsigned)((nc + 160 + 255) / 256);
-                    CN_LAUNCH(h, "sdust_prep", sd_prep<<<dim3(nbp), dim3(256), 0, h->stream>>>(A, d_flag, d_perm));
-                    // passes of the queue over the input: a run can grow to `passes` chunks before it meets a queue start
                     SdPasses ps;
                     ps.P = (uint32_t)std::min(64, std::max(1, env_int("CORNETTO_SDUST_PASSES", 8)));
-                    {
-                        int bits = 0;
-                        while ((1u << bits) < ps.P) ++bits;
-                        std::vector<std::pair<uint32_t, uint32_t>> key;      // (bit-reversed phase, phase)
-                        for (uint32_t ph = 0; ph < ps.P; ++ph) {
-                            uint32_t rev = 0;
-                            for (int b = 0; b < bits; ++b) rev |= ((ph >> b) & 1u) << (bits - 1 - b);
-                            key.emplace_back(rev, ph);
-                        }
-                        std::sort(key.begin(), key.end());
-                        for (uint32_t t = 0; t < ps.P; ++t) ps.turn[key[t].second] = (uint8_t)t;
-                    }
-                    CN_TRY(cnscan::exclusive_u32(h, "sdust_prep", d_flag, (int64_t)nc, 1, d_rank, d_pp, d_tot + 7));
-                    // The number of flagged chunks comes back to the host: it decides whether the dense kernel is worth its
-                    // latency (one job = one chunk = several milliseconds for a wave), and the dense blocks (28 KB of LDS each)
-                    // must be resident BEFORE the main kernel takes every wave slot of the chip, or they would wait for its
-                    // last wave; launched from here, a few microseconds ahead of it, they are.
+                    // The plan of a call — which chunks are sampled as low-complexity, the order of the queue, the list for the
+                    // dense kernel, the initial claim flags — depends on the resident assembly and the chunk table only: it is
+                    // built by the first call and kept with the assembly (like the chunk table itself); later calls copy the
+                    // claim flags back and clear the counts, two small asynchronous operations instead of five launches that
+                    // queue behind whatever else the device is running.
+                    const int64_t plan_key = key * 4 + (dense_mode & 3) + ((int64_t)ps.P << 56);
                     unsigned long long n_dense = 0;
-                    if (dense_mode) {
-                        // (the count is a property of the assembly and the chunk size: asked for once per resident assembly)
-                        if (a->sd_flagged < 0) {
-                            CN_HIP(h, hipMemcpyAsync(p_tot + 200, d_tot + 7, 8, hipMemcpyDeviceToHost, h->stream));
-                            CN_HIP(h, hipStreamSynchronize(h->stream));
-                            a->sd_flagged = (int64_t)p_tot[200];
+                    if (a->sd_plan_key != plan_key || !a->d_sd_plan) {
+                        const unsigned nbp = (unsigned)((nc + 160 + 255) / 256);
+                        CN_LAUNCH(h, "sdust_prep", sd_prep<<<dim3(nbp), dim3(256), 0, h->stream>>>(A, d_flag, d_perm));
+                        // passes of the queue over the input: a run can grow to `passes` chunks before it meets a queue start
+                        {
+                            int bits = 0;
+                            while ((1u << bits) < ps.P) ++bits;
+                            std::vector<std::pair<uint32_t, uint32_t>> key2;      // (bit-reversed phase, phase)
+                            for (uint32_t ph = 0; ph < ps.P; ++ph) {
+                                uint32_t rev = 0;
+                                for (int b = 0; b < bits; ++b) rev |= ((ph >> b) & 1u) << (bits - 1 - b);
+                                key2.emplace_back(rev, ph);
+                            }
+                            std::sort(key2.begin(), key2.end());
+                            for (uint32_t t = 0; t < ps.P; ++t) ps.turn[key2[t].second] = (uint8_t)t;
                         }
-                        n_dense = (unsigned long long)a->sd_flagged;
+                        CN_TRY(cnscan::exclusive_u32(h, "sdust_prep", d_flag, (int64_t)nc, 1, d_rank, d_pp, d_tot + 7));
+                        // The number of flagged chunks comes back to the host: it decides whether the dense kernel is worth its
+                        // latency (one job = one chunk = several milliseconds for a wave)
+                        CN_HIP(h, hipMemcpyAsync(p_tot + 200, d_tot + 7, 8, hipMemcpyDeviceToHost, h->stream));
+                        CN_HIP(h, hipStreamSynchronize(h->stream));
+                        a->sd_flagged = (int64_t)p_tot[200];
+                        n_dense = dense_mode ? (unsigned long long)a->sd_flagged : 0;
                         if (dense_mode == 1 && n_dense < std::max<unsigned long long>(1024, nc / 256)) n_dense = 0;
+                        CN_LAUNCH(h, "sdust_prep", sd_order<<<dim3(nbs), dim3(256), 0, h->stream>>>(d_flag, d_rank, d_tot + 7, (int32_t)nc, d_perm, ps,
+                                                                                               n_dense ? d_list : nullptr, d_claim, (int32_t)a->sd_tail0));
+                        // keep {claim, perm, dense list} (contiguous in the workspace) with the assembly
+                        if (a->d_sd_plan) { (void)hipFree(a->d_sd_plan); a->d_sd_plan = nullptr; }
+                        if (hipMalloc((void **)&a->d_sd_plan, (3 * nc + 160) * 4) != hipSuccess) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: device allocation failed");
+                        CN_HIP(h, hipMemcpyAsync(a->d_sd_plan, d_claim, (3 * nc + 160) * 4, hipMemcpyDeviceToDevice, h->stream));
+                        a->sd_plan_key = plan_key;
+                        a->sd_plan_dense = (int64_t)n_dense;
+                    } else {
+                        n_dense = (unsigned long long)a->sd_plan_dense;
+                        CN_HIP(h, hipMemcpyAsync(d_claim, a->d_sd_plan, nc * 4, hipMemcpyDeviceToDevice, h->stream));
+                        CN_HIP(h, hipMemsetAsync(d_cnt, 0, nc * 4, h->stream));
                     }
-                    CN_LAUNCH(h, "sdust_prep", sd_order<<<dim3(nbs), dim3(256), 0, h->stream>>>(d_flag, d_rank, d_tot + 7, (int32_t)nc, d_perm, ps,
-                                                                                           n_dense ? d_list : nullptr, d_claim, (int32_t)a->sd_tail0));
+                    d_perm = a->d_sd_plan + nc;            // (read-only from here on: the assembly's copy)
+                    d_list = d_perm + nc + 160;
                     A.perm = d_perm;
                     A.q_len = (int32_t)nc + 160;
                     if (n_dense > 0) {
@@ -1685,7 +1698,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                         }
                         volatile uint32_t *started = reinterpret_cast<volatile uint32_t *>(p_tot + 201);
                         *started = 0;
-                        sdust_dense<<<dim3(nbd), dim3(64), 0, h->stream2>>>(A, d_list, d_tot + 7, const_cast<uint32_t *>(started));
+                        sdust_dense<<<dim3(nbd), dim3(64), 0, h->stream2>>>(A, d_list, (int)n_dense, const_cast<uint32_t *>(started));
                         CN_HIP(h, hipGetLastError());
                         {
                             // wait (bounded: 2 ms) until its first block runs: the main kernel, launched next, fills every
@@ -1732,6 +1745,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             stamp("main kernel done");
             if (want_stats) {
                 memcpy(h->sd_last, p_tot, 2048);
+                if (a->sd_flagged >= 0) h->sd_last[7] = (unsigned long long)a->sd_flagged;   // (counted by the call that built the plan)
                 h->sd_last[254] = nb;
                 h->sd_last[255] = nc;
             }

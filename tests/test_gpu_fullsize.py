@@ -218,10 +218,13 @@ def test_offsets_beyond_2_pow_32():
         del w
 
 
-def test_satellite_dense_assembly_equals_the_oracle():
+@pytest.mark.parametrize("dense", ["2", "0"])
+def test_satellite_dense_assembly_equals_the_oracle(monkeypatch, dense):
     """bench.py --profile satellite at 30 Mb: (CATTC)n / (GGAAT)n arrays over > 3 % of the bases, microsatellites,
-    poly-A runs — thousands of consecutive low-complexity chunks for the sdust queue"""
+    poly-A runs — thousands of consecutive low-complexity chunks: through sdust_dense beside the main kernel (2; the default
+    takes that route from 1024 such chunks on) and through the main kernel's queue alone (0)"""
     import bench
+    monkeypatch.setenv("CORNETTO_SDUST_DENSE", dense)
     lens = bench.contig_lengths(30_000_000)
     w = _make(lens, 5, "satellite", coverage=False)
     try:
@@ -229,6 +232,8 @@ def test_satellite_dense_assembly_equals_the_oracle():
         thr = acc.telowin_threshold(0.4, 99.9)
         hits, wins = acc.telo_scan(asm, b"TTAGGG", thr)
         ivls = acc.sdust(asm, 20, 64)
+        again = acc.sdust(asm, 20, 64)                      # the second call runs from the plan kept with the assembly
+        assert np.array_equal(ivls, again)
         masked = int((ivls["finish"].astype(np.int64) - ivls["start"]).sum())
         assert masked > 0.03 * sum(lens)
         _compare_contigs(w, list(range(len(lens))), hits, wins, ivls, thr, stages=("telo", "sdust"))

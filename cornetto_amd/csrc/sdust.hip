@@ -1370,6 +1370,28 @@ __device__ int sd_find_start(const SdArgs &A, const SdChunk ch, const uint8_t *s
 // results do not depend on it.
 // Also resets what the main kernel expects cleared per chunk (claim flag, interval count) and the queue order array
 // (`perm`, n_chunks + 160 positions of "nothing here"): one launch instead of three memsets in front of the scan.
+// the 64 bytes in the middle of a chunk: few distinct 3-mers = inside a repeat array
+__device__ __forceinline__ uint32_t sd_sample_heavy(const SdChunk ch, const uint8_t *seq)
+{
+    const int at = (ch.start + ((ch.end - ch.start) >> 1)) & ~63;      // blocks never leave the (64-byte padded) contig
+    const uint4 *src = reinterpret_cast<const uint4 *>(seq + at);
+    const uint4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
+    const uint32_t w16[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
+    uint32_t seen_lo = 0, seen_hi = 0;
+    unsigned t = 0;
+#pragma unroll
+    for (int d = 0; d < 16; ++d)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            // letters only, case folded: (c >> 1) & 3 separates A C G T; anything else just lands on one of them
+            t = ((t << 2) | ((w16[d] >> (8 * b + 1)) & 3u)) & 63u;
+            const uint32_t bit = 1u << (t & 31u);
+            seen_lo |= t < 32u ? bit : 0u;
+            seen_hi |= t < 32u ? 0u : bit;
+        }
+    return __popc(seen_lo) + __popc(seen_hi) <= 20 ? 1u : 0u;
+}
+
 __global__ void sd_prep(SdArgs A, uint32_t *flag, uint32_t *perm)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1378,29 +1400,16 @@ __global__ void sd_prep(SdArgs A, uint32_t *flag, uint32_t *perm)
     A.claim[c] = 0;
     A.out_n[c] = 0;
     const SdChunk ch = A.chunks[c];
-    const uint8_t *seq = A.bases + A.ctg_off[ch.ctg];
-    // the middle 64 bytes of the chunk
-    uint32_t heavy = 0;
-    {
-        const int at = (ch.start + ((ch.end - ch.start) >> 1)) & ~63;      // blocks never leave the (64-byte padded) contig
-        const uint4 *src = reinterpret_cast<const uint4 *>(seq + at);
-        const uint4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
-        const uint32_t w16[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
-        uint32_t seen_lo = 0, seen_hi = 0;
-        unsigned t = 0;
-#pragma unroll
-        for (int d = 0; d < 16; ++d)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                // letters only, case folded: (c >> 1) & 3 separates A C G T; anything else just lands on one of them
-                t = ((t << 2) | ((w16[d] >> (8 * b + 1)) & 3u)) & 63u;
-                const uint32_t bit = 1u << (t & 31u);
-                seen_lo |= t < 32u ? bit : 0u;
-                seen_hi |= t < 32u ? 0u : bit;
-            }
-        if (__popc(seen_lo) + __popc(seen_hi) <= 20) heavy = 1;
-    }
-    flag[c] = heavy;
+    flag[c] = sd_sample_heavy(ch, A.bases + A.ctg_off[ch.ctg]);
+}
+
+// the flags alone, as bytes (first call for an assembly: the host cuts the flagged chunks into shorter ones)
+__global__ void sd_flags(const SdChunk *chunks, int32_t n_chunks, const uint8_t *bases, const int64_t *ctg_off, uint8_t *flag)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const SdChunk ch = chunks[c];
+    flag[c] = (uint8_t)sd_sample_heavy(ch, bases + ctg_off[ch.ctg]);
 }
 
 // Queue order: flagged chunks first, but only one in every S = min(64, chunks / flagged) positions, the rest filled
@@ -1579,6 +1588,50 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
         a->sd_chunk = key;
         a->sd_n_chunks = (int64_t)chunks.size();
         a->sd_flagged = -1;
+        a->sd_refined = false;
+        a->sd_plan_key = -1;
+    }
+    // First call for this table: the chunks sampled as low-complexity are cut into DENSE_SPLIT shorter ones when they will go to
+    // the dense kernel (enough of them: see below) — one job of that kernel is one chunk for one lane, and a wave that is alone
+    // on its SIMD takes ~10 us per step: shorter jobs, more of them, are what keeps several waves per SIMD busy.  One-time cost
+    // per resident assembly (a launch, 1 byte per chunk back to the host, a new table).
+    if (w64_path && !a->sd_refined && a->sd_n_chunks > 0 && env_int("CORNETTO_SDUST_ORDER", 1)) {
+        a->sd_refined = true;
+        const int dense_mode = env_int("CORNETTO_SDUST_DENSE", 1);
+        const int split = std::min(16, std::max(1, env_int("CORNETTO_SDUST_DENSE_SPLIT", 4)));
+        const size_t n0 = (size_t)a->sd_n_chunks;
+        if (dense_mode && split > 1) {
+            uint8_t *d_f = (uint8_t *)cn_ws(h, WS_SD_PERM, n0 + 64);
+            std::vector<uint8_t> f(n0);
+            if (!d_f) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
+            sd_flags<<<dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, h->stream>>>(reinterpret_cast<const SdChunk *>(a->d_sd_chunks), (int32_t)n0, a->d_bases, a->d_off, d_f);
+            CN_HIP(h, hipGetLastError());
+            CN_HIP(h, hipMemcpyAsync(f.data(), d_f, n0, hipMemcpyDeviceToHost, h->stream));
+            CN_HIP(h, hipStreamSynchronize(h->stream));
+            size_t nf = 0;
+            for (size_t i = 0; i < n0; ++i) nf += f[i];
+            if (nf > 0 && (dense_mode == 2 || nf >= std::max<size_t>(1024, n0 / 256))) {
+                std::vector<SdChunk> old(n0), chunks;
+                CN_HIP(h, hipMemcpy(old.data(), a->d_sd_chunks, n0 * sizeof(SdChunk), hipMemcpyDeviceToHost));
+                chunks.reserve(n0 + nf * (size_t)(split - 1));
+                int64_t tail0 = -1;
+                for (size_t i = 0; i < n0; ++i) {
+                    if ((int64_t)i == a->sd_tail0) tail0 = (int64_t)chunks.size();
+                    const int32_t len_i = old[i].end - old[i].start;
+                    const int32_t piece = std::max(64, ((len_i + split - 1) / split + 63) / 64 * 64);
+                    if (!f[i] || len_i <= piece) { chunks.push_back(old[i]); continue; }
+                    for (int32_t st = old[i].start; st < old[i].end; st += piece) chunks.push_back(SdChunk{old[i].ctg, st, std::min(old[i].end, st + piece)});
+                }
+                if (chunks.size() > 0x7fffffffull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "sdust: too many chunks");
+                (void)hipFree(a->d_sd_chunks);
+                a->d_sd_chunks = nullptr;
+                if (hipMalloc(&a->d_sd_chunks, chunks.size() * sizeof(SdChunk)) != hipSuccess) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: device allocation failed");
+                CN_HIP(h, hipMemcpy(a->d_sd_chunks, chunks.data(), chunks.size() * sizeof(SdChunk), hipMemcpyHostToDevice));
+                a->sd_tail0 = tail0 < 0 ? (int64_t)chunks.size() : tail0;
+                a->sd_n_chunks = (int64_t)chunks.size();
+                a->sd_plan_key = -1;
+            }
+        }
     }
     const size_t nc = (size_t)a->sd_n_chunks;
     cornetto_ivl_t *o = nullptr;

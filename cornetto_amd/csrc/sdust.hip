@@ -1591,14 +1591,17 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
         a->sd_refined = false;
         a->sd_plan_key = -1;
     }
-    // First call for this table: the chunks sampled as low-complexity are cut into DENSE_SPLIT shorter ones when they will go to
-    // the dense kernel (enough of them: see below) — one job of that kernel is one chunk for one lane, and a wave that is alone
-    // on its SIMD takes ~10 us per step: shorter jobs, more of them, are what keeps several waves per SIMD busy.  One-time cost
-    // per resident assembly (a launch, 1 byte per chunk back to the host, a new table).
+    // Optionally (CORNETTO_SDUST_DENSE_SPLIT = n > 1; default 1 = off) the first call for a table cuts the chunks sampled as
+    // low-complexity into n shorter ones when they will go to the dense kernel: one job of that kernel is one chunk for one
+    // lane, and a wave that is alone on its SIMD issues one instruction every ~6 cycles — ~10 us per step, 20 ms per 1.7 kb job.
+    // Measured on the satellite profile (3.16 Gbp, 1 056 dense jobs): n = 1 dense 20 ms beside a 29 ms main kernel, n = 2
+    // 28 / 31 ms, n = 4 27-32 / 34 ms, n = 8 35-40 / 38 ms: at 28 KB of LDS per dense wave only five fit on a CU, so more jobs
+    // are more rounds (plus their warm-ups), not more waves per SIMD.  The split pays only once the dense state is smaller
+    // (16-bit P slots, 12-bit ring entries: ~18 KB) — DESIGN.md section 8.
     if (w64_path && !a->sd_refined && a->sd_n_chunks > 0 && env_int("CORNETTO_SDUST_ORDER", 1)) {
         a->sd_refined = true;
         const int dense_mode = env_int("CORNETTO_SDUST_DENSE", 1);
-        const int split = std::min(16, std::max(1, env_int("CORNETTO_SDUST_DENSE_SPLIT", 4)));
+        const int split = std::min(16, std::max(1, env_int("CORNETTO_SDUST_DENSE_SPLIT", 1)));
         const size_t n0 = (size_t)a->sd_n_chunks;
         if (dense_mode && split > 1) {
             uint8_t *d_f = (uint8_t *)cn_ws(h, WS_SD_PERM, n0 + 64);

@@ -225,6 +225,7 @@ def test_satellite_dense_assembly_equals_the_oracle(monkeypatch, dense):
     takes that route from 1024 such chunks on) and through the main kernel's queue alone (0)"""
     import bench
     monkeypatch.setenv("CORNETTO_SDUST_DENSE", dense)
+    monkeypatch.setenv("CORNETTO_SDUST_DENSE_SPLIT", "3")     # the flagged chunks cut in three on the first call (off by default)
     lens = bench.contig_lengths(30_000_000)
     w = _make(lens, 5, "satellite", coverage=False)
     try:

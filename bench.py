@@ -731,8 +731,8 @@ def profile_leg(R, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--gbases", type=float, default=0.0, help="assembly size in Gbases (0 = the full 3.16 Gbp fixture)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: one assembly per rank; strong: one assembly, contigs split over the ranks (LPT)")

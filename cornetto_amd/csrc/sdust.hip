@@ -845,6 +845,9 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
     const int T = A.T, W = A.W, CAPW = W - 2;
     const int m = (T << 1) / 10;                     // cv[t]*10 > T<<1  <=>  cv[t] > m   (:79)
     const int capT = CAPW * T;
+    // find_perfect, lane <-> window position: with a full window the suffix of this lane has l_full words after its first
+    const int l_full = CAPW - 64 + lane;
+    const uint32_t m_full = l_full >= 2 ? (uint32_t)((0x100000000ull + (unsigned)l_full - 1ull) / (unsigned)l_full) : 0u;
 
     // ---- jobs.  The grid is as many waves as fit on the chip at once; every LANE takes chunks from one global
     // queue (A.perm order: chunks sampled as low-complexity first) until it is empty, so nothing waits for a
@@ -1226,7 +1229,11 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
                   // Ratios r / l are compared through key = floor(r * 2^13 / l) (sd_ratio_key): exact for l <= 64.  All that
                   // :113-118 need of P is, for every start, the best ratio among the entries with a start at or after it.
                   const uint32_t key_e = e & 0xFFFFFFu;                              // 0: no entry with this start
-                  const uint32_t key_c = cand ? sd_ratio_key((uint32_t)r, (uint32_t)new_l) : 0u;
+                  // (the window is full almost always: new_l = lane - 64 + (W - 2) is then a constant of the lane and the division
+                  // of the key a multiplication by its reciprocal, exact for numerators < 2^24 and divisors <= 64)
+                  uint32_t key_c = 0u;
+                  if (o_size == CAPW) key_c = cand ? (l_full == 1 ? ((uint32_t)r & 0x7FFu) << 13 : __umulhi(((uint32_t)r & 0x7FFu) << 13, m_full)) : 0u;
+                  else key_c = cand ? sd_ratio_key((uint32_t)r, (uint32_t)new_l) : 0u;
                   // X_j = better of (existing entry with this start, candidate j); inclusive maximum over positions >= j
                   const uint32_t xs = wave_scan_max(key_e > key_c ? key_e : key_c);
                   // maximum over positions > j = the scan value one lane down (wave_shr:1; lane 0 gets 0)

@@ -179,8 +179,9 @@ static void *bb_worker(void *p)
                 return NULL;
             }
         }
+        if (d->n == 0) return NULL; /* more devices than contigs: nothing to do here */
         d->rc = cornetto_cov_shard(d->h_src, d->src, d->h, d->ctgs, d->n, &d->part);
-        if (d->rc == CORNETTO_OK && d->n > 0) d->rc = cornetto_cov_prepare(d->h, d->part, d->opt->window_size, d->opt->window_inc, d->sums);
+        if (d->rc == CORNETTO_OK) d->rc = cornetto_cov_prepare(d->h, d->part, d->opt->window_size, d->opt->window_inc, d->sums);
     } else if (d->n > 0) {
         d->rc = cornetto_cov_select(d->h, d->part, d->lo, d->hi, d->opt->low_mq_cov_thresh, d->opt->edge_len, d->opt->min_ctg_len, d->boring, &d->recs, &d->n_recs);
     }

@@ -103,7 +103,7 @@ def test_panel(cli, golden_dir, plain, args, exp):
     assert out == golden(golden_dir, exp)
 
 
-@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0,0"])
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0,0", "0,0,0,0,0,0,0,0,0,0,0,0"])
 @pytest.mark.parametrize("args,exp", PANEL)
 def test_panel_window_stage_over_several_devices(cli, golden_dir, plain, args, exp, devices):
     """CORNETTO_DEVICES: the contigs are dealt to the devices after the ingest (cornetto_cov_shard), every device sums and

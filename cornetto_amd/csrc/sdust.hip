@@ -525,14 +525,14 @@ __global__ __launch_bounds__(64) void sdust_kernel_g(SdArgs A, uint8_t *g_ring, 
 // sdust_w64: the production kernel for W - 2 <= 64 (default W = 64).  Same recurrence, but every
 // data-dependent LOOP of the reference is replaced by wave-cooperative, loop-free code, because in a
 // 64-lane wave "rare per lane" is "every step per wave":
-//   * cv / rv are not maintained at all.  L (the longest suffix of the window in which no 3-mer occurs
-//     more than m = 2T/10 times, :79-85) is kept as the absolute index `vs` of the first word of that
-//     suffix; pushing word t can only move vs just past the (m+1)-th most recent occurrence of t, which is
-//     looked up — only when cw[t] > m — by ONE ballot over the owner's ring (lane j reads ring slot j).
+//   * cv / rv / rw / L are not maintained at all: find_perfect over EVERY suffix of the window, without the gate of :149,
+//     is the same function (a suffix inside v is never a candidate of :112, and a candidate implies the gate: DESIGN.md
+//     section 4.2b), so v only ever decided WHEN to call.  That decision is a per-lane lower bound M of the smallest margin
+//     T (q - 1) - 10 r over the suffixes that hold m + 1 copies of some word (see its declaration): no pass while M >= 0.
 //   * find_perfect (:104-128): lane j takes window position j of the owning lane; suffix scores r_j
 //     come from 6 ballots (equal-word mask), mbcnt and a suffix-sum scan; the running maximum over P entries /
-//     earlier candidates is a max-scan of exact integer ratio keys (sd_ratio_key).  Calls that provably find
-//     nothing are skipped (the `sl` bound).
+//     earlier candidates is a max-scan of exact integer ratio keys (sd_ratio_key).  Every pass leaves the exact minimum
+//     margin behind as the owner's new M.
 //   * P occupancy is a 64-bit mask per lane (bit = start & 63), so save_masked_regions (:88-102) and the
 //     N flush (:153) are rotates / ctz instead of list walks.
 //     Per-lane LDS state is just the ring and the 64 byte counters (8.4 KB per wave): 19 waves per CU.
@@ -638,7 +638,6 @@ __device__ __forceinline__ int wave_min_all(int x)      // minimum over the wave
 #undef SD_MIN_STEP
     return x;
 }
-constexpr int SD_SLACK_NONE = -(1 << 30);
 typedef uint32_t sd_v16u __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ unsigned long long sd_ballot(bool x) { return __builtin_amdgcn_ballot_w64(x); }
 __device__ __forceinline__ bool sd_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0; }
@@ -844,10 +843,19 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
 
     const int T = A.T, W = A.W, CAPW = W - 2;
     const int m = (T << 1) / 10;                     // cv[t]*10 > T<<1  <=>  cv[t] > m   (:79)
-    const int capT = CAPW * T;
     // find_perfect, lane <-> window position: with a full window the suffix of this lane has l_full words after its first
     const int l_full = CAPW - 64 + lane;
     const uint32_t m_full = l_full >= 2 ? (uint32_t)((0x100000000ull + (unsigned)l_full - 1ull) / (unsigned)l_full) : 0u;
+    // smallest margin of a suffix with exactly m + 1 copies of one word and every other word at most m times:
+    // all of its words equal (q = m + 1): m (T - 5m - 5); with o >= 1 other words: T (m + o) - 5 m (m + 1) - 10 g(o),
+    // g(o) = most pairs o words make with at most m copies each
+    const int bound_eq = m * (T - 5 * m - 5);
+    int bound_ne = 1 << 29;
+    for (int oo = 1; oo <= CAPW; ++oo) {
+        const int g = (oo / m) * (m * (m - 1) / 2) + (oo % m) * (oo % m - 1) / 2;
+        const int v = T * (m + oo) - 5 * m * (m + 1) - 10 * g;
+        bound_ne = v < bound_ne ? v : bound_ne;
+    }
 
     // ---- jobs.  The grid is as many waves as fit on the chip at once; every LANE takes chunks from one global
     // queue (A.perm order: chunks sampled as low-complexity first) until it is empty, so nothing waits for a
@@ -869,11 +877,20 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
     // ---- per-lane sequential state; word indices are counts of pushed words since the chunk's warm-up start
     int p = -1;                 // index of the newest word in the window
     int o = 0;                  // index of the oldest word in the window (size = p - o + 1)
-    int vs = 0;                 // index of the first word of v (the suffix with all counts <= m)
-    int rw10 = 0;               // 10 * rw
-    int ltv = 0;                // T * (p - vs + 1): T times the length v would have in an unbounded window
-    int ct = 0;                 // copies of the newest word that were in the window before it (kept from the lane's last word step)
-    int sl = SD_SLACK_NONE;     // sl + T * p <= min over the positions find_perfect examines of (T * new_l - 10 * r): >= 0 proves it finds nothing
+    // No v, L, rv, rw (section 4.2b of DESIGN.md: find_perfect over every suffix of the window, without the gate of :149, is the
+    // same function).  What decides WHEN the cooperative pass runs is a lower bound M of the smallest margin T (q - 1) - 10 r
+    // over the suffixes that hold m + 1 copies of some 3-mer (only those can be candidates of :112): no pass while M >= 0.
+    //   push of a word with ct copies in the window:  every such suffix gets one word longer and at most ct pairs richer,
+    //       M += T - 10 ct;  new ones appear only when ct >= m:
+    //   ct == m: a suffix that just got its (m+1)-th copy of t (all other words <= m times) has margin >= bound_eq if its
+    //       m + 1 newest words are all t (then the previous word is t), >= bound_ne otherwise (both computed below);
+    //   ct > m:  the pass runs;
+    //   the pass leaves the exact minimum over all suffixes of >= m + 1 words behind.
+    // tools/sim/sdust_trigger_sim.c ("hot-suffix tracker") checks the bound on 10^7 steps for a dozen (T, W): never above the
+    // true minimum; in random sequence it asks for 0.49 passes per wave-step — the gate with its exact L asked for 0.15, but
+    // needed 1.06 cooperative trims per wave-step to keep L.
+    int M = -1;                 // (no bound yet: the first word runs the pass)
+    unsigned tprev = 0xFFu;     // the word pushed before this one
     unsigned s_pref = 0;        // ring[o]: the word the next pop removes
     unsigned long long occ = 0; // occupied P slots, bit = start & 63
     int minstart = 0;
@@ -923,7 +940,7 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
     uint32_t pcn = 0x04040404u;                      // codes of the previous 4 positions (before u: non-bases, l = 0)
     uint8_t *const myring = &S.ring[lane][0];
 
-    unsigned st_steps = 0, st_fp = 0, st_trim = 0, st_full = 0, st_jobs = 0, st_iter = 0, st_qt = 0;
+    unsigned st_steps = 0, st_fp = 0, st_full = 0, st_jobs = 0, st_iter = 0, st_qt = 0;
     const unsigned long long st_t0 = STATS ? wall_clock64() : 0ull;
     for (int k64 = 0;; k64 += 64) {
       // ---- a lane whose chunk ends inside the coming block runs on into the next chunk of the contig if nobody has
@@ -998,7 +1015,7 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
                       blk64 = (uint32_t)((A.ctg_off[ch.ctg] + u) >> 6) - (uint32_t)(k64 >> 6);
                       endk = (ch.end - u) + k64;
                       islast = (ch.end - u) + k64 == A.ctg_len[ch.ctg] - ubase;
-                      p = -1; o = 0; vs = 0; rw10 = 0; ltv = 0; ct = 0; s_pref = 0; sl = SD_SLACK_NONE;
+                      p = -1; o = 0; s_pref = 0; M = -1; tprev = 0xFFu;
                       LN = k64 - 1;
                       pcn = 0x04040404u;
                       for (int i = 0; i < 16; ++i) S.cw[i][lane] = 0;
@@ -1112,64 +1129,28 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
           const bool isword = f < 64u;
           const unsigned long long wordmask = sd_ballot(f < 64u);
           if (isword) {
-              // shift_window (:66-86) without cv / rv: the two counters are byte fields of LDS dwords, updated by
-              // returning atomics (one LDS op each instead of a read and a write)
+              // shift_window (:66-86) without cv / rv / rw: the two counters are byte fields of LDS dwords, updated by
+              // atomics (one LDS op each instead of a read and a write); only the push needs the old value back
               const bool pop = p >= CAPW - 1;                  // size >= W - 2 (:68): o = max(0, p - (W - 3)) at all times
               const unsigned s = s_pref;
               // byte field of the counter inside its dword: 8 * (word & 3); shifts use the low 5 bits of the amount only
               const unsigned sh_s = (s << 3) & 31u, sh_t = (f << 3) & 31u;
-              const uint32_t old_s = __hip_atomic_fetch_sub(&S.cw[s >> 2][lane], pop ? 1u << sh_s : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              (void)__hip_atomic_fetch_sub(&S.cw[s >> 2][lane], pop ? 1u << sh_s : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
               const uint32_t old_t = __hip_atomic_fetch_add(&S.cw[f >> 2][lane], 1u << sh_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
               o += pop ? 1 : 0;
               ++p;
-              ltv += T;
               myring[p & 63] = (uint8_t)f;                                                     // :75
               s_pref = myring[o & 63];
-              const int cs = (int)__builtin_amdgcn_ubfe(old_s, s << 3, 8u) - 1;                // --cw[s]   (:71)  (v_bfe_u32 reads offset[4:0])
-              ct = (int)__builtin_amdgcn_ubfe(old_t, f << 3, 8u);                              // cw[t]++   (:77), after the pop
-              rw10 = __mul24(ct - (pop ? cs : 0), 10) + rw10;
-              sl = __mul24(ct, -10) + sl;      // every examined suffix gains at most ct pairs and one word (see below)
+              const int ct = (int)__builtin_amdgcn_ubfe(old_t, f << 3, 8u);                    // cw[t]++   (:77), after the pop
+              // the bound (see the declaration of M)
+              const int adv = __mul24(ct, -10) + M + T;
+              const int bn = f == tprev ? bound_eq : bound_ne;
+              const int at_m = adv < bn ? adv : bn;
+              M = ct < m ? adv : (ct == m ? at_m : -1);
+              tprev = f;
           }
-          // v must not hold more than m copies of t.  Only when the window now holds more than m can v,
-          // a suffix of it, do so: those lanes get their v start moved by the cooperative pass below.
-          const unsigned long long trim_todo = sd_ballot(ct >= m) & wordmask;
-          // v may shrink: find_perfect then examines positions the bound never covered (a lane without a word may drop
-          // its bound needlessly: harmless)
-          sl = ct >= m ? SD_SLACK_NONE : sl;
-          // ---- cooperative trim: vs moves just past the (m+1)-th most recent occurrence of t inside v --------
-          // (one ballot over the owner's ring: lane j reads ring slot j; about one lane per wave-step needs it
-          // in non-repetitive sequence)
-          if (trim_todo) {
-              if (STATS) st_trim += (unsigned)__popcll(trim_todo);
-              unsigned long long todo = trim_todo;
-              while (todo) {
-                  const int ol = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
-                  todo &= todo - 1;
-                  const int o_p = rdlane(p, ol), o_o = rdlane(o, ol), o_vs = rdlane(vs, ol);
-                  const unsigned o_t = (unsigned)rdlane((int)f, ol);
-                  const unsigned mine = S.ring[ol][lane];                                    // ring slot `lane` of the owner
-                  const unsigned long long eq = sd_ballot(mine == o_t);
-                  // chronological order: bit k <-> absolute word index o_p - 63 + k
-                  const unsigned long long chron = rotr64(eq, (o_p + 1) & 63);
-                  const int first = o_vs > o_o ? o_vs : o_o;                                 // first word of v before the trim
-                  const int Lc = o_p - first + 1;                                            // 1..64
-                  const unsigned long long inv = chron & (Lc >= 64 ? ~0ull : ~0ull << (64 - Lc));
-                  if (__popcll(inv) > m) {
-                      const int nvs = o_p - 63 + __builtin_ctzll(inv) + 1;                   // just past the oldest occurrence of t inside v
-                      vs = sd_writelane(vs, nvs, ol);
-                      ltv = sd_writelane(ltv, (o_p - nvs + 1) * T, ol);
-                  }
-              }
-          }
-          unsigned long long fp_todo;
-          {
-              // L = min(p - vs + 1, window size); the window holds W - 2 words whenever that bound matters
-              fp_todo = sd_ballot(rw10 > (ltv < capT ? ltv : capT)) & wordmask;         // :149
-              // find_perfect changes nothing unless some suffix older than v has 10 r > T l.  A call that found none
-              // left the smallest T l - 10 r it saw; since then every such suffix got one word longer per push and
-              // gained at most ct pairs (sl, kept relative to T * p): while that bound is >= 0 the call is skipped.
-              if (fp_todo) fp_todo &= sd_ballot(__mul24(p, T) + sl < 0);
-          }
+          // the lanes whose bound does not exclude a candidate
+          unsigned long long fp_todo = sd_ballot(M < 0) & wordmask;
           // ---- cooperative find_perfect (:104-128) ------------------------------------------------------
           // lane <-> window position j = 63 - lane, so that "suffix of the window" = "prefix of the wave" and
           // both scans are forward DPP scans (no LDS round trips).
@@ -1179,10 +1160,8 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
               while (todo) {
                   const int ol = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
                   todo &= todo - 1;
-                  const int o_p = rdlane(p, ol), ws = rdlane(o, ol), o_vs = rdlane(vs, ol);
+                  const int o_p = rdlane(p, ol), ws = rdlane(o, ol);
                   const int o_size = o_p - ws + 1;
-                  const int first = o_vs > ws ? o_vs : ws;
-                  const int i0 = first - ws - 1;                                     // = size - L - 1
                   const int j = 63 - lane;                                           // window position (0 = oldest)
                   const bool inwin = j < o_size;
                   const unsigned wj = S.ring[ol][(ws + j) & 63];
@@ -1204,13 +1183,14 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
                   const int new_l = o_size - j - 1;                                  // :111
                   // :112 (new_l < 64, T < 2^17)
                   const int margin = __mul24(T, new_l) - __mul24(r, 10);
-                  const unsigned long long exam = sd_ballot(j <= i0) & inb;          // the positions :107 walks over
-                  const unsigned long long candmask = sd_ballot(margin < 0) & exam;
-                  if (candmask == 0) {                                               // nothing can be inserted: remember by how much
-                      const int mn = rdlane(wave_min_all(((exam >> lane) & 1ull) ? margin : (1 << 29)), 63);
-                      sl = sd_writelane(sl, mn - o_p * T, ol);
-                      continue;
+                  // every suffix of the window is examined (:107 starts behind v: the suffixes inside v are never candidates); the
+                  // exact minimum over those of at least m + 1 words becomes the owner's bound
+                  const unsigned long long candmask = sd_ballot(margin < 0) & inb;
+                  {
+                      const int mn = rdlane(wave_min_all((inwin && new_l >= m) ? margin : (1 << 29)), 63);
+                      M = sd_writelane(M, mn, ol);
                   }
+                  if (candmask == 0) continue;                                       // nothing can be inserted
                   if (STATS) ++st_full;
                   const bool cand = (candmask >> lane) & 1ull;
                   int startv;                                                        // :146 for every lane's own state
@@ -1266,7 +1246,6 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
     if (STATS && A.stats && lane == 0) {
         atomicAdd(&A.stats[0], (unsigned long long)st_steps);
         atomicAdd(&A.stats[1], (unsigned long long)st_fp);
-        atomicAdd(&A.stats[2], (unsigned long long)st_trim);
         const unsigned long long dt = wall_clock64() - st_t0;      // 100 MHz ticks this wave spent in the loop
         atomicAdd(&A.stats[3], dt);
         atomicMax(&A.stats[4], dt);

@@ -48,6 +48,7 @@ int main(int argc, char **argv)
         if (v < B1) B1 = v;
     }
     const long B0 = (long)m * (T - 5 * m - 5);
+    long M8 = 0, have_M8 = 0, t8 = 0, viol8 = 0, a8 = 0, t8_ev_gt = 0, t8_ev_eq = 0, t8_decay = 0;
     long M3 = 0, have_M3 = 0, t6 = 0, viol4 = 0; int tprev = -1;
     long since_event = 0, words_since_start = 0, t2 = 0, t3 = 0, t_gate_and_M = 0, viol3 = 0, M2 = 0, have_M2 = 0, t5 = 0, trims = 0;
     for (long i = 0; i < n; ++i) {
@@ -81,14 +82,17 @@ int main(int argc, char **argv)
             M = have_M ? (adv < bnew ? adv : bnew) : -1;     /* no bound yet: trigger */
         }
         /* exact: every suffix */
-        int c[64] = {0}, r = 0, cand_all = 0, cand_long = 0;
-        long minmargin = 1L << 40;
+        int c[64] = {0}, r = 0, cand_all = 0, cand_long = 0, hot = 0;
+        long minmargin = 1L << 40, minhot = 1L << 30;
         for (int q = 1; q <= size; ++q) {
             int w = ring[(front + size - q) % 512];
             r += c[w]++;
             long margin = (long)T * (q - 1) - 10L * r;
             if (margin < 0) { ++cand_all; if (q > L) ++cand_long; else ++viol1; }
             if (q >= m + 1 && margin < minmargin) minmargin = margin;
+            if (c[w] >= m + 1) hot = 1;                                /* this suffix holds m+1 copies of some word */
+            if (hot && margin < minhot) minhot = margin;
+            if (margin < 0 && !hot) ++viol1;                            /* a candidate is always hot */
         }
         const int gate = rw * 10 > L * T;
         {
@@ -122,6 +126,20 @@ int main(int argc, char **argv)
             } else M7 = -1;
             if (have_M7 && M7 >= 0 && cand_all) ++viol7;
             if (M7 < 0) { ++t7; M7 = size >= m + 1 ? minmargin : (1L << 30); have_M7 = 1; }
+            /* T8: M bounds the margins of the HOT suffixes only (those holding m+1 copies of some word); a8 = pushes since the last event */
+            {
+                int cause = 0;
+                if (have_M8) {
+                    const long adv = M8 + T - 10L * ct;
+                    if (ct < m) { M8 = adv; cause = 3; }
+                    else if (ct == m) { const long bn = (int)t == tprev ? B0 : B1; M8 = adv < bn ? adv : bn; cause = 2; }
+                    else if (getenv("T8_GAP")) { const long k1 = ct + 1; const long bn = 5L * (a8 + m) - T - 5L * k1 * (k1 - m); M8 = adv < bn ? adv : bn; cause = 1; }
+                    else { M8 = -1; cause = 1; }       /* the kernel's form: a push with ct > m always runs the pass */
+                } else M8 = -1;
+                if (ct >= m) a8 = 0; else ++a8;
+                if (have_M8 && M8 >= 0 && cand_all) ++viol8;
+                if (M8 < 0) { ++t8; if (cause == 1) ++t8_ev_gt; else if (cause == 2) ++t8_ev_eq; else ++t8_decay; M8 = getenv("T8_HOT") ? minhot : (size >= m + 1 ? minmargin : (1L << 30)); have_M8 = 1; }
+            }
             tprev = (int)t;
         }
         if (gate) ++ref_calls;
@@ -138,9 +156,9 @@ int main(int argc, char **argv)
     }
     printf("T=%d W=%d m=%d: %ld words; reference calls %ld (%.3f%%), of which with candidates %ld (%.3f%%); steps with a candidate suffix %ld;\n"
            "tracker passes %ld (%.3f%% of the words; %.2f per 64-lane wave-step); FACT 1 violations %ld, FACT 2 violations %ld\n"
-           "events (ct >= m) %.3f%%; gate with the lower bound of L %.3f%%; that gate & tracker %.3f%%; exact gate & tracker %.3f%%; gate' & tracker refreshed only then %.3f%% ; violations %ld\ntracker with the previous-word test: %.3f%% (%.2f per wave-step), violations %ld\nevent tracker: %.3f%% (%.3f per wave-step), violations %ld (B0 %ld B1 %ld)\n",
+           "events (ct >= m) %.3f%%; gate with the lower bound of L %.3f%%; that gate & tracker %.3f%%; exact gate & tracker %.3f%%; gate' & tracker refreshed only then %.3f%% ; violations %ld\ntracker with the previous-word test: %.3f%% (%.2f per wave-step), violations %ld\nevent tracker: %.3f%% (%.3f per wave-step), violations %ld (B0 %ld B1 %ld)\nhot-suffix tracker T8: %.3f%% (%.3f per wave-step; at ct>m events %.3f%%, at ct==m events %.3f%%, at other pushes %.3f%%), violations %ld\n",
            T, W, m, words, ref_calls, 100.0 * ref_calls / words, ref_effect, 100.0 * ref_effect / words, any_cand, trig, 100.0 * trig / words,
-           64.0 * trig / words, viol1, viol2, 100.0 * trims / words, 100.0 * t2 / words, 100.0 * t3 / words, 100.0 * t_gate_and_M / words, 100.0 * t5 / words, viol3, 100.0 * t6 / words, 64.0 * t6 / words, viol4, 100.0 * t7 / words, 64.0 * t7 / words, viol7, B0, B1);
+           64.0 * trig / words, viol1, viol2, 100.0 * trims / words, 100.0 * t2 / words, 100.0 * t3 / words, 100.0 * t_gate_and_M / words, 100.0 * t5 / words, viol3, 100.0 * t6 / words, 64.0 * t6 / words, viol4, 100.0 * t7 / words, 64.0 * t7 / words, viol7, B0, B1, 100.0 * t8 / words, 64.0 * t8 / words, 100.0 * t8_ev_gt / words, 100.0 * t8_ev_eq / words, 100.0 * t8_decay / words, viol8);
     (void)old_skip_calls;
     return viol1 || viol2;
 }

@@ -628,14 +628,15 @@ __device__ __forceinline__ int sd_writelane(int vdst, int val, int lane)
 }
 __device__ __forceinline__ int wave_min_all(int x)      // minimum over the wave, in lane 63
 {
-#define SD_MIN_STEP(ctrl, rmask) { const int y = __builtin_amdgcn_update_dpp(x, x, (ctrl), (rmask), 0xF, false); x = y < x ? y : x; }
-    SD_MIN_STEP(DPP_ROW_SHR(1), 0xF)
-    SD_MIN_STEP(DPP_ROW_SHR(2), 0xF)
-    SD_MIN_STEP(DPP_ROW_SHR(4), 0xF)
-    SD_MIN_STEP(DPP_ROW_SHR(8), 0xF)
-    SD_MIN_STEP(DPP_ROW_BCAST15, 0xA)
-    SD_MIN_STEP(DPP_ROW_BCAST31, 0xC)
-#undef SD_MIN_STEP
+    // one v_min_i32 with a DPP source per step: lanes without a source in their row keep their value (bound_ctrl off)
+    asm volatile("s_nop 1\n\t"
+                 "v_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(x));
     return x;
 }
 typedef uint32_t sd_v16u __attribute__((ext_vector_type(16)));
@@ -1174,8 +1175,9 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
                       const int ext = __builtin_amdgcn_sbfe((int)wj, bb, 1);                     // all ones / zero
                       unsigned long long bal;
                       asm("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(bal) : "v"(ext));                  // ballot of the bit
-                      eq_lo &= ~((uint32_t)ext ^ (uint32_t)bal);
-                      eq_hi &= ~((uint32_t)ext ^ (uint32_t)(bal >> 32));
+                      // eq &= ~(ext ^ bal): one 3-input logic op per half (table 0x90 = src0 & ~(src1 ^ src2))
+                      asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x90" : "+v"(eq_lo) : "v"(ext), "s"((uint32_t)bal));
+                      asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x90" : "+v"(eq_hi) : "v"(ext), "s"((uint32_t)(bal >> 32)));
                   }
                   // suffix score r_j = inclusive prefix sum
                   // (mbcnt: set bits of the mask below this lane)

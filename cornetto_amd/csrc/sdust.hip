@@ -850,9 +850,10 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
     // smallest margin of a suffix with exactly m + 1 copies of one word and every other word at most m times:
     // all of its words equal (q = m + 1): m (T - 5m - 5); with o >= 1 other words: T (m + o) - 5 m (m + 1) - 10 g(o),
     // g(o) = most pairs o words make with at most m copies each
-    const int bound_eq = m * (T - 5 * m - 5);
-    int bound_ne = 1 << 29;
-    for (int oo = 1; oo <= CAPW; ++oo) {
+    // (bound_eq < bound_ne: the difference at o is T o - 10 g(o) >= o (T - 5m + 5) > 0).  T < 5 (m = 0): the pass always runs.
+    const int bound_eq = m ? m * (T - 5 * m - 5) : -1;
+    int bound_ne = m ? 1 << 29 : -1;
+    for (int oo = 1; m && oo <= CAPW; ++oo) {
         const int g = (oo / m) * (m * (m - 1) / 2) + (oo % m) * (oo % m - 1) / 2;
         const int v = T * (m + oo) - 5 * m * (m + 1) - 10 * g;
         bound_ne = v < bound_ne ? v : bound_ne;
@@ -883,12 +884,12 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
     // over the suffixes that hold m + 1 copies of some 3-mer (only those can be candidates of :112): no pass while M >= 0.
     //   push of a word with ct copies in the window:  every such suffix gets one word longer and at most ct pairs richer,
     //       M += T - 10 ct;  new ones appear only when ct >= m:
-    //   ct == m: a suffix that just got its (m+1)-th copy of t (all other words <= m times) has margin >= bound_eq if its
-    //       m + 1 newest words are all t (then the previous word is t), >= bound_ne otherwise (both computed below);
-    //   ct > m:  the pass runs;
+    //   ct >= m: a suffix that was not hot before holds exactly m + 1 copies of t (the m + 1 newest; one more and it held
+    //       m + 1 before the push) and every other word at most m times: margin >= bound_eq if its m + 1 newest words are
+    //       all t (then the previous word is t), >= bound_ne otherwise (both computed above);
     //   the pass leaves the exact minimum over all suffixes of >= m + 1 words behind.
     // tools/sim/sdust_trigger_sim.c ("hot-suffix tracker") checks the bound on 10^7 steps for a dozen (T, W): never above the
-    // true minimum; in random sequence it asks for 0.49 passes per wave-step — the gate with its exact L asked for 0.15, but
+    // true minimum; in random sequence it asks for 0.39 passes per wave-step — the gate with its exact L asked for 0.15, but
     // needed 1.06 cooperative trims per wave-step to keep L.
     int M = -1;                 // (no bound yet: the first word runs the pass)
     unsigned tprev = 0xFFu;     // the word pushed before this one
@@ -1147,7 +1148,7 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
               const int adv = __mul24(ct, -10) + M + T;
               const int bn = f == tprev ? bound_eq : bound_ne;
               const int at_m = adv < bn ? adv : bn;
-              M = ct < m ? adv : (ct == m ? at_m : -1);
+              M = ct < m ? adv : at_m;
               tprev = f;
           }
           // the lanes whose bound does not exclude a candidate

@@ -256,7 +256,8 @@ def _rand_seqs(rng, n_seq, kind):
 
 
 @pytest.mark.parametrize("T,W,chunk", [(20, 64, "37"), (20, 64, "512"), (10, 32, "64"), (5, 64, "200"), (30, 16, "16"),
-                                       (25, 100, "300"), (20, 8, "50"), (20, 257, "700"), (1, 3, "40")])
+                                       (25, 100, "300"), (20, 8, "50"), (20, 257, "700"), (1, 3, "40"),
+                                       (0, 64, "90"), (4, 64, "300"), (3, 20, "64"), (9, 64, "256"), (100, 64, "256")])
 def test_sdust_random_vs_oracle(acc, monkeypatch, T, W, chunk):
     monkeypatch.setenv("CORNETTO_SDUST_CHUNK", chunk)
     # a small grid: every lane takes many chunks from the queue, of unequal lengths, one after the other

@@ -134,7 +134,8 @@ int main(int argc, char **argv)
                     if (ct < m) { M8 = adv; cause = 3; }
                     else if (ct == m) { const long bn = (int)t == tprev ? B0 : B1; M8 = adv < bn ? adv : bn; cause = 2; }
                     else if (getenv("T8_GAP")) { const long k1 = ct + 1; const long bn = 5L * (a8 + m) - T - 5L * k1 * (k1 - m); M8 = adv < bn ? adv : bn; cause = 1; }
-                    else { M8 = -1; cause = 1; }       /* the kernel's form: a push with ct > m always runs the pass */
+                    else if (getenv("T8_OLD")) { M8 = -1; cause = 1; }       /* first form of the kernel: a push with ct > m always runs the pass */
+                    else { const long bn = (int)t == tprev ? B0 : B1; M8 = adv < bn ? adv : bn; cause = 1; }   /* the newly hot suffixes hold exactly m+1 copies of t here as well */
                 } else M8 = -1;
                 if (ct >= m) a8 = 0; else ++a8;
                 if (have_M8 && M8 >= 0 && cand_all) ++viol8;

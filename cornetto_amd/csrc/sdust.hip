@@ -539,10 +539,28 @@ __global__ __launch_bounds__(64) void sdust_kernel_g(SdArgs A, uint8_t *g_ring, 
 // The waves stay resident and every lane takes chunks from one queue (low-complexity chunks first, one per wave):
 // see "jobs" in the kernel.
 // ---------------------------------------------------------------------------------------------------
+#ifndef SD_EQT
+#define SD_EQT 1
+#endif
 struct SdLds64 {
     uint32_t cw[16][64];       // [3-mer >> 2][lane]: four byte counters (3-mer & 3) = copies of the 3-mer in the window
-    uint8_t ring[64][68];      // [lane][absolute word index & 63]; 68-byte rows: lanes in phase fall on distinct banks
+    uint8_t ring[64][64];      // [lane][(absolute word index & 63) ^ 4 ((lane >> 2) & 15)]: lanes in phase fall on distinct banks
+#if SD_EQT
+    uint32_t eqt[64];          // find_perfect: [3-mer] -> lanes of one half of the wave that hold it (zero between passes)
+#endif
 };
+// byte offset into SdLds64::ring of word index i of the lane whose key is X = 64 lane | 4 ((lane >> 2) & 15): one 3-input logic op
+#ifndef SD_WPB
+#define SD_WPB 1                // waves per workgroup of sdust_w64 (independent waves; 2, 5 and 10 measured slower: a workgroup's waves crowd onto the same SIMDs)
+#endif
+#define SD_RING_KEY(l) ((uint32_t)(l) << 6 | (((uint32_t)(l) >> 2) & 15u) << 2)
+#define SD_RING_OFF(X, i) (((X) & ~63u) | (((uint32_t)(i) ^ (X)) & 63u))
+__device__ __forceinline__ uint32_t sd_ring_off(uint32_t X, uint32_t i)       // SD_RING_OFF as the single instruction it is: 63 ? i ^ X : X
+{
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, 63 bitop3:0x6c" : "=v"(r) : "v"(i), "v"(X));
+    return r;
+}
 
 // seq_nt4_table (src/sdust/sdust.c:23-40) without a table: A/a C/c G/g T/t -> 0..3, bytes 0..3 -> themselves, else 4
 __device__ __forceinline__ int nt4_code(uint32_t c)
@@ -836,11 +854,18 @@ __global__ __launch_bounds__(64) void sdust_dense(SdArgs A, const uint32_t *list
 
 // Requires 1 <= m = 2T/10 and T <= 100000 (24-bit products exact); other thresholds take the legacy kernel.
 template <bool STATS>
-__global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
+__global__ __launch_bounds__(64 * SD_WPB) void sdust_w64(SdArgs A)
 {
-    __shared__ SdLds64 S;
-    const int lane = threadIdx.x;
+    // SD_WPB independent waves per workgroup (no barrier, nothing shared): a CU holds 16 workgroups at most, whatever their size
+    __shared__ SdLds64 SS[SD_WPB];
+    SdLds64 &S = SS[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    const size_t wave_id = (size_t)blockIdx.x * SD_WPB + (threadIdx.x >> 6);
     for (int i = 0; i < 16; ++i) S.cw[i][lane] = 0;
+    for (int i = 0; i < 16; ++i) reinterpret_cast<uint32_t *>(&S.ring[lane][0])[i] = 0;     // (ring bytes index eqt: always < 64)
+#if SD_EQT
+    S.eqt[lane] = 0;
+#endif
 
     const int T = A.T, W = A.W, CAPW = W - 2;
     const int m = (T << 1) / 10;                     // cv[t]*10 > T<<1  <=>  cv[t] > m   (:79)
@@ -921,7 +946,7 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
         // acknowledged by L2, where the sc1 loads look, before a slot is read — waited for here, in front of the load, so
         // that the store itself does not hold the wave up.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t sl = __hip_atomic_load(&A.slots[((size_t)blockIdx.x * 64 + lane) * 64 + (minstart & 63)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t sl = __hip_atomic_load(&A.slots[(wave_id * 64 + lane) * 64 + (minstart & 63)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (nowk >= A.chunks[cid].start - ubase && nowk < SD_NRUN) emit(minstart, minstart + (int)(sl >> 24) + 3);
         const int gone = start - minstart;           // starts minstart .. start-1 leave the window
         if (gone >= 64) {
@@ -940,7 +965,9 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
     sd_v16u blk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // the lane's current 64-byte block; each half is refilled half a block ahead
     int lenk = 0;                                  // contig length as a step (len - ubase): blocks are fetched while the contig goes on
     uint32_t pcn = 0x04040404u;                      // codes of the previous 4 positions (before u: non-bases, l = 0)
-    uint8_t *const myring = &S.ring[lane][0];
+    uint8_t *const ring0 = &S.ring[0][0];
+    const uint32_t ringX = SD_RING_KEY(lane);
+    const uint32_t bit_lo = lane < 32 ? 1u << lane : 0u, bit_hi = lane < 32 ? 0u : 1u << (lane - 32);
 
     unsigned st_steps = 0, st_fp = 0, st_full = 0, st_jobs = 0, st_iter = 0, st_qt = 0;
     const unsigned long long st_t0 = STATS ? wall_clock64() : 0ull;
@@ -1108,7 +1135,7 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
           const unsigned f = (tw >> (8 * kk)) & 0xFFu;
           // ---- P maintenance, rare: save_masked_regions (:147) when the oldest start leaves the window, and the
           // flush at a non-base (:152-153)
-          if (sd_any(k >= evict_k)) {
+          {   // (a plain divergent branch: the compiler's skip-if-no-lane is the wave-wide test)
               if (k >= evict_k) {
                   const uint32_t nb4 = nmask & (kk == 0 ? 0u : 0xFFFFFFFFu >> (32 - 8 * kk));          // non-bases before this step
                   const int lastN = ubase + (nb4 ? k4 + ((31 - __builtin_clz(nb4)) >> 3) : LN);
@@ -1141,15 +1168,15 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
               const uint32_t old_t = __hip_atomic_fetch_add(&S.cw[f >> 2][lane], 1u << sh_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
               o += pop ? 1 : 0;
               ++p;
-              myring[p & 63] = (uint8_t)f;                                                     // :75
-              s_pref = myring[o & 63];
+              ring0[sd_ring_off(ringX, (uint32_t)p)] = (uint8_t)f;                            // :75
+              s_pref = ring0[sd_ring_off(ringX, (uint32_t)o)];
               const int ct = (int)__builtin_amdgcn_ubfe(old_t, f << 3, 8u);                    // cw[t]++   (:77), after the pop
               // the bound (see the declaration of M)
               const int adv = __mul24(ct, -10) + M + T;
               const int bn = f == tprev ? bound_eq : bound_ne;
               const int at_m = adv < bn ? adv : bn;
               M = ct < m ? adv : at_m;
-              tprev = f;
+              tprev = f;                                       // (the previous WORD: the window lives on across non-bases)
           }
           // the lanes whose bound does not exclude a candidate
           unsigned long long fp_todo = sd_ballot(M < 0) & wordmask;
@@ -1165,11 +1192,28 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
                   const int o_p = rdlane(p, ol), ws = rdlane(o, ol);
                   const int o_size = o_p - ws + 1;
                   const int j = 63 - lane;                                           // window position (0 = oldest)
+                  const uint32_t Xo = SD_RING_KEY(ol);
+                  const unsigned wj = ring0[SD_RING_OFF(Xo, ws + j)];
+                  // lanes holding the same word at a later window position (= lower lanes): the lanes of each half of the wave
+                  // in turn set their bit in the table entry of their word, everybody reads the entry of its own word and clears
+                  // it (the LDS operations of a wave execute in order, each for all its lanes)
                   const bool inwin = j < o_size;
-                  const unsigned wj = S.ring[ol][(ws + j) & 63];
-                  // lanes holding the same word at a later window position (= lower lanes): one ballot per bit of the
-                  // word, kept as two 32-bit halves (per bit: sign-extended bit, compare, two 3-input logic ops)
-                  const unsigned long long inb = sd_ballot(inwin);
+                  const unsigned long long inb = ~0ull << (64 - o_size);             // (1 <= o_size <= 62)
+#if SD_EQT
+                  uint32_t *const te = &S.eqt[wj];
+                  (void)__hip_atomic_fetch_or(te, inwin ? bit_lo : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  __builtin_amdgcn_wave_barrier();
+                  const uint32_t eq_lo = __hip_atomic_load(te, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  __builtin_amdgcn_wave_barrier();
+                  __hip_atomic_store(te, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  __builtin_amdgcn_wave_barrier();
+                  (void)__hip_atomic_fetch_or(te, inwin ? bit_hi : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  __builtin_amdgcn_wave_barrier();
+                  const uint32_t eq_hi = __hip_atomic_load(te, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  __builtin_amdgcn_wave_barrier();
+                  __hip_atomic_store(te, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+                  // one ballot per bit of the word, kept as two 32-bit halves (per bit: sign-extended bit, compare, two 3-input logic ops)
                   uint32_t eq_lo = (uint32_t)inb, eq_hi = (uint32_t)(inb >> 32);
 #pragma unroll
                   for (int bb = 0; bb < 6; ++bb) {
@@ -1180,6 +1224,7 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
                       asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x90" : "+v"(eq_lo) : "v"(ext), "s"((uint32_t)bal));
                       asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x90" : "+v"(eq_hi) : "v"(ext), "s"((uint32_t)(bal >> 32)));
                   }
+#endif
                   // suffix score r_j = inclusive prefix sum
                   // (mbcnt: set bits of the mask below this lane)
                   const int r = wave_scan_add(inwin ? (int)__builtin_amdgcn_mbcnt_hi(eq_hi, __builtin_amdgcn_mbcnt_lo(eq_lo, 0u)) : 0);
@@ -1190,7 +1235,7 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
                   // exact minimum over those of at least m + 1 words becomes the owner's bound
                   const unsigned long long candmask = sd_ballot(margin < 0) & inb;
                   {
-                      const int mn = rdlane(wave_min_all((inwin && new_l >= m) ? margin : (1 << 29)), 63);
+                      const int mn = rdlane(wave_min_all(lane >= 64 - o_size + m ? margin : (1 << 29)), 63);   // in the window, new_l >= m
                       M = sd_writelane(M, mn, ol);
                   }
                   if (candmask == 0) continue;                                       // nothing can be inserted
@@ -1204,7 +1249,7 @@ __global__ __launch_bounds__(64, STATS ? 4 : 5) void sdust_w64(SdArgs A)
                   }
                   const int o_start = rdlane(startv, ol);
                   const unsigned long long o_occ = rdlane64(occ, ol);
-                  uint32_t *orow = A.slots + ((size_t)blockIdx.x * 64 + ol) * 64;
+                  uint32_t *orow = A.slots + (wave_id * 64 + ol) * 64;
                   const int sidx = (o_start + j) & 63;
                   const bool has_e = inwin && ((o_occ >> sidx) & 1ull);
                   if (o_occ) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (see save_evict)
@@ -1517,7 +1562,15 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                                inst ? " (statistics build)" : "", (size_t)fa.localSizeBytes);
         }
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sdust_w64<false>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 16;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sdust_w64<false>, 64 * SD_WPB, 0) != hipSuccess || per_cu < 1) per_cu = 16;
+        {
+            // MI355X hands LDS out in 1280-byte granules (tools/ubench/lds_occupancy: 8192..8960 bytes -> 18 workgroups per CU,
+            // 9216..10240 -> 16), which the occupancy query does not know: the waves beyond that would start when the others end
+            hipFuncAttributes fa;
+            if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&sdust_w64<false>)) == hipSuccess && fa.sharedSizeBytes > 0)
+                per_cu = std::min<int>(per_cu, (int)(163840 / ((fa.sharedSizeBytes + 1279) / 1280 * 1280)));
+        }
+        per_cu *= SD_WPB;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus < 1) cus = 256;
         h->sd_slots = per_cu * cus;
         h->sd_cus = cus;
@@ -1648,7 +1701,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             if (!d_out) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation of %zu bytes failed", nc * cap * sizeof(uint2));
             CN_HIP(h, hipMemsetAsync(d_tot, 0, 2048, h->stream));
             // P slot rows: one per resident lane (sdust_w64) / unused by the older kernels
-            uint32_t *d_slots = (uint32_t *)cn_ws(h, WS_SD_OFF, (size_t)std::max<int64_t>(sd_waves, 1) * 64 * 64 * sizeof(uint32_t));
+            uint32_t *d_slots = (uint32_t *)cn_ws(h, WS_SD_OFF, (size_t)(std::max<int64_t>(sd_waves, 1) + SD_WPB) * 64 * 64 * sizeof(uint32_t));
             if (!d_slots) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
             const bool use_w64 = w64_path;                              // CORNETTO_SDUST_VARIANT=1 forces the per-lane reference-shaped kernel
             SdArgs A{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, d_out, d_cnt, (uint32_t)cap,
@@ -1763,10 +1816,11 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                         dense_pending = true;
                     }
                 }
-                // as many waves as the chip holds at once (LDS-bound: ~19 per CU); each lane works through the queue
+                // as many waves as the chip holds at once (LDS-bound: 18 per CU); each lane works through the queue
                 if ((unsigned)sd_waves < nb) nb = (unsigned)sd_waves;
-                if (want_stats) CN_LAUNCH(h, "sdust_kernel", sdust_w64<true><<<dim3(nb), dim3(64), 0, h->stream>>>(A));
-                else CN_LAUNCH(h, "sdust_kernel", sdust_w64<false><<<dim3(nb), dim3(64), 0, h->stream>>>(A));
+                nb = (nb + SD_WPB - 1) / SD_WPB * SD_WPB;
+                if (want_stats) CN_LAUNCH(h, "sdust_kernel", sdust_w64<true><<<dim3(nb / SD_WPB), dim3(64 * SD_WPB), 0, h->stream>>>(A));
+                else CN_LAUNCH(h, "sdust_kernel", sdust_w64<false><<<dim3(nb / SD_WPB), dim3(64 * SD_WPB), 0, h->stream>>>(A));
             } else if (W - 2 <= 64) {
                 CN_LAUNCH(h, "sdust_kernel", sdust_kernel<64><<<dim3(nb), dim3(64), 0, h->stream>>>(A));
             } else if (W - 2 <= 255) {

@@ -1192,8 +1192,9 @@ __global__ __launch_bounds__(64 * SD_WPB) void sdust_w64(SdArgs A)
                   const int o_p = rdlane(p, ol), ws = rdlane(o, ol);
                   const int o_size = o_p - ws + 1;
                   const int j = 63 - lane;                                           // window position (0 = oldest)
-                  const uint32_t Xo = SD_RING_KEY(ol);
-                  const unsigned wj = ring0[SD_RING_OFF(Xo, ws + j)];
+                  uint32_t woff;
+                  asm("v_bitop3_b32 %0, %1, %2, 63 bitop3:0x6c" : "=v"(woff) : "v"(ws + j), "s"(SD_RING_KEY(ol)));   // sd_ring_off, the key in an SGPR
+                  const unsigned wj = ring0[woff];
                   // lanes holding the same word at a later window position (= lower lanes): the lanes of each half of the wave
                   // in turn set their bit in the table entry of their word, everybody reads the entry of its own word and clears
                   // it (the LDS operations of a wave execute in order, each for all its lanes)
@@ -1227,7 +1228,9 @@ __global__ __launch_bounds__(64 * SD_WPB) void sdust_w64(SdArgs A)
 #endif
                   // suffix score r_j = inclusive prefix sum
                   // (mbcnt: set bits of the mask below this lane)
-                  const int r = wave_scan_add(inwin ? (int)__builtin_amdgcn_mbcnt_hi(eq_hi, __builtin_amdgcn_mbcnt_lo(eq_lo, 0u)) : 0);
+                  int below;
+                  asm("v_mbcnt_lo_u32_b32 %0, %1, 0\n\tv_mbcnt_hi_u32_b32 %0, %2, %0" : "=&v"(below) : "v"(eq_lo), "v"(eq_hi));   // (opaque: a select, not a branch)
+                  const int r = wave_scan_add(inwin ? below : 0);
                   const int new_l = o_size - j - 1;                                  // :111
                   // :112 (new_l < 64, T < 2^17)
                   const int margin = __mul24(T, new_l) - __mul24(r, 10);
@@ -1243,8 +1246,10 @@ __global__ __launch_bounds__(64 * SD_WPB) void sdust_w64(SdArgs A)
                   const bool cand = (candmask >> lane) & 1ull;
                   int startv;                                                        // :146 for every lane's own state
                   {
+                      int ln = LN;
+                      asm volatile("" : "+v"(ln));                                   // (keeps this arithmetic inside the passes that have candidates)
                       const uint32_t nb4 = nmask & (kk == 0 ? 0u : 0xFFFFFFFFu >> (32 - 8 * kk));
-                      const int lastN = ubase + (nb4 ? k4 + ((31 - __builtin_clz(nb4)) >> 3) : LN);
+                      const int lastN = ubase + (nb4 ? k4 + ((31 - __builtin_clz(nb4)) >> 3) : ln);
                       startv = ubase + k + 1 - W > lastN + 1 ? ubase + k + 1 - W : lastN + 1;
                   }
                   const int o_start = rdlane(startv, ol);

@@ -26,6 +26,7 @@
 // LDS (lane-minor layout, [index][lane] in 4-byte columns: bank-conflict free for any per-lane index).
 // One wavefront per workgroup; no barriers.  VALU-issue bound by nature, not HBM bound.
 #include <algorithm>
+#include <type_traits>
 #include <ctime>
 
 #include "common.hpp"
@@ -857,8 +858,12 @@ template <bool STATS>
 __global__ __launch_bounds__(64 * SD_WPB) void sdust_w64(SdArgs A)
 {
     // SD_WPB independent waves per workgroup (no barrier, nothing shared): a CU holds 16 workgroups at most, whatever their size
+#if SD_WPB == 1
+    __shared__ SdLds64 S;
+#else
     __shared__ SdLds64 SS[SD_WPB];
     SdLds64 &S = SS[threadIdx.x >> 6];
+#endif
     const int lane = threadIdx.x & 63;
     const size_t wave_id = (size_t)blockIdx.x * SD_WPB + (threadIdx.x >> 6);
     for (int i = 0; i < 16; ++i) S.cw[i][lane] = 0;
@@ -969,7 +974,7 @@ __global__ __launch_bounds__(64 * SD_WPB) void sdust_w64(SdArgs A)
     const uint32_t ringX = SD_RING_KEY(lane);
     const uint32_t bit_lo = lane < 32 ? 1u << lane : 0u, bit_hi = lane < 32 ? 0u : 1u << (lane - 32);
 
-    unsigned st_steps = 0, st_fp = 0, st_full = 0, st_jobs = 0, st_iter = 0, st_qt = 0;
+    unsigned st_plain = 0, st_steps = 0, st_fp = 0, st_full = 0, st_jobs = 0, st_iter = 0, st_qt = 0;
     const unsigned long long st_t0 = STATS ? wall_clock64() : 0ull;
     for (int k64 = 0;; k64 += 64) {
       // ---- a lane whose chunk ends inside the coming block runs on into the next chunk of the contig if nobody has
@@ -1128,14 +1133,17 @@ __global__ __launch_bounds__(64 * SD_WPB) void sdust_w64(SdArgs A)
             return occ ? (ev < nn ? ev : nn) : SD_NEVER;
         };
         if (grp_n) evict_k = next_evict(0xFFFFFFFFu);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        // One step.  PLAIN: every lane has a word at each of the 4 steps and no lane's P needs attention before the group
+        // ends (3 of 4 groups in ordinary sequence): no gate, no maintenance test.  Returns whether some lane's P got an
+        // entry (evict_k changed: the rest of the group takes the general steps).
+        auto word_step = [&](auto plain_c, const int kk) __attribute__((always_inline)) -> bool {
+          constexpr bool PLAIN = decltype(plain_c)::value;
           const int k = k4 + kk;
           if (STATS) ++st_steps;
           const unsigned f = (tw >> (8 * kk)) & 0xFFu;
           // ---- P maintenance, rare: save_masked_regions (:147) when the oldest start leaves the window, and the
           // flush at a non-base (:152-153)
-          {   // (a plain divergent branch: the compiler's skip-if-no-lane is the wave-wide test)
+          if (!PLAIN) {   // (a plain divergent branch: the compiler's skip-if-no-lane is the wave-wide test)
               if (k >= evict_k) {
                   const uint32_t nb4 = nmask & (kk == 0 ? 0u : 0xFFFFFFFFu >> (32 - 8 * kk));          // non-bases before this step
                   const int lastN = ubase + (nb4 ? k4 + ((31 - __builtin_clz(nb4)) >> 3) : LN);
@@ -1155,8 +1163,8 @@ __global__ __launch_bounds__(64 * SD_WPB) void sdust_w64(SdArgs A)
                   evict_k = next_evict(kk >= 3 ? 0u : 0xFFFFFFFFu << (8 * (kk + 1)));
               }
           }
-          const bool isword = f < 64u;
-          const unsigned long long wordmask = sd_ballot(f < 64u);
+          const bool isword = PLAIN || f < 64u;
+          const unsigned long long wordmask = PLAIN ? ~0ull : sd_ballot(f < 64u);
           if (isword) {
               // shift_window (:66-86) without cv / rv / rw: the two counters are byte fields of LDS dwords, updated by
               // atomics (one LDS op each instead of a read and a write); only the push needs the old value back
@@ -1180,6 +1188,7 @@ __global__ __launch_bounds__(64 * SD_WPB) void sdust_w64(SdArgs A)
           }
           // the lanes whose bound does not exclude a candidate
           unsigned long long fp_todo = sd_ballot(M < 0) & wordmask;
+          bool inserted = false;                               // (uniform) P of some lane got an entry: evict_k changed
           // ---- cooperative find_perfect (:104-128) ------------------------------------------------------
           // lane <-> window position j = 63 - lane, so that "suffix of the window" = "prefix of the wave" and
           // both scans are forward DPP scans (no LDS round trips).
@@ -1278,6 +1287,7 @@ __global__ __launch_bounds__(64 * SD_WPB) void sdust_w64(SdArgs A)
                   // the store must have reached L2, where their sc1 loads look, before any of them reads — they wait (vmcnt(0)) in
                   // front of their loads.
                   const unsigned long long insj = __brevll(sd_ballot(ins));           // bit j <-> window position j
+                  inserted |= insj != 0;
                   if (insj && lane == ol) {
                       const int lowest = o_start + __builtin_ctzll(insj);
                       if (occ == 0 || lowest < minstart) minstart = lowest;
@@ -1286,7 +1296,19 @@ __global__ __launch_bounds__(64 * SD_WPB) void sdust_w64(SdArgs A)
                   }
               }
           }
+          return inserted;
+        };
+        int kk0 = 0;
+        if (!sd_any((tw & 0xC0C0C0C0u) != 0 || evict_k < k4 + 4)) {
+            kk0 = 4;
+            if (STATS) ++st_plain;
+            if (word_step(std::true_type{}, 0)) kk0 = 1;
+            else if (word_step(std::true_type{}, 1)) kk0 = 2;
+            else if (word_step(std::true_type{}, 2)) kk0 = 3;
+            else (void)word_step(std::true_type{}, 3);
         }
+#pragma clang loop unroll(disable)
+        for (int kk = kk0; kk < 4; ++kk) (void)word_step(std::false_type{}, kk);
         if (grp_n && nmask) LN = k4 + ((31 - __builtin_clz(nmask)) >> 3);
       }
       if (more) {
@@ -1299,6 +1321,7 @@ __global__ __launch_bounds__(64 * SD_WPB) void sdust_w64(SdArgs A)
     if (STATS && A.stats && lane == 0) {
         atomicAdd(&A.stats[0], (unsigned long long)st_steps);
         atomicAdd(&A.stats[1], (unsigned long long)st_fp);
+        atomicAdd(&A.stats[2], (unsigned long long)st_plain);
         const unsigned long long dt = wall_clock64() - st_t0;      // 100 MHz ticks this wave spent in the loop
         atomicAdd(&A.stats[3], dt);
         atomicMax(&A.stats[4], dt);
@@ -1859,7 +1882,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                         fprintf(stderr, "[sdust stats]   waves that ran %4.1f-%4.1f ms: %6llu, job fetches %llu, find_perfect calls %llu (%llu with candidates)\n", b * 0.5, b * 0.5 + 0.5,
                                 p_tot[16 + 4 * b], p_tot[18 + 4 * b], p_tot[19 + 4 * b], p_tot[17 + 4 * b]);
             if (env_stats)
-                fprintf(stderr, "[sdust stats] flagged low-complexity %llu; chunks %zu waves %u wave-steps %llu find_perfect calls %llu (%llu with candidates) trims %llu; wave time avg %.1f us max %.1f us; queue: %.1f fetch rounds and %.1f us per wave\n", p_tot[7], nc, nb,
+                fprintf(stderr, "[sdust stats] flagged low-complexity %llu; chunks %zu waves %u wave-steps %llu find_perfect calls %llu (%llu with candidates) plain groups %llu; wave time avg %.1f us max %.1f us; queue: %.1f fetch rounds and %.1f us per wave\n", p_tot[7], nc, nb,
                         p_tot[2], p_tot[3], p_tot[10], p_tot[4], nb ? (double)p_tot[5] / nb / 100.0 : 0.0, (double)p_tot[6] / 100.0, nb ? (double)p_tot[11] / nb : 0.0, nb ? (double)p_tot[12] / nb / 100.0 : 0.0);
             const uint32_t ovf = (uint32_t)(p_tot[1] & 0xFFFFFFFFull);
             const bool need_wtab = (p_tot[1] >> 32) != 0;

@@ -1,0 +1,7 @@
+# development aid: bench step time against the share of the CU wave slots given to sdust
+for sh in ${@:-70 80 85 90 100}; do for i in 1 2; do
+python bench.py --steps 40 --no-profiles --no-e2e --no-cpu --sdust-share $sh 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('share', $sh, 'ms/step', d['ms_per_step'], {k: v for k, v in d.items() if 'stage' in k or 'kernel' in k})"
+done; done

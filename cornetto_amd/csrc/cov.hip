@@ -51,7 +51,30 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
     return v;
 }
 
-template <bool STAGE>
+// the same scan in six DPP additions (row shifts, then the two row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v)
+{
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);      // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);      // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);      // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);      // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);     // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);     // row_bcast:31 into rows 2 and 3
+    return (uint32_t)x;
+}
+typedef unsigned short cb_us2 __attribute__((ext_vector_type(2)));
+// acc + both halves of a dword of two u16 values: one instruction (v_dot2_u32_u16 with a vector of ones)
+__device__ __forceinline__ uint32_t add_u16x2(uint32_t acc, uint32_t pair)
+{
+    const cb_us2 ones = {1, 1};
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(cb_us2, pair), ones, acc, false);
+}
+
+typedef unsigned int cb_u4 __attribute__((ext_vector_type(4)));
+
+// INC: the block size when it is known at compile time (50, the default step), else 0
+template <bool STAGE, int INC>
 __global__ __launch_bounds__(CB_THREADS) void cov_blocks(CbArgs A)
 {
     __builtin_amdgcn_s_setprio(3);   // short streaming kernel: issue ahead of a long compute-bound kernel of another stream
@@ -64,7 +87,7 @@ __global__ __launch_bounds__(CB_THREADS) void cov_blocks(CbArgs A)
     const int2 tile = A.tiles[blockIdx.x];
     const int len = A.ctg_len[tile.x];
     const int64_t off = A.ctg_off[tile.x];
-    const int inc = A.inc, r = A.r;
+    const int inc = INC ? INC : A.inc, r = A.r;
     const int64_t e0 = (int64_t)tile.y * inc;           // first element of the tile within the contig
     const int64_t p0 = e0 + (int64_t)t * inc;           // first element of my block
 
@@ -80,41 +103,69 @@ __global__ __launch_bounds__(CB_THREADS) void cov_blocks(CbArgs A)
         const int base = (t % PB) * inc;
         const int nval = p0 >= len ? 0 : (int)(len - p0 < inc ? len - p0 : inc);   // elements of my block inside the contig
         const int nh = r < nval ? r : nval;
+        // INC known (<= 64: at most 4 vectors per thread and part): the loads of all four phases (2 arrays x 2 parts: the whole
+        // tile, 4 x 12.8 KB at INC = 50) are issued before the first LDS store — beside another stream's resident kernel only
+        // one or two of these workgroups fit on a CU, and what bounds the kernel then is the bytes it keeps in flight.
+        constexpr int NVI = 4;
+        cb_u4 pre[2][CB_PARTS][NVI];
+        if (INC) {
+#pragma unroll
+            for (int which = 0; which < 2; ++which)
+#pragma unroll
+                for (int part = 0; part < CB_PARTS; ++part) {
+                    const int64_t pe0 = e0 + (int64_t)part * PB * inc;
+                    const int64_t left = ((int64_t)len - pe0) * 2;
+                    const uint32_t nrec = left <= 0 ? 0u : (uint32_t)(left < (int64_t)nvec * 16 ? (left + 15) & ~15LL : (int64_t)nvec * 16);
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((which ? A.mq : A.depth) + off + pe0), 0, (int)nrec, 0x00020000);
+#pragma unroll
+                    for (int k = 0; k < NVI; ++k) pre[which][part][k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (t + k * CB_THREADS) * 16, 0, 0);
+                }
+        }
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
 #pragma unroll
             for (int part = 0; part < CB_PARTS; ++part) {
                 const int64_t pe0 = e0 + (int64_t)part * PB * inc;      // first element of this part within the contig
-                const uint4 *g = reinterpret_cast<const uint4 *>((which ? A.mq : A.depth) + off + pe0);
+                // The part as a raw buffer that ends with the contig (rounded up to a whole vector, as far as a plain load of
+                // the vector holding the last element reads): loads past it return zeros, so no load needs a bounds test.
+                const int64_t left = ((int64_t)len - pe0) * 2;
+                const uint32_t nrec = left <= 0 ? 0u : (uint32_t)(left < (int64_t)nvec * 16 ? (left + 15) & ~15LL : (int64_t)nvec * 16);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((which ? A.mq : A.depth) + off + pe0), 0, (int)nrec, 0x00020000);
                 if (which | part) __syncthreads();      // everyone is done reading the previous part
                 // all loads of a thread in flight before the first LDS store
                 constexpr int NV = 4;
-                for (int v0 = t; v0 < nvec; v0 += NV * CB_THREADS) {
-                    uint4 a[NV];
+                if (INC) {
 #pragma unroll
-                    for (int k = 0; k < NV; ++k) {
-                        const int v = v0 + k * CB_THREADS;
-                        a[k] = make_uint4(0, 0, 0, 0);
-                        if (v < nvec && pe0 + 8LL * v < len) a[k] = g[v];     // vectors at or past the contig end are zeros
+                    for (int k = 0; k < NVI; ++k) {
+                        const int v = t + k * CB_THREADS;
+                        if (v < nvec) reinterpret_cast<cb_u4 *>(sv)[v] = pre[which][part][k];
                     }
+                } else
+                for (int v0 = t; v0 < nvec; v0 += NV * CB_THREADS) {
+                    cb_u4 a[NV];
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) a[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (v0 + k * CB_THREADS) * 16, 0, 0);
 #pragma unroll
                     for (int k = 0; k < NV; ++k) {
                         const int v = v0 + k * CB_THREADS;
-                        if (v < nvec) reinterpret_cast<uint4 *>(sv)[v] = a[k];
+                        if (v < nvec) reinterpret_cast<cb_u4 *>(sv)[v] = a[k];
                     }
                 }
                 __syncthreads();
                 if (t / PB == part) {
                     uint32_t f = 0, hh = 0;
-                    if (nval == inc && (inc & 1) == 0) {
+                    if (INC && (INC & 1) == 0 && nval == inc) {   // whole dwords, unrolled
                         const uint32_t *wd = reinterpret_cast<const uint32_t *>(sv + base);
-                        for (int i = 0; i < inc / 2; ++i) {
-                            const uint32_t a = wd[i];
-                            f += (a & 0xFFFFu) + (a >> 16);
-                        }
+#pragma unroll
+                        for (int i = 0; i < (INC ? INC : 2) / 2; ++i) f = add_u16x2(f, wd[i]);
+                    } else if (nval == inc && (inc & 1) == 0) {
+                        const uint32_t *wd = reinterpret_cast<const uint32_t *>(sv + base);
+                        for (int i = 0; i < inc / 2; ++i) f = add_u16x2(f, wd[i]);
                     } else {
+#pragma clang loop vectorize(disable) unroll(disable)
                         for (int i = 0; i < nval; ++i) f += sv[base + i];
                     }
+#pragma clang loop vectorize(disable) unroll(disable)
                     for (int i = 0; i < nh; ++i) hh += sv[base + i];
                     if (which) { fq = f; hq = hh; } else { fd = f; hd = hh; }
                 }
@@ -138,20 +189,30 @@ __global__ __launch_bounds__(CB_THREADS) void cov_blocks(CbArgs A)
         fq = (uint32_t)xq;
     }
 
-    // workgroup inclusive scan of (fd, fq), wrapping; exact totals in u64
+    // workgroup inclusive scan of (fd, fq), wrapping; exact totals in u64.  On the staging path (inc <= 128) a tile total is
+    // below 256 x 128 x 65535 < 2^32: the u32 scan does not wrap inside a tile and its last value is the exact total.
     const int lane = t & 63, wv = t >> 6;
-    const uint32_t sdv = wave_incl_scan(fd, lane), sqv = wave_incl_scan(fq, lane);
-    unsigned long long td = xd, tq = xq;
+    uint32_t sdv, sqv;
+    unsigned long long td = 0, tq = 0;
+    if (STAGE) {
+        sdv = wave_incl_scan_dpp(fd);
+        sqv = wave_incl_scan_dpp(fq);
+    } else {
+        sdv = wave_incl_scan(fd, lane);
+        sqv = wave_incl_scan(fq, lane);
+        td = xd;
+        tq = xq;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        td += ((unsigned long long)__shfl_xor((unsigned)(td >> 32), d) << 32) | __shfl_xor((unsigned)td, d);
-        tq += ((unsigned long long)__shfl_xor((unsigned)(tq >> 32), d) << 32) | __shfl_xor((unsigned)tq, d);
+        for (int d = 32; d >= 1; d >>= 1) {
+            td += ((unsigned long long)__shfl_xor((unsigned)(td >> 32), d) << 32) | __shfl_xor((unsigned)td, d);
+            tq += ((unsigned long long)__shfl_xor((unsigned)(tq >> 32), d) << 32) | __shfl_xor((unsigned)tq, d);
+        }
     }
     if (lane == 63) {
         wsum[0][wv] = sdv;
         wsum[1][wv] = sqv;
     }
-    if (lane == 0) {
+    if (!STAGE && lane == 0) {
         wsum64[0][wv] = td;
         wsum64[1][wv] = tq;
     }
@@ -167,8 +228,13 @@ __global__ __launch_bounds__(CB_THREADS) void cov_blocks(CbArgs A)
     if (t == CB_THREADS - 1) {
         A.tile_tot32[blockIdx.x] = make_uint2(sdv + pd, sqv + pq);
         ulonglong2 x;
-        x.x = wsum64[0][0] + wsum64[0][1] + wsum64[0][2] + wsum64[0][3];
-        x.y = wsum64[1][0] + wsum64[1][1] + wsum64[1][2] + wsum64[1][3];
+        if (STAGE) {
+            x.x = sdv + pd;
+            x.y = sqv + pq;
+        } else {
+            x.x = wsum64[0][0] + wsum64[0][1] + wsum64[0][2] + wsum64[0][3];
+            x.y = wsum64[1][0] + wsum64[1][1] + wsum64[1][2] + wsum64[1][3];
+        }
         A.tile_tot64[blockIdx.x] = x;
     }
 }
@@ -383,10 +449,16 @@ int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int3
     CbArgs A{c->d_depth, c->d_mq, c->d_off, c->d_len, c->d_cb_tiles, inc, r, d_blk, d_t32, d_t64};
     if (inc <= CB_MAX_INC_LDS) {
         const size_t lds = (size_t)CB_THREADS / CB_PARTS * inc * sizeof(uint16_t);
-        CN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&cov_blocks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CN_LAUNCH(h, "cov_blocks", cov_blocks<true><<<dim3((unsigned)nt), dim3(CB_THREADS), lds, h->stream>>>(A));
+        static_assert(CB_THREADS / CB_PARTS * 50 / 8 <= 4 * CB_THREADS, "cov_blocks<true, INC>: at most 4 vectors per thread and part");
+        if (A.inc == 50) {                               // the default step (-i 50)
+            CN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&cov_blocks<true, 50>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            CN_LAUNCH(h, "cov_blocks", cov_blocks<true, 50><<<dim3((unsigned)nt), dim3(CB_THREADS), lds, h->stream>>>(A));
+        } else {
+            CN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&cov_blocks<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            CN_LAUNCH(h, "cov_blocks", cov_blocks<true, 0><<<dim3((unsigned)nt), dim3(CB_THREADS), lds, h->stream>>>(A));
+        }
     } else {
-        CN_LAUNCH(h, "cov_blocks", cov_blocks<false><<<dim3((unsigned)nt), dim3(CB_THREADS), 0, h->stream>>>(A));
+        CN_LAUNCH(h, "cov_blocks", cov_blocks<false, 0><<<dim3((unsigned)nt), dim3(CB_THREADS), 0, h->stream>>>(A));
     }
     CN_TRY(cnscan::exclusive_u32(h, "cov_tilescan", reinterpret_cast<const uint32_t *>(d_t32), (int64_t)nt, 2, d_toff_d, d_part, nullptr));
     CN_TRY(cnscan::exclusive_u32(h, "cov_tilescan", reinterpret_cast<const uint32_t *>(d_t32) + 1, (int64_t)nt, 2, d_toff_q, d_part, nullptr));

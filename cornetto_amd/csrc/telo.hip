@@ -58,12 +58,32 @@ __device__ __forceinline__ unsigned long long shfl_up64(unsigned long long v, in
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// union of [p, p+k) over set bits p of (prev:cur), restricted to cur's 64 positions
+// union of [p, p+k) over set bits p of (prev:cur), restricted to cur's 64 positions (k <= 64): the covered width doubles
+// per step (1, 2, 4, ... then the rest), on the 128-bit pair
 __device__ __forceinline__ unsigned long long smear(unsigned long long cur, unsigned long long prev, int k)
 {
-    unsigned long long c = cur;
-    for (int j = 1; j < k; ++j) c |= (cur << j) | (prev >> (64 - j));
-    return c;
+    unsigned long long lo = prev, hi = cur;            // bit i of lo = position i - 64
+    int w = 1;                                          // every set bit p covers [p, p + w) so far
+    while (w < k) {
+        const int s = w < k - w ? w : k - w;            // shift by s: covers [p, p + w + s)
+        hi |= (hi << s) | (lo >> (64 - s));
+        lo |= lo << s;
+        w += s;
+    }
+    return hi;
+}
+
+// inclusive scan over the wave in six DPP additions (row shifts, then the two row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v)
+{
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+    return (uint32_t)x;
 }
 
 template <int H>  // halo bytes behind the 64 positions of a thread; motif length k <= H + 1
@@ -191,13 +211,9 @@ __global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
     // packed 4 x 16-bit exclusive scan over the workgroup (a tile holds < 2^15 heads per list)
     unsigned long long pk = (unsigned long long)__popcll(q0) | ((unsigned long long)__popcll(q1) << 16) |
                             ((unsigned long long)__popcll(q2) << 32) | ((unsigned long long)__popcll(q3) << 48);
-    unsigned long long inc = pk;
+    // (two 16-bit counters per half, each below 2^15 for a whole tile: the halves scan independently, no carry between them)
     const int lane = t & 63, wv = t >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        unsigned long long o = shfl_up64(inc, d);
-        if (lane >= d) inc += o;
-    }
+    const unsigned long long inc = (unsigned long long)wave_incl_scan_dpp((uint32_t)pk) | ((unsigned long long)wave_incl_scan_dpp((uint32_t)(pk >> 32)) << 32);
     if (lane == 63) wtot[wv] = inc;
     __syncthreads();
     unsigned long long wpre = 0, total = 0;

@@ -329,6 +329,41 @@ def test_telofind_random_vs_oracle(acc):
         assert [tuple(map(int, h)) for h in hits] == exp, motif
 
 
+def test_telofind_lookalike_bytes_vs_oracle(acc):
+    """copies of the motif in which letters are replaced by other bytes that share bits with them (N and F with G, U and D with
+    T, @ and H with A, B and K with C; lower case likewise) must not be reported, copies flush with the contig ends and around
+    the tile size (16256) must.  (A 2-bit-code compare with byte-wise confirmation of the candidates was built against this
+    test and measured: as many instructions as the automaton — DESIGN.md section 8 — so the automaton stayed.)"""
+    rng = np.random.default_rng(4242)
+    alias = {ord("A"): b"@HhPp`\x10\x08", ord("C"): b"BKkSs\x02\x03", ord("G"): b"NnFfOo\x06\x07", ord("T"): b"UuDdEe\x04\x05"}
+    for motif in (b"TTAGGG", b"CCCTAA", b"TTTAGGG", b"AC", b"G", b"ACGTACGT", b"GGGGGG"):
+        seqs = []
+        for n in (0, 1, 5, 63, 64, 65, 127, 128, 16255, 16256, 16257, 16256 + 63, 2 * 16256 + 5, 40000, 33000):
+            s = np.frombuffer(b"ACGTNacgtn", dtype=np.uint8)[rng.integers(0, 10, size=n)].copy()
+            for _k in range(12):
+                if n > 200:
+                    p = int(rng.integers(0, n - 100))
+                    rep = np.frombuffer(motif * int(rng.integers(1, 12)), dtype=np.uint8).copy()
+                    rep = rep[: n - p]
+                    if _k % 3:                                   # look-alikes instead of some letters
+                        for i in rng.integers(0, len(rep), size=max(1, len(rep) // 7)):
+                            a = alias.get(int(rep[i]) & 0xDF)
+                            if a:
+                                rep[i] = a[int(rng.integers(0, len(a)))]
+                    s[p:p + len(rep)] = rep
+            if n >= len(motif):                                  # copies flush with both ends of the contig
+                s[:len(motif)] = np.frombuffer(motif, dtype=np.uint8)
+                s[n - len(motif):] = np.frombuffer(motif, dtype=np.uint8)
+            seqs.append(s)
+        asm = acc.asm_upload(seqs)
+        hits = acc.telofind(asm, motif)
+        asm.close()
+        exp = []
+        for ci, s in enumerate(seqs):
+            exp += [(ci, int(h["strand"]), int(h["start"]), int(h["end"])) for h in ob.telofind(s, motif)]
+        assert [tuple(map(int, h)) for h in hits] == exp, motif
+
+
 # ---------------------------------------------------------------------------------------------------
 # coverage windows
 # ---------------------------------------------------------------------------------------------------

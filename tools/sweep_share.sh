@@ -3,5 +3,5 @@ for sh in ${@:-70 80 85 90 100}; do for i in 1 2; do
 python bench.py --steps 40 --no-profiles --no-e2e --no-cpu --sdust-share $sh 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('share', $sh, 'ms/step', d['ms_per_step'], {k: v for k, v in d.items() if 'stage' in k or 'kernel' in k})"
+print('share', $sh, 'ms/step', d['ms_per_step'], d.get('stage_wall_ms'), {k: v['ms'] for k, v in d['kernels'].items() if v['ms'] > 0.25})"
 done; done

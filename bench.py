@@ -743,7 +743,7 @@ def main():
     ap.add_argument("--check-steps", type=int, default=-1, help="extra untimed steps whose results are digested and compared (-1: min(steps, 20); 0: none)")
     ap.add_argument("--no-profiles", action="store_true", help="skip the second workload profile")
     ap.add_argument("--no-e2e", action="store_true", help="skip the CLI end-to-end leg")
-    ap.add_argument("--sdust-share", type=int, default=80, help="percent of every CU the sdust kernel may occupy while the other stream runs beside it")
+    ap.add_argument("--sdust-share", type=int, default=85, help="percent of the wave slots sdust could hold on a CU (18) that it takes while the other stream runs beside it: 85 = 15 waves per CU")
     ap.add_argument("--timing", type=int, default=2, help="HIP events around: 1 the main kernels only (roofline), 2 every launch, 0 none")
     ap.add_argument("--gather", action="store_true", help="also gather every result record to rank 0 inside the step (not part of the path: each rank owns the output of its contigs)")
     ap.add_argument("--allreduce-always", action="store_true", help="weak scaling: all-reduce the depth totals as well (treats the N assemblies as one)")

@@ -315,7 +315,7 @@ class Accel:
             if w:
                 hist.append({"ms": [b * 0.5, b * 0.5 + 0.5], "waves": w, "jobs": s[18 + 4 * b], "find_perfect": s[19 + 4 * b], "find_perfect_with_candidates": s[17 + 4 * b]})
         return {"waves": waves, "chunks": s[255], "chunks_sampled_low_complexity": s[7], "wave_steps": s[2], "find_perfect_calls": s[3],
-                "find_perfect_with_candidates": s[10], "trims": s[4], "wave_ms_avg": round(s[5] / waves / 1e5, 3), "wave_ms_max": round(s[6] / 1e5, 3),
+                "find_perfect_with_candidates": s[10], "plain_groups": s[4], "wave_ms_avg": round(s[5] / waves / 1e5, 3), "wave_ms_max": round(s[6] / 1e5, 3),
                 "queue_fetch_rounds_per_wave": round(s[11] / waves, 1), "wave_time_histogram": hist}
 
     # ---- panel interval stage ---------------------------------------------------------------------

@@ -111,7 +111,7 @@ int cornetto_accel_set_share(cornetto_accel_t *h, int percent);
 /* Statistics of the production sdust kernel (development / bench aid).  `enable` != 0 makes the following
  * cornetto_sdust_asm() calls on this handle run the counting build of the kernel (a few percent slower); `out`, if not
  * NULL, receives up to `cap` (<= 256) counters of the most recent such call: [2] wave steps, [3] find_perfect calls,
- * [4] trims, [5] sum and [6] maximum over the waves of their run time in 10 ns ticks, [7] chunks sampled as low-complexity,
+ * [4] groups of 4 steps that took the ungated path, [5] sum and [6] maximum over the waves of their run time in 10 ns ticks, [7] chunks sampled as low-complexity,
  * [10] find_perfect calls with candidates, [11] queue fetch rounds, [12] ticks spent fetching, [16 + 4b ...] per 0.5 ms bin b
  * of wave run time: waves, find_perfect calls with candidates, jobs, find_perfect calls; [254] waves launched, [255] chunks.
  * Returns the number of counters copied.  Results of sdust do not depend on it. */

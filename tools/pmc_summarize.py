@@ -14,14 +14,14 @@ def counters(pattern, want):
     return {k: v / max(1, len(n[k])) for k, v in agg.items()}          # per launch
 sq = counters("gpurun_out/pmc_%s_s*/**/*_counter_collection.csv" % tag, ["sdust_w64", "sdust_dense"])
 stats = open("gpurun_out/%s_stats.txt" % tag).read()
-m = re.search(r"wave-steps (\d+) find_perfect calls (\d+) \((\d+) with candidates\) trims (\d+)", stats)
+m = re.search(r"wave-steps (\d+) find_perfect calls (\d+) \((\d+) with candidates\) plain groups (\d+)", stats)
 steps = int(m.group(1)) if m else 0
 out = {"workload": "tools/perf_probe.py sdust --mbases %g --features 1 --profile %s (the bench assembly, sdust alone on the chip)" % (mb, profile),
        "wave_steps": steps, "find_perfect_calls": int(m.group(2)) if m else None, "find_perfect_with_candidates": int(m.group(3)) if m else None,
-       "trims": int(m.group(4)) if m else None, "per_launch": {}, "per_wave_step": {}}
+       "plain_groups_of_4_steps": int(m.group(4)) if m else None, "per_launch": {}, "per_wave_step": {}}
 for (k, c), v in sorted(sq.items()):
     out["per_launch"].setdefault(k, {})[c] = v
-    if k == "sdust_w64" and steps and c.startswith("SQ_INSTS"):
+    if k == "sdust_w64" and steps and (c.startswith("SQ_INSTS") or c == "SQ_ACTIVE_INST_MISC"):
         out["per_wave_step"][c] = round(v / steps, 2)
 w = out["per_launch"].get("sdust_w64", {})
 if w.get("SQ_BUSY_CYCLES") and w.get("SQ_ACTIVE_INST_VALU"):

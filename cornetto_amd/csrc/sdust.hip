@@ -545,16 +545,19 @@ __global__ __launch_bounds__(64) void sdust_kernel_g(SdArgs A, uint8_t *g_ring, 
 #endif
 struct SdLds64 {
     uint32_t cw[16][64];       // [3-mer >> 2][lane]: four byte counters (3-mer & 3) = copies of the 3-mer in the window
-    uint8_t ring[64][64];      // [lane][(absolute word index & 63) ^ 4 ((lane >> 2) & 15)]: lanes in phase fall on distinct banks
+    uint8_t ring[64][64];      // [lane][(absolute word index & 63) ^ swizzle(lane)]: lanes in phase fall on distinct banks, counted in 32 banks per half wave or in 64
 #if SD_EQT
     uint32_t eqt[64];          // find_perfect: [3-mer] -> lanes of one half of the wave that hold it (zero between passes)
 #endif
 };
-// byte offset into SdLds64::ring of word index i of the lane whose key is X = 64 lane | 4 ((lane >> 2) & 15): one 3-input logic op
+// byte offset into SdLds64::ring of word index i of the lane whose key is X = 64 lane | 4 swizzle(lane): one 3-input logic op.
+// swizzle = ((lane >> 2) & 15) ^ 8 ((lane >> 1) & 1): the 16 lanes that share lane & 1 within a half wave (row bases 64 bytes apart =
+// 16 dwords: banks 0 or 16 of 32) get 16 different dwords, and so do the 16 lanes that share lane & 3 (64 banks); with the plain
+// (lane >> 2) & 15 of the first version rocprofv3 counted 200 M more LDS bank-conflict cycles per launch
 #ifndef SD_WPB
 #define SD_WPB 1                // waves per workgroup of sdust_w64 (independent waves; 2, 5 and 10 measured slower: a workgroup's waves crowd onto the same SIMDs)
 #endif
-#define SD_RING_KEY(l) ((uint32_t)(l) << 6 | (((uint32_t)(l) >> 2) & 15u) << 2)
+#define SD_RING_KEY(l) ((uint32_t)(l) << 6 | ((((uint32_t)(l) >> 2) & 15u) ^ (((uint32_t)(l) >> 1) & 1u) << 3) << 2)
 #define SD_RING_OFF(X, i) (((X) & ~63u) | (((uint32_t)(i) ^ (X)) & 63u))
 __device__ __forceinline__ uint32_t sd_ring_off(uint32_t X, uint32_t i)       // SD_RING_OFF as the single instruction it is: 63 ? i ^ X : X
 {
@@ -1202,13 +1205,13 @@ __global__ __launch_bounds__(64 * SD_WPB) void sdust_w64(SdArgs A)
                   const int o_size = o_p - ws + 1;
                   const int j = 63 - lane;                                           // window position (0 = oldest)
                   uint32_t woff;
-                  asm("v_bitop3_b32 %0, %1, %2, 63 bitop3:0x6c" : "=v"(woff) : "v"(ws + j), "s"(SD_RING_KEY(ol)));   // sd_ring_off, the key in an SGPR
+                  asm("v_bitop3_b32 %0, %1, %2, 63 bitop3:0x6c" : "=v"(woff) : "v"(ws + j), "s"(rdlane((int)ringX, ol)));   // sd_ring_off, the owner's key in an SGPR
                   const unsigned wj = ring0[woff];
                   // lanes holding the same word at a later window position (= lower lanes): the lanes of each half of the wave
                   // in turn set their bit in the table entry of their word, everybody reads the entry of its own word and clears
                   // it (the LDS operations of a wave execute in order, each for all its lanes)
                   const bool inwin = j < o_size;
-                  const unsigned long long inb = ~0ull << (64 - o_size);             // (1 <= o_size <= 62)
+                  const unsigned long long inb = ~0ull << (64 - o_size);             // (1 <= o_size <= 64)
 #if SD_EQT
                   uint32_t *const te = &S.eqt[wj];
                   (void)__hip_atomic_fetch_or(te, inwin ? bit_lo : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

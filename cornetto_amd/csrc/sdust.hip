@@ -924,6 +924,8 @@ __global__ __launch_bounds__(64 * SD_WPB) void sdust_w64(SdArgs A)
     // tools/sim/sdust_trigger_sim.c ("hot-suffix tracker") checks the bound on 10^7 steps for a dozen (T, W): never above the
     // true minimum; in random sequence it asks for 0.39 passes per wave-step — the gate with its exact L asked for 0.15, but
     // needed 1.06 cooperative trims per wave-step to keep L.
+    int bound_eq_v = bound_eq, bound_ne_v = bound_ne;           // both in vector registers: the select needs no move per word
+    asm volatile("" : "+v"(bound_eq_v), "+v"(bound_ne_v));
     int M = -1;                 // (no bound yet: the first word runs the pass)
     unsigned tprev = 0xFFu;     // the word pushed before this one
     unsigned s_pref = 0;        // ring[o]: the word the next pop removes
@@ -1136,8 +1138,8 @@ __global__ __launch_bounds__(64 * SD_WPB) void sdust_w64(SdArgs A)
             return occ ? (ev < nn ? ev : nn) : SD_NEVER;
         };
         if (grp_n) evict_k = next_evict(0xFFFFFFFFu);
-        // One step.  PLAIN: every lane has a word at each of the 4 steps and no lane's P needs attention before the group
-        // ends (3 of 4 groups in ordinary sequence): no gate, no maintenance test.  Returns whether some lane's P got an
+        // One step.  PLAIN: every lane has a word at each of the 4 steps, every lane's window is full and no lane's P needs
+        // attention before the group ends (6 of 7 groups in ordinary sequence): no gate, no maintenance test, every step pops.  Returns whether some lane's P got an
         // entry (evict_k changed: the rest of the group takes the general steps).
         auto word_step = [&](auto plain_c, const int kk) __attribute__((always_inline)) -> bool {
           constexpr bool PLAIN = decltype(plain_c)::value;
@@ -1171,7 +1173,7 @@ __global__ __launch_bounds__(64 * SD_WPB) void sdust_w64(SdArgs A)
           if (isword) {
               // shift_window (:66-86) without cv / rv / rw: the two counters are byte fields of LDS dwords, updated by
               // atomics (one LDS op each instead of a read and a write); only the push needs the old value back
-              const bool pop = p >= CAPW - 1;                  // size >= W - 2 (:68): o = max(0, p - (W - 3)) at all times
+              const bool pop = PLAIN || p >= CAPW - 1;         // size >= W - 2 (:68): o = max(0, p - (W - 3)) at all times; plain groups: every window is full
               const unsigned s = s_pref;
               // byte field of the counter inside its dword: 8 * (word & 3); shifts use the low 5 bits of the amount only
               const unsigned sh_s = (s << 3) & 31u, sh_t = (f << 3) & 31u;
@@ -1184,7 +1186,7 @@ __global__ __launch_bounds__(64 * SD_WPB) void sdust_w64(SdArgs A)
               const int ct = (int)__builtin_amdgcn_ubfe(old_t, f << 3, 8u);                    // cw[t]++   (:77), after the pop
               // the bound (see the declaration of M)
               const int adv = __mul24(ct, -10) + M + T;
-              const int bn = f == tprev ? bound_eq : bound_ne;
+              const int bn = f == tprev ? bound_eq_v : bound_ne_v;
               const int at_m = adv < bn ? adv : bn;
               M = ct < m ? adv : at_m;
               tprev = f;                                       // (the previous WORD: the window lives on across non-bases)
@@ -1302,7 +1304,7 @@ __global__ __launch_bounds__(64 * SD_WPB) void sdust_w64(SdArgs A)
           return inserted;
         };
         int kk0 = 0;
-        if (!sd_any((tw & 0xC0C0C0C0u) != 0 || evict_k < k4 + 4)) {
+        if (!sd_any((int)((tw & 0xC0C0C0C0u) != 0u) | (int)(evict_k < k4 + 4) | (int)(p < CAPW - 1))) {
             kk0 = 4;
             if (STATS) ++st_plain;
             if (word_step(std::true_type{}, 0)) kk0 = 1;

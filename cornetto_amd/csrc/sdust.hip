@@ -858,7 +858,7 @@ __global__ __launch_bounds__(64) void sdust_dense(SdArgs A, const uint32_t *list
 
 // Requires 1 <= m = 2T/10 and T <= 100000 (24-bit products exact); other thresholds take the legacy kernel.
 template <bool STATS>
-__global__ __launch_bounds__(64 * SD_WPB) void sdust_w64(SdArgs A)
+__global__ __launch_bounds__(64 * SD_WPB, STATS ? 4 : 5) void sdust_w64(SdArgs A)      // (5 waves per SIMD: at most 96 VGPRs)
 {
     // SD_WPB independent waves per workgroup (no barrier, nothing shared): a CU holds 16 workgroups at most, whatever their size
 #if SD_WPB == 1
@@ -1128,6 +1128,7 @@ __global__ __launch_bounds__(64 * SD_WPB) void sdust_w64(SdArgs A)
             pcn = cn;
         }
         const uint32_t nmask = tw & 0x80808080u;
+        const uint32_t tw8 = tw >> 8;
         const bool grp_n = sd_any(nmask != 0);
         // next step at which P needs attention: the oldest start leaves the window (i >= minstart + W, :146-147), or
         // the next non-base of this group among the bytes selected by `above`
@@ -1181,7 +1182,9 @@ __global__ __launch_bounds__(64 * SD_WPB) void sdust_w64(SdArgs A)
               const uint32_t old_t = __hip_atomic_fetch_add(&S.cw[f >> 2][lane], 1u << sh_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
               o += pop ? 1 : 0;
               ++p;
-              ring0[sd_ring_off(ringX, (uint32_t)p)] = (uint8_t)f;                            // :75
+              // :75 (the byte straight out of the group's dword or of its copy shifted by one byte: bits 0-7 or 16-23, which a
+              // byte store can take without a shift)
+              ring0[sd_ring_off(ringX, (uint32_t)p)] = (uint8_t)(((kk & 1) ? tw8 : tw) >> (8 * (kk & 2)));
               s_pref = ring0[sd_ring_off(ringX, (uint32_t)o)];
               const int ct = (int)__builtin_amdgcn_ubfe(old_t, f << 3, 8u);                    // cw[t]++   (:77), after the pop
               // the bound (see the declaration of M)

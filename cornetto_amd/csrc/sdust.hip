@@ -1253,12 +1253,12 @@ __global__ __launch_bounds__(64 * SD_WPB, STATS ? 4 : 5) void sdust_w64(SdArgs A
                   const int margin = __mul24(T, new_l) - __mul24(r, 10);
                   // every suffix of the window is examined (:107 starts behind v: the suffixes inside v are never candidates); the
                   // exact minimum over those of at least m + 1 words becomes the owner's bound
+                  const int mn = rdlane(wave_min_all(lane >= 64 - o_size + m ? margin : (1 << 29)), 63);   // in the window, new_l >= m
+                  M = sd_writelane(M, mn, ol);
+                  // a suffix of fewer than m + 1 words is never a candidate (r <= q (q - 1) / 2, 5 q <= 5 m <= T): with a minimum >= 0
+                  // over the others nothing can be inserted, and the ballot of the candidates is not even taken
+                  if (mn >= 0) continue;
                   const unsigned long long candmask = sd_ballot(margin < 0) & inb;
-                  {
-                      const int mn = rdlane(wave_min_all(lane >= 64 - o_size + m ? margin : (1 << 29)), 63);   // in the window, new_l >= m
-                      M = sd_writelane(M, mn, ol);
-                  }
-                  if (candmask == 0) continue;                                       // nothing can be inserted
                   if (STATS) ++st_full;
                   const bool cand = (candmask >> lane) & 1ull;
                   int startv;                                                        // :146 for every lane's own state

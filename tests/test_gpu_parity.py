@@ -276,6 +276,28 @@ def test_sdust_random_vs_oracle(acc, monkeypatch, T, W, chunk):
     assert got == exp
 
 
+@pytest.mark.parametrize("seed", list(range(48)))
+def test_sdust_random_thresholds_vs_oracle(acc, monkeypatch, seed):
+    """thresholds and windows drawn at random (T 5..120, W 3..66: m = T / 5 from 1 to 24, the bounds of the pass trigger change with
+    every pair), chunk sizes down to a few windows, on random / tandem / two-letter sequences with non-bases"""
+    rng = np.random.default_rng(9000 + seed)
+    T = int(rng.integers(5, 121))
+    W = int(rng.integers(3, 67))
+    monkeypatch.setenv("CORNETTO_SDUST_CHUNK", str(int(rng.integers(max(16, W), 900))))
+    monkeypatch.setenv("CORNETTO_SDUST_WAVES", str(1 + seed % 3))
+    seqs = _rand_seqs(rng, 40, -1)
+    asm = acc.asm_upload(seqs)
+    iv = acc.sdust(asm, T, W)
+    asm.close()
+    got = [(int(x["ctg"]), int(x["start"]), int(x["finish"])) for x in iv]
+    exp = []
+    for ci, q in enumerate(seqs):
+        for r in ob.sdust(q, T, W):
+            r = int(r)
+            exp.append((ci, r >> 32, r & 0xFFFFFFFF))
+    assert got == exp, (T, W)
+
+
 def test_sdust_largest_window_on_homopolymers(acc):
     """W = 257: the window holds 255 words and a homopolymer fills it with 255 copies of one 3-mer — the most the byte
     counters of the older kernel hold; from W = 258 on another kernel (32-bit counters, state in global memory) takes over"""

@@ -67,6 +67,7 @@ struct SdArgs {
     const uint32_t *wtab;        //   exclusive prefix of per-256-base-block word-emission counts, or NULL
     const int64_t *wtab_base;    //   first table entry of each contig
     uint32_t *need_wtab;         //   set when a lane gave up and no table was supplied (host builds it and reruns)
+    const uint32_t *q_len_dev;   // sdust_w64: when set, the number of queue positions is read from here (the list sd_slowlist made)
 };
 
 constexpr int SD_SCAN_CAP = 1024;   // bases a lane scans backwards by itself before using the table
@@ -876,6 +877,7 @@ __global__ __launch_bounds__(64 * SD_WPB, STATS ? 4 : 5) void sdust_w64(SdArgs A
 #endif
 
     const int T = A.T, W = A.W, CAPW = W - 2;
+    const int q_len = A.q_len_dev ? (int)__builtin_amdgcn_readfirstlane((int)*A.q_len_dev) : A.q_len;
     const int m = (T << 1) / 10;                     // cv[t]*10 > T<<1  <=>  cv[t] > m   (:79)
     // find_perfect, lane <-> window position: with a full window the suffix of this lane has l_full words after its first
     const int l_full = CAPW - 64 + lane;
@@ -1021,7 +1023,7 @@ __global__ __launch_bounds__(64 * SD_WPB, STATS ? 4 : 5) void sdust_w64(SdArgs A
               base = rdlane(base, first);
               if (want) {
                   const int idx = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(wmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wmask, 0u));
-                  if (idx < 0 || idx >= A.q_len) {
+                  if (idx < 0 || idx >= q_len) {
                       want = false;                    // the queue is empty
                   } else {
                       const uint32_t c = A.perm ? A.perm[idx] : (uint32_t)idx;
@@ -1435,6 +1437,8 @@ __device__ int sd_find_start(const SdArgs &A, const SdChunk ch, const uint8_t *s
     return u;
 }
 
+#include "sdust_sift.hpp"
+
 // ---- scheduling hint per chunk, before the main kernel: the 64 bytes in the middle of the chunk; a sample whose 62
 // 3-mers take few distinct values (random sequence: ~40 of 64) lies in a repeat array.  The flag only orders the work;
 // results do not depend on it.
@@ -1629,17 +1633,23 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
     }
     chunk = std::max<int64_t>(16, chunk);
     if (W > 257 && env_int("CORNETTO_SDUST_CHUNK", 0) <= 0) chunk = std::max<int64_t>(chunk, 32 * (int64_t)W);   // (warm-up: 3 W bases per chunk)
+    // The sift / resolve stages (sdust_sift.hpp) take every chunk of plain letters; they want chunks of whole 64-base tiles,
+    // at least 256 bases (the look-back of a chunk stays inside the chunk before it), at most 62 tiles.  CORNETTO_SDUST_SIFT=0 keeps the
+    // per-lane recurrence of sdust_w64 for everything (also what an explicit chunk size outside that range does: the tests
+    // with tiny chunks stress exactly that kernel).
+    bool sift_on = w64_path && env_int("CORNETTO_SDUST_SIFT", 1) != 0;
+    if (sift_on && (chunk % 64 != 0 || chunk < 256 || chunk > 3968)) sift_on = false;     // (64 tiles with the two in front)
     // Optionally the last part of the work is cut into shorter chunks, handed out last and in one pass: when the queue runs
     // dry every wave still has to finish the chunks its lanes hold, and a wave-step costs the same with 3 busy lanes as with
     // 64.  Measured on the 3.16 Gbp assembly (tools/perf_probe.py, 5 launches each): 0 % 8.5-9.1 ms, 10 % / 4x 8.5-8.8,
     // 20 % / 4x 8.7-9.1, 20 % / 2x 8.5-9.0, 30 % / 4x 8.9-9.2 — the extra warm-ups cost what the shorter drain saves, so it is
     // OFF by default.  CORNETTO_SDUST_TAIL = percent of the bases, CORNETTO_SDUST_TAILDIV = how many times shorter (4).
     // Results do not depend on the decomposition.
-    const int tail_pct = std::min(90, std::max(0, env_int("CORNETTO_SDUST_TAIL", 0)));
+    const int tail_pct = sift_on ? 0 : std::min(90, std::max(0, env_int("CORNETTO_SDUST_TAIL", 0)));
     const int tail_div = std::min(16, std::max(1, env_int("CORNETTO_SDUST_TAILDIV", 4)));
     const int64_t small = std::max<int64_t>(64, (chunk / tail_div + 63) / 64 * 64);
     const int64_t tail_from = tail_pct > 0 && tail_div > 1 ? a->total - a->total * tail_pct / 100 : a->total + 1;   // in bases, assembly order
-    const int64_t key = chunk + (int64_t)tail_pct * (1ll << 40) + (int64_t)tail_div * (1ll << 48);
+    const int64_t key = chunk + (int64_t)tail_pct * (1ll << 40) + (int64_t)tail_div * (1ll << 48) + (sift_on ? 1ll << 56 : 0);
     if (a->sd_chunk != key) {
         std::vector<SdChunk> chunks;
         int64_t seen = 0;
@@ -1676,7 +1686,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
     // 28 / 31 ms, n = 4 27-32 / 34 ms, n = 8 35-40 / 38 ms: at 28 KB of LDS per dense wave only five fit on a CU, so more jobs
     // are more rounds (plus their warm-ups), not more waves per SIMD.  The split pays only once the dense state is smaller
     // (16-bit P slots, 12-bit ring entries: ~18 KB) — DESIGN.md section 8.
-    if (w64_path && !a->sd_refined && a->sd_n_chunks > 0 && env_int("CORNETTO_SDUST_ORDER", 1)) {
+    if (w64_path && !sift_on && !a->sd_refined && a->sd_n_chunks > 0 && env_int("CORNETTO_SDUST_ORDER", 1)) {
         a->sd_refined = true;
         const int dense_mode = env_int("CORNETTO_SDUST_DENSE", 1);
         const int split = std::min(16, std::max(1, env_int("CORNETTO_SDUST_DENSE_SPLIT", 1)));
@@ -1745,7 +1755,20 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                      reinterpret_cast<uint32_t *>(d_tot + 8), nullptr, 0, env_int("CORNETTO_SDUST_RUNON", 1), (int32_t)chunk, a->d_wtab, a->d_wtab_base, reinterpret_cast<uint32_t *>(d_tot + 1) + 1};
             unsigned nb = (unsigned)((nc + 63) / 64);
             bool dense_pending = false;
-            if (use_w64) {
+            if (use_w64 && sift_on) {
+                // ---- one launch: sift + resolve over the chunks of plain letters, the base-by-base walk over the others ----
+                CN_HIP(h, hipMemsetAsync(d_cnt, 0, nc * 4, h->stream));       // (a wave that asks for the word-count table publishes nothing)
+                const uint32_t reg_cap = (uint32_t)(chunk + 128);
+                const uint32_t lds_wave = sift_lds_bytes(reg_cap);
+                int lmin = 1;
+                while (5 * (lmin + 1) <= T && lmin < 16) ++lmin;
+                SiftArgs S{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, lds_wave, reg_cap, T / 10 + 1, lmin, env_int("CORNETTO_SIFT_ABL", 0)};
+                SdArgs R = A;
+                R.stats = want_stats ? d_tot + 200 : nullptr;
+                const unsigned nbk = (unsigned)((nc + SIFT_WPB - 1) / SIFT_WPB);
+                if (want_stats) CN_LAUNCH(h, "sdust_kernel", sd_sift<true><<<dim3(nbk), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream>>>(S, R));
+                else CN_LAUNCH(h, "sdust_kernel", sd_sift<false><<<dim3(nbk), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream>>>(S, R));
+            } else if (use_w64) {
                 // warm-up starts, the order of the queue, the claim flags:
                 // flag (nc) + rank (nc) + claim (nc) + perm (nc + 80) + dense list (nc) + scan partials
                 uint32_t *d_flag = (uint32_t *)cn_ws(h, WS_SD_PERM, (nc * 5 + 160) * 4 + ((nc + 4095) / 4096 + 1) * 4);
@@ -1889,6 +1912,9 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                     if (p_tot[16 + 4 * b])
                         fprintf(stderr, "[sdust stats]   waves that ran %4.1f-%4.1f ms: %6llu, job fetches %llu, find_perfect calls %llu (%llu with candidates)\n", b * 0.5, b * 0.5 + 0.5,
                                 p_tot[16 + 4 * b], p_tot[18 + 4 * b], p_tot[19 + 4 * b], p_tot[17 + 4 * b]);
+            if (env_stats && sift_on)
+                fprintf(stderr, "[sdust stats] sift: tiles %llu, positions with ct > T/10 %llu, after L1 %llu, after L2 %llu; resolve: steps %llu, window reads %llu; passes with candidates %llu; base-by-base steps of chunks with other bytes %llu\n",
+                        p_tot[206], p_tot[203], p_tot[204], p_tot[205], p_tot[200], p_tot[201], p_tot[202], p_tot[207]);
             if (env_stats)
                 fprintf(stderr, "[sdust stats] flagged low-complexity %llu; chunks %zu waves %u wave-steps %llu find_perfect calls %llu (%llu with candidates) plain groups %llu; wave time avg %.1f us max %.1f us; queue: %.1f fetch rounds and %.1f us per wave\n", p_tot[7], nc, nb,
                         p_tot[2], p_tot[3], p_tot[10], p_tot[4], nb ? (double)p_tot[5] / nb / 100.0 : 0.0, (double)p_tot[6] / 100.0, nb ? (double)p_tot[11] / nb : 0.0, nb ? (double)p_tot[12] / nb / 100.0 : 0.0);

@@ -1,0 +1,572 @@
+// sdust_sift.hpp — the round-3 decomposition of symmetric DUST for plain A/C/G/T sequence (included by sdust.hip, same
+// anonymous namespace).  Replaces the per-lane recurrence of sdust_w64 wherever a chunk and the 128 bases in front of it
+// hold nothing but A/C/G/T (either case); every other chunk is left to sdust_w64, which is exact for any input.
+//
+// What the reference computes there (src/sdust/sdust.c:104-128,:88-102, restated; tools/sim/sdust_sift_sim.c checks every
+// statement below against the oracle for a dozen (T, W), chunk sizes down to W, mixed clean / unclean chunks):
+//   * find_perfect over EVERY suffix of the window, without the gate of :149, is the same function, and the
+//     result list is the canonical union (:94-98) of the intervals it inserts.
+//   * An interval [s, i] (first base of its first word .. last base of its last word, l = words - 1, r = equal-word pairs)
+//     is inserted iff it is PERFECT: 10 r > T l, and r / l >= the ratio of every sub-interval.  (Induction over the
+//     sub-intervals: the running maximum of :113-118 is the best ratio among the inserted sub-intervals, and the best
+//     sub-interval is itself inserted.)  So the result is a LOCAL function of the sequence: no state has to be carried.
+//   * Necessary for [s, i] to be perfect (c_j = equal words in front of the j-th last word, inside the interval):
+//       removing the last k words never raises the ratio:   sum_{j<k} 10 c_j > T k   for every k <= l,
+//     and c_j <= ct(i - j), the equal words among the W - 3 words in front of position i - j.
+// One kernel, one wave per chunk, three stages over the chunk and the two 64-base tiles in front of it (words in LDS):
+//   sift     position-parallel: one lane per base of a tile.  ct(i) comes from two 64-entry tables of lane masks in LDS (this
+//            tile, the tile before): every lane ORs its bit into the entry of its word, reads both entries and counts the bits
+//            inside its window — five LDS operations per 64 bases instead of two counter updates per base.
+//            Positions with ct > T / 10 (7 % of random sequence) are compacted, 64 at a time, into
+//              L1: the partial sums above over the last min(lmin, 16) and 16 words (lmin = shortest candidate) -> 1.4 %
+//              L2: an exact walk over the suffixes of up to 16 words (4-bit counters in LDS), or the 16-term sum for the longer
+//                  ones -> 0.07 % of the positions of random sequence: one bit per base.  Any superset of the positions at
+//                  which something is inserted would do.
+//   resolve  the wave steps through the set bits with lane <-> age of the window's words (newest = lane 0), everything in
+//            registers: word, suffix score r, P slot (ratio key | l << 24).  Consecutive positions are one incremental step
+//            (equal-word ballot, mbcnt, three DPP shifts: ~11 vector instructions, ~30 with candidates); after a gap the window
+//            is re-read from LDS and the slots shifted by the gap.  It starts W - 2 steps in front of its chunk with an EMPTY P:
+//            an entry whose start is >= the first step - 2 only ever meets entries that were computed from there on, so it is
+//            exact; entries are recorded by the time they leave the window (start + W), the rule the chunk rows and the stitch
+//            already follow.
+//   walk     A chunk that holds a byte other than A/C/G/T/a/c/g/t within [start - 128, end) is stepped through base by base by
+//            the same wave with the same lane <-> age state, from the warm-up start sd_find_start() gives: the reference's loop
+//            (:139-157) with its flush at a non-base and the window that lives on across it (P slots are keyed by start VALUE:
+//            while a run is shorter than W behind a non-base the window start stands still and the slots do not age).
+#pragma once
+
+struct SiftArgs {
+    const uint8_t *bases;
+    const int64_t *ctg_off;
+    const int32_t *ctg_len;
+    const SdChunk *chunks;
+    int32_t n_chunks;
+    int32_t T, W;
+    uint32_t lds_per_wave;    // bytes of dynamic LDS per wave
+    uint32_t reg_cap;         // positions the word / count buffer holds (multiple of 64): chunk + 128
+    int32_t thr, lmin;        // equal words a last word needs (T / 10 + 1); shortest l with 10 l (l + 1) / 2 > T l, capped at 16
+    int32_t abl;              // development aid (CORNETTO_SIFT_ABL): 1 no resolve, 2 no L1 / L2, 4 no tiles: timing only, results are wrong
+};
+
+#ifndef SIFT_WPB
+#define SIFT_WPB 1               // waves (= chunks) per workgroup; the waves share nothing
+#endif
+constexpr int SIFT_PAD = 16;     // positions in front of the word / count buffer (look-back of L1 / L2 below offset 0)
+constexpr int SIFT_LS = 15;      // L2 walks the suffixes with l <= SIFT_LS
+// fixed part of the LDS of a wave: tables 4 x 64 x u32 | lists 2 x 128 x u16 | counters 8 x 64 x u32; then bits (cap / 8) and the
+// word / count buffer, two bytes per position (word, count)
+constexpr int SIFT_FIXED = 1024 + 512 + 2048;
+__host__ __device__ constexpr uint32_t sift_lds_bytes(uint32_t cap) { return (SIFT_FIXED + cap / 8 + 2 * (SIFT_PAD + cap) + 15) / 16 * 16; }
+
+#define SD_LDS_ORDER()                                                \
+    do {                                                              \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        \
+        __builtin_amdgcn_wave_barrier();                              \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");        \
+    } while (0)
+
+// four bytes -> four codes: bits 0-1 the base (A0 C1 G2 T3), bit 2 set for anything that is not A/C/G/T/a/c/g/t
+__device__ __forceinline__ uint32_t sd_codes4(uint32_t word)
+{
+    const uint32_t y = word & 0xDFDFDFDFu, idx = y & 0x07070707u;                    // fold case; low 3 bits: A1 C3 T4 G7
+    const uint32_t code = __builtin_amdgcn_perm(0x02000003u, 0x01000000u, idx);
+    const uint32_t d = y ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, idx);     // the letter that must be there
+    const uint32_t nz = ((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d;                        // bit 7 of a byte: byte != 0
+    return code | ((nz >> 5) & 0x04040404u);
+}
+// the words that end at the four positions of `cn` (codes), `pcn` = the codes of the four positions before: bits 0-5 the
+// word (:144), bit 6 = not a word (one of its three bases is not a base)
+__device__ __forceinline__ uint32_t sd_words4(uint32_t cn, uint32_t pcn)
+{
+    const uint32_t y1 = __builtin_amdgcn_alignbyte(cn, pcn, 3);      // code of the previous position
+    const uint32_t y2 = __builtin_amdgcn_alignbyte(cn, pcn, 2);      // and of the one before
+    const uint32_t t = (cn & 0x03030303u) | ((y1 & 0x03030303u) << 2) | ((y2 & 0x03030303u) << 4);
+    return t | (((cn | y1 | y2) & 0x04040404u) << 4);
+}
+
+__device__ __forceinline__ int sd_mbcnt64(unsigned long long m)       // set bits of m below this lane
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ int sd_dpp_shr1(int old, int src, bool zero_fill)   // lane l <- lane l - 1; lane 0 <- 0 or `old`
+{
+    return zero_fill ? __builtin_amdgcn_update_dpp(0, src, 0x138, 0xF, 0xF, true) : __builtin_amdgcn_update_dpp(old, src, 0x138, 0xF, 0xF, false);
+}
+
+// ceil(2^32 / l) for l = 2 .. 63: floor(x * 2^13 / l) = umulhi(x << 13, this) for x < 2^11 (sd_ratio_key)
+__device__ const uint32_t sd_recip_tab[64] = {0x0u, 0x0u, 0x80000000u, 0x55555556u, 0x40000000u, 0x33333334u, 0x2AAAAAABu, 0x24924925u, 0x20000000u, 0x1C71C71Du, 0x1999999Au, 0x1745D175u, 0x15555556u, 0x13B13B14u, 0x12492493u, 0x11111112u, 0x10000000u, 0xF0F0F10u, 0xE38E38Fu, 0xD79435Fu, 0xCCCCCCDu, 0xC30C30Du, 0xBA2E8BBu, 0xB21642Du, 0xAAAAAABu, 0xA3D70A4u, 0x9D89D8Au, 0x97B425Fu, 0x924924Au, 0x8D3DCB1u, 0x8888889u, 0x8421085u, 0x8000000u, 0x7C1F07Du, 0x7878788u, 0x7507508u, 0x71C71C8u, 0x6EB3E46u, 0x6BCA1B0u, 0x6906907u, 0x6666667u, 0x63E7064u, 0x6186187u, 0x5F417D1u, 0x5D1745Eu, 0x5B05B06u, 0x590B217u, 0x572620Bu, 0x5555556u, 0x539782Au, 0x51EB852u, 0x5050506u, 0x4EC4EC5u, 0x4D4873Fu, 0x4BDA130u, 0x4A7904Bu, 0x4924925u, 0x47DC120u, 0x469EE59u, 0x456C798u, 0x4444445u, 0x4325C54u, 0x4210843u, 0x4104105u};
+
+template <bool STATS>
+__global__ __launch_bounds__(64 * SIFT_WPB) void sd_sift(SiftArgs A, SdArgs O)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t sift_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = SIFT_WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // (uniform: the chunk table is read with scalar loads)
+    uint8_t *const L = sift_lds + (size_t)wave * A.lds_per_wave;
+    // equal-word tables: [tile parity][half of the wave][word] -> the lanes of that half that hold the word.  32-bit entries, 64 per
+    // table: the entry of word w lies in LDS bank w of every table.
+    uint32_t *const tab = reinterpret_cast<uint32_t *>(L);
+    uint16_t *const tl = reinterpret_cast<uint16_t *>(L + 1024);
+    uint16_t *const tl2 = tl + 128;
+    uint32_t *const cnt = reinterpret_cast<uint32_t *>(L + 1536);
+    uint32_t *const sb = reinterpret_cast<uint32_t *>(L + SIFT_FIXED);
+    const uint32_t cap = A.reg_cap;
+    // wc[2 p] = the word that ends at offset p of the region (bit 6: none), wc[2 p + 1] = ct(p): one address serves both
+    uint8_t *const wc = L + SIFT_FIXED + cap / 8 + 2 * SIFT_PAD;
+    const int T = A.T, W = A.W, CAPW = W - 2;
+
+    // ---- per-lane constants -----------------------------------------------------------------------------------------
+    // sift: which bits of the table entries lie inside the window of lane's position: positions i - (CAPW - 1) .. i - 1; in this
+    // tile: lanes max(0, lane - (CAPW - 1)) .. lane - 1; in the tile before: the rest
+    const int lo = lane - (CAPW - 1);
+    const unsigned long long below = lane ? ~0ull >> (64 - lane) : 0ull;
+    const unsigned long long mc = lo > 0 ? below & (~0ull << lo) : below;
+    const unsigned long long mp = lo < 0 ? ~0ull << (64 + lo) : 0ull;
+    const uint32_t mc_lo = (uint32_t)mc, mc_hi = (uint32_t)(mc >> 32), mp_lo = (uint32_t)mp, mp_hi = (uint32_t)(mp >> 32);
+    const uint32_t mybit = 1u << (lane & 31);
+    uint32_t *const tab_mine = tab + ((lane >> 5) << 6);     // the table of this lane's half (of parity 0)
+    const int thr = A.thr, lmin = A.lmin;             // c > T / 10; the partial sums of L1 have lmin terms
+    const int LS = CAPW - 1 < SIFT_LS ? CAPW - 1 : SIFT_LS;
+    const bool long_ok = CAPW - 1 > LS;               // suffixes longer than the walk exist
+    // stepping stages: lane = l
+    const int Tl = T * lane;
+    const uint32_t m_recip = sd_recip_tab[lane];
+
+    // ---- one chunk per wave (the hardware's workgroup dispatch balances chunks of very different cost: resident waves with
+    // a static stride were measured 10-50 % slower) ---------------------------------------------------------------------
+    struct Meta {
+        SdChunk ch;
+        int len;
+        const uint8_t *seq;
+    };
+    struct Data {
+        uint4 q[2];
+        uint32_t pw[2];
+    };
+    auto meta = [&](int kk) {
+        Meta m;
+        m.ch = A.chunks[kk];
+        m.len = A.ctg_len[m.ch.ctg];
+        m.seq = A.bases + A.ctg_off[m.ch.ctg];
+        return m;
+    };
+    auto fetch = [&](const Meta &m) {
+        Data d;
+        const int rb = m.ch.start - (m.ch.start > 0 ? 128 : 0), rlen = m.ch.end - rb;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int b16 = lane * 16 + it * 1024;
+            d.q[it] = make_uint4(0, 0, 0, 0);
+            d.pw[it] = 0;
+            if (b16 < rlen) {
+                d.q[it] = *reinterpret_cast<const uint4 *>(m.seq + rb + b16);
+                if (rb + b16 > 0) d.pw[it] = *reinterpret_cast<const uint32_t *>(m.seq + rb + b16 - 4);
+            }
+        }
+        return d;
+    };
+    const int k0 = (int)blockIdx.x * SIFT_WPB + wave;
+    if (k0 >= A.n_chunks) return;                     // (whole waves leave: nothing is shared, there are no barriers)
+
+  auto process = [&](const int k, const Meta &M, const Data &D) {
+    const SdChunk ch = M.ch;
+    const int len = M.len;
+    const uint8_t *seq = M.seq;
+    const int halo = ch.start > 0 ? 128 : 0;          // two tiles in front of the chunk: the first only feeds the "tile before" table
+    const int rb = ch.start - halo;                   // region = [rb, ch.end), rb a multiple of 64
+    const int rlen = ch.end - rb;
+    const int ntile = (rlen + 63) >> 6;
+    const bool islast = ch.end == len;
+    const int rec_from = ch.start;
+
+    // ---- stage the words of the region --------------------------------------------------------------------------------
+    tab[lane] = 0;
+    tab[64 + lane] = 0;
+    tab[128 + lane] = 0;
+    tab[192 + lane] = 0;
+    for (int i = lane; i < (int)(cap >> 5); i += 64) sb[i] = 0;
+    if (lane < SIFT_PAD) reinterpret_cast<uint16_t *>(wc)[lane - SIFT_PAD] = halo ? 0xFF40 : 0x0040;   // no word; count unknown (large) / none
+    bool bad = false;
+    for (int b16 = lane * 16, it = 0; b16 < rlen; b16 += 1024, ++it) {
+        const int p0 = rb + b16;
+        uint4 q;
+        uint32_t pw;
+        if (it < 2) {
+            q = D.q[it];
+            pw = D.pw[it];
+        } else {                                      // (regions beyond 2 KB: chunk sizes chosen by hand)
+            q = *reinterpret_cast<const uint4 *>(seq + p0);
+            pw = *reinterpret_cast<const uint32_t *>(seq + p0 - 4);
+        }
+        uint32_t pcn = 0x04040404u;
+        if (p0 > 0) pcn = sd_codes4(pw);
+        const uint32_t in[4] = {q.x, q.y, q.z, q.w};
+        uint32_t wo[8];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t cn = sd_codes4(in[d]);
+            if (p0 + 4 * d + 4 > len) {               // (the contig's last dwords only)
+                const int rem = len - (p0 + 4 * d);   // bytes of this dword inside the contig
+                const uint32_t beyond = rem <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * rem);
+                bad = bad || (cn & 0x04040404u & ~beyond) != 0u;
+                cn |= 0x04040404u & beyond;
+            } else {
+                bad = bad || (cn & 0x04040404u) != 0u;
+            }
+            const uint32_t w4 = sd_words4(cn, pcn);
+            wo[2 * d] = __builtin_amdgcn_perm(0u, w4, 0x0C010C00u);         // bytes 0, 1 -> halfwords
+            wo[2 * d + 1] = __builtin_amdgcn_perm(0u, w4, 0x0C030C02u);     // bytes 2, 3
+            pcn = cn;
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(wc + 2 * b16);
+        dst[0] = make_uint4(wo[0], wo[1], wo[2], wo[3]);
+        dst[1] = make_uint4(wo[4], wo[5], wo[6], wo[7]);
+    }
+    const bool unclean = sd_any(bad);
+    SD_LDS_ORDER();
+
+    // ---- state of the stepping stages (resolve, walk): lane <-> age of the window's words -----------------------------
+    int w = 0, r = 0, slot = 0;                       // the word that entered `lane` steps ago, the score of the suffix that starts there, its P slot
+    int sv0 = 0;                                      // start value (:121) of lane 0's slot: lane a holds the entry that starts at sv0 - a
+    unsigned st_steps = 0, st_jumps = 0, st_cand = 0, st_trig = 0, st_l1 = 0, st_l2 = 0, st_walk = 0;
+    // the chunk's own list (:93-99); everything here is wave-uniform
+    bool have_last = false;
+    uint32_t last_s = 0, last_f = 0, n_out = 0;
+    uint2 *const out = O.out + (size_t)k * O.cap;
+    auto emit = [&](int ps, int pf, int tm) {
+        if (tm < rec_from) return;
+        if (have_last && ps <= (int)last_f) {
+            if (pf > (int)last_f) last_f = (uint32_t)pf;
+        } else {
+            if (have_last) {
+                if (n_out < O.cap && lane == 0) out[n_out] = make_uint2(last_s, last_f);
+                ++n_out;
+            }
+            have_last = true;
+            last_s = (uint32_t)ps;
+            last_f = (uint32_t)pf;
+        }
+    };
+    // every slot among lanes [from, CAPW), smallest start first, saved at time tm (:88-102 called with growing starts, :153)
+    auto emit_slots = [&](int from, int tm) {
+        unsigned long long em = sd_ballot(slot != 0 && lane >= from && lane < CAPW);
+        while (em) {
+            const int a = 63 - __builtin_clzll(em);
+            em &= ~(1ull << a);
+            const uint32_t so = (uint32_t)rdlane(slot, a);
+            const int s = sv0 - a;
+            emit(s, s + (int)(so >> 24) + 3, tm);
+        }
+    };
+    // a word enters: the others age by one (those beyond amax leave); the slots age with them unless the window start stands still
+    auto push_word = [&](int tw, int amax, bool age_slots) {
+        const unsigned long long e = sd_ballot(w == tw && lane < amax);      // old ages 0 .. amax - 1 stay in the window
+        r = sd_dpp_shr1(0, r, true) + sd_mbcnt64(e);                          // + equal words younger than the new age
+        w = sd_dpp_shr1(tw, w, false);
+        if (age_slots) slot = sd_dpp_shr1(0, slot, true);
+    };
+    // find_perfect (:104-128) over every suffix: lane = l; the running maximum of :113-118 is a scan of exact ratio keys
+    auto pass = [&](int amax) {
+        const bool cand = lane >= 1 && lane <= amax && __mul24(r, 10) > Tl;
+        if (sd_any(cand)) {
+            if (STATS) ++st_cand;
+            uint32_t key_c = 0u;
+            if (cand) key_c = lane == 1 ? ((uint32_t)r & 0x7FFu) << 13 : __umulhi(((uint32_t)r & 0x7FFu) << 13, m_recip);
+            const uint32_t key_e = (uint32_t)slot & 0xFFFFFFu;
+            const uint32_t xs = wave_scan_max(key_e > key_c ? key_e : key_c);
+            const uint32_t sk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)xs, 0x138, 0xF, 0xF, true);
+            const uint32_t km = sk > key_e ? sk : key_e;           // :113-117: entries with start >= this one
+            if (cand && key_c >= km) slot = (int)(key_c | ((uint32_t)lane << 24));   // :118
+        }
+    };
+    auto finish = [&]() {
+        if (have_last) {
+            if (n_out < O.cap && lane == 0) out[n_out] = make_uint2(last_s, last_f);
+            ++n_out;
+        }
+        if (lane == 0) {
+            O.out_n[k] = n_out;
+            if (n_out > O.cap) atomicMax(O.ovf, n_out);
+            if (STATS && O.stats) {
+                atomicAdd(&O.stats[0], (unsigned long long)st_steps);
+                atomicAdd(&O.stats[1], (unsigned long long)st_jumps);
+                atomicAdd(&O.stats[2], (unsigned long long)st_cand);
+                atomicAdd(&O.stats[3], (unsigned long long)st_trig);
+                atomicAdd(&O.stats[4], (unsigned long long)st_l1);
+                atomicAdd(&O.stats[5], (unsigned long long)st_l2);
+                atomicAdd(&O.stats[6], (unsigned long long)ntile);
+                atomicAdd(&O.stats[7], (unsigned long long)st_walk);
+            }
+        }
+    };
+
+    if (unclean) {
+        // ---- walk: the reference's loop (:139-157), one base per step, from the warm-up start --------------------------
+        const int u = __builtin_amdgcn_readfirstlane(sd_find_start(O, ch, seq));
+        if (u < 0) return;                            // (the word-count table is needed: the host builds it and runs again)
+        const int stop = islast ? len + 1 : ch.end;   // the contig's last chunk also takes the sentinel step i == len
+        int l = 0, size = 0, cv = 4, ctile = -1;
+        unsigned t = 0;
+        for (int i = u; i < stop; ++i) {
+            if ((i >> 6) != ctile) {
+                ctile = i >> 6;
+                const int p = ctile * 64 + lane;
+                cv = p < len ? nt4_code(seq[p]) : 4;
+            }
+            const int b = rdlane(cv, i & 63);
+            if (STATS) ++st_walk;
+            if (b < 4) {
+                ++l;
+                t = (t << 2 | (unsigned)b) & 63u;                            // :144
+                if (l >= 3) {
+                    const int start = (l - W > 0 ? l - W : 0) + (i + 1 - l);  // :146
+                    const bool full = size >= CAPW;
+                    // the window start moves on only in a run longer than W; then the oldest start leaves (:147).  While it stands
+                    // still behind a non-base nothing leaves, and the entries keep their lanes: they are keyed by start VALUE
+                    const bool moves = l > W;
+                    if (full && moves) {
+                        const uint32_t so = (uint32_t)rdlane(slot, CAPW - 1);
+                        if (so) {
+                            const int s = sv0 - (CAPW - 1);
+                            emit(s, s + (int)(so >> 24) + 3, i);
+                        }
+                    }
+                    size = full ? CAPW : size + 1;
+                    push_word((int)t, size - 1, !full || moves);                // shift_window (:66-86)
+                    sv0 = start + size - 1;
+                    pass(size - 1);
+                }
+            } else {
+                emit_slots(0, i);                                               // :152-153
+                slot = 0;
+                l = 0;
+                t = 0;                                                          // :154 — the window lives on
+            }
+        }
+        finish();
+        return;
+    }
+
+    int ntl = 0, ntl2 = 0;                            // (uniform) entries in the two lists
+    // L2: the 16-term sums (every candidate of more than 16 words needs them positive), the exact walk over the shorter suffixes
+    auto run_l2 = [&](int nb) {
+        const bool on = lane < nb;
+        const int o = on ? (int)tl2[lane] : 0;
+        const uint8_t *const p = wc + 2 * o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cnt[j * 64 + lane] = 0;
+        int d = 0, dmin = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            d += 10 * (int)p[1 - 2 * j] - T;
+            dmin = d < dmin ? d : dmin;
+        }
+        SD_LDS_ORDER();
+        int rr = 0;
+        bool alive = on, sc = false;
+        for (int a = 0; a <= LS; ++a) {
+            const uint32_t wv = p[-2 * a];
+            alive = alive && wv < 64u;
+            const uint32_t sh = (wv & 7u) << 2;
+            const uint32_t old = __hip_atomic_fetch_add(&cnt[((wv >> 3) & 7u) * 64 + lane], alive ? 1u << sh : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            rr += alive ? (int)((old >> sh) & 15u) : 0;
+            sc = sc || (alive && a >= 1 && rr * 10 > T * a);
+        }
+        const bool keep = on && (sc || (dmin > 0 && long_ok));
+        if (STATS) st_l2 += (unsigned)__popcll(sd_ballot(keep));
+        if (keep) (void)__hip_atomic_fetch_or(&sb[o >> 5], 1u << (o & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // L1: the partial sums of 10 ct - T over the last k words must be positive for k = 1 .. lmin (every candidate has more words)
+    auto run_l1 = [&](int nb) {
+        const bool on = lane < nb;
+        const int o = on ? (int)tl[lane] : 0;
+        const uint8_t *const p = wc + 2 * o;
+        int d = 0, dmin = 0x7fffffff;
+        for (int j = 0; j < lmin; ++j) {
+            d += 10 * (int)p[1 - 2 * j] - T;
+            dmin = d < dmin ? d : dmin;
+        }
+        const bool ok = on && dmin > 0;
+        const unsigned long long m = sd_ballot(ok);
+        if (m) {
+            if (STATS) st_l1 += (unsigned)__popcll(m);
+            if (ok) tl2[ntl2 + sd_mbcnt64(m)] = (uint16_t)o;
+            ntl2 += __popcll(m);
+            SD_LDS_ORDER();
+            if (ntl2 >= 64) {
+                run_l2(64);
+                const uint16_t mv = tl2[64 + lane];
+                SD_LDS_ORDER();
+                tl2[lane] = mv;
+                ntl2 -= 64;
+                SD_LDS_ORDER();
+            }
+        }
+    };
+
+    // ---- the tiles ---------------------------------------------------------------------------------------------------
+    // PAR: parity of the tile (which pair of tables is "this tile").  GENERAL: lanes without a word (the first two positions of
+    // a contig, behind its end) stay out of the tables.  TABLE_ONLY: the first tile in front of a chunk.
+    uint8_t *pq = wc + 2 * lane;                      // this lane's position in the current tile
+    auto tile = [&](auto par_c, auto general_c, auto only_c, const int q) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_c)::value;
+        constexpr bool GENERAL = decltype(general_c)::value, TABLE_ONLY = decltype(only_c)::value;
+        constexpr int CUR = PAR * 128, PREV = (PAR ^ 1) * 128;
+        const uint32_t wv = pq[0];
+        const bool valid = !GENERAL || (wv < 64u && q * 64 + lane < rlen);
+        const uint32_t wi = GENERAL ? wv & 63u : wv;
+        if (valid) (void)__hip_atomic_fetch_or(&tab_mine[CUR + wi], mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        SD_LDS_ORDER();
+        const uint32_t ec_lo = tab[CUR + wi], ec_hi = tab[CUR + 64 + wi], ep_lo = tab[PREV + wi], ep_hi = tab[PREV + 64 + wi];
+        SD_LDS_ORDER();
+        tab[PREV + lane] = 0;                          // the tables of the tile before become the tables of the next tile
+        tab[PREV + 64 + lane] = 0;
+        const int ct = __popc(ec_lo & mc_lo) + __popc(ec_hi & mc_hi) + __popc(ep_lo & mp_lo) + __popc(ep_hi & mp_hi);
+        pq[1] = (uint8_t)(TABLE_ONLY ? 255 : (valid ? ct : 0));      // (no word there: nothing to count)
+        pq += 128;
+        if (!TABLE_ONLY) {
+            const bool trig = valid && ct >= thr;
+            const unsigned long long m = sd_ballot(trig);
+            if (m) {
+                if (STATS) st_trig += (unsigned)__popcll(m);
+                if (trig) tl[ntl + sd_mbcnt64(m)] = (uint16_t)(q * 64 + lane);
+                ntl += __popcll(m);
+                SD_LDS_ORDER();
+                if (ntl >= 64) {
+                    if (!(A.abl & 2)) run_l1(64);
+                    const uint16_t mv = tl[64 + lane];
+                    SD_LDS_ORDER();
+                    tl[lane] = mv;
+                    ntl -= 64;
+                    SD_LDS_ORDER();
+                }
+            }
+        }
+    };
+    if (!(A.abl & 4)) {
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        int q = 0;
+        if (halo) tile(P0{}, std::false_type{}, std::true_type{}, q++);        // (a halo lies inside the contig: every lane has a word)
+        else tile(P0{}, std::true_type{}, std::false_type{}, q++);
+        // pairs of whole tiles, then what is left: at most one whole tile and the contig's last, partial one
+        for (; q + 1 < ntile - 1; q += 2) {
+            tile(P1{}, std::false_type{}, std::false_type{}, q);
+            tile(P0{}, std::false_type{}, std::false_type{}, q + 1);
+        }
+        if (q < ntile - 1) { tile(P1{}, std::false_type{}, std::false_type{}, q); ++q; }
+        if (q < ntile) {
+            if (q & 1) tile(P1{}, std::true_type{}, std::false_type{}, q);
+            else tile(P0{}, std::true_type{}, std::false_type{}, q);
+        }
+    }
+    SD_LDS_ORDER();
+    if (ntl > 0 && !(A.abl & 2)) run_l1(ntl);
+    if (ntl2 > 0) run_l2(ntl2);
+    if (A.abl & 1) { finish(); return; }
+    SD_LDS_ORDER();
+
+    // ---- resolve: the set bits in order ---------------------------------------------------------------------------------
+    unsigned long long sw = 0;
+    if (lane < ntile) sw = (unsigned long long)sb[2 * lane] | (unsigned long long)sb[2 * lane + 1] << 32;
+    // steps in front of start - W + 2 (of 2 at a contig start) are not taken: offsets below 128 - W + 2 (2)
+    if (halo) {
+        if (lane == 0) sw = 0;
+        if (lane == 1) sw &= ~0ull << (66 - W);
+    } else if (lane == 0) {
+        sw &= ~3ull;
+    }
+    tab[lane] = 0;                                    // (the equal-word table of the window reads: the first pair)
+    tab[64 + lane] = 0;
+    SD_LDS_ORDER();
+
+    int cur = 0;                                      // (a position of the contig)
+    bool have = false;
+    int wt = 0, wt_tile = -1;                         // words of tile wt_tile of the region, lane <-> position
+    for (int t = 0; t < ntile; ++t) {
+        unsigned long long m = rdlane64(sw, t);
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            const int o = 64 * t + b;                 // offset in the region
+            const int i = rb + o;
+            const int amax = i - 2 < CAPW - 1 ? i - 2 : CAPW - 1;
+            if (have && i - cur == 1) {
+                if (STATS) ++st_steps;
+                // ---- one step: the oldest start leaves the window (:147), the words age by one, the new word comes in
+                const uint32_t so = (uint32_t)rdlane(slot, CAPW - 1);
+                if (so) {
+                    const int s = sv0 - (CAPW - 1);
+                    emit(s, s + (int)(so >> 24) + 3, s + W);
+                }
+                if (t != wt_tile) {
+                    wt_tile = t;
+                    wt = wc[2 * (t * 64 + lane)];
+                }
+                push_word(rdlane(wt, b), amax, true);
+            } else {
+                if (STATS) ++st_jumps;
+                if (have) {
+                    // ---- a gap: the starts that leave the window meanwhile, oldest first; the others age by the gap
+                    const int g = i - cur;
+                    // (a start s leaves at time s + W)
+                    unsigned long long em = sd_ballot(slot != 0 && lane >= (CAPW - g > 0 ? CAPW - g : 0) && lane < CAPW);
+                    while (em) {
+                        const int a = 63 - __builtin_clzll(em);
+                        em &= ~(1ull << a);
+                        const uint32_t so = (uint32_t)rdlane(slot, a);
+                        const int s = sv0 - a;
+                        emit(s, s + (int)(so >> 24) + 3, s + W);
+                    }
+                    const int moved = __builtin_amdgcn_ds_bpermute(((lane - g) & 63) << 2, slot);
+                    slot = (g < CAPW && lane >= g) ? moved : 0;
+                } else {
+                    slot = 0;
+                }
+                // ---- the window at i, read from the staged words; equal words at younger ages through the LDS table
+                const bool ok = lane <= amax;
+                w = ok ? (int)wc[2 * (o - lane)] : 0;
+                if (ok) (void)__hip_atomic_fetch_or(&tab_mine[w], mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                SD_LDS_ORDER();
+                const unsigned long long e = (unsigned long long)tab[w] | (unsigned long long)tab[64 + w] << 32;
+                SD_LDS_ORDER();
+                if (ok) tab_mine[w] = 0;
+                SD_LDS_ORDER();
+                r = wave_scan_add(ok ? sd_mbcnt64(e) : 0);
+            }
+            cur = i;
+            sv0 = i - 2;
+            have = true;
+            pass(amax);
+        }
+    }
+    // ---- the end of the chunk: what has left the window by then; the end of the contig flushes everything (:152-153)
+    if (have) {
+        if (islast) {
+            // (a start that would have left before the contig's end was saved then; the others at the sentinel step)
+            unsigned long long em = sd_ballot(slot != 0 && lane < CAPW);
+            while (em) {
+                const int a = 63 - __builtin_clzll(em);
+                em &= ~(1ull << a);
+                const uint32_t so = (uint32_t)rdlane(slot, a);
+                const int s = sv0 - a, tm = s + W;
+                emit(s, s + (int)(so >> 24) + 3, tm < len ? tm : len);
+            }
+        } else {
+            const int g = ch.end - 1 - cur;            // as if the walk went on to the chunk's last step
+            unsigned long long em = sd_ballot(slot != 0 && lane >= (CAPW - g > 0 ? CAPW - g : 0) && lane < CAPW);
+            while (em) {
+                const int a = 63 - __builtin_clzll(em);
+                em &= ~(1ull << a);
+                const uint32_t so = (uint32_t)rdlane(slot, a);
+                const int s = sv0 - a;
+                emit(s, s + (int)(so >> 24) + 3, s + W);
+            }
+        }
+    }
+    finish();
+  };
+
+    const Meta m0 = meta(k0);
+    process(k0, m0, fetch(m0));
+}

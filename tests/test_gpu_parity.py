@@ -119,7 +119,7 @@ SDUST_CASES = [
 
 
 @pytest.mark.parametrize("dense", ["2", "0"])
-@pytest.mark.parametrize("chunk", ["0", "16", "100", "1000", "4096"])
+@pytest.mark.parametrize("chunk", ["0", "16", "100", "256", "1000", "2048", "4096"])
 @pytest.mark.parametrize("fa,T,W,exp", SDUST_CASES)
 def test_sdust_golden(acc, golden_dir, monkeypatch, fa, T, W, exp, chunk, dense):
     """chunk = bases per lane (0 = default heuristic); tiny chunks stress the speculative warm-up.  dense = 2: the chunks
@@ -296,6 +296,75 @@ def test_sdust_random_thresholds_vs_oracle(acc, monkeypatch, seed):
             r = int(r)
             exp.append((ci, r >> 32, r & 0xFFFFFFFF))
     assert got == exp, (T, W)
+
+
+def _sift_stress_seq(rng, n, kind):
+    """n bases for the sift / resolve stages: random sequence with tandem repeats of every period, satellite arrays (exact and
+    with substitutions), homopolymers, and — kind 1 — N runs, lower case and bytes that are not letters, which send the chunks
+    around them to the sequential kernel"""
+    s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].copy()
+    for _ in range(n // 1500):
+        p = int(rng.integers(0, n))
+        u = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(rng.integers(1, 8)))]
+        L = int(rng.integers(8, 400 if rng.random() < 0.3 else 60))
+        rep = np.tile(u, L // len(u) + 1)[:L].copy()
+        sub = rng.random(L) < 0.02
+        rep[sub] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(sub.sum()))]
+        s[p:p + L] = rep[:len(s[p:p + L])]
+    if n > 20000:
+        p, L = n // 3, n // 6
+        arr = np.tile(np.frombuffer(b"CATTC", dtype=np.uint8), L // 5 + 1)[:L].copy()
+        sub = rng.random(L) < 0.02
+        arr[sub] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(sub.sum()))]
+        s[p:p + L] = arr
+        s[n - 3000:n - 1000] = np.tile(np.frombuffer(b"GGAAT", dtype=np.uint8), 400)      # exact, up to near the end
+    if kind == 1 and n >= 3:
+        for _ in range(max(1, n // 20000)):
+            p = int(rng.integers(0, n))
+            L = int(rng.integers(1, 300))
+            s[p:p + L] = ord("N")
+        for _ in range(max(1, n // 30000)):
+            p = int(rng.integers(0, n))
+            s[p:p + int(rng.integers(1, 200))] |= 0x20
+        for _ in range(max(1, n // 50000)):
+            s[int(rng.integers(0, n))] = int(rng.choice(np.frombuffer(b"RYKM-*\x01\x03", dtype=np.uint8)))
+    return s
+
+
+@pytest.mark.parametrize("T,W,chunk,kind", [
+    (20, 64, "0", 0), (20, 64, "0", 1), (20, 64, "256", 0), (20, 64, "256", 1), (20, 64, "320", 1), (20, 64, "1024", 1),
+    (20, 64, "3968", 1), (10, 32, "256", 1), (10, 32, "0", 0), (5, 64, "512", 1), (30, 16, "256", 1), (25, 66, "448", 1),
+    (7, 20, "256", 0), (50, 50, "1792", 1), (100, 64, "0", 1), (12, 3, "256", 1), (20, 4, "256", 1), (20, 65, "640", 1)])
+def test_sdust_sift_vs_oracle(acc, monkeypatch, T, W, chunk, kind):
+    """the sift / resolve stages (sdust_sift.hpp) on sequences of many chunks: chunk borders inside repeat arrays, contigs that
+    end inside an array, contigs shorter than a tile, chunks handed to the sequential kernel beside chunks that are not"""
+    monkeypatch.setenv("CORNETTO_SDUST_CHUNK", chunk)
+    rng = np.random.default_rng(4242 + T * 131 + W + int(chunk) + kind)
+    seqs = [_sift_stress_seq(rng, n, kind) for n in (150_000, 70_001, 4097, 1792, 1793, 257, 256, 255, 130, 65, 64, 63, 5, 3, 2, 1, 0, 30_000)]
+    seqs.append(np.tile(np.frombuffer(b"A", dtype=np.uint8), 5000))
+    seqs.append(np.tile(np.frombuffer(b"AC", dtype=np.uint8), 2500))
+    asm = acc.asm_upload(seqs)
+    iv = acc.sdust(asm, T, W)
+    asm.close()
+    got = [(int(x["ctg"]), int(x["start"]), int(x["finish"])) for x in iv]
+    exp = []
+    for ci, q in enumerate(seqs):
+        for r in ob.sdust(q, T, W):
+            r = int(r)
+            exp.append((ci, r >> 32, r & 0xFFFFFFFF))
+    assert got == exp, (T, W, chunk)
+
+
+def test_sdust_sift_off_equals_on(acc, monkeypatch):
+    """CORNETTO_SDUST_SIFT=0 (the per-lane recurrence of sdust_w64 for every chunk) and the default give the same intervals"""
+    rng = np.random.default_rng(77)
+    seqs = [_sift_stress_seq(rng, 400_000, 1), _sift_stress_seq(rng, 90_000, 0)]
+    asm = acc.asm_upload(seqs)
+    on = acc.sdust(asm, 20, 64)
+    monkeypatch.setenv("CORNETTO_SDUST_SIFT", "0")
+    off = acc.sdust(asm, 20, 64)
+    asm.close()
+    assert len(on) > 200 and np.array_equal(on, off)
 
 
 def test_sdust_largest_window_on_homopolymers(acc):
@@ -618,6 +687,6 @@ def test_timing_levels(acc):
         acc.set_timing(2)
         asm.close()
     assert np.array_equal(ref, one) and np.array_equal(ref, zero)
-    assert names0 == set() and names1 == {"sdust_kernel"} and "sdust_prep" in names2 and "sdust_kernel" in names2
+    assert names0 == set() and names1 == {"sdust_kernel"} and "sdust_scan" in names2 and "sdust_kernel" in names2
     with pytest.raises(Exception):
         acc.set_timing(3)

@@ -1638,6 +1638,9 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
     // per-lane recurrence of sdust_w64 for everything (also what an explicit chunk size outside that range does: the tests
     // with tiny chunks stress exactly that kernel).
     bool sift_on = w64_path && env_int("CORNETTO_SDUST_SIFT", 1) != 0;
+    // (its own default: 1536 bases = 26 tiles with the two in front; 7.2 KB of LDS per wave = six 1280-byte granules, 21 waves per
+    // CU; 1792 needs a seventh granule: measured 6.85 against 7.2 ms on the 3.16 Gbp assembly)
+    if (sift_on && env_int("CORNETTO_SDUST_CHUNK", 0) <= 0) chunk = 1536;
     if (sift_on && (chunk % 64 != 0 || chunk < 256 || chunk > 3968)) sift_on = false;     // (64 tiles with the two in front)
     // Optionally the last part of the work is cut into shorter chunks, handed out last and in one pass: when the queue runs
     // dry every wave still has to finish the chunks its lanes hold, and a wave-step costs the same with 3 busy lanes as with

@@ -96,6 +96,21 @@ __device__ __forceinline__ int sd_dpp_shr1(int old, int src, bool zero_fill)   /
 // ceil(2^32 / l) for l = 2 .. 63: floor(x * 2^13 / l) = umulhi(x << 13, this) for x < 2^11 (sd_ratio_key)
 __device__ const uint32_t sd_recip_tab[64] = {0x0u, 0x0u, 0x80000000u, 0x55555556u, 0x40000000u, 0x33333334u, 0x2AAAAAABu, 0x24924925u, 0x20000000u, 0x1C71C71Du, 0x1999999Au, 0x1745D175u, 0x15555556u, 0x13B13B14u, 0x12492493u, 0x11111112u, 0x10000000u, 0xF0F0F10u, 0xE38E38Fu, 0xD79435Fu, 0xCCCCCCDu, 0xC30C30Du, 0xBA2E8BBu, 0xB21642Du, 0xAAAAAABu, 0xA3D70A4u, 0x9D89D8Au, 0x97B425Fu, 0x924924Au, 0x8D3DCB1u, 0x8888889u, 0x8421085u, 0x8000000u, 0x7C1F07Du, 0x7878788u, 0x7507508u, 0x71C71C8u, 0x6EB3E46u, 0x6BCA1B0u, 0x6906907u, 0x6666667u, 0x63E7064u, 0x6186187u, 0x5F417D1u, 0x5D1745Eu, 0x5B05B06u, 0x590B217u, 0x572620Bu, 0x5555556u, 0x539782Au, 0x51EB852u, 0x5050506u, 0x4EC4EC5u, 0x4D4873Fu, 0x4BDA130u, 0x4A7904Bu, 0x4924925u, 0x47DC120u, 0x469EE59u, 0x456C798u, 0x4444445u, 0x4325C54u, 0x4210843u, 0x4104105u};
 
+// inclusive running maximum over the lanes, one v_max_u32 with a DPP source per step (lanes without a source in their row keep
+// their value: bound_ctrl off); the s_nop are the two wait states a DPP read of a just-written register needs
+__device__ __forceinline__ uint32_t sd_scan_max_dpp(uint32_t x)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(x));
+    return x;
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(64 * SIFT_WPB) void sd_sift(SiftArgs A, SdArgs O)
 {
@@ -260,20 +275,22 @@ __global__ __launch_bounds__(64 * SIFT_WPB) void sd_sift(SiftArgs A, SdArgs O)
     };
     // a word enters: the others age by one (those beyond amax leave); the slots age with them unless the window start stands still
     auto push_word = [&](int tw, int amax, bool age_slots) {
-        const unsigned long long e = sd_ballot(w == tw && lane < amax);      // old ages 0 .. amax - 1 stay in the window
+        const unsigned long long e = sd_ballot(w == tw) & ~(~1ull << (amax - 1 < 0 ? 0 : amax - 1)) & (amax > 0 ? ~0ull : 0ull);   // old ages 0 .. amax - 1 stay in the window
         r = sd_dpp_shr1(0, r, true) + sd_mbcnt64(e);                          // + equal words younger than the new age
         w = sd_dpp_shr1(tw, w, false);
         if (age_slots) slot = sd_dpp_shr1(0, slot, true);
     };
     // find_perfect (:104-128) over every suffix: lane = l; the running maximum of :113-118 is a scan of exact ratio keys
     auto pass = [&](int amax) {
-        const bool cand = lane >= 1 && lane <= amax && __mul24(r, 10) > Tl;
-        if (sd_any(cand)) {
+        // (lanes 1 .. amax: a scalar mask)
+        const unsigned long long cm = sd_ballot(__mul24(r, 10) > Tl) & ~(~1ull << amax) & ~1ull;
+        if (cm) {
+            const bool cand = (cm >> lane) & 1ull;
             if (STATS) ++st_cand;
             uint32_t key_c = 0u;
             if (cand) key_c = lane == 1 ? ((uint32_t)r & 0x7FFu) << 13 : __umulhi(((uint32_t)r & 0x7FFu) << 13, m_recip);
             const uint32_t key_e = (uint32_t)slot & 0xFFFFFFu;
-            const uint32_t xs = wave_scan_max(key_e > key_c ? key_e : key_c);
+            const uint32_t xs = sd_scan_max_dpp(key_e > key_c ? key_e : key_c);
             const uint32_t sk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)xs, 0x138, 0xF, 0xF, true);
             const uint32_t km = sk > key_e ? sk : key_e;           // :113-117: entries with start >= this one
             if (cand && key_c >= km) slot = (int)(key_c | ((uint32_t)lane << 24));   // :118

@@ -504,24 +504,37 @@ __global__ __launch_bounds__(64 * SIFT_WPB) void sd_sift(SiftArgs A, SdArgs O)
         unsigned long long m = rdlane64(sw, t);
         while (m) {
             const int b = __builtin_ctzll(m);
-            m &= m - 1;
             const int o = 64 * t + b;                 // offset in the region
             const int i = rb + o;
-            const int amax = i - 2 < CAPW - 1 ? i - 2 : CAPW - 1;
             if (have && i - cur == 1) {
-                if (STATS) ++st_steps;
-                // ---- one step: the oldest start leaves the window (:147), the words age by one, the new word comes in
-                const uint32_t so = (uint32_t)rdlane(slot, CAPW - 1);
-                if (so) {
-                    const int s = sv0 - (CAPW - 1);
-                    emit(s, s + (int)(so >> 24) + 3, s + W);
-                }
+                // ---- a run of consecutive positions (inside a repeat array: every position): one step each — the oldest start
+                // leaves the window (:147), the words age by one, the new word comes in
+                const unsigned long long inv = ~(m >> b);
+                const int run = inv ? __builtin_ctzll(inv) : 64 - b;          // set bits from b on
+                m &= run + b >= 64 ? ~(~0ull << b) : ~(~(~0ull << run) << b);
                 if (t != wt_tile) {
                     wt_tile = t;
                     wt = wc[2 * (t * 64 + lane)];
                 }
-                push_word(rdlane(wt, b), amax, true);
-            } else {
+                for (int j = 0; j < run; ++j) {
+                    if (STATS) ++st_steps;
+                    const int ii = i + j;
+                    const int amax = ii - 2 < CAPW - 1 ? ii - 2 : CAPW - 1;
+                    const uint32_t so = (uint32_t)rdlane(slot, CAPW - 1);
+                    if (so) {
+                        const int s = sv0 - (CAPW - 1);
+                        emit(s, s + (int)(so >> 24) + 3, s + W);
+                    }
+                    push_word(rdlane(wt, b + j), amax, true);
+                    sv0 = ii - 2;
+                    pass(amax);
+                }
+                cur = i + run - 1;
+                continue;
+            }
+            m &= m - 1;
+            const int amax = i - 2 < CAPW - 1 ? i - 2 : CAPW - 1;
+            {
                 if (STATS) ++st_jumps;
                 if (have) {
                     // ---- a gap: the starts that leave the window meanwhile, oldest first; the others age by the gap

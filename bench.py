@@ -37,7 +37,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
+SQ_FILE = os.path.join("profiles", "r03_sq_sd_sift.json")
 
 
 def contig_lengths(total_target):
@@ -482,39 +483,51 @@ class Rank:
         self.worker.start()
 
     # ---- workload --------------------------------------------------------------------------------------
-    def load(self, profile):
+    def load(self, profile, scaling=None):
         """generate the rank's inputs in HBM and wrap the contigs this rank owns"""
         args, torch = self.args, self.torch
+        self.scaling = scaling or args.scaling
         self.lens = contig_lengths(int(args.gbases * 1e9) if args.gbases > 0 else 0)
         nctg = len(self.lens)
-        if args.scaling == "strong":
+        if self.scaling == "strong":
             from cornetto_amd.dist import lpt_partition
             asm_index = args.assembly_index
-            self.own = lpt_partition(self.lens, self.world)[self.rank]       # ascending global contig indices
-            self.gl_ctg = np.array(self.own, dtype=np.int64)
+            own = lpt_partition(self.lens, self.world)[self.rank]            # ascending global contig indices
             self.job_bases = int(sum(self.lens))
+            self.gl_of = lambda own_: np.array(own_, dtype=np.int64)
         else:
             asm_index = args.assembly_index + self.rank
-            self.own = list(range(nctg))
-            self.gl_ctg = np.arange(nctg, dtype=np.int64) + self.rank * nctg   # global contig ids: assembly-major
+            own = list(range(nctg))
             self.job_bases = int(sum(self.lens)) * self.world
+            self.gl_of = lambda own_: np.array(own_, dtype=np.int64) + self.rank * nctg   # global contig ids: assembly-major
         seed = 0xC0FFEE + asm_index
         self.bases, self.offs = make_assembly(torch, self.dev, self.lens, seed, profile)
         self.depth, self.mq = make_coverage(torch, self.dev, self.lens, self.offs, seed)
         torch.cuda.synchronize()
-        own = self.own
-        self.lens_own = [self.lens[i] for i in own]
+        self.profile = profile
+        self.asm = self.asm2 = self.cov = None
+        self.wrap(own)
+
+    def wrap(self, own):
+        """(re-)wrap a subset of the resident contigs: what this process scans in a step"""
+        self.unwrap()
+        self.own = list(own)
+        self.gl_ctg = self.gl_of(self.own)
+        self.lens_own = [self.lens[i] for i in self.own]
         self.my_bases = int(sum(self.lens_own))
-        o = self.offs[own] if len(own) else np.zeros(0, np.int64)
+        o = self.offs[self.own] if len(self.own) else np.zeros(0, np.int64)
         self.asm = self.acc.asm_wrap(self.bases.data_ptr(), o, np.array(self.lens_own, dtype=np.int64))
         self.asm2 = self.acc2.asm_wrap(self.bases.data_ptr(), o, np.array(self.lens_own, dtype=np.int64))
         self.cov = self.acc.cov_wrap(self.depth.data_ptr(), self.mq.data_ptr(), o, np.array(self.lens_own, dtype=np.int32))
-        self.profile = profile
+
+    def unwrap(self):
+        for x in ("asm", "asm2", "cov"):
+            if getattr(self, x, None) is not None:
+                getattr(self, x).close()
+                setattr(self, x, None)
 
     def unload(self):
-        self.asm.close()
-        self.asm2.close()
-        self.cov.close()
+        self.unwrap()
         del self.bases, self.depth, self.mq
         self.torch.cuda.empty_cache()
 
@@ -561,7 +574,7 @@ class Rank:
             self._note(acc)
         # the one real exchange: the assembly-wide mean depth behind the thresholds (boringbits_main.c:293-294 -> :518-519).
         # Weak scaling keeps every assembly's own mean (N independent assemblies); strong scaling needs the all-reduce.
-        if world > 1 and (self.args.scaling == "strong" or self.args.allreduce_always):
+        if world > 1 and (self.scaling == "strong" or self.args.allreduce_always):
             sd, sq, n = allreduce_sums(sums, device=self.cdev)
         else:
             sd, sq, n = sums
@@ -615,6 +628,7 @@ class Rank:
             counts.append(tuple(self.counts))
         self.fence()
         elapsed = time.perf_counter() - t0
+        self.elapsed_local = elapsed
         if self.world > 1:
             el = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self.cdev)
             self.dist.all_reduce(el, op=self.dist.ReduceOp.MAX)
@@ -728,27 +742,362 @@ def profile_leg(R, steps):
     return out
 
 
+def _shm_dir():
+    return "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+
+
+def make_bedgraph_text(torch, dev, n, seed, mq):
+    """n lines `ptg000001l\t%09d\t%09d\t%02d\n` (34 bytes; %d reads the zero-padded numbers the same) on the device: one contig,
+    depth around 30 with a 20 kb dip every 400 kb (mq: a quarter of the depth in a 20 kb segment every 500 kb)"""
+    pos = torch.arange(n, device=dev, dtype=torch.int64)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    depth = 28 + torch.randint(0, 5, (n,), device=dev, generator=g)
+    depth = torch.where((pos % 400000) < 20000, depth // 5, depth)
+    if mq:
+        depth = torch.where(((pos + 100000) % 500000) < 20000, depth // 4, depth)
+    out = torch.empty((n, 34), dtype=torch.uint8, device=dev)
+    out[:, :10] = torch.tensor(list(b"ptg000001l"), dtype=torch.uint8, device=dev)
+    out[:, 10] = 9
+    out[:, 20] = 9
+    out[:, 30] = 9
+    out[:, 33] = 10
+
+    def digits(v, col, nd):
+        for k in range(nd):
+            out[:, col + nd - 1 - k] = (v % 10 + 48).to(torch.uint8)
+            v = v // 10
+
+    digits(pos.clone(), 11, 9)
+    digits(pos + 1, 21, 9)
+    digits(depth.clone(), 31, 2)
+    return out.reshape(-1)
+
+
+def e2e_noboringbits(R, torch, cornetto_amd, mlines=100.0):
+    """BASELINE config 3 end to end: the C CLI `cornetto noboringbits cov-total.bg -q cov-mq20.bg` on two per-base bedgraph FILES
+    (memory-backed): process start, HIP initialisation, file read, H2D, text parse on the device (the reference's fscanf loop is 95 %
+    of its wall time, boringbits_main.c:204-287), window stage, selection, printing"""
+    import subprocess
+    shm = _shm_dir()
+    n = int(mlines * 1e6)
+    out = {"where": shm}
+    paths = [os.path.join(shm, "cornetto_bench_cov_%s.%d.bg" % (t, os.getpid())) for t in ("total", "mq20")]
+    try:
+        fs = os.statvfs(shm)
+        while n >= 10_000_000 and fs.f_bavail * fs.f_frsize < 2 * 34 * n + (2 << 30):
+            n //= 2
+        if n < 10_000_000:
+            return {"skipped": "not enough free space under %s" % shm}
+        for path, seed, mq in zip(paths, (11, 12), (False, True)):
+            t = make_bedgraph_text(torch, R.dev, n, 11, mq)       # (same seed: mq differs from depth only in its segments)
+            t.cpu().numpy().tofile(path)
+            del t
+        torch.cuda.empty_cache()
+        nbytes = sum(os.path.getsize(p) for p in paths)
+        best, so = None, b""
+        for _ in range(2):
+            t0 = time.perf_counter()
+            p = subprocess.run([cornetto_amd.CLI_PATH, "noboringbits", paths[0], "-q", paths[1]], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                               env=dict(os.environ, CORNETTO_DEVICE=str(R.local_dev)))
+            dt = time.perf_counter() - t0
+            if p.returncode != 0:
+                return {"error": p.stderr[-300:].decode("replace")}
+            so = p.stdout
+            best = dt if best is None else min(best, dt)
+        out.update({"positions": n, "text_bytes": nbytes, "wall_s": round(best, 3), "text_GBps": round(nbytes / best / 1e9, 2),
+                    "gbases_s": round(n / best / 1e9, 3), "stdout_bytes": len(so), "stdout_lines": so.count(b"\n"),
+                    "command": "cornetto noboringbits cov-total.bg -q cov-mq20.bg (defaults: -w 2500 -i 50 -L 0.4 -H 2.5 -Q 0.4)"})
+    except Exception as e:                               # an extra: never fail the bench line over it
+        out["error"] = repr(e)
+    finally:
+        for path in paths:
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+    return out
+
+
+FQ_HEAD = b"@read%07d runid=5c1f3b2a9d ch=%03d\n"
+
+
+def make_fastq_piece(torch, dev, target_bases, seed):
+    """One piece of ONT-like FASTQ text built on the device: read lengths log-normal(mu 9.2, sigma 0.9)
+    clipped to [200, 200 000], uniform bases with a 200-base poly-A / poly-T stretch in every fourth read, qualities U[3, 40] + 33,
+    header `@read%07d runid=... ch=%03d`.  -> (uint8 tensor of the text, read lengths, byte offset of every record)"""
+    rng = np.random.default_rng(seed)
+    m = int(target_bases / 14000 * 1.3) + 16
+    L = np.clip(rng.lognormal(9.2, 0.9, size=m), 200, 200000).astype(np.int64)
+    n = int(np.searchsorted(np.cumsum(L), target_bases)) + 1
+    L = L[:n]
+    hl = len(FQ_HEAD % (0, 0))
+    size = hl + 2 * L + 4
+    off = np.concatenate([[0], np.cumsum(size)[:-1]]).astype(np.int64)
+    total = int(size.sum())
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    text = torch.empty(total, dtype=torch.uint8, device=dev)
+    step = 1 << 28
+    for s0 in range(0, total, step):
+        e0 = min(total, s0 + step)
+        text[s0:e0] = lut[torch.randint(0, 4, (e0 - s0,), device=dev, generator=g)]
+    # quality bytes: [hl + L + 3, hl + 2 L + 3) of every record
+    seg = np.empty(2 * n, dtype=np.int64)
+    seg[0::2] = hl + L + 3
+    seg[1::2] = L + 1
+    isq = torch.repeat_interleave(torch.tensor([0, 1], dtype=torch.uint8, device=dev).repeat(n), torch.from_numpy(seg).to(dev)).bool()
+    for s0 in range(0, total, step):
+        e0 = min(total, s0 + step)
+        q = torch.randint(36, 74, (e0 - s0,), dtype=torch.uint8, device=dev, generator=g)
+        text[s0:e0] = torch.where(isq[s0:e0], q, text[s0:e0])
+    del isq
+    offd = torch.from_numpy(off).to(dev)
+    Ld = torch.from_numpy(L).to(dev)
+    heads = np.frombuffer(b"".join(FQ_HEAD % (i, i % 512) for i in range(n)), dtype=np.uint8).reshape(n, hl)
+    text[(offd[:, None] + torch.arange(hl, device=dev)[None, :]).reshape(-1)] = torch.from_numpy(heads.copy()).to(dev).reshape(-1)
+    sep = offd + hl + Ld
+    text[sep] = 10
+    text[sep + 1] = 43
+    text[sep + 2] = 10
+    text[offd + torch.from_numpy(size).to(dev) - 1] = 10
+    pick = np.nonzero((np.arange(n) % 4 == 0) & (L > 400))[0]
+    if len(pick):
+        pa = (offd[torch.from_numpy(pick).to(dev)] + hl + 100)[:, None] + torch.arange(200, device=dev)[None, :]
+        letter = torch.where(torch.from_numpy((pick % 8 == 0)).to(dev), torch.tensor(84, dtype=torch.uint8, device=dev), torch.tensor(65, dtype=torch.uint8, device=dev))
+        text[pa.reshape(-1)] = letter[:, None].expand(-1, 200).reshape(-1)
+    return text, L, off
+
+
+def reads_leg(R, torch, cornetto_amd, gbases):
+    """BASELINE config 5 on one GPU: FASTQ text in pinned host memory -> records framed on the device with the length test of
+    `seq -m 10000` (src/seq.c:120) -> reads packed in HBM -> sdust per read (src/sdust/sdust.c:196-203) -> intervals on the host.
+    Two host threads with a handle (= HIP stream) each take the pieces alternately, so the H2D copy of one piece runs beside
+    the kernels of the other.  The first ~200 Mbases are also run through the reference's own `seq -m 10000 | sdust` (oracle/_ref)
+    on one core and compared line for line."""
+    import ctypes as C
+    import subprocess
+    import threading
+    out = {"min_len": 10000, "sdust": "-w 64 -t 20"}
+    L = cornetto_amd.lib()
+    pins = []
+    try:
+        piece_bases = 1.0e9
+        pieces = []
+        for pi in range(2):
+            text, lens, off = make_fastq_piece(torch, R.dev, piece_bases, 500 + pi)
+            n = int(text.numel())
+            pin = L.cornetto_pinned_alloc(n + 64)
+            if not pin:
+                return {"skipped": "no pinned host memory for a %d-byte piece" % n}
+            pins.append(pin)
+            host = text.cpu().numpy()
+            C.memmove(pin, host.ctypes.data, n)
+            pieces.append({"pin": pin, "n": n, "lens": lens, "off": off, "host": host if pi == 0 else None})
+            del text
+        torch.cuda.empty_cache()
+        n_pieces = max(2, int(np.ceil(gbases * 1e9 / piece_bases)))
+        accs = [cornetto_amd.Accel(R.local_dev), cornetto_amd.Accel(R.local_dev)]
+        for a in accs:
+            a.set_timing(1)
+        res = [None] * n_pieces
+        ktime = [0.0, 0.0]
+        err = []
+
+        def work(w):
+            try:
+                for j in range(w, n_pieces, 2):
+                    p = pieces[j % 2]
+                    recs, used, plain, reads = accs[w].fastq_split((p["pin"], p["n"]), final=True, min_len=10000, want_reads=True)
+                    iv = accs[w].sdust(reads, 20, 64)
+                    ktime[w] += sum(ms for k, ms in accs[w].last_timing() if k == "sdust_kernel")
+                    reads.close()
+                    if not plain or used != p["n"] or len(recs) != len(p["lens"]):
+                        raise RuntimeError("piece %d: framing fell back (plain %r, used %d of %d, %d of %d records)" % (j, plain, used, p["n"], len(recs), len(p["lens"])))
+                    res[j] = (int(recs["keep"].sum()), int(recs["len"][recs["keep"] == 1].sum()), len(iv), digest([iv]))
+            except BaseException as e:
+                err.append(repr(e))
+
+        for rep in range(2):                          # the first pass warms the workspaces up
+            np_run = 2 if rep == 0 else n_pieces
+            keep_n = n_pieces
+            n_pieces = np_run
+            ktime[0] = ktime[1] = 0.0
+            th = [threading.Thread(target=work, args=(w,)) for w in range(2)]
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            wall = time.perf_counter() - t0
+            n_pieces = keep_n
+            if err:
+                return {"error": err[0]}
+        done = [r for r in res if r is not None]
+        text_bytes = sum(pieces[j % 2]["n"] for j in range(n_pieces))
+        bases_in = sum(int(pieces[j % 2]["lens"].sum()) for j in range(n_pieces))
+        same = all(res[j][3] == res[j % 2][3] for j in range(n_pieces))
+        out.update({"pieces": n_pieces, "text_bytes": text_bytes, "reads_in": sum(len(pieces[j % 2]["lens"]) for j in range(n_pieces)), "bases_in": bases_in,
+                    "reads_kept": sum(r[0] for r in done), "bases_kept": sum(r[1] for r in done), "sdust_intervals": sum(r[2] for r in done),
+                    "wall_s": round(wall, 3), "gbases_s_text_in": round(bases_in / wall / 1e9, 3), "gbases_s_kept": round(sum(r[1] for r in done) / wall / 1e9, 3),
+                    "pcie_GBps": round(text_bytes / wall / 1e9, 2), "sdust_kernel_ms_sum": round(ktime[0] + ktime[1], 2), "repeats_identical": bool(same),
+                    "how": "2 host threads x 1 handle each, pieces of ~1 Gbase (2 GB of text) from pinned memory: cornetto_fastq_split(min_len = 10000) + cornetto_sdust_asm; "
+                           "the two distinct pieces are streamed alternately"})
+        for a in accs:
+            a.close()
+        # ---- the reference on a sample: seq -m 10000 | sdust, one core ------------------------------------------
+        ref_cli = os.path.join(ROOT, "oracle", "_ref", "cornetto")
+        if os.path.exists(ref_cli):
+            p0 = pieces[0]
+            j = int(np.searchsorted(np.cumsum(p0["lens"]), 200e6)) + 1
+            cut = int(p0["off"][j]) if j < len(p0["off"]) else p0["n"]
+            shm = _shm_dir()
+            f1 = os.path.join(shm, "cornetto_bench_reads.%d.fq" % os.getpid())
+            f2 = os.path.join(shm, "cornetto_bench_reads_m.%d.fq" % os.getpid())
+            try:
+                p0["host"][:cut].tofile(f1)
+                t0 = time.perf_counter()
+                with open(f2, "wb") as fh:
+                    subprocess.run([ref_cli, "seq", "-m", "10000", f1], stdout=fh, stderr=subprocess.DEVNULL, check=True)
+                t1 = time.perf_counter()
+                exp = subprocess.run([ref_cli, "sdust", f2], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+                t2 = time.perf_counter()
+                acc = cornetto_amd.Accel(R.local_dev)
+                sample = np.ascontiguousarray(p0["host"][:cut])
+                recs, used, plain, reads = acc.fastq_split(sample, final=True, min_len=10000, want_reads=True)
+                iv = acc.sdust(reads, 20, 64)
+                reads.close()
+                acc.close()
+                kept = recs[recs["keep"] == 1]
+                names = [bytes(sample[int(h) + 1:int(h) + 1 + int(nl)]) for h, nl in zip(kept["head"], kept["name_len"])]
+                got = b"".join(b"%s\t%d\t%d\n" % (names[int(x["ctg"])], x["start"], x["finish"]) for x in iv)
+                sb = int(p0["lens"][:j].sum())
+                out["parity"] = {"ok": bool(got == exp), "sample_bases": sb, "reads_kept": len(kept), "intervals": len(iv),
+                                 "against": "oracle/_ref/cornetto seq -m 10000 | oracle/_ref/cornetto sdust (the unmodified reference)"}
+                out["cpu_reference"] = {"cores": 1, "seq_s": round(t1 - t0, 2), "sdust_s": round(t2 - t1, 2), "gbases_s": round(sb / (t2 - t0) / 1e9, 4), "sample_bases": sb}
+            finally:
+                for f in (f1, f2):
+                    try:
+                        os.remove(f)
+                    except OSError:
+                        pass
+    except Exception as e:                               # an extra: never fail the bench line over it (a parity mismatch does)
+        out["error"] = repr(e)
+    finally:
+        for pin in pins:
+            L.cornetto_pinned_free(pin)
+    return out
+
+
+def emulate_ranks(R, ns, steps, t1_ms):
+    """Strong scaling modelled on ONE GPU: for N in ns the contigs are split exactly as an N-rank run splits them
+    (cornetto_amd.dist.lpt_partition), and every rank's share is run as its own resident workload, one after the other, with
+    the normal two-stream step.  A real N-GPU step ends when its slowest rank ends (plus one 24-byte all-reduce, not modelled):
+    step_ms = max over the shares; efficiency = t1 / (N * step_ms).  What this measures is how well the fixed costs of a step
+    (small launches, event pairs, host hand-offs, result copies) scale down with the share — the part of the curve one GPU can show."""
+    from cornetto_amd.dist import lpt_partition
+    out = {"modelled": True, "t1_ms": round(t1_ms, 3), "steps_per_share": steps,
+           "what": "per-rank shares of the LPT contig partition run one after the other on one GPU; step = slowest share; the 3 x int64 all-reduce is not modelled"}
+    full = list(range(len(R.lens)))
+    for n in ns:
+        parts = lpt_partition(R.lens, n)
+        per, bases = [], []
+        for own in parts:
+            R.wrap(own)
+            el = R.timed(steps, 1)
+            per.append(round(el / steps * 1e3, 3))
+            bases.append(R.my_bases)
+        mx = max(per)
+        out[str(n)] = {"per_rank_ms": per, "bases_per_rank": bases, "step_ms": mx, "efficiency": round(t1_ms / (n * mx), 4),
+                       "gbases_s": round(sum(bases) / (mx * 1e-3) / 1e9, 2)}
+    R.wrap(full)
+    return out
+
+
+def device_identity(torch, idx):
+    """what tells two GPUs of a node apart: PCI domain:bus:device, else the uuid, else the ordinal"""
+    p = torch.cuda.get_device_properties(idx)
+    for names in (("pci_domain_id", "pci_bus_id", "pci_device_id"),):
+        if all(hasattr(p, n) for n in names):
+            return "%04x:%02x:%02x" % tuple(int(getattr(p, n)) for n in names)
+    if hasattr(p, "uuid"):
+        return str(p.uuid)
+    return "ordinal:%d" % idx
+
+
+def collectives_info(R, dist, torch, elapsed_local, steps):
+    """who ran where and what the exchange costs: backend, world size, (host, device) of every rank, per-rank step times,
+    the latency of the 3 x int64 all-reduce.  Rank 0 gets the dict; every rank gets `shared` (two ranks on one device)."""
+    import socket
+    me = (socket.gethostname(), device_identity(torch, R.local_dev), round(elapsed_local / steps * 1e3, 3))
+    allr = [None] * R.world
+    dist.all_gather_object(allr, me)
+    t = torch.tensor([1, 2, 3], dtype=torch.int64, device=R.cdev)
+    for _ in range(5):
+        dist.all_reduce(t)
+    if R.cdev.type == "cuda":
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 50
+    for _ in range(reps):
+        dist.all_reduce(t)
+    if R.cdev.type == "cuda":
+        torch.cuda.synchronize()
+    ar_us = (time.perf_counter() - t0) / reps * 1e6
+    devs = [(h, d) for h, d, _ in allr]
+    shared = len(set(devs)) != len(devs)
+    info = {"backend": dist.get_backend(), "world": dist.get_world_size(), "devices": ["%s/%s" % d for d in devs],
+            "distinct_devices": not shared, "per_rank_ms": [x[2] for x in allr], "allreduce_3xi64_us": round(ar_us, 1),
+            "data_path": "strong: one all-reduce of 3 x int64 per step (boringbits_main.c:293-294 -> :518-519); weak: none; --gather: all_gather of counts + gather of the record arrays to rank 0"}
+    return info, shared
+
+
+def measure(R, args, scaling, profile, steps, warmup, gather):
+    """load (when the scaling or profile differs from what is resident), time, return (elapsed seconds, serial kernel times)"""
+    if getattr(R, "bases", None) is None or R.scaling != scaling or R.profile != profile:
+        if getattr(R, "bases", None) is not None:
+            R.unload()
+        R.load(profile, scaling)
+    keep = args.gather
+    args.gather = gather
+    try:
+        el = R.timed(steps, warmup)
+    finally:
+        args.gather = keep
+    return el
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--gbases", type=float, default=0.0, help="assembly size in Gbases (0 = the full 3.16 Gbp fixture)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak: one assembly per rank; strong: one assembly, contigs split over the ranks (LPT)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="strong (default for --gpus > 1: BASELINE's metric is ONE 3 Gbp assembly at 1/2/4/8 GPUs): one assembly, contigs split "
+                         "over the ranks (LPT), one all-reduce per step; weak: one assembly per rank, no collective.  With --gpus > 1 the other one "
+                         "is measured too (with the gather of all records to rank 0) and reported under 'second'")
     ap.add_argument("--profile", choices=("uniform", "satellite"), default="uniform", help="main workload (the other one is reported under 'profiles' at N=1)")
     ap.add_argument("--assembly-index", type=int, default=0, help="seed offset of the (first) assembly: rank r of a weak run uses index + r")
     ap.add_argument("--cpu-sample-mbases", type=float, default=500.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU leg (cpu_baseline and parity)")
     ap.add_argument("--check-steps", type=int, default=-1, help="extra untimed steps whose results are digested and compared (-1: min(steps, 20); 0: none)")
     ap.add_argument("--no-profiles", action="store_true", help="skip the second workload profile")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the CLI end-to-end leg")
-    ap.add_argument("--sdust-share", type=int, default=85, help="percent of the wave slots sdust could hold on a CU (18) that it takes while the other stream runs beside it: 85 = 15 waves per CU")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the CLI end-to-end legs")
+    ap.add_argument("--no-reads", action="store_true", help="skip the read-level leg (BASELINE config 5)")
+    ap.add_argument("--reads-gbases", type=float, default=10.0, help="bases of FASTQ streamed through the read-level leg")
+    ap.add_argument("--no-second", action="store_true", help="--gpus > 1: skip the second measurement (the other scaling mode with --gather)")
+    ap.add_argument("--emulate-ranks", type=str, default="2,4,8", help="N=1: model the strong-scaling curve for these rank counts on this one GPU ('' = skip)")
+    ap.add_argument("--allow-shared-device", action="store_true", help="--gpus > 1 with fewer GPUs than ranks (tests): ranks share devices, collectives over gloo")
+    ap.add_argument("--sdust-share", type=int, default=85, help="percent of the wave slots sdust could hold on a CU that it takes while the other stream runs beside it (only the resident-wave kernel of CORNETTO_SDUST_SIFT=0 looks at it)")
     ap.add_argument("--timing", type=int, default=2, help="HIP events around: 1 the main kernels only (roofline), 2 every launch, 0 none")
     ap.add_argument("--gather", action="store_true", help="also gather every result record to rank 0 inside the step (not part of the path: each rank owns the output of its contigs)")
     ap.add_argument("--allreduce-always", action="store_true", help="weak scaling: all-reduce the depth totals as well (treats the N assemblies as one)")
     ap.add_argument("--serial", action="store_true", help="run the stages one after the other on one stream (per-kernel timing without overlap)")
     args = ap.parse_args()
+    if args.scaling is None:
+        args.scaling = "strong" if args.gpus > 1 else "weak"
 
     import torch
     import torch.distributed as dist
@@ -756,11 +1105,26 @@ def main():
 
     R = Rank(args, torch, dist, cornetto_amd)
     rank, world = R.rank, R.world
+    t_first = time.perf_counter()
     R.load(args.profile)
+    t_first = time.perf_counter()
+    R.step(False)                                   # the first step of a resident assembly builds its decomposition tables
+    first_step_ms = (time.perf_counter() - t_first) * 1e3
 
     elapsed = R.timed(args.steps, args.warmup)
+    elapsed_local = R.elapsed_local
     serial = R.serial_kernel_times()
     n_bases = R.my_bases
+
+    coll, shared = None, False
+    if world > 1:
+        coll, shared = collectives_info(R, dist, torch, elapsed_local, args.steps)
+        if shared and not args.allow_shared_device:
+            if rank == 0:
+                sys.stderr.write("bench.py: two ranks share one device (%s): refusing to report a multi-GPU number; --allow-shared-device is for tests\n" % coll["devices"])
+            R.unload()
+            R.close()
+            sys.exit(3)
 
     # ---- determinism: digest of the four result arrays of every step of an extra, untimed run ---------------
     nchk = min(args.steps, 20) if args.check_steps < 0 else args.check_steps
@@ -795,17 +1159,26 @@ def main():
         kavg, alg, kern = kernel_table(R, serial, n_bases)
         dom = "sdust_kernel"
         ach = alg[dom] / (kavg[dom] * 1e-3) / 1e9 if kavg.get(dom, 0) > 0 else 0.0
-        # HBM/fabric bytes per launch of the dominant kernel: NOT measured in this run — taken from the committed
-        # rocprofv3 PMC passes of this workload (profiles/README.md), scaled to the bases of this run
-        traffic, traffic_source = None, None
-        for cand in (PMC_FILE, os.path.join("profiles", "r01_pmc_traffic.json")):
+        # HBM/fabric bytes per launch of the dominant kernel and its instruction mix: NOT measured in this run — taken from the
+        # committed rocprofv3 PMC passes of this workload (profiles/README.md), scaled to the bases of this run
+        traffic, traffic_source, issue = None, None, None
+        for cand in (PMC_FILE, os.path.join("profiles", "r02_pmc_traffic.json")):
             try:
-                pmc = json.load(open(os.path.join(ROOT, cand)))["sdust_w64"]
-                per_base = pmc["hbm_bytes"] / pmc["bases"] if "hbm_bytes" in pmc else (pmc["fetch_bytes_corrected_x2"] + pmc["write_bytes"]) / pmc.get("bases", 3160108082)
-                traffic, traffic_source = round(per_base * n_bases, 0), cand
+                pmcs = json.load(open(os.path.join(ROOT, cand)))
+                pmc = pmcs.get("sd_sift") or pmcs["sdust_w64"]
+                traffic, traffic_source = round(pmc["hbm_bytes"] / pmc["bases"] * n_bases, 0), cand
                 break
             except Exception:
                 continue
+        try:
+            sq = json.load(open(os.path.join(ROOT, SQ_FILE)))
+            pl = sq["per_launch"]
+            issue = {"valu_insts": pl["SQ_INSTS_VALU"], "salu_insts": pl["SQ_INSTS_SALU"], "lds_insts": pl["SQ_INSTS_LDS"],
+                     "valu_busy": sq.get("valu_busy_of_kernel_time"), "per_64_bases": sq.get("per_tile"), "source": SQ_FILE,
+                     "note": "a wave-64 vector instruction holds its SIMD's ALU for 4 cycles: valu_busy = 4 x SQ_INSTS_VALU / (SIMDs x cycles of the kernel); "
+                             "not measured in this run: the committed rocprofv3 --pmc passes of the same workload"}
+        except Exception:
+            pass
         nst = 2 if R.overlap else 1
         wl = "%s over %s synthetic HG002-like hifiasm assembly%s (%d contigs, %.3f Gbp%s, planted telomeres/STRs/N runs%s; per-base u16 depth+mq)" % (
             "telowin+sdust+noboringbits", "one" if args.scaling == "strong" or world == 1 else "%d" % world,
@@ -821,14 +1194,21 @@ def main():
                        "parallelism": "contig-sharded (%s), %d process(es), 1 GPU each; per GPU %s" % (
                            "LPT over the contigs of one assembly" if args.scaling == "strong" else "one assembly per rank", world,
                            "2 HIP streams (sdust || telofind+coverage)" if nst == 2 else "stages serial on one stream")},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
-                         "note": "sdust is an integer recurrence, VALU-issue bound (profiles/r02_sq_sdust.json); reported against HBM as the contract asks. "
-                                 "traffic is not measured in this run: it is the committed rocprofv3 PMC figure scaled by bases"},
+            "roofline": {"bound": "valu-issue", "kernel": dom, "kernel_symbol": "sd_sift", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source, "issue": issue,
+                         "note": "sdust is integer work per base, bound by instruction issue, not by HBM (profiles/r03_sq_sd_sift.json); achieved / peak / frac are "
+                                 "against the HBM roofline as the contract asks (1 B/base algorithmic). traffic and issue are not measured in this run: "
+                                 "the committed rocprofv3 PMC figures scaled by bases"},
             "kernels": kern,
             "stage_wall_ms": {k: round(float(np.mean(v)), 3) for k, v in R.wall.items()},
             "results_per_rank": dict(zip(("telomere_runs", "telomere_windows", "sdust_intervals", "selected_cov_windows"), R.counts)),
+            "cached_across_steps": ["tile / chunk / window decomposition tables of the resident assembly and coverage (functions of the contig lengths only; built by the first "
+                                    "step, %0.1f ms against %0.1f ms for a timed step)" % (first_step_ms, ms_per_step),
+                                    "device workspaces and pinned result buffers (no allocation in a timed step)"],
+            "first_step_ms": round(first_step_ms, 3),
         }
+        if coll:
+            line["collectives"] = coll
         if det:
             line["determinism"] = det
         if gathered_digests:
@@ -848,9 +1228,24 @@ def main():
     if det and not det["identical"]:
         ok = False
     last = None
+    if rank == 0 and world == 1 and args.emulate_ranks.strip():
+        ns = [int(x) for x in args.emulate_ranks.split(",") if x.strip()]
+        line["scaling_model"] = emulate_ranks(R, ns, max(3, min(args.steps, 10)), line["ms_per_step"])
+    if world > 1 and not args.no_second:
+        # the other scaling mode, with the gather of every record to rank 0: BASELINE config 4 is "8 assemblies, RCCL gather of BED intervals"
+        other = "weak" if args.scaling == "strong" else "strong"
+        st2 = max(3, min(args.steps, 10))
+        el2 = measure(R, args, other, args.profile, st2, 1, True)
+        if rank == 0:
+            line["second"] = {"scaling": other, "gather": True, "steps": st2, "ms_per_step": round(el2 / st2 * 1e3, 3),
+                              "value": round(R.job_bases / (el2 / st2) / 1e9, 4), "unit": "Gbases/s", "bases_job": R.job_bases,
+                              "stage_wall_ms": {k: round(float(np.mean(v)), 3) for k, v in R.wall.items()}}
     if rank == 0 and world == 1 and not args.no_e2e:
         line["e2e"] = e2e_cli(R, cornetto_amd)
     if rank == 0 and world == 1 and not args.no_profiles:
+        if R.scaling != args.scaling or R.profile != args.profile:
+            R.unload()
+            R.load(args.profile, args.scaling)
         profs = {args.profile: {"ms_per_step": line["ms_per_step"], "gbases_s": line["value"],
                                 "sdust_kernel_ms": line["kernels"].get("sdust_kernel", {}).get("ms"),
                                 "sdust_kernel_ms_uncontended": line["kernels"].get("sdust_kernel", {}).get("ms_uncontended"),
@@ -863,9 +1258,15 @@ def main():
         R.load(other)
         profs[other] = profile_leg(R, min(args.steps, 5))
         line["profiles"] = profs
+    R.unload()
+    if rank == 0 and world == 1 and not args.no_e2e:
+        line["e2e"]["noboringbits"] = e2e_noboringbits(R, torch, cornetto_amd)
+    if rank == 0 and world == 1 and not args.no_reads:
+        line["reads"] = reads_leg(R, torch, cornetto_amd, args.reads_gbases)
+        if line["reads"].get("parity") is not None and not line["reads"]["parity"].get("ok", True):
+            ok = False
     if rank == 0:
         print(json.dumps(line), flush=True)
-    R.unload()
     R.close()
     if not ok:
         sys.stderr.write("bench.py: parity or determinism check FAILED (see the JSON line)\n")

@@ -215,13 +215,7 @@ static void bb_multi(cornetto_accel_t *h0, const cornetto_cov_t *cov, int32_t n_
     memset(dv, 0, sizeof(dv));
     int32_t *order = (int32_t *)cli_xmalloc(((size_t)n_ctg + 1) * sizeof(int32_t));
     int32_t *owner = (int32_t *)cli_xmalloc(((size_t)n_ctg + 1) * sizeof(int32_t));
-    for (int32_t i = 0; i < n_ctg; ++i) order[i] = i;
-    for (int32_t i = 1; i < n_ctg; ++i) { /* by descending length, ties in input order */
-        const int32_t x = order[i];
-        int32_t j = i;
-        while (j > 0 && lens[order[j - 1]] < lens[x]) { order[j] = order[j - 1]; --j; }
-        order[j] = x;
-    }
+    cli_order_by_length_desc(NULL, lens, n_ctg, order);   /* by descending length, ties in input order (read-level coverage sets: 10^5..10^6 contigs) */
     int64_t load[CLI_MAX_DEV];
     for (int d = 0; d < n_dev; ++d) {
         load[d] = 0;

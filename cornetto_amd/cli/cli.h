@@ -42,6 +42,8 @@ double cli_realtime(void);
 double cli_cputime(void);
 long cli_peakrss(void);
 void *cli_xmalloc(size_t n);
+/* order[k] = index of the k-th longest record, ties in input order (one of the two length arrays is NULL) */
+void cli_order_by_length_desc(const int64_t *lens64, const int32_t *lens32, int32_t n, int32_t *order);
 void *cli_xrealloc(void *p, size_t n);
 char *cli_xstrdup(const char *s);
 

@@ -175,13 +175,7 @@ static void multi_batch(multi_dev_t *dv, int n_dev, const cli_batch_t *b)
 {
     /* LPT: records by descending length (ties: input order), each to the least loaded device */
     int32_t *order = (int32_t *)cli_xmalloc(((size_t)b->n + 1) * sizeof(*order));
-    for (int32_t i = 0; i < b->n; ++i) order[i] = i;
-    for (int32_t i = 1; i < b->n; ++i) { /* batches hold a few hundred contigs — or many short reads, nearly sorted runs: insertion sort by length */
-        const int32_t x = order[i];
-        int32_t j = i;
-        while (j > 0 && b->lens[order[j - 1]] < b->lens[x]) { order[j] = order[j - 1]; --j; }
-        order[j] = x;
-    }
+    cli_order_by_length_desc(b->lens, NULL, b->n, order);   /* (a batch may hold hundreds of thousands of reads) */
     int64_t load[CLI_MAX_DEV];
     int32_t *owner = (int32_t *)cli_xmalloc(((size_t)b->n + 1) * sizeof(*owner));
     for (int d = 0; d < n_dev; ++d) { load[d] = 0; dv[d].n_mine = 0; dv[d].b = b; }

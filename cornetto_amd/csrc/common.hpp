@@ -37,6 +37,7 @@ struct cornetto_accel {
     Ws pin[32];
     int sd_slots = 0;   // sdust: waves the device holds at once (occupancy query, cached)
     int sd_cus = 0;
+    int sift_per_cu = 0; // sdust sift: workgroups per CU by the occupancy query (cached)
     int share = 100;    // percent of every CU the resident sdust kernel may take (cornetto_accel_set_share)
     int sd_stats = 0;   // sdust: run the statistics build of the kernel (cornetto_accel_sdust_stats)
     unsigned long long sd_last[256] = {0};   // its counters from the most recent such run

@@ -85,7 +85,10 @@ void cornetto_accel_close(cornetto_accel_t *h)
         if (w.p) (void)hipHostFree(w.p);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
-    if (h->stream2) (void)hipStreamDestroy(h->stream2);
+    if (h->stream2) {
+        (void)hipStreamSynchronize(h->stream2);       // (a dense kernel of a call that failed half-way may still be writing workspaces)
+        (void)hipStreamDestroy(h->stream2);
+    }
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }

@@ -1758,6 +1758,13 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                      reinterpret_cast<uint32_t *>(d_tot + 8), nullptr, 0, env_int("CORNETTO_SDUST_RUNON", 1), (int32_t)chunk, a->d_wtab, a->d_wtab_base, reinterpret_cast<uint32_t *>(d_tot + 1) + 1};
             unsigned nb = (unsigned)((nc + 63) / 64);
             bool dense_pending = false;
+            // (whatever path leaves this attempt — a failed launch, a failed allocation — the dense kernel on the second stream is
+            // through before the workspaces it writes can be handed to anybody else)
+            struct DenseJoin {
+                cornetto_accel_t *h;
+                bool *pending;
+                ~DenseJoin() { if (*pending && h->stream2) (void)hipStreamSynchronize(h->stream2); }
+            } dense_join{h, &dense_pending};
             if (use_w64 && sift_on) {
                 // ---- one launch: sift + resolve over the chunks of plain letters, the base-by-base walk over the others ----
                 CN_HIP(h, hipMemsetAsync(d_cnt, 0, nc * 4, h->stream));       // (a wave that asks for the word-count table publishes nothing)
@@ -1765,10 +1772,21 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                 const uint32_t lds_wave = sift_lds_bytes(reg_cap);
                 int lmin = 1;
                 while (5 * (lmin + 1) <= T && lmin < 16) ++lmin;
-                SiftArgs S{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, lds_wave, reg_cap, T / 10 + 1, lmin, env_int("CORNETTO_SIFT_ABL", 0)};
+                SiftArgs S{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, lds_wave, reg_cap, reinterpret_cast<uint32_t *>(d_tot + 210), T / 10 + 1, lmin, env_int("CORNETTO_SIFT_ABL", 0)};
                 SdArgs R = A;
                 R.stats = want_stats ? d_tot + 200 : nullptr;
-                const unsigned nbk = (unsigned)((nc + SIFT_WPB - 1) / SIFT_WPB);
+                // Resident waves: as many workgroups as the chip holds at once (LDS is handed out in 1280-byte granules), a share of them
+                // when another stream computes beside this one (cornetto_accel_set_share): a launch of one workgroup per chunk keeps
+                // the other stream's kernels waiting until it is through (13.1 instead of 9 ms per bench step).  The waves take their
+                // chunks from one counter (static strides were measured 10-50 % slower: chunks differ a lot in cost).
+                if (h->sift_per_cu == 0) {
+                    int per_cu = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sd_sift<false>, 64 * SIFT_WPB, lds_wave * SIFT_WPB) != hipSuccess || per_cu < 1) per_cu = 8;
+                    h->sift_per_cu = per_cu;
+                }
+                int per_cu = std::min<int>(h->sift_per_cu, (int)(163840 / ((lds_wave * SIFT_WPB + 1279) / 1280 * 1280)));
+                per_cu = std::max(1, per_cu * h->share / 100);
+                const unsigned nbk = (unsigned)std::min<size_t>((nc + SIFT_WPB - 1) / SIFT_WPB, (size_t)env_int("CORNETTO_SIFT_BLOCKS", per_cu * std::max(h->sd_cus, 1)));
                 if (want_stats) CN_LAUNCH(h, "sdust_kernel", sd_sift<true><<<dim3(nbk), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream>>>(S, R));
                 else CN_LAUNCH(h, "sdust_kernel", sd_sift<false><<<dim3(nbk), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream>>>(S, R));
             } else if (use_w64) {
@@ -1897,7 +1915,10 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                 uint8_t *g_ring = reinterpret_cast<uint8_t *>(g_slot + (size_t)rc * NL);
                 CN_LAUNCH(h, "sdust_kernel", sdust_kernel_g<<<dim3(nb), dim3(64), 0, h->stream>>>(A, g_ring, g_cw, g_cv, g_slot, rc));
             }
-            if (dense_pending) CN_HIP(h, hipStreamWaitEvent(h->stream, h->ev2, 0));
+            if (dense_pending) {
+                CN_HIP(h, hipStreamWaitEvent(h->stream, h->ev2, 0));
+                dense_pending = false;                 // (joined on the device: the stream's later work waits for it)
+            }
             // ordered position of every chunk's intervals (chunks are in contig order) + grand total
             CN_TRY(cnscan::exclusive_u32(h, "sdust_scan", d_cnt, (int64_t)nc, 1, d_off, d_part, d_tot));
             stamp("main kernel queued");

@@ -44,6 +44,7 @@ struct SiftArgs {
     int32_t T, W;
     uint32_t lds_per_wave;    // bytes of dynamic LDS per wave
     uint32_t reg_cap;         // positions the word / count buffer holds (multiple of 64): chunk + 128
+    uint32_t *counter;        // zero before the launch: chunks handed out beyond the first one of every wave
     int32_t thr, lmin;        // equal words a last word needs (T / 10 + 1); shortest l with 10 l (l + 1) / 2 > T l, capped at 16
     int32_t abl;              // development aid (CORNETTO_SIFT_ABL): 1 no resolve, 2 no L1 / L2, 4 no tiles: timing only, results are wrong
 };
@@ -147,8 +148,6 @@ __global__ __launch_bounds__(64 * SIFT_WPB) void sd_sift(SiftArgs A, SdArgs O)
     const int Tl = T * lane;
     const uint32_t m_recip = sd_recip_tab[lane];
 
-    // ---- one chunk per wave (the hardware's workgroup dispatch balances chunks of very different cost: resident waves with
-    // a static stride were measured 10-50 % slower) ---------------------------------------------------------------------
     struct Meta {
         SdChunk ch;
         int len;
@@ -182,6 +181,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) void sd_sift(SiftArgs A, SdArgs O)
     };
     const int k0 = (int)blockIdx.x * SIFT_WPB + wave;
     if (k0 >= A.n_chunks) return;                     // (whole waves leave: nothing is shared, there are no barriers)
+    const int G = (int)gridDim.x * SIFT_WPB;          // the first G chunks by position, the others from the counter
 
   auto process = [&](const int k, const Meta &M, const Data &D) {
     const SdChunk ch = M.ch;
@@ -597,6 +597,14 @@ __global__ __launch_bounds__(64 * SIFT_WPB) void sd_sift(SiftArgs A, SdArgs O)
     finish();
   };
 
-    const Meta m0 = meta(k0);
-    process(k0, m0, fetch(m0));
+    // The waves stay (as many as the caller lets this kernel hold of the chip: the other stream needs its share) and take
+    // chunks from one counter; the request for the next index is in flight while the current chunk is worked on.
+    for (int k = k0;;) {
+        uint32_t nxt = 0;
+        if (lane == 0) nxt = atomicAdd(A.counter, 1u);
+        const Meta m = meta(k);
+        process(k, m, fetch(m));
+        k = G + __builtin_amdgcn_readfirstlane((int)nxt);
+        if (k >= A.n_chunks) break;
+    }
 }

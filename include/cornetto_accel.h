@@ -133,7 +133,10 @@ int cornetto_asm_upload(cornetto_accel_t *h, const uint8_t *const *seqs, const i
 
 /* Wrap bases that already are in device memory: contig i occupies d_bases[offsets[i] .. offsets[i]+lens[i]).
  * Every offset must be a multiple of 64 and the buffer must stay readable for 128 bytes past the last
- * contig (padding content is ignored).  The buffer is borrowed, never freed. */
+ * contig (padding content is ignored).  The buffer is borrowed, never freed.  Its CONTENT must not change while the object
+ * exists: work decompositions derived from it (chunk / tile tables; with CORNETTO_SDUST_SIFT=0 also the order in which the
+ * chunks are handed out, which depends on a sample of the bases) are kept with the object by the first call that needs them.
+ * Results stay exact if it does change (the order is a scheduling hint only), the balance of the work does not: wrap again. */
 int cornetto_asm_wrap(cornetto_accel_t *h, const void *d_bases, const int64_t *offsets, const int64_t *lens,
                       int32_t n, cornetto_asm_t **out);
 void cornetto_asm_free(cornetto_accel_t *h, cornetto_asm_t *a);

@@ -15,7 +15,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COMMON = ["--gbases", "0.05", "--steps", "2", "--warmup", "1", "--check-steps", "2", "--gather", "--no-cpu", "--no-profiles", "--no-e2e"]
+COMMON = ["--gbases", "0.05", "--steps", "2", "--warmup", "1", "--check-steps", "2", "--gather", "--no-cpu", "--no-profiles", "--no-e2e", "--no-reads",
+          "--emulate-ranks", "", "--no-second"]
 
 
 def _free_port():
@@ -26,7 +27,12 @@ def _free_port():
     return p
 
 
-def _run(n, extra):
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+def _run(n, extra, rc_ok=(0,)):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     if n == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + COMMON + extra
@@ -34,7 +40,9 @@ def _run(n, extra):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + COMMON + extra
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900, cwd=ROOT)
-    assert p.returncode == 0, p.stderr.decode("replace")[-3000:]
+    assert p.returncode in rc_ok, p.stderr.decode(errors="replace")[-3000:]
+    if p.returncode != 0:
+        return {"rc": p.returncode, "stderr": p.stderr.decode(errors="replace")}
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout.decode()[-2000:]
     return json.loads(lines[0])
@@ -42,21 +50,61 @@ def _run(n, extra):
 
 @pytest.mark.timeout(1800)
 def test_two_ranks_strong_scaling_equals_one_rank():
+    shared = [] if _n_gpus() >= 2 else ["--allow-shared-device"]
     one = _run(1, ["--scaling", "strong"])
-    two = _run(2, ["--scaling", "strong"])
+    two = _run(2, ["--scaling", "strong"] + shared)
     assert one["scaling"] == "strong" and two["scaling"] == "strong" and two["n_gpus"] == 2
     assert one["determinism"]["identical"] and two["determinism"]["identical"]
     assert len(one["gathered_digests"]) == 1
     assert two["gathered_digests"] == one["gathered_digests"]
     assert two["config"]["bases_job"] == one["config"]["bases_job"]              # one assembly, whatever the rank count
     assert 0 < two["config"]["contigs_rank0"] < one["config"]["contigs_rank0"]
+    c = two["collectives"]
+    assert c["world"] == 2 and len(c["devices"]) == 2 and len(c["per_rank_ms"]) == 2 and c["allreduce_3xi64_us"] > 0
+    assert c["backend"] == ("nccl" if _n_gpus() >= 2 else "gloo") and c["distinct_devices"] == (_n_gpus() >= 2)
+
+
+@pytest.mark.timeout(900)
+def test_ranks_sharing_a_device_are_refused():
+    """a --gpus 2 run whose ranks land on ONE device must not print a multi-GPU line (exit 3) unless the test flag is given"""
+    if _n_gpus() >= 2:
+        pytest.skip("needs a box with fewer GPUs than ranks")
+    r = _run(2, ["--scaling", "strong"], rc_ok=(1, 3))       # torch.distributed.run reports the failure of its workers as 1
+    assert "share one device" in r["stderr"]
+
+
+@pytest.mark.timeout(1800)
+def test_default_of_two_ranks_is_strong_with_a_second_weak_measurement():
+    """`--gpus 2` without --scaling: the metric's mode (ONE assembly, strong scaling) is `value`, the other mode with the gather of
+    all records comes second in the same line"""
+    shared = [] if _n_gpus() >= 2 else ["--allow-shared-device"]
+    env_common = [x for x in COMMON if x not in ("--no-second", "--gather")]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + env_common + shared
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    line = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert line["scaling"] == "strong" and line["second"]["scaling"] == "weak" and line["second"]["gather"] is True
+    assert line["second"]["bases_job"] == 2 * line["config"]["bases_job"] and line["second"]["value"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_scaling_model_of_one_rank():
+    one = _run(1, ["--emulate-ranks", "2,4"])
+    m = one["scaling_model"]
+    assert m["modelled"] is True and set(m) >= {"2", "4"}
+    for n in ("2", "4"):
+        assert len(m[n]["per_rank_ms"]) == int(n) and sum(m[n]["bases_per_rank"]) == one["config"]["bases_job"]
+        assert m[n]["step_ms"] == max(m[n]["per_rank_ms"]) and 0 < m[n]["efficiency"] <= 1.5
 
 
 @pytest.mark.timeout(1800)
 def test_two_ranks_weak_scaling_equals_two_one_rank_runs():
+    shared = [] if _n_gpus() >= 2 else ["--allow-shared-device"]
     a0 = _run(1, ["--assembly-index", "0"])
     a1 = _run(1, ["--assembly-index", "1"])
-    two = _run(2, [])
+    two = _run(2, ["--scaling", "weak"] + shared)
     assert two["scaling"] == "weak" and two["n_gpus"] == 2
     assert a0["gathered_digests"] != a1["gathered_digests"]
     assert two["gathered_digests"] == a0["gathered_digests"] + a1["gathered_digests"]

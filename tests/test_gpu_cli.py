@@ -167,6 +167,42 @@ def test_several_devices_print_the_output_of_one(cli, golden_dir, args, exp, dev
     assert out == golden(golden_dir, exp)
 
 
+def _device_count():
+    import cornetto_amd
+    return int(cornetto_amd.lib().cornetto_accel_device_count())
+
+
+@pytest.mark.parametrize("args,exp", [
+    (["sdust", "mix.fa.gz"], "mix.sdust.exp"),
+    (["telofind", "mix.fa.gz"], "mix.telofind.exp"),
+    (["sdust", "reads.fq"], "reads.sdust.exp"),
+])
+def test_distinct_devices_print_the_output_of_one(cli, golden_dir, args, exp):
+    """CORNETTO_DEVICES over DISTINCT GPUs (handles, streams and result buffers of different devices side by side): runs wherever
+    at least two are visible, skipped on a one-GPU box"""
+    n = _device_count()
+    if n < 2:
+        pytest.skip("one GPU visible")
+    a = [os.path.join(golden_dir, x) if os.path.exists(os.path.join(golden_dir, x)) else x for x in args]
+    for devices in ("0,1", ",".join(str(i) for i in range(min(n, 8)))):
+        rc, out, err = run(cli, a, {"CORNETTO_DEVICES": devices, "CORNETTO_BATCH_BASES": "200000"})
+        assert rc == 0, err[-500:]
+        assert out == golden(golden_dir, exp)
+
+
+@pytest.mark.parametrize("args,exp", PANEL[:3])
+def test_panel_window_stage_over_distinct_devices(cli, golden_dir, plain, args, exp):
+    """cornetto_cov_shard with peer copies between DISTINCT GPUs (skipped on a one-GPU box)"""
+    n = _device_count()
+    if n < 2:
+        pytest.skip("one GPU visible")
+    a = [plain["cov-total.bg"] if x == "T" else plain["cov-mq20.bg"] if x == "Q" else x for x in args]
+    for devices in ("0,1", "1,0", ",".join(str(i) for i in range(min(n, 8)))):
+        rc, out, err = run(cli, a, {"CORNETTO_DEVICES": devices})
+        assert rc == 0, err.decode()
+        assert out == golden(golden_dir, exp)
+
+
 def test_device_list_errors(cli, golden_dir):
     rc, out, err = run(cli, ["sdust", os.path.join(golden_dir, "probe.fa")], {"CORNETTO_DEVICES": "0,banana"})
     assert rc == 1 and out == b"" and b"CORNETTO_DEVICES" in err

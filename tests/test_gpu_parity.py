@@ -285,7 +285,13 @@ def test_sdust_random_thresholds_vs_oracle(acc, monkeypatch, seed):
     W = int(rng.integers(3, 67))
     monkeypatch.setenv("CORNETTO_SDUST_CHUNK", str(int(rng.integers(max(16, W), 900))))
     monkeypatch.setenv("CORNETTO_SDUST_WAVES", str(1 + seed % 3))
+    if seed % 2:
+        monkeypatch.setenv("CORNETTO_SDUST_DENSE", "2")     # every chunk sampled as low-complexity goes to the per-lane kernel sdust_dense
     seqs = _rand_seqs(rng, 40, -1)
+    if seed % 2:                                            # ... and there are such chunks: tandem arrays longer than a chunk
+        u = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(rng.integers(1, 7)))]
+        seqs.append(np.tile(u, 6000 // len(u)))
+        seqs.append(np.concatenate([seqs[0][:500], np.tile(np.frombuffer(b"CATTC", dtype=np.uint8), 700), seqs[0][:300]]))
     asm = acc.asm_upload(seqs)
     iv = acc.sdust(asm, T, W)
     asm.close()

@@ -90,6 +90,90 @@ def test_panel_recreate_script_constants_hand_worked():
     assert [tuple(int(x) for x in r) for r in got] == [(0, 200_000, 860_000), (0, 960_000, 2_800_000)]
 
 
+def _hg002_fixture(golden_dir):
+    """the reference's own bigenough fixture (test/bigenough/hg002-cornetto-E_3): chroms.bed = the assembly BED of a real HG002
+    hifiasm assembly, in.boringbits.bed = what steps 1-9 of scripts/create-cornetto.sh (awk, sort, bedtools merge / subtract) made
+    of it — the one piece of real bedtools output the reference holds for this stage"""
+    import os
+    names, lens = [], []
+    for l in open(os.path.join(golden_dir, "bigenough", "chroms.bed")):
+        n, _a, b = l.split()
+        names.append(n)
+        lens.append(int(b))
+    idx = {n: i for i, n in enumerate(names)}
+    rows = [(idx[l.split()[0]], int(l.split()[1]), int(l.split()[2])) for l in open(os.path.join(golden_dir, "bigenough", "in.boringbits.bed"))]
+    return names, np.array(lens, np.int32), rows
+
+
+def _panel_invariants(lens, rows):
+    """what `merge -d 200000`, the 200 kb edges and the 800 kb cut of create-cornetto.sh:55-66 imply for ANY input, read off the
+    reference-held bedtools output first: rows ordered by contig then start, disjoint; every row starts at or after 200 000 and
+    ends at or before length - 200 000; a row is longer than 200 000 (two fun blocks closer than that were merged); no row on a
+    contig shorter than 800 000"""
+    prev = None
+    for c, a, b in rows:
+        assert 0 <= a < b <= lens[c]
+        assert a >= 200_000 and b <= lens[c] - 200_000, (c, a, b)
+        assert b - a > 200_000, (c, a, b)
+        assert lens[c] >= 800_000
+        if prev is not None:
+            assert (c, a) > (prev[0], prev[2]) or c > prev[0]
+            if c == prev[0]:
+                assert a > prev[2]
+        prev = (c, a, b)
+
+
+def test_reference_held_bedtools_output_invariants_hold_for_the_product(golden_dir):
+    """(1) the invariants are facts of the reference's fixture; (2) cornetto_panel_boring keeps them for random fun / lowQ sets over the
+    same assembly; (3) the oracle agrees row for row.  The stage stays UNPINNED (no bedtools run), this is the structural pin."""
+    names, lens, rows = _hg002_fixture(golden_dir)
+    _panel_invariants(lens, rows)
+    assert min(b - a for _c, a, b in rows) == 209_966 and sum(1 for c, a, b in rows if a == 200_000) == 35
+    for seed in range(8):
+        rng = np.random.default_rng(700 + seed)
+        def draw(k, lo, hi):
+            out = []
+            for _ in range(k):
+                c = int(rng.integers(0, len(lens)))
+                a = int(rng.integers(0, lens[c]))
+                out.append((c, a, min(int(lens[c]), a + int(rng.integers(lo, hi)))))
+            return np.array(out, cornetto_amd.IVL_DT).reshape(-1)
+        fun, lowq = draw(int(rng.integers(50, 600)), 30_000, 400_000), draw(int(rng.integers(0, 300)), 1, 40_000)
+        got = cornetto_amd.panel_boring(lens, fun, lowq)
+        _panel_invariants(lens, [(int(r["ctg"]), int(r["start"]), int(r["finish"])) for r in got])
+        assert np.array_equal(_p2o(got), ob.panel_boring(lens, _p2o(fun), _p2o(lowq)))
+
+
+def test_panel_reproduces_the_reference_held_bedtools_output(golden_dir):
+    """Solved backwards: the fun blocks are the complement of in.boringbits.bed inside every contig; an inner block (e, s) is what
+    one fun row [e + 40000, s - 40000) becomes after step 5's +-40 kb; the block at a contig's start / end is the 200 kb edge
+    merged with a row that reaches it within 200 kb.  Fed with those rows, steps 4-9 must give the reference's file exactly."""
+    names, lens, rows = _hg002_fixture(golden_dir)
+    by_ctg = {}
+    for c, a, b in rows:
+        by_ctg.setdefault(c, []).append((a, b))
+    fun = []
+    for c, L in enumerate(lens.tolist()):
+        if L < 800_000:
+            continue
+        v = by_ctg.get(c, [])
+        if not v:                                         # (one contig of the fixture: everything is fun)
+            fun.append((c, 240_000, L - 240_000))
+            continue
+        for (_a, e), (s, _b) in zip(v, v[1:]):            # inner blocks
+            assert s - e >= 80_000 + 1
+            fun.append((c, e + 40_000, s - 40_000))
+        S, E = v[0][0], v[-1][1]
+        if S > 200_000:                                   # left edge grown to S
+            fun.append((c, 240_000 if S - 40_000 > 240_000 else S - 41_000, S - 40_000))
+        if E < L - 200_000:                               # right edge grown down to E
+            fun.append((c, E + 40_000, L - 240_000 if L - 240_000 > E + 40_000 else E + 41_000))
+    fun = np.array(sorted(fun), cornetto_amd.IVL_DT)
+    got = cornetto_amd.panel_boring(lens, fun, np.zeros(0, cornetto_amd.IVL_DT))
+    assert [(int(r["ctg"]), int(r["start"]), int(r["finish"])) for r in got] == rows
+    assert np.array_equal(_p2o(got), ob.panel_boring(lens, _p2o(fun), np.zeros(0, ob.SPAN_DT)))
+
+
 def _bed(golden_dir, name):
     import os
     rows = [l.split("\t") for l in open(os.path.join(golden_dir, "bedtools", name)).read().splitlines() if l]

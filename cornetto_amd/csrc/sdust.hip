@@ -1548,6 +1548,21 @@ __global__ void sdust_gather(const uint2 *in, const uint32_t *cnt, const uint32_
     for (uint32_t i = 0; i < n; ++i) d[i] = cornetto_ivl_t{ctg, (int32_t)src[i].x, (int32_t)src[i].y};
 }
 
+// one sample per 2048 bases of every contig (blockIdx.y = contig): how many lie inside a repeat array (sd_sample_heavy)
+__global__ void sd_sample_count(const uint8_t *bases, const int64_t *ctg_off, const int32_t *ctg_len, unsigned long long *count)
+{
+    const int c = blockIdx.y;
+    const int len = ctg_len[c];
+    const uint8_t *seq = bases + ctg_off[c];
+    unsigned n = 0;
+    for (long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x; s * 2048 + 64 <= len; s += (long long)gridDim.x * blockDim.x)
+        n += sd_sample_heavy(SdChunk{c, (int32_t)(s * 2048), (int32_t)std::min<long long>(len, s * 2048 + 2048)}, seq);
+    const unsigned long long m = sd_ballot(n != 0);
+    (void)m;
+    for (int d = 32; d > 0; d >>= 1) n += __shfl_down(n, d);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(count, (unsigned long long)n);
+}
+
 int env_int(const char *name, int dflt)
 {
     const char *s = getenv(name);
@@ -1637,7 +1652,33 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
     // at least 256 bases (the look-back of a chunk stays inside the chunk before it), at most 62 tiles.  CORNETTO_SDUST_SIFT=0 keeps the
     // per-lane recurrence of sdust_w64 for everything (also what an explicit chunk size outside that range does: the tests
     // with tiny chunks stress exactly that kernel).
-    bool sift_on = w64_path && env_int("CORNETTO_SDUST_SIFT", 1) != 0;
+    // Which one is faster depends on the sequence: on the uniform bench assembly both take 7 ms alone, but the resident waves of sdust_w64
+    // leave more room to a second stream (9.6 against 10.2 ms per bench step); with 3 % of the bases in satellite arrays the step
+    // takes 39.5 against 21 ms.  CORNETTO_SDUST_SIFT unset: decided once per resident assembly from one 64-byte sample per 2048
+    // bases (sift when at least 1 in 256 lies inside a repeat array — the rule that used to switch sdust_dense on; read-level sets
+    // of more than 4096 records: sift); 1 / 0 force one or the other.
+    const int sift_env = env_int("CORNETTO_SDUST_SIFT", -1);
+    if (w64_path && sift_env < 0 && a->sd_auto < 0) {
+        if (a->n > 4096 || a->total < 65536) {
+            a->sd_auto = 1;
+        } else {
+            unsigned long long *d_cnt8 = (unsigned long long *)cn_ws(h, WS_SD_STATS, 2048 + 64 * 64);
+            unsigned long long *p_cnt8 = (unsigned long long *)cn_pin(h, PIN_SMALL, 2048);
+            if (!d_cnt8 || !p_cnt8) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
+            CN_HIP(h, hipMemsetAsync(d_cnt8, 0, 8, h->stream));
+            int32_t maxlen = 0;
+            for (int32_t c = 0; c < a->n; ++c) maxlen = std::max(maxlen, a->len[c]);
+            const unsigned bx = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, (maxlen / 2048 + 255) / 256));
+            sd_sample_count<<<dim3(bx, (unsigned)a->n), dim3(256), 0, h->stream>>>(a->d_bases, a->d_off, a->d_len, d_cnt8);
+            CN_HIP(h, hipGetLastError());
+            CN_HIP(h, hipMemcpyAsync(p_cnt8 + 220, d_cnt8, 8, hipMemcpyDeviceToHost, h->stream));
+            CN_HIP(h, hipStreamSynchronize(h->stream));
+            const int64_t samples = a->total / 2048, heavy = (int64_t)p_cnt8[220];
+            a->sd_auto = heavy * 256 >= std::max<int64_t>(samples, 1) && heavy >= 64 ? 1 : 0;
+            if (trace) fprintf(stderr, "[sdust trace] %lld of %lld samples inside repeat arrays: %s\n", (long long)heavy, (long long)samples, a->sd_auto ? "sift / resolve" : "per-lane recurrence");
+        }
+    }
+    bool sift_on = w64_path && (sift_env > 0 || (sift_env < 0 && a->sd_auto == 1));
     // (its own default: 1536 bases = 26 tiles with the two in front; 7.2 KB of LDS per wave = six 1280-byte granules, 21 waves per
     // CU; 1792 needs a seventh granule: measured 6.85 against 7.2 ms on the 3.16 Gbp assembly)
     if (sift_on && env_int("CORNETTO_SDUST_CHUNK", 0) <= 0) chunk = 1536;
@@ -1734,7 +1775,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
         const SdChunk *d_chunks = reinterpret_cast<const SdChunk *>(a->d_sd_chunks);
         // per chunk: count (4 B) + ordered offset (4 B) + scan partials; then {total u64, ovf u32}
         uint32_t *d_cnt = (uint32_t *)cn_ws(h, WS_SD_CNT, nc * 8 + ((nc + 4095) / 4096 + 1) * 4);
-        unsigned long long *d_tot = (unsigned long long *)cn_ws(h, WS_SD_STATS, 2048);   // [0] total [1] overflow | table request [2..6] stats [7] flagged [8] queue
+        unsigned long long *d_tot = (unsigned long long *)cn_ws(h, WS_SD_STATS, 2048 + 64 * 64);   // (+ the chunk counters of sd_sift)   // [0] total [1] overflow | table request [2..6] stats [7] flagged [8] queue
         unsigned long long *p_tot = (unsigned long long *)cn_pin(h, PIN_SMALL, 2048);
         if (!d_cnt || !d_tot || !p_tot) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
         uint32_t *d_off = d_cnt + nc, *d_part = d_off + nc;
@@ -1748,7 +1789,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
         for (int attempt = 0; attempt < 4; ++attempt) {
             d_out = (uint2 *)cn_ws(h, WS_SD_OUT, nc * cap * sizeof(uint2));
             if (!d_out) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation of %zu bytes failed", nc * cap * sizeof(uint2));
-            CN_HIP(h, hipMemsetAsync(d_tot, 0, 2048, h->stream));
+            CN_HIP(h, hipMemsetAsync(d_tot, 0, 2048 + 64 * 64, h->stream));
             // P slot rows: one per resident lane (sdust_w64) / unused by the older kernels
             uint32_t *d_slots = (uint32_t *)cn_ws(h, WS_SD_OFF, (size_t)(std::max<int64_t>(sd_waves, 1) + SD_WPB) * 64 * 64 * sizeof(uint32_t));
             if (!d_slots) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
@@ -1772,13 +1813,13 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                 const uint32_t lds_wave = sift_lds_bytes(reg_cap);
                 int lmin = 1;
                 while (5 * (lmin + 1) <= T && lmin < 16) ++lmin;
-                SiftArgs S{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, lds_wave, reg_cap, reinterpret_cast<uint32_t *>(d_tot + 210), T / 10 + 1, lmin, env_int("CORNETTO_SIFT_ABL", 0)};
+                SiftArgs S{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, lds_wave, reg_cap, reinterpret_cast<uint32_t *>(d_tot + 256), T / 10 + 1, lmin, env_int("CORNETTO_SIFT_ABL", 0)};
                 SdArgs R = A;
                 R.stats = want_stats ? d_tot + 200 : nullptr;
                 // Resident waves: as many workgroups as the chip holds at once (LDS is handed out in 1280-byte granules), a share of them
                 // when another stream computes beside this one (cornetto_accel_set_share): a launch of one workgroup per chunk keeps
                 // the other stream's kernels waiting until it is through (13.1 instead of 9 ms per bench step).  The waves take their
-                // chunks from one counter (static strides were measured 10-50 % slower: chunks differ a lot in cost).
+                // chunks from one counter (static strides were measured 10-50 % slower: chunks differ a lot in cost; 64 counters: one was a 14 ns serial point).
                 if (h->sift_per_cu == 0) {
                     int per_cu = 0;
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sd_sift<false>, 64 * SIFT_WPB, lds_wave * SIFT_WPB) != hipSuccess || per_cu < 1) per_cu = 8;

@@ -118,10 +118,17 @@ SDUST_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dense", ["2", "0"])
+@pytest.mark.parametrize("dense", ["2", "0", "sift"])
 @pytest.mark.parametrize("chunk", ["0", "16", "100", "256", "1000", "2048", "4096"])
 @pytest.mark.parametrize("fa,T,W,exp", SDUST_CASES)
 def test_sdust_golden(acc, golden_dir, monkeypatch, fa, T, W, exp, chunk, dense):
+    """dense = "sift": the sift / resolve stages (chunk sizes they do not take fall back to the per-lane kernel by themselves);
+    "2" / "0": the per-lane recurrence with / without its kernel for repeat arrays"""
+    monkeypatch.setenv("CORNETTO_SDUST_SIFT", "1" if dense == "sift" else "0")
+    _sdust_golden(acc, golden_dir, monkeypatch, fa, T, W, exp, chunk, "1" if dense == "sift" else dense)
+
+
+def _sdust_golden(acc, golden_dir, monkeypatch, fa, T, W, exp, chunk, dense):
     """chunk = bases per lane (0 = default heuristic); tiny chunks stress the speculative warm-up.  dense = 2: the chunks
     sampled as low-complexity always go to the per-lane kernel (sdust_dense) beside the main one (the default, 1, does that
     only when there are many of them), 0: everything to the main kernel"""
@@ -345,6 +352,7 @@ def test_sdust_sift_vs_oracle(acc, monkeypatch, T, W, chunk, kind):
     """the sift / resolve stages (sdust_sift.hpp) on sequences of many chunks: chunk borders inside repeat arrays, contigs that
     end inside an array, contigs shorter than a tile, chunks handed to the sequential kernel beside chunks that are not"""
     monkeypatch.setenv("CORNETTO_SDUST_CHUNK", chunk)
+    monkeypatch.setenv("CORNETTO_SDUST_SIFT", "1")
     rng = np.random.default_rng(4242 + T * 131 + W + int(chunk) + kind)
     seqs = [_sift_stress_seq(rng, n, kind) for n in (150_000, 70_001, 4097, 1792, 1793, 257, 256, 255, 130, 65, 64, 63, 5, 3, 2, 1, 0, 30_000)]
     seqs.append(np.tile(np.frombuffer(b"A", dtype=np.uint8), 5000))
@@ -366,11 +374,33 @@ def test_sdust_sift_off_equals_on(acc, monkeypatch):
     rng = np.random.default_rng(77)
     seqs = [_sift_stress_seq(rng, 400_000, 1), _sift_stress_seq(rng, 90_000, 0)]
     asm = acc.asm_upload(seqs)
+    monkeypatch.setenv("CORNETTO_SDUST_SIFT", "1")
     on = acc.sdust(asm, 20, 64)
     monkeypatch.setenv("CORNETTO_SDUST_SIFT", "0")
     off = acc.sdust(asm, 20, 64)
     asm.close()
     assert len(on) > 200 and np.array_equal(on, off)
+
+
+def test_sdust_kernel_family_is_chosen_by_the_sequence(acc, monkeypatch):
+    """CORNETTO_SDUST_SIFT unset: one 64-byte sample per 2048 bases decides once per resident assembly — sift / resolve when at least
+    1 sample in 256 lies inside a repeat array, the per-lane recurrence otherwise; the intervals are the same either way"""
+    monkeypatch.delenv("CORNETTO_SDUST_SIFT", raising=False)
+    monkeypatch.delenv("CORNETTO_SDUST_CHUNK", raising=False)
+    rng = np.random.default_rng(5)
+    plain = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=1_000_000)].copy()
+    rich = plain.copy()
+    rich[200_000:400_000] = np.tile(np.frombuffer(b"CATTC", dtype=np.uint8), 40_000)        # (97 of 488 samples; at least 64 are asked for)
+    acc.set_timing(2)
+    for seq, sift in ((plain, False), (rich, True)):
+        asm = acc.asm_upload([seq])
+        iv = acc.sdust(asm, 20, 64)
+        names = {n for n, _ in acc.last_timing()}
+        assert ("sdust_prep" not in names) == sift, names          # (only the per-lane kernel plans its queue)
+        iv2 = acc.sdust(asm, 20, 64)
+        asm.close()
+        assert np.array_equal(iv, iv2)
+        assert [(int(x["start"]), int(x["finish"])) for x in iv] == [(int(r) >> 32, int(r) & 0xFFFFFFFF) for r in ob.sdust(seq, 20, 64)]
 
 
 def test_sdust_largest_window_on_homopolymers(acc):

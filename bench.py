@@ -37,8 +37,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
-SQ_FILE = os.path.join("profiles", "r03_sq_sd_sift.json")
+PMC_FILE = os.path.join("profiles", "r03_pmc_traffic_%s.json")      # % kernel symbol
+SQ_FILE = os.path.join("profiles", "r03_sq_%s.json")
 
 
 def contig_lengths(total_target):
@@ -1158,23 +1158,26 @@ def main():
         value = R.job_bases / (elapsed / args.steps) / 1e9
         kavg, alg, kern = kernel_table(R, serial, n_bases)
         dom = "sdust_kernel"
+        # which kernel family the library chose for this assembly (CORNETTO_SDUST_SIFT unset: by a sample of the bases)
+        st0 = R.acc2.sdust_stats(R.asm2, 20, 64)
+        symbol = "sd_sift" if st0 and st0.get("kernel") == "sd_sift" else "sdust_w64"
         ach = alg[dom] / (kavg[dom] * 1e-3) / 1e9 if kavg.get(dom, 0) > 0 else 0.0
         # HBM/fabric bytes per launch of the dominant kernel and its instruction mix: NOT measured in this run — taken from the
         # committed rocprofv3 PMC passes of this workload (profiles/README.md), scaled to the bases of this run
         traffic, traffic_source, issue = None, None, None
-        for cand in (PMC_FILE, os.path.join("profiles", "r02_pmc_traffic.json")):
+        for cand in (PMC_FILE % symbol, os.path.join("profiles", "r02_pmc_traffic.json")):
             try:
                 pmcs = json.load(open(os.path.join(ROOT, cand)))
-                pmc = pmcs.get("sd_sift") or pmcs["sdust_w64"]
+                pmc = pmcs.get(symbol) or pmcs["sdust_w64"]
                 traffic, traffic_source = round(pmc["hbm_bytes"] / pmc["bases"] * n_bases, 0), cand
                 break
             except Exception:
                 continue
         try:
-            sq = json.load(open(os.path.join(ROOT, SQ_FILE)))
+            sq = json.load(open(os.path.join(ROOT, SQ_FILE % symbol)))
             pl = sq["per_launch"]
             issue = {"valu_insts": pl["SQ_INSTS_VALU"], "salu_insts": pl["SQ_INSTS_SALU"], "lds_insts": pl["SQ_INSTS_LDS"],
-                     "valu_busy": sq.get("valu_busy_of_kernel_time"), "per_64_bases": sq.get("per_tile"), "source": SQ_FILE,
+                     "valu_busy": sq.get("valu_busy_of_kernel_time"), "per_64_bases": sq.get("per_64_bases"), "source": SQ_FILE % symbol,
                      "note": "a wave-64 vector instruction holds its SIMD's ALU for 4 cycles: valu_busy = 4 x SQ_INSTS_VALU / (SIMDs x cycles of the kernel); "
                              "not measured in this run: the committed rocprofv3 --pmc passes of the same workload"}
         except Exception:
@@ -1194,9 +1197,9 @@ def main():
                        "parallelism": "contig-sharded (%s), %d process(es), 1 GPU each; per GPU %s" % (
                            "LPT over the contigs of one assembly" if args.scaling == "strong" else "one assembly per rank", world,
                            "2 HIP streams (sdust || telofind+coverage)" if nst == 2 else "stages serial on one stream")},
-            "roofline": {"bound": "valu-issue", "kernel": dom, "kernel_symbol": "sd_sift", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "valu-issue", "kernel": dom, "kernel_symbol": symbol, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source, "issue": issue,
-                         "note": "sdust is integer work per base, bound by instruction issue, not by HBM (profiles/r03_sq_sd_sift.json); achieved / peak / frac are "
+                         "note": "sdust is integer work per base, bound by instruction issue, not by HBM (profiles/r03_sq_<kernel>.json); achieved / peak / frac are "
                                  "against the HBM roofline as the contract asks (1 B/base algorithmic). traffic and issue are not measured in this run: "
                                  "the committed rocprofv3 PMC figures scaled by bases"},
             "kernels": kern,

@@ -544,6 +544,16 @@ __global__ __launch_bounds__(64) void sdust_kernel_g(SdArgs A, uint8_t *g_ring, 
 #ifndef SD_EQT
 #define SD_EQT 1
 #endif
+// Lanes of ONE wave hand data to each other through LDS (the equal-word tables) and through global memory (P slots): the
+// hardware executes a wave's memory instructions in order, and this keeps the COMPILER from reordering them — release / acquire
+// fences at wavefront scope around a wave barrier.  No instruction comes out of it (checked in the ISA: the s_waitcnt the
+// surrounding loads and stores need anyway are all there is).
+#define SD_LDS_ORDER()                                                \
+    do {                                                              \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        \
+        __builtin_amdgcn_wave_barrier();                              \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");        \
+    } while (0)
 struct SdLds64 {
     uint32_t cw[16][64];       // [3-mer >> 2][lane]: four byte counters (3-mer & 3) = copies of the 3-mer in the window
     uint8_t ring[64][64];      // [lane][(absolute word index & 63) ^ swizzle(lane)]: lanes in phase fall on distinct banks, counted in 32 banks per half wave or in 64
@@ -958,6 +968,7 @@ __global__ __launch_bounds__(64 * SD_WPB, STATS ? 4 : 5) void sdust_w64(SdArgs A
         // acknowledged by L2, where the sc1 loads look, before a slot is read — waited for here, in front of the load, so
         // that the store itself does not hold the wave up.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SD_LDS_ORDER();
         const uint32_t sl = __hip_atomic_load(&A.slots[(wave_id * 64 + lane) * 64 + (minstart & 63)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (nowk >= A.chunks[cid].start - ubase && nowk < SD_NRUN) emit(minstart, minstart + (int)(sl >> 24) + 3);
         const int gone = start - minstart;           // starts minstart .. start-1 leave the window
@@ -1222,15 +1233,15 @@ __global__ __launch_bounds__(64 * SD_WPB, STATS ? 4 : 5) void sdust_w64(SdArgs A
 #if SD_EQT
                   uint32_t *const te = &S.eqt[wj];
                   (void)__hip_atomic_fetch_or(te, inwin ? bit_lo : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                  __builtin_amdgcn_wave_barrier();
+                  SD_LDS_ORDER();
                   const uint32_t eq_lo = __hip_atomic_load(te, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                  __builtin_amdgcn_wave_barrier();
+                  SD_LDS_ORDER();
                   __hip_atomic_store(te, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                  __builtin_amdgcn_wave_barrier();
+                  SD_LDS_ORDER();
                   (void)__hip_atomic_fetch_or(te, inwin ? bit_hi : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                  __builtin_amdgcn_wave_barrier();
+                  SD_LDS_ORDER();
                   const uint32_t eq_hi = __hip_atomic_load(te, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                  __builtin_amdgcn_wave_barrier();
+                  SD_LDS_ORDER();
                   __hip_atomic_store(te, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #else
                   // one ballot per bit of the word, kept as two 32-bit halves (per bit: sign-extended bit, compare, two 3-input logic ops)
@@ -1277,6 +1288,7 @@ __global__ __launch_bounds__(64 * SD_WPB, STATS ? 4 : 5) void sdust_w64(SdArgs A
                   const int sidx = (o_start + j) & 63;
                   const bool has_e = inwin && ((o_occ >> sidx) & 1ull);
                   if (o_occ) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (see save_evict)
+                  SD_LDS_ORDER();
                   const uint32_t e = has_e ? __hip_atomic_load(&orow[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                   // Ratios r / l are compared through key = floor(r * 2^13 / l) (sd_ratio_key): exact for l <= 64.  All that
                   // :113-118 need of P is, for every start, the best ratio among the entries with a start at or after it.
@@ -1292,7 +1304,8 @@ __global__ __launch_bounds__(64 * SD_WPB, STATS ? 4 : 5) void sdust_w64(SdArgs A
                   const uint32_t sk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)xs, 0x138, 0xF, 0xF, true);
                   const uint32_t km = sk > key_e ? sk : key_e;                       // :113-117: entries with start >= i + start
                   const bool ins = cand && key_c >= km;                              // :118
-                  if (ins) orow[sidx] = key_c | ((uint32_t)new_l << 24);             // start = i + start, finish = start + l + 3
+                  if (ins) __hip_atomic_store(&orow[sidx], key_c | ((uint32_t)new_l << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // start = i + start, finish = start + l + 3
+                  SD_LDS_ORDER();
                   // The entry is read back by OTHER lanes (the owner in save_masked_regions, lane j' of a later find_perfect):
                   // the store must have reached L2, where their sc1 loads look, before any of them reads — they wait (vmcnt(0)) in
                   // front of their loads.

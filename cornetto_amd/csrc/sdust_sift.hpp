@@ -60,12 +60,6 @@ constexpr int SIFT_LS = 15;      // L2 walks the suffixes with l <= SIFT_LS
 constexpr int SIFT_FIXED = 1024 + 512 + 2048;
 __host__ __device__ constexpr uint32_t sift_lds_bytes(uint32_t cap) { return (SIFT_FIXED + cap / 8 + 2 * (SIFT_PAD + cap) + 15) / 16 * 16; }
 
-#define SD_LDS_ORDER()                                                \
-    do {                                                              \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        \
-        __builtin_amdgcn_wave_barrier();                              \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");        \
-    } while (0)
 
 // four bytes -> four codes: bits 0-1 the base (A0 C1 G2 T3), bit 2 set for anything that is not A/C/G/T/a/c/g/t
 __device__ __forceinline__ uint32_t sd_codes4(uint32_t word)

@@ -158,6 +158,46 @@ def test_large_piece_many_reads(acc):
 
 
 # ---- through the CLI: `cornetto sdust reads.fastq` frames the records on the device ---------------------------------
+def test_config5_generator_100_mbases_vs_oracle(acc, monkeypatch):
+    """BASELINE config 5 at 100 Mbases: the SURVEY 8d generator (bench.make_fastq_piece: log-normal lengths 200 .. 200 000, every
+    fourth read with a homopolymer stretch) -> cornetto_fastq_split with the length test of `seq -m 10000` (src/seq.c:120) ->
+    sdust per kept read; the oracle frames the same text (kseq restatement), filters by length and runs sdust read by read"""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from concurrent.futures import ThreadPoolExecutor
+    monkeypatch.delenv("CORNETTO_SDUST_SIFT", raising=False)
+    text_d, lens, off = bench.make_fastq_piece(torch, torch.device("cuda", 0), 100e6, 77)
+    text = text_d.cpu().numpy()
+    del text_d
+    assert lens.min() >= 200 and lens.max() <= 200_000 and 95e6 < lens.sum() < 105e6
+    recs, used, plain, reads = acc.fastq_split(text, final=True, min_len=10000, want_reads=True)
+    assert plain and used == text.size and len(recs) == len(lens) and np.array_equal(recs["len"], lens.astype(np.int32))
+    assert np.array_equal(recs["keep"] == 1, lens >= 10000)
+    iv = acc.sdust(reads, 20, 64)
+    reads.close()
+    kept = np.nonzero(lens >= 10000)[0]
+    hl = len(bench.FQ_HEAD % (0, 0))
+    ob.lib()
+
+    def one(i):
+        a = int(off[i]) + hl
+        return np.asarray(ob.sdust(text[a:a + int(lens[i])], 20, 64), dtype=np.uint64)
+
+    with ThreadPoolExecutor(max(1, min(16, (os.cpu_count() or 2) - 1))) as ex:
+        exp = list(ex.map(one, kept.tolist()))
+    got_c = iv["ctg"].astype(np.int64)
+    got = (iv["start"].astype(np.uint64) << np.uint64(32)) | iv["finish"].astype(np.uint32).astype(np.uint64)
+    assert len(got) == sum(len(e) for e in exp) and len(got) > len(kept) // 8
+    assert np.array_equal(got, np.concatenate(exp))
+    assert np.array_equal(got_c, np.concatenate([np.full(len(e), k, dtype=np.int64) for k, e in enumerate(exp)]))
+    # the framing itself against the oracle's kseq restatement, on the first 5 MB
+    cut = int(off[np.searchsorted(off, 5_000_000)])
+    ex_recs, rc = ob.fastx_parse(text[:cut])
+    assert rc == -1 and [len(r[2]) for r in ex_recs] == lens[:len(ex_recs)].tolist()
+
+
 def run_cli(args, env=None, data=None):
     import subprocess
     import cornetto_amd

@@ -218,13 +218,43 @@ def test_offsets_beyond_2_pow_32():
         del w
 
 
-@pytest.mark.parametrize("dense", ["2", "0"])
+def test_satellite_dense_1gbp_through_the_sift_stages(monkeypatch):
+    """bench.py --profile satellite at 1 Gbp, the kernel family chosen from the sample of the bases (sift / resolve: 3 % of them
+    lie in satellite arrays): canonical result, two calls equal, and the four smallest of the contigs that hold arrays — each
+    of 12 Mb or more, arrays of 0.1-5 Mb — record for record against the oracle"""
+    import bench
+    monkeypatch.delenv("CORNETTO_SDUST_SIFT", raising=False)
+    monkeypatch.delenv("CORNETTO_SDUST_CHUNK", raising=False)
+    lens = bench.contig_lengths(1_000_000_000)
+    w = _make(lens, 0xC0FFEE, "satellite", coverage=False)
+    try:
+        acc, asm = w["acc"], w["asm"]
+        acc.set_timing(2)
+        ivls = acc.sdust(asm, 20, 64)
+        assert "sdust_prep" not in {n for n, _ in acc.last_timing()}          # (the per-lane kernel would have planned its queue)
+        again = acc.sdust(asm, 20, 64)
+        assert np.array_equal(ivls, again)
+        masked = int((ivls["finish"].astype(np.int64) - ivls["start"]).sum())
+        assert masked > 0.03 * sum(lens)
+        c, st, fi = ivls["ctg"].astype(np.int64), ivls["start"].astype(np.int64), ivls["finish"].astype(np.int64)
+        same = c[1:] == c[:-1]
+        assert np.all(np.diff(c) >= 0) and np.all(st[1:][same] > fi[:-1][same]) and np.all(fi > st)
+        big = sorted([i for i in range(len(lens)) if lens[i] >= 12_000_000], key=lambda i: lens[i])[:4]
+        assert big
+        thr = acc.telowin_threshold(0.4, 99.9)
+        _compare_contigs(w, big, None, None, ivls, thr, stages=("sdust",))
+    finally:
+        _close(w)
+
+
+@pytest.mark.parametrize("dense", ["2", "0", "sift"])
 def test_satellite_dense_assembly_equals_the_oracle(monkeypatch, dense):
     """bench.py --profile satellite at 30 Mb: (CATTC)n / (GGAAT)n arrays over > 3 % of the bases, microsatellites,
     poly-A runs — thousands of consecutive low-complexity chunks: through sdust_dense beside the main kernel (2; the default
     takes that route from 1024 such chunks on) and through the main kernel's queue alone (0)"""
     import bench
-    monkeypatch.setenv("CORNETTO_SDUST_DENSE", dense)
+    monkeypatch.setenv("CORNETTO_SDUST_SIFT", "1" if dense == "sift" else "0")
+    monkeypatch.setenv("CORNETTO_SDUST_DENSE", "1" if dense == "sift" else dense)
     monkeypatch.setenv("CORNETTO_SDUST_DENSE_SPLIT", "3")     # the flagged chunks cut in three on the first call (off by default)
     lens = bench.contig_lengths(30_000_000)
     w = _make(lens, 5, "satellite", coverage=False)

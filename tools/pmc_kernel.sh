@@ -1,25 +1,28 @@
 #!/bin/bash
-# SQ counters of one kernel of the sdust call (separate rocprofv3 --pmc passes, no other tracing):
-#   bash tools/pmc_kernel.sh <tag> <kernel name substring> [mbases] [profile]     -> gpurun_out/<tag>_sq_<substring>.json
+# SQ counters and HBM traffic of one kernel of the sdust call (separate rocprofv3 --pmc passes, no other tracing):
+#   bash tools/pmc_kernel.sh <tag> <kernel name substring> [mbases] [profile] [CORNETTO_SDUST_SIFT value]
+#   -> gpurun_out/<tag>_sq_<substring>.json, gpurun_out/<tag>_pmc_traffic_<substring>.json      (copy them to profiles/)
 TAG=${1:-r03}
 KERN=${2:-sd_sift}
 MB=${3:-3160}
 PROFILE=${4:-uniform}
+export CORNETTO_SDUST_SIFT=${5:-1}
 R=$PWD
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-PROBE="python3 $R/tools/perf_probe.py sdust --mbases $MB --features 1 --reps 1 --profile $PROFILE"
-CORNETTO_SDUST_STATS=1 $PROBE 2> $R/gpurun_out/${TAG}_stats.txt > /dev/null
+PROBE="python3 $R/tools/perf_probe.py sdust --mbases $MB --features 1 --reps 2 --profile $PROFILE"
+CORNETTO_SDUST_STATS=1 $PROBE 2> $R/gpurun_out/${TAG}_stats.txt > $R/gpurun_out/${TAG}_probe.txt
 i=0
-for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM" "SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_WAVES" "GRBM_GUI_ACTIVE" "SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_MEM_VIOLATIONS SQ_LDS_ATOMIC_RETURN"; do
+for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM" "SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_WAVES" "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   rm -rf $R/gpurun_out/pmck_${TAG}_s$i
   timeout 300 rocprofv3 --pmc $set -d $R/gpurun_out/pmck_${TAG}_s$i --output-format csv -- $PROBE > $R/gpurun_out/pmck_${TAG}_s$i.log 2>&1
 done
 cd $R
-python3 - "$TAG" "$KERN" "$MB" "$PROFILE" <<'PY'
-import collections, csv, glob, json, sys, re
-tag, kern, mb, profile = sys.argv[1:5]
+python3 - "$TAG" "$KERN" "$MB" "$PROFILE" "$CORNETTO_SDUST_SIFT" <<'PY'
+import collections, csv, glob, json, sys, re, os
+sys.path.insert(0, os.getcwd())
+tag, kern, mb, profile, sift = sys.argv[1:6]
 agg, n = collections.defaultdict(float), collections.defaultdict(set)
 for f in glob.glob("gpurun_out/pmck_%s_s*/**/*_counter_collection.csv" % tag, recursive=True):
     for r in csv.DictReader(open(f)):
@@ -27,15 +30,33 @@ for f in glob.glob("gpurun_out/pmck_%s_s*/**/*_counter_collection.csv" % tag, re
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
             n[r["Counter_Name"]].add((f, r["Dispatch_Id"]))
 per = {k: v / max(1, len(n[k])) for k, v in agg.items()}
+import bench
+bases = sum(bench.contig_lengths(int(float(mb) * 1e6)))
 stats = open("gpurun_out/%s_stats.txt" % tag).read()
-m = re.search(r"sift: tiles (\d+)", stats)
-tiles = int(m.group(1)) if m else 0
-out = {"workload": "tools/perf_probe.py sdust --mbases %s --features 1 --profile %s (sdust alone on the chip)" % (mb, profile), "kernel": kern,
-       "stats_line": [l for l in stats.splitlines() if "sift:" in l][:1], "tiles": tiles, "per_launch": per,
-       "per_tile": {k: round(v / tiles, 2) for k, v in per.items() if tiles and (k.startswith("SQ_INSTS") or k in ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS"))}}
-if per.get("SQ_BUSY_CYCLES") and per.get("SQ_ACTIVE_INST_VALU"):
-    out["valu_busy"] = round(4 * per["SQ_ACTIVE_INST_VALU"] / (per["SQ_BUSY_CYCLES"] * 4), 4)
+probe = open("gpurun_out/%s_probe.txt" % tag).read()
+m = re.findall(r"\('sdust_kernel', ([0-9.]+)\)", probe)
+kernel_ms = float(m[-1]) if m else None
+units = bases / 64.0
+out = {"workload": "tools/perf_probe.py sdust --mbases %s --features 1 --profile %s, CORNETTO_SDUST_SIFT=%s (sdust alone on the chip)" % (mb, profile, sift), "kernel": kern,
+       "stats_line": [l for l in stats.splitlines() if "sift:" in l or "wave-steps" in l][:2], "bases": bases, "kernel_ms": kernel_ms, "per_launch": per,
+       "per_64_bases": {k: round(v / units, 2) for k, v in per.items() if k.startswith("SQ_INSTS") or k in ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS")}}
+if kernel_ms and per.get("SQ_INSTS_VALU"):
+    # 1024 SIMDs; a wave-64 vector instruction holds its SIMD's ALU for 4 cycles; the kernel's cycles from GRBM_GUI_ACTIVE (summed over 8 XCDs)
+    cyc = per.get("GRBM_GUI_ACTIVE", 0) / 8.0
+    if cyc:
+        out["valu_busy_of_kernel_time"] = round(4 * per["SQ_INSTS_VALU"] / (1024 * cyc), 4)
+        out["clock_GHz_from_counters"] = round(cyc / (kernel_ms * 1e-3) / 1e9, 3)
 json.dump(out, open("gpurun_out/%s_sq_%s.json" % (tag, kern), "w"), indent=1)
-print(json.dumps(out, indent=1))
+f, w = per.get("FETCH_SIZE"), per.get("WRITE_SIZE")
+if f is not None and w is not None:
+    # FETCH_SIZE / WRITE_SIZE count kilobytes; on gfx950 a coalesced stream is counted at half its bytes (profiles/r02_pmc_traffic.json:
+    # tools/ubench/fetch_calib measured 2.000), the per-lane 32-byte requests of sdust_w64 at 1 / 1.68
+    scale = 2.0 if kern == "sd_sift" else 1.68
+    tr = {kern: {"bases": bases, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "fetch_scale_used": scale, "fetch_bytes": f * 1024 * scale, "write_bytes": w * 1024,
+                 "hbm_bytes": f * 1024 * scale + w * 1024, "bytes_per_base": round((f * 1024 * scale + w * 1024) / bases, 4)},
+          "workload": out["workload"], "calibration_note": "profiles/r02_pmc_traffic.json holds the calibration runs (tools/ubench/fetch_calib)"}
+    json.dump(tr, open("gpurun_out/%s_pmc_traffic_%s.json" % (tag, kern), "w"), indent=1)
+    print(json.dumps(tr[kern]))
+print(json.dumps({k: out[k] for k in ("kernel_ms", "per_64_bases", "valu_busy_of_kernel_time", "clock_GHz_from_counters") if k in out}, indent=1))
 PY
 rm -rf gpurun_out/pmck_${TAG}_s*

@@ -232,6 +232,8 @@ struct cornetto_asm {
     int64_t sd_plan_key = -1, sd_plan_dense = 0;
     bool sd_refined = false;             // sdust: the flagged chunks of the table have been cut into shorter ones (or need not be)
     int64_t sd_tail0 = 0;                // sdust: first chunk of the part of the table that is made of short chunks
+    uint32_t *d_sd_walk = nullptr;       // sdust sift: [0] = n, [1 ..] the chunks that hold other bytes than letters (found by the first call: handed out first afterwards), then a byte per chunk
+    int64_t sd_walk_key = -1;            //   chunk table it belongs to; -1: none yet
     int sd_auto = -1;                    // sdust: which kernel family takes this assembly (-1 not decided, 0 the per-lane recurrence, 1 sift / resolve)
     int64_t sd_flagged = -1;             // sdust: chunks of this table that sd_prep samples as low-complexity (-1: not known yet)
     // sdust: per-256-base-block word-emission prefix table, built only if a lane needs it (N-dense input)

@@ -185,6 +185,7 @@ void cornetto_asm_free(cornetto_accel_t *h, cornetto_asm_t *a)
     if (a->d_len) (void)hipFree(a->d_len);
     if (a->d_tf_tiles) (void)hipFree(a->d_tf_tiles);
     if (a->d_sd_chunks) (void)hipFree(a->d_sd_chunks);
+    if (a->d_sd_walk) (void)hipFree(a->d_sd_walk);
     if (a->d_sd_plan) (void)hipFree(a->d_sd_plan);
     if (a->d_wtab) (void)hipFree(a->d_wtab);
     if (a->d_wtab_base) (void)hipFree(a->d_wtab_base);

@@ -1576,6 +1576,16 @@ __global__ void sd_sample_count(const uint8_t *bases, const int64_t *ctg_off, co
     if ((threadIdx.x & 63) == 0 && n) atomicAdd(count, (unsigned long long)n);
 }
 
+// order[] of sd_sift: the chunks of the walk list first, then the others as they come (rank = how many of the list lie in front)
+__global__ void sd_make_order(const uint32_t *walk, const uint32_t *iswalk, const uint32_t *rank, int32_t n_chunks, uint32_t *order)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_chunks) return;
+    const uint32_t nw = walk[0];
+    if ((uint32_t)k < nw) order[k] = walk[2 + k];
+    if (!iswalk[k]) order[nw + (uint32_t)k - rank[k]] = (uint32_t)k;
+}
+
 int env_int(const char *name, int dflt)
 {
     const char *s = getenv(name);
@@ -1669,10 +1679,12 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
     // leave more room to a second stream (9.6 against 10.2 ms per bench step); with 3 % of the bases in satellite arrays the step
     // takes 39.5 against 21 ms.  CORNETTO_SDUST_SIFT unset: decided once per resident assembly from one 64-byte sample per 2048
     // bases (sift when at least 1 in 256 lies inside a repeat array — the rule that used to switch sdust_dense on; read-level sets
-    // of more than 4096 records: sift); 1 / 0 force one or the other.
+    // of more than 4096 records and assemblies below 2 Gbases: sift); 1 / 0 force one or the other.
     const int sift_env = env_int("CORNETTO_SDUST_SIFT", -1);
     if (w64_path && sift_env < 0 && a->sd_auto < 0) {
-        if (a->n > 4096 || a->total < 65536) {
+        // (below ~2 Gbases the resident lanes of sdust_w64 have less than one chunk each and its time stops falling — one chunk is 4 ms
+        // of sequential steps for a lane: 395 Mb take 4.7 ms against 1.0 ms in sd_sift, whose unit of work is a wave)
+        if (a->n > 4096 || a->total < 2000000000ll) {
             a->sd_auto = 1;
         } else {
             unsigned long long *d_cnt8 = (unsigned long long *)cn_ws(h, WS_SD_STATS, 2048 + 64 * 64);
@@ -1811,6 +1823,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                      want_stats ? d_tot + 2 : nullptr, reinterpret_cast<uint32_t *>(d_tot + 1), d_slots, nullptr,
                      reinterpret_cast<uint32_t *>(d_tot + 8), nullptr, 0, env_int("CORNETTO_SDUST_RUNON", 1), (int32_t)chunk, a->d_wtab, a->d_wtab_base, reinterpret_cast<uint32_t *>(d_tot + 1) + 1};
             unsigned nb = (unsigned)((nc + 63) / 64);
+            bool sift_walk_pending = false;
             bool dense_pending = false;
             // (whatever path leaves this attempt — a failed launch, a failed allocation — the dense kernel on the second stream is
             // through before the workspaces it writes can be handed to anybody else)
@@ -1826,7 +1839,21 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                 const uint32_t lds_wave = sift_lds_bytes(reg_cap);
                 int lmin = 1;
                 while (5 * (lmin + 1) <= T && lmin < 16) ++lmin;
-                SiftArgs S{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, lds_wave, reg_cap, reinterpret_cast<uint32_t *>(d_tot + 256), T / 10 + 1, lmin, env_int("CORNETTO_SIFT_ABL", 0)};
+                // the chunks that are walked base by base, kept with the assembly's chunk table (see SiftArgs):
+                // [0] count [1] pad | list [nc] | flags [nc] | rank [nc] | order [nc] | scan partials
+                const bool walk_known = a->d_sd_walk && a->sd_walk_key == key;
+                const size_t walk_words = 2 + 4 * nc + ((nc + 4095) / 4096 + 2);
+                if (!walk_known) {
+                    if (a->d_sd_walk) { (void)hipFree(a->d_sd_walk); a->d_sd_walk = nullptr; }
+                    a->sd_walk_key = -1;
+                    if (hipMalloc((void **)&a->d_sd_walk, walk_words * 4) != hipSuccess) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: device allocation failed");
+                    CN_HIP(h, hipMemsetAsync(a->d_sd_walk, 0, (2 + 2 * nc) * 4, h->stream));
+                }
+                uint32_t *d_wflag = a->d_sd_walk + 2 + nc, *d_wrank = d_wflag + nc, *d_worder = d_wrank + nc, *d_wpart = d_worder + nc;
+                SiftArgs S{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, lds_wave, reg_cap,
+                           walk_known ? d_worder : nullptr, walk_known ? nullptr : a->d_sd_walk, walk_known ? nullptr : d_wflag,
+                           reinterpret_cast<uint32_t *>(d_tot + 256), T / 10 + 1, lmin, env_int("CORNETTO_SIFT_ABL", 0)};
+                sift_walk_pending = !walk_known;
                 SdArgs R = A;
                 R.stats = want_stats ? d_tot + 200 : nullptr;
                 // Resident waves: as many workgroups as the chip holds at once (LDS is handed out in 1280-byte granules), a share of them
@@ -1843,6 +1870,10 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                 const unsigned nbk = (unsigned)std::min<size_t>((nc + SIFT_WPB - 1) / SIFT_WPB, (size_t)env_int("CORNETTO_SIFT_BLOCKS", per_cu * std::max(h->sd_cus, 1)));
                 if (want_stats) CN_LAUNCH(h, "sdust_kernel", sd_sift<true><<<dim3(nbk), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream>>>(S, R));
                 else CN_LAUNCH(h, "sdust_kernel", sd_sift<false><<<dim3(nbk), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream>>>(S, R));
+                if (sift_walk_pending) {
+                    CN_TRY(cnscan::exclusive_u32(h, "sdust_order", d_wflag, (int64_t)nc, 1, d_wrank, d_wpart, nullptr));
+                    CN_LAUNCH(h, "sdust_order", sd_make_order<<<dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, h->stream>>>(a->d_sd_walk, d_wflag, d_wrank, (int32_t)nc, d_worder));
+                }
             } else if (use_w64) {
                 // warm-up starts, the order of the queue, the claim flags:
                 // flag (nc) + rank (nc) + claim (nc) + perm (nc + 80) + dense list (nc) + scan partials
@@ -2022,6 +2053,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                 if (e != hipSuccess) return cn_fail(h, CORNETTO_E_HIP, "sdust: word-count table build failed");
                 continue;
             }
+            if (sift_walk_pending && !need_wtab) a->sd_walk_key = key;      // (the list is complete: every chunk was looked at)
             if (ovf <= cap) {
                 tot = p_tot[0];
                 break;

@@ -44,6 +44,13 @@ struct SiftArgs {
     int32_t T, W;
     uint32_t lds_per_wave;    // bytes of dynamic LDS per wave
     uint32_t reg_cap;         // positions the word / count buffer holds (multiple of 64): chunk + 128
+    // The chunks that hold other bytes than letters are stepped through base by base: half a millisecond each.  The first call for a
+    // chunk table notes them (walk_out: [0] = count, [2 ..] ids; iswalk_out: a flag per chunk); from them the host makes `order`
+    // (those chunks first, then the others), and later calls take chunk order[i] where they would have taken chunk i: the last
+    // walk does not start when everything else is done.
+    const uint32_t *order;
+    uint32_t *walk_out;
+    uint32_t *iswalk_out;
     uint32_t *counter;        // [SIFT_NCTR * 16], zero before the launch: counter c (at index 16 c) hands out the chunks c + j SIFT_NCTR
     int32_t thr, lmin;        // equal words a last word needs (T / 10 + 1); shortest l with 10 l (l + 1) / 2 > T l, capped at 16
     int32_t abl;              // development aid (CORNETTO_SIFT_ABL): 1 no resolve, 2 no L1 / L2, 4 no tiles: timing only, results are wrong
@@ -310,6 +317,10 @@ __global__ __launch_bounds__(64 * SIFT_WPB) void sd_sift(SiftArgs A, SdArgs O)
     };
 
     if (unclean) {
+        if (A.walk_out && lane == 0) {
+            A.iswalk_out[k] = 1u;
+            A.walk_out[2 + atomicAdd(&A.walk_out[0], 1u)] = (uint32_t)k;
+        }
         // ---- walk: the reference's loop (:139-157), one base per step, from the warm-up start --------------------------
         const int u = __builtin_amdgcn_readfirstlane(sd_find_start(O, ch, seq));
         if (u < 0) return;                            // (the word-count table is needed: the host builds it and runs again)
@@ -611,7 +622,8 @@ __global__ __launch_bounds__(64 * SIFT_WPB) void sd_sift(SiftArgs A, SdArgs O)
         }
         dry = 0;
         nxt = ask(c);
-        const Meta m = meta((int)kk);
-        process((int)kk, m, fetch(m));
+        const int ko = A.order ? __builtin_amdgcn_readfirstlane((int)A.order[kk]) : (int)kk;
+        const Meta m = meta(ko);
+        process(ko, m, fetch(m));
     }
 }

@@ -715,6 +715,19 @@ def e2e_cli(R, cornetto_amd):
                 best = dt if best is None else min(best, dt)
             if best is not None:
                 out[sub] = {"wall_s": round(best, 3), "gbases_s": round(R.my_bases / best / 1e9, 3), "stdout_bytes": nbytes}
+        # where the time of `cornetto sdust` goes (CORNETTO_CLI_TRACE: milliseconds since process start at each point; the pinned piece
+        # can only be allocated once the HIP runtime is up, so "pinned piece allocated" = runtime initialisation + code object + pinning)
+        t0 = time.perf_counter()
+        p = subprocess.run([cornetto_amd.CLI_PATH, "sdust", path], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                           env=dict(os.environ, CORNETTO_DEVICE=str(R.local_dev), CORNETTO_CLI_TRACE="1"))
+        tr = []
+        for l in p.stderr.decode(errors="replace").splitlines():
+            if l.startswith("[cli trace]"):
+                f = l[len("[cli trace]"):].rsplit(None, 2)
+                tr.append([f[0].strip(), float(f[1])])
+        if tr:
+            out["sdust_trace_ms"] = tr[:4] + ([["..."]] if len(tr) > 8 else []) + tr[-4:] if len(tr) > 8 else tr
+            out["sdust_trace_wall_s"] = round(time.perf_counter() - t0, 3)
     except Exception as e:                               # the e2e figure is an extra: never fail the bench line over it
         out["error"] = repr(e)
     finally:

@@ -44,8 +44,8 @@ struct SiftArgs {
     int32_t T, W;
     uint32_t lds_per_wave;    // bytes of dynamic LDS per wave
     uint32_t reg_cap;         // positions the word / count buffer holds (multiple of 64): chunk + 128
-    // The chunks that hold other bytes than letters are stepped through base by base: half a millisecond each.  The first call for a
-    // chunk table notes them (walk_out: [0] = count, [2 ..] ids; iswalk_out: a flag per chunk); from them the host makes `order`
+    // The chunks that hold other bytes than letters are stepped through base by base, the chunks inside repeat arrays position by
+    // position: up to a millisecond of sequential work each.  The first call for a chunk table notes them (walk_out: [0] = count, [2 ..] ids; iswalk_out: a flag per chunk); from them the host makes `order`
     // (those chunks first, then the others), and later calls take chunk order[i] where they would have taken chunk i: the last
     // walk does not start when everything else is done.
     const uint32_t *order;
@@ -112,6 +112,28 @@ __device__ __forceinline__ uint32_t sd_scan_max_dpp(uint32_t x)
                  "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
                  : "+v"(x));
     return x;
+}
+
+// Where the base-by-base walk of a chunk starts: at or before the point sd_find_start() gives (W - 2 word emissions in front of
+// chunk start - 2 W; starting earlier is exact as well).  That function is written for one lane among 64 busy ones: behind a run
+// of non-bases it steps backwards one dependent byte load at a time — up to a millisecond when a whole wave waits for it.  Here
+// the wave looks at 64 bases per load: a word ends at lane q >= 2 of a tile when lanes q - 2 .. q hold bases (words that begin in
+// the tile before are not counted: the count can only be too small); the first tile border with W - 2 counted words behind it
+// is the start.  Sequence without words for 4096 bases: the caller falls back to sd_find_start() and its word-count table.
+__device__ __forceinline__ int sd_wave_find_start(const SdChunk ch, const uint8_t *seq, int W, int lane)
+{
+    if (ch.start <= 0) return 0;
+    const int y = ch.start - 2 * W;
+    if (y <= 2) return 0;
+    int need = W - 2;
+    for (int tile = (y - 1) >> 6, it = 0; tile >= 0 && it < 64; --tile, ++it) {
+        const int p = tile * 64 + lane;
+        const bool isb = p < y && nt4_code(seq[p]) < 4;
+        const unsigned long long b = sd_ballot(isb);
+        need -= __popcll(b & (b << 1) & (b << 2));
+        if (need <= 0 || tile == 0) return tile * 64;
+    }
+    return -2;
 }
 
 template <bool STATS>
@@ -322,7 +344,8 @@ __global__ __launch_bounds__(64 * SIFT_WPB) void sd_sift(SiftArgs A, SdArgs O)
             A.walk_out[2 + atomicAdd(&A.walk_out[0], 1u)] = (uint32_t)k;
         }
         // ---- walk: the reference's loop (:139-157), one base per step, from the warm-up start --------------------------
-        const int u = __builtin_amdgcn_readfirstlane(sd_find_start(O, ch, seq));
+        int u = sd_wave_find_start(ch, seq, W, lane);
+        if (u == -2) u = __builtin_amdgcn_readfirstlane(sd_find_start(O, ch, seq));
         if (u < 0) return;                            // (the word-count table is needed: the host builds it and runs again)
         const int stop = islast ? len + 1 : ch.end;   // the contig's last chunk also takes the sentinel step i == len
         int l = 0, size = 0, cv = 4, ctile = -1;
@@ -501,6 +524,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) void sd_sift(SiftArgs A, SdArgs O)
     SD_LDS_ORDER();
 
     int cur = 0;                                      // (a position of the contig)
+    int n_dense = 0;                                  // steps taken in runs of consecutive positions
     bool have = false;
     int wt = 0, wt_tile = -1;                         // words of tile wt_tile of the region, lane <-> position
     for (int t = 0; t < ntile; ++t) {
@@ -519,6 +543,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) void sd_sift(SiftArgs A, SdArgs O)
                     wt_tile = t;
                     wt = wc[2 * (t * 64 + lane)];
                 }
+                n_dense += run;
                 for (int j = 0; j < run; ++j) {
                     if (STATS) ++st_steps;
                     const int ii = i + j;
@@ -596,6 +621,11 @@ __global__ __launch_bounds__(64 * SIFT_WPB) void sd_sift(SiftArgs A, SdArgs O)
                 emit(s, s + (int)(so >> 24) + 3, s + W);
             }
         }
+    }
+    // (a chunk inside a repeat array is a long sequential piece of work too: noted like the walked ones, handed out first next time)
+    if (A.walk_out && n_dense >= 256 && lane == 0) {
+        A.iswalk_out[k] = 1u;
+        A.walk_out[2 + atomicAdd(&A.walk_out[0], 1u)] = (uint32_t)k;
     }
     finish();
   };

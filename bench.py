@@ -472,7 +472,8 @@ class Rank:
         self.overlap = not args.serial
         if self.overlap:
             # the sdust waves stay resident until their queue is empty: leave part of every CU to the other stream
-            self.acc2.set_share(args.sdust_share)
+            self.share = args.sdust_share if args.sdust_share > 0 else 70
+            self.acc2.set_share(self.share)
         self.thr = self.acc.telowin_threshold(0.4, 99.9)
         self.ktime, self.wall = {}, {}
         # the sdust side runs on one persistent worker thread (no thread start inside the timed steps)
@@ -614,10 +615,33 @@ class Rank:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
+    def tune_share(self):
+        """untimed, part of the warm-up: which share of a CU's wave slots the resident sdust waves take beside the other stream depends on
+        what the sequence makes of sdust (uniform: the two host threads are balanced at 70 %; repeat-rich: sdust is three times the rest and
+        wants nearly all of the chip).  Three steps at each of a few shares, the best is kept (cornetto_accel_set_share); every rank
+        tunes for itself."""
+        if not self.overlap or self.args.sdust_share > 0:
+            return
+        best = None
+        for sh in (60, 70, 85, 100):
+            self.acc2.set_share(sh)
+            self.step(False)
+            self.torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                self.step(False)
+            self.torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, sh)
+        self.share = best[1]
+        self.acc2.set_share(self.share)
+
     def timed(self, steps, warmup):
         """`warmup` untimed steps, then exactly `steps` steps between two fences; max over ranks -> seconds"""
         for _ in range(warmup):
             self.step(False)
+        self.tune_share()
         self.ktime.clear()
         self.wall.clear()
         self.fence()
@@ -647,8 +671,12 @@ class Rank:
         self.ktime.clear()
         self.overlap = False
         self.acc2.set_share(100)
+        self.acc.set_timing(2)
+        self.acc2.set_timing(2)
         self.step(True)
-        self.acc2.set_share(self.args.sdust_share)
+        self.acc.set_timing(self.args.timing)
+        self.acc2.set_timing(self.args.timing)
+        self.acc2.set_share(self.share)
         self.overlap = True
         serial, self.ktime, self.wall = self.ktime, timed, wall
         return serial
@@ -668,9 +696,10 @@ def kernel_table(R, serial, n_bases):
     # cov_blocks reads 4 B/base (u16 depth + u16 mq)
     alg = {"sdust_kernel": 1.0 * n_bases, "tf_scan": 1.0 * n_bases, "cov_blocks": 4.0 * n_bases}
     kern = {}
-    for k, ms in sorted(kavg.items()):
-        kern[k] = {"ms": round(ms, 4)}
-        if k in alg and ms > 0:
+    for k in sorted(set(kavg) | set(serial or {})):
+        ms = kavg.get(k)
+        kern[k] = {"ms": round(ms, 4)} if ms is not None else {}     # (the timed steps carry events around the main kernels only: --timing)
+        if ms and k in alg:
             kern[k]["algorithmic_GBps"] = round(alg[k] / (ms * 1e-3) / 1e9, 2)
         if serial and k in serial:
             sm = float(np.mean(serial[k]))
@@ -742,7 +771,7 @@ def profile_leg(R, steps):
     """ms/step and the sdust kernel on the workload currently loaded, plus the kernel's own statistics run"""
     el = R.timed(steps, 1)
     kavg = {k: float(np.mean(v)) for k, v in R.ktime.items()}
-    out = {"ms_per_step": round(el / steps * 1e3, 3), "gbases_s": round(R.job_bases / (el / steps) / 1e9, 3),
+    out = {"ms_per_step": round(el / steps * 1e3, 3), "gbases_s": round(R.job_bases / (el / steps) / 1e9, 3), "sdust_share_percent": getattr(R, "share", None),
            "sdust_kernel_ms": round(kavg.get("sdust_kernel", 0.0), 3), "tf_scan_ms": round(kavg.get("tf_scan", 0.0), 3),
            "cov_blocks_ms": round(kavg.get("cov_blocks", 0.0), 3),
            "results": dict(zip(("telomere_runs", "telomere_windows", "sdust_intervals", "selected_cov_windows"), R.counts))}
@@ -1103,8 +1132,8 @@ def main():
     ap.add_argument("--no-second", action="store_true", help="--gpus > 1: skip the second measurement (the other scaling mode with --gather)")
     ap.add_argument("--emulate-ranks", type=str, default="2,4,8", help="N=1: model the strong-scaling curve for these rank counts on this one GPU ('' = skip)")
     ap.add_argument("--allow-shared-device", action="store_true", help="--gpus > 1 with fewer GPUs than ranks (tests): ranks share devices, collectives over gloo")
-    ap.add_argument("--sdust-share", type=int, default=85, help="percent of the wave slots sdust could hold on a CU that it takes while the other stream runs beside it (only the resident-wave kernel of CORNETTO_SDUST_SIFT=0 looks at it)")
-    ap.add_argument("--timing", type=int, default=2, help="HIP events around: 1 the main kernels only (roofline), 2 every launch, 0 none")
+    ap.add_argument("--sdust-share", type=int, default=0, help="percent of the wave slots the resident sdust waves could hold on a CU that they take while the other stream runs beside them (70: 14 of 21 per CU); 0: probed during warm-up (60 / 70 / 85 / 100)")
+    ap.add_argument("--timing", type=int, default=1, help="HIP events in the timed steps around: 1 the three main kernels only (roofline), 2 every launch, 0 none; the extra serial pass that fills the kernel table always uses 2")
     ap.add_argument("--gather", action="store_true", help="also gather every result record to rank 0 inside the step (not part of the path: each rank owns the output of its contigs)")
     ap.add_argument("--allreduce-always", action="store_true", help="weak scaling: all-reduce the depth totals as well (treats the N assemblies as one)")
     ap.add_argument("--serial", action="store_true", help="run the stages one after the other on one stream (per-kernel timing without overlap)")
@@ -1209,7 +1238,7 @@ def main():
                        "contigs_rank0": len(R.own), "motif": "TTAGGG", "sdust": "-w 64 -t 20", "windows": "-w 2500 -i 50",
                        "parallelism": "contig-sharded (%s), %d process(es), 1 GPU each; per GPU %s" % (
                            "LPT over the contigs of one assembly" if args.scaling == "strong" else "one assembly per rank", world,
-                           "2 HIP streams (sdust || telofind+coverage)" if nst == 2 else "stages serial on one stream")},
+                           "2 HIP streams (sdust || telofind+coverage), sdust on %d %% of the wave slots" % getattr(R, "share", 100) if nst == 2 else "stages serial on one stream")},
             "roofline": {"bound": "valu-issue", "kernel": dom, "kernel_symbol": symbol, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source, "issue": issue,
                          "note": "sdust is integer work per base, bound by instruction issue, not by HBM (profiles/r03_sq_<kernel>.json); achieved / peak / frac are "

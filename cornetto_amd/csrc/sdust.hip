@@ -1675,12 +1675,12 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
     // at least 256 bases (the look-back of a chunk stays inside the chunk before it), at most 62 tiles.  CORNETTO_SDUST_SIFT=0 keeps the
     // per-lane recurrence of sdust_w64 for everything (also what an explicit chunk size outside that range does: the tests
     // with tiny chunks stress exactly that kernel).
-    // Which one is faster depends on the sequence: on the uniform bench assembly both take 7 ms alone, but the resident waves of sdust_w64
-    // leave more room to a second stream (9.6 against 10.2 ms per bench step); with 3 % of the bases in satellite arrays the step
-    // takes 39.5 against 21 ms.  CORNETTO_SDUST_SIFT unset: decided once per resident assembly from one 64-byte sample per 2048
-    // bases (sift when at least 1 in 256 lies inside a repeat array — the rule that used to switch sdust_dense on; read-level sets
-    // of more than 4096 records and assemblies below 2 Gbases: sift); 1 / 0 force one or the other.
-    const int sift_env = env_int("CORNETTO_SDUST_SIFT", -1);
+    // The sift / resolve stages are the default (3.16 Gbp uniform: 6.4 against 7.0-7.3 ms alone, 9.7 against 10.0 ms per two-stream bench
+    // step; with 3 % of the bases in satellite arrays 16.3 against 29.5 ms; a 395 Mb share 0.96 against 4.7 ms).  CORNETTO_SDUST_SIFT=0
+    // keeps the per-lane recurrence; -1 decides once per resident assembly from one 64-byte sample per 2048 bases (sift when at least 1 in
+    // 256 lies inside a repeat array, for read-level sets and for assemblies below 2 Gbases) — how the choice was made while the
+    // per-lane kernel was still ahead on uniform sequence.
+    const int sift_env = env_int("CORNETTO_SDUST_SIFT", 1);      // 1 (default) sift / resolve, 0 the per-lane recurrence, -1 decide by the sample
     if (w64_path && sift_env < 0 && a->sd_auto < 0) {
         // (below ~2 Gbases the resident lanes of sdust_w64 have less than one chunk each and its time stops falling — one chunk is 4 ms
         // of sequential steps for a lane: 395 Mb take 4.7 ms against 1.0 ms in sd_sift, whose unit of work is a wave)

@@ -171,6 +171,8 @@ __global__ __launch_bounds__(64 * SIFT_WPB) void sd_sift(SiftArgs A, SdArgs O)
     // stepping stages: lane = l
     const int Tl = T * lane;
     const uint32_t m_recip = sd_recip_tab[lane];
+    // statistics build: counted per wave, added up once at the end
+    unsigned long long st_steps = 0, st_jumps = 0, st_cand = 0, st_trig = 0, st_l1 = 0, st_l2 = 0, st_walk = 0, st_tiles = 0;
 
     struct Meta {
         SdChunk ch;
@@ -264,7 +266,6 @@ __global__ __launch_bounds__(64 * SIFT_WPB) void sd_sift(SiftArgs A, SdArgs O)
     // ---- state of the stepping stages (resolve, walk): lane <-> age of the window's words -----------------------------
     int w = 0, r = 0, slot = 0;                       // the word that entered `lane` steps ago, the score of the suffix that starts there, its P slot
     int sv0 = 0;                                      // start value (:121) of lane 0's slot: lane a holds the entry that starts at sv0 - a
-    unsigned st_steps = 0, st_jumps = 0, st_cand = 0, st_trig = 0, st_l1 = 0, st_l2 = 0, st_walk = 0;
     // the chunk's own list (:93-99); everything here is wave-uniform
     bool have_last = false;
     uint32_t last_s = 0, last_f = 0, n_out = 0;
@@ -325,16 +326,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) void sd_sift(SiftArgs A, SdArgs O)
         if (lane == 0) {
             O.out_n[k] = n_out;
             if (n_out > O.cap) atomicMax(O.ovf, n_out);
-            if (STATS && O.stats) {
-                atomicAdd(&O.stats[0], (unsigned long long)st_steps);
-                atomicAdd(&O.stats[1], (unsigned long long)st_jumps);
-                atomicAdd(&O.stats[2], (unsigned long long)st_cand);
-                atomicAdd(&O.stats[3], (unsigned long long)st_trig);
-                atomicAdd(&O.stats[4], (unsigned long long)st_l1);
-                atomicAdd(&O.stats[5], (unsigned long long)st_l2);
-                atomicAdd(&O.stats[6], (unsigned long long)ntile);
-                atomicAdd(&O.stats[7], (unsigned long long)st_walk);
-            }
+            if (STATS) st_tiles += (unsigned long long)ntile;
         }
     };
 
@@ -416,7 +408,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) void sd_sift(SiftArgs A, SdArgs O)
             sc = sc || (alive && a >= 1 && rr * 10 > T * a);
         }
         const bool keep = on && (sc || (dmin > 0 && long_ok));
-        if (STATS) st_l2 += (unsigned)__popcll(sd_ballot(keep));
+        if (STATS) st_l2 += (unsigned long long)__popcll(sd_ballot(keep));
         if (keep) (void)__hip_atomic_fetch_or(&sb[o >> 5], 1u << (o & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     // L1: the partial sums of 10 ct - T over the last k words must be positive for k = 1 .. lmin (every candidate has more words)
@@ -432,7 +424,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) void sd_sift(SiftArgs A, SdArgs O)
         const bool ok = on && dmin > 0;
         const unsigned long long m = sd_ballot(ok);
         if (m) {
-            if (STATS) st_l1 += (unsigned)__popcll(m);
+            if (STATS) st_l1 += (unsigned long long)__popcll(m);
             if (ok) tl2[ntl2 + sd_mbcnt64(m)] = (uint16_t)o;
             ntl2 += __popcll(m);
             SD_LDS_ORDER();
@@ -471,7 +463,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) void sd_sift(SiftArgs A, SdArgs O)
             const bool trig = valid && ct >= thr;
             const unsigned long long m = sd_ballot(trig);
             if (m) {
-                if (STATS) st_trig += (unsigned)__popcll(m);
+                if (STATS) st_trig += (unsigned long long)__popcll(m);
                 if (trig) tl[ntl + sd_mbcnt64(m)] = (uint16_t)(q * 64 + lane);
                 ntl += __popcll(m);
                 SD_LDS_ORDER();
@@ -655,5 +647,15 @@ __global__ __launch_bounds__(64 * SIFT_WPB) void sd_sift(SiftArgs A, SdArgs O)
         const int ko = A.order ? __builtin_amdgcn_readfirstlane((int)A.order[kk]) : (int)kk;
         const Meta m = meta(ko);
         process(ko, m, fetch(m));
+    }
+    if (STATS && O.stats && lane == 0) {
+        atomicAdd(&O.stats[0], st_steps);
+        atomicAdd(&O.stats[1], st_jumps);
+        atomicAdd(&O.stats[2], st_cand);
+        atomicAdd(&O.stats[3], st_trig);
+        atomicAdd(&O.stats[4], st_l1);
+        atomicAdd(&O.stats[5], st_l2);
+        atomicAdd(&O.stats[6], st_tiles);
+        atomicAdd(&O.stats[7], st_walk);
     }
 }

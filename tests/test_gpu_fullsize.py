@@ -223,7 +223,7 @@ def test_satellite_dense_1gbp_through_the_sift_stages(monkeypatch):
     lie in satellite arrays): canonical result, two calls equal, and the four smallest of the contigs that hold arrays — each
     of 12 Mb or more, arrays of 0.1-5 Mb — record for record against the oracle"""
     import bench
-    monkeypatch.delenv("CORNETTO_SDUST_SIFT", raising=False)
+    monkeypatch.setenv("CORNETTO_SDUST_SIFT", "-1")          # (decided by the sample of the bases: sift, as by default)
     monkeypatch.delenv("CORNETTO_SDUST_CHUNK", raising=False)
     lens = bench.contig_lengths(1_000_000_000)
     w = _make(lens, 0xC0FFEE, "satellite", coverage=False)

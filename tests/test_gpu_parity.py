@@ -383,9 +383,9 @@ def test_sdust_sift_off_equals_on(acc, monkeypatch):
 
 
 def test_sdust_kernel_family_is_chosen_by_the_sequence(acc, monkeypatch):
-    """CORNETTO_SDUST_SIFT unset: one 64-byte sample per 2048 bases decides once per resident assembly — sift / resolve when at least
+    """CORNETTO_SDUST_SIFT=-1: one 64-byte sample per 2048 bases decides once per resident assembly — sift / resolve when at least
     1 sample in 256 lies inside a repeat array, the per-lane recurrence otherwise; the intervals are the same either way"""
-    monkeypatch.delenv("CORNETTO_SDUST_SIFT", raising=False)
+    monkeypatch.setenv("CORNETTO_SDUST_SIFT", "-1")
     monkeypatch.delenv("CORNETTO_SDUST_CHUNK", raising=False)
     pytest.skip("assemblies below 2 Gbases always take the sift stages (the per-lane kernel has a 4 ms floor); the choice by sample is "
                 "exercised at full size: tests/test_gpu_fullsize.py, bench.py")

@@ -563,6 +563,7 @@ class Rank:
         from cornetto_amd.dist import allreduce_sums, gather_records
         acc, world = self.acc, self.world
         if self.overlap:
+            self.acc2.boost(False)                    # this thread's kernels want their share of the chip again
             self.jobs.put(record)
         t0 = time.perf_counter()
         hits, wins = acc.telo_scan(self.asm, b"TTAGGG", self.thr)
@@ -594,6 +595,9 @@ class Rank:
             recs = acc.unpack_regs(recs_pk, ctg_first, self.lens_own, 2500)
         if not self.overlap:
             self.jobs.put(record)
+        else:
+            if os.environ.get("CORNETTO_BENCH_BOOST", "1") != "0":
+                self.acc2.boost(True)                 # this thread's GPU work is through: the waves sdust had left to it join in (cornetto_accel_boost)
         box = self.done.get()
         if "err" in box:
             raise box["err"]
@@ -1132,7 +1136,7 @@ def main():
     ap.add_argument("--no-second", action="store_true", help="--gpus > 1: skip the second measurement (the other scaling mode with --gather)")
     ap.add_argument("--emulate-ranks", type=str, default="2,4,8", help="N=1: model the strong-scaling curve for these rank counts on this one GPU ('' = skip)")
     ap.add_argument("--allow-shared-device", action="store_true", help="--gpus > 1 with fewer GPUs than ranks (tests): ranks share devices, collectives over gloo")
-    ap.add_argument("--sdust-share", type=int, default=0, help="percent of the wave slots the resident sdust waves could hold on a CU that they take while the other stream runs beside them (70: 14 of 21 per CU); 0: probed during warm-up (60 / 70 / 85 / 100)")
+    ap.add_argument("--sdust-share", type=int, default=70, help="percent of the wave slots the resident sdust waves could hold on a CU that they take while the other stream runs beside them (70: 14 of 21 per CU; the rest joins in when the other thread of the step is through: cornetto_accel_boost); 0: probed during warm-up (60 / 70 / 85 / 100)")
     ap.add_argument("--timing", type=int, default=1, help="HIP events in the timed steps around: 1 the three main kernels only (roofline), 2 every launch, 0 none; the extra serial pass that fills the kernel table always uses 2")
     ap.add_argument("--gather", action="store_true", help="also gather every result record to rank 0 inside the step (not part of the path: each rank owns the output of its contigs)")
     ap.add_argument("--allreduce-always", action="store_true", help="weak scaling: all-reduce the depth totals as well (treats the N assemblies as one)")

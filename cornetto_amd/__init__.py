@@ -77,6 +77,7 @@ def lib():
         "cornetto_free": (None, [vp]),
         "cornetto_accel_last_timing": (C.c_int, [vp, C.POINTER(cp), C.POINTER(C.c_float), C.c_int]),
         "cornetto_accel_set_share": (C.c_int, [vp, C.c_int]),
+        "cornetto_accel_boost": (C.c_int, [vp, C.c_int]),
         "cornetto_accel_set_timing": (C.c_int, [vp, C.c_int]),
         "cornetto_accel_sdust_stats": (C.c_int, [vp, C.c_int, vp, C.c_int]),
         "cornetto_cov_select_merged": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_int, C.c_int32, C.c_int32, C.POINTER(vp), C.POINTER(C.c_int64)]),
@@ -199,6 +200,10 @@ class Accel:
         if rc != 0:
             raise AccelError(rc, self.L.cornetto_accel_last_error(self.h).decode() or
                              self.L.cornetto_accel_strerror(rc).decode())
+
+    def boost(self, on=True):
+        """the rest of the device is free (on) / in use again (off): see cornetto_accel_boost(); callable from another thread"""
+        self.L.cornetto_accel_boost(self.h, 1 if on else 0)
 
     def set_share(self, percent):
         """percent of every CU the resident sdust kernel may occupy (another handle computes beside this one)"""

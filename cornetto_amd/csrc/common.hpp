@@ -38,6 +38,8 @@ struct cornetto_accel {
     int sd_slots = 0;   // sdust: waves the device holds at once (occupancy query, cached)
     int sd_cus = 0;
     int sift_per_cu = 0; // sdust sift: workgroups per CU by the occupancy query (cached)
+    volatile int boost = 0;  // cornetto_accel_boost(): the other users of the device are through (set from another host thread)
+    hipEvent_t ev3 = nullptr;
     int share = 100;    // percent of every CU the resident sdust kernel may take (cornetto_accel_set_share)
     int sd_stats = 0;   // sdust: run the statistics build of the kernel (cornetto_accel_sdust_stats)
     unsigned long long sd_last[256] = {0};   // its counters from the most recent such run

@@ -85,6 +85,7 @@ void cornetto_accel_close(cornetto_accel_t *h)
         if (w.p) (void)hipHostFree(w.p);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
+    if (h->ev3) (void)hipEventDestroy(h->ev3);
     if (h->stream2) {
         (void)hipStreamSynchronize(h->stream2);       // (a dense kernel of a call that failed half-way may still be writing workspaces)
         (void)hipStreamDestroy(h->stream2);
@@ -137,6 +138,13 @@ int cornetto_accel_set_share(cornetto_accel_t *h, int percent)
     if (!h) return CORNETTO_E_ARG;
     if (percent < 10 || percent > 100) return cn_fail(h, CORNETTO_E_ARG, "set_share: %d outside 10..100", percent);
     h->share = percent;
+    return CORNETTO_OK;
+}
+
+int cornetto_accel_boost(cornetto_accel_t *h, int on)
+{
+    if (!h) return CORNETTO_E_ARG;
+    __atomic_store_n(&h->boost, on ? 1 : 0, __ATOMIC_RELEASE);
     return CORNETTO_OK;
 }
 

@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <type_traits>
 #include <ctime>
+#include <sched.h>
 
 #include "common.hpp"
 #include "scan.hpp"
@@ -1865,11 +1866,39 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sd_sift<false>, 64 * SIFT_WPB, lds_wave * SIFT_WPB) != hipSuccess || per_cu < 1) per_cu = 8;
                     h->sift_per_cu = per_cu;
                 }
-                int per_cu = std::min<int>(h->sift_per_cu, (int)(163840 / ((lds_wave * SIFT_WPB + 1279) / 1280 * 1280)));
-                per_cu = std::max(1, per_cu * h->share / 100);
-                const unsigned nbk = (unsigned)std::min<size_t>((nc + SIFT_WPB - 1) / SIFT_WPB, (size_t)env_int("CORNETTO_SIFT_BLOCKS", per_cu * std::max(h->sd_cus, 1)));
+                const int per_cu_all = std::max(1, std::min<int>(h->sift_per_cu, (int)(163840 / ((lds_wave * SIFT_WPB + 1279) / 1280 * 1280))));
+                const bool free_now = __atomic_load_n(&h->boost, __ATOMIC_ACQUIRE) != 0;        // (cornetto_accel_boost)
+                const int per_cu = free_now ? per_cu_all : std::max(1, per_cu_all * h->share / 100);
+                const size_t all_blocks = (nc + SIFT_WPB - 1) / SIFT_WPB;
+                const unsigned nbk = (unsigned)std::min<size_t>(all_blocks, (size_t)env_int("CORNETTO_SIFT_BLOCKS", per_cu * std::max(h->sd_cus, 1)));
                 if (want_stats) CN_LAUNCH(h, "sdust_kernel", sd_sift<true><<<dim3(nbk), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream>>>(S, R));
                 else CN_LAUNCH(h, "sdust_kernel", sd_sift<false><<<dim3(nbk), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream>>>(S, R));
+                // The waves left to the other stream: when its owner says it is through (cornetto_accel_boost, from another host thread) while
+                // this kernel still runs, they are launched as a second kernel on a second stream — same arguments, same chunk counters: the two
+                // launches drain them together — and the stream of this call waits for both.
+                const unsigned extra = (unsigned)std::min<size_t>(all_blocks > nbk ? all_blocks - nbk : 0, (size_t)(per_cu_all - per_cu) * std::max(h->sd_cus, 1));
+                if (extra > 0 && !want_stats) {
+                    if (!h->stream2) {
+                        int pr_least = 0, pr_greatest = 0;
+                        (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+                        CN_HIP(h, hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, pr_greatest));
+                        CN_HIP(h, hipEventCreateWithFlags(&h->ev2, hipEventDisableTiming));
+                        CN_HIP(h, hipEventCreateWithFlags(&h->ev1, hipEventDisableTiming));
+                    }
+                    if (!h->ev3) CN_HIP(h, hipEventCreateWithFlags(&h->ev3, hipEventDisableTiming));
+                    CN_HIP(h, hipEventRecord(h->ev3, h->stream));
+                    bool helped = false;
+                    while (hipEventQuery(h->ev3) == hipErrorNotReady) {
+                        if (!helped && __atomic_load_n(&h->boost, __ATOMIC_ACQUIRE) != 0) {
+                            sd_sift<false><<<dim3(extra), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream2>>>(S, R);
+                            CN_HIP(h, hipGetLastError());
+                            CN_HIP(h, hipEventRecord(h->ev2, h->stream2));
+                            helped = true;
+                        }
+                        sched_yield();
+                    }
+                    if (helped) CN_HIP(h, hipStreamWaitEvent(h->stream, h->ev2, 0));
+                }
                 if (sift_walk_pending) {
                     CN_TRY(cnscan::exclusive_u32(h, "sdust_order", d_wflag, (int64_t)nc, 1, d_wrank, d_wpart, nullptr));
                     CN_LAUNCH(h, "sdust_order", sd_make_order<<<dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, h->stream>>>(a->d_sd_walk, d_wflag, d_wrank, (int32_t)nc, d_worder));

@@ -108,6 +108,12 @@ int cornetto_accel_last_timing(const cornetto_accel_t *h, const char **names, fl
  * Scheduling only: results do not depend on it. */
 int cornetto_accel_set_share(cornetto_accel_t *h, int percent);
 
+/* "The rest of the device is free now" (on != 0) / "is in use again" (on == 0): may be called from ANOTHER host thread than the one that is
+ * inside cornetto_sdust_asm() on this handle.  While it is on, a running sdust call whose share is below 100 launches the waves it had left
+ * to the other stream as a second kernel that draws from the same chunk counters, and later calls start with the whole chip.  bench.py
+ * switches it on when the telofind + coverage thread of a step is through and off when the next step begins.  Scheduling only. */
+int cornetto_accel_boost(cornetto_accel_t *h, int on);
+
 /* Statistics of the production sdust kernel (development / bench aid).  `enable` != 0 makes the following
  * cornetto_sdust_asm() calls on this handle run the counting build of the kernel (a few percent slower); `out`, if not
  * NULL, receives up to `cap` (<= 256) counters of the most recent such call: [2] wave steps, [3] find_perfect calls,

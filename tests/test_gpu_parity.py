@@ -382,6 +382,37 @@ def test_sdust_sift_off_equals_on(acc, monkeypatch):
     assert len(on) > 200 and np.array_equal(on, off)
 
 
+def test_sdust_boost_from_another_thread_does_not_change_results(acc, monkeypatch):
+    """cornetto_accel_set_share + cornetto_accel_boost: the resident sift waves take part of the chip; another host thread says "the rest is
+    free now" while the call runs and the remaining waves are launched as a second kernel on the same chunk counters — same intervals,
+    whenever the flag arrives (before the call, early, late, never)"""
+    import threading
+    import time
+    monkeypatch.setenv("CORNETTO_SDUST_SIFT", "1")
+    monkeypatch.delenv("CORNETTO_SDUST_CHUNK", raising=False)
+    rng = np.random.default_rng(31)
+    seqs = [_sift_stress_seq(rng, 20_000_000, 1), _sift_stress_seq(rng, 3_000_000, 0)]
+    asm = acc.asm_upload(seqs)
+    try:
+        ref = acc.sdust(asm, 20, 64)
+        acc.set_share(40)
+        for delay in (None, 0.0, 0.0005, 0.003, -1.0):
+            acc.boost(delay is not None and delay < 0)              # -1: on before the call starts
+            t = None
+            if delay is not None and delay >= 0:
+                t = threading.Thread(target=lambda d=delay: (time.sleep(d), acc.boost(True)))
+                t.start()
+            got = acc.sdust(asm, 20, 64)
+            if t:
+                t.join()
+            assert np.array_equal(got, ref), delay
+    finally:
+        acc.boost(False)
+        acc.set_share(100)
+        asm.close()
+    assert len(ref) > 5000
+
+
 def test_sdust_kernel_family_is_chosen_by_the_sequence(acc, monkeypatch):
     """CORNETTO_SDUST_SIFT=-1: one 64-byte sample per 2048 bases decides once per resident assembly — sift / resolve when at least
     1 sample in 256 lies inside a repeat array, the per-lane recurrence otherwise; the intervals are the same either way"""

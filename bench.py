@@ -474,6 +474,9 @@ class Rank:
             # the sdust waves stay resident until their queue is empty: leave part of every CU to the other stream
             self.share = args.sdust_share if args.sdust_share > 0 else 70
             self.acc2.set_share(self.share)
+        # the two large result arrays of this thread (telomere runs, selected windows) travel beside its next kernels
+        self.lazy = self.overlap and os.environ.get("CORNETTO_BENCH_LAZY", "1") != "0"
+        self.acc.set_lazy(self.lazy)
         self.thr = self.acc.telowin_threshold(0.4, 99.9)
         self.ktime, self.wall = {}, {}
         # the sdust side runs on one persistent worker thread (no thread start inside the timed steps)
@@ -590,14 +593,18 @@ class Rank:
         if record:
             self._note(acc)
             self._lap("cov_select", t0)
+        if self.overlap and os.environ.get("CORNETTO_BENCH_BOOST", "1") != "0":
+            self.acc2.boost(True)                     # this thread's kernels are through: the waves sdust had left to it join in (cornetto_accel_boost)
+        if self.lazy:
+            t0 = time.perf_counter()
+            acc.wait()                                # the copies of the telomere runs and of the selected windows (cornetto_accel_set_lazy)
+            if record:
+                self._lap("result_copies", t0)
         recs = recs_pk
         if keep or self.args.gather:                  # rows with their contig and end, as cornetto_cov_select() returns them
             recs = acc.unpack_regs(recs_pk, ctg_first, self.lens_own, 2500)
         if not self.overlap:
             self.jobs.put(record)
-        else:
-            if os.environ.get("CORNETTO_BENCH_BOOST", "1") != "0":
-                self.acc2.boost(True)                 # this thread's GPU work is through: the waves sdust had left to it join in (cornetto_accel_boost)
         box = self.done.get()
         if "err" in box:
             raise box["err"]

@@ -78,6 +78,8 @@ def lib():
         "cornetto_accel_last_timing": (C.c_int, [vp, C.POINTER(cp), C.POINTER(C.c_float), C.c_int]),
         "cornetto_accel_set_share": (C.c_int, [vp, C.c_int]),
         "cornetto_accel_boost": (C.c_int, [vp, C.c_int]),
+        "cornetto_accel_set_lazy": (C.c_int, [vp, C.c_int]),
+        "cornetto_accel_wait": (C.c_int, [vp]),
         "cornetto_accel_set_timing": (C.c_int, [vp, C.c_int]),
         "cornetto_accel_sdust_stats": (C.c_int, [vp, C.c_int, vp, C.c_int]),
         "cornetto_cov_select_merged": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_int, C.c_int32, C.c_int32, C.POINTER(vp), C.POINTER(C.c_int64)]),
@@ -200,6 +202,13 @@ class Accel:
         if rc != 0:
             raise AccelError(rc, self.L.cornetto_accel_last_error(self.h).decode() or
                              self.L.cornetto_accel_strerror(rc).decode())
+
+    def set_lazy(self, on=True):
+        """large result copies on a stream of their own; the arrays the calls return hold their content after wait(): cornetto_accel_set_lazy()"""
+        self._chk(self.L.cornetto_accel_set_lazy(self.h, 1 if on else 0))
+
+    def wait(self):
+        self._chk(self.L.cornetto_accel_wait(self.h))
 
     def boost(self, on=True):
         """the rest of the device is free (on) / in use again (off): see cornetto_accel_boost(); callable from another thread"""

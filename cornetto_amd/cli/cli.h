@@ -52,6 +52,8 @@ char *cli_xstrdup(const char *s);
 cornetto_accel_t *cli_accel_open(void);
 /* the same, with the HIP initialisation running on a helper thread between _begin() and _end() (while the input is read);
  * _cancel() drops it when no device work turned up */
+/* `want` bytes at file offset `off` with up to n_threads pread() threads -> bytes read (short only at the end of the file), -1 on a read error */
+int64_t cli_pread_parallel(int fd, char *dst, int64_t want, int64_t off, int n_threads);
 void cli_accel_open_begin(void);
 cornetto_accel_t *cli_accel_open_end(void);
 void cli_accel_open_cancel(void);

@@ -316,59 +316,7 @@ static int64_t piece_bytes(int fasta, const char *path, gzFile fp)
     return v;
 }
 
-/* an uncompressed regular file is read with a few pread() threads straight into the pinned piece (one thread copies
- * from the page cache at 5-8 GB/s: the largest share of the wall time of a 3 GB assembly) */
-#define READ_THREADS 4
-typedef struct {
-    int fd;
-    char *dst;
-    int64_t off, want, got;
-    int failed; /* a pread() returned < 0 (EIO, ESTALE ...): not an end of file */
-} pread_job_t;
-
-static void *pread_thread(void *p)
-{
-    pread_job_t *j = (pread_job_t *)p;
-    j->got = 0;
-    j->failed = 0;
-    while (j->got < j->want) {
-        const ssize_t r = pread(j->fd, j->dst + j->got, (size_t)(j->want - j->got), (off_t)(j->off + j->got));
-        if (r < 0 && errno == EINTR) continue;
-        if (r < 0) j->failed = 1;
-        if (r <= 0) break; /* r == 0: end of the file */
-        j->got += r;
-    }
-    return NULL;
-}
-
-/* bytes read at file offset `off` (short only at the end of the file); -1 when a read failed */
-static int64_t pread_parallel(int fd, char *dst, int64_t want, int64_t off)
-{
-    pread_job_t job[READ_THREADS];
-    pthread_t th[READ_THREADS];
-    int started[READ_THREADS];
-    const int64_t part = ((want + READ_THREADS - 1) / READ_THREADS + 4095) & ~4095LL;
-    int nj = 0;
-    for (int64_t o = 0; o < want; o += part, ++nj) {
-        job[nj].fd = fd;
-        job[nj].dst = dst + o;
-        job[nj].off = off + o;
-        job[nj].want = want - o < part ? want - o : part;
-        started[nj] = nj > 0 && pthread_create(&th[nj], NULL, pread_thread, &job[nj]) == 0;
-    }
-    int64_t total = 0;
-    int open_end = 1;
-    for (int i = 0; i < nj; ++i) {
-        if (i == 0 || !started[i]) pread_thread(&job[i]);
-    }
-    for (int i = 0; i < nj; ++i) {
-        if (started[i]) pthread_join(th[i], NULL);
-        if (open_end) total += job[i].got;
-        if (open_end && job[i].failed) return -1; /* an error inside the bytes that count, not behind the end of the file */
-        if (job[i].got < job[i].want) open_end = 0;
-    }
-    return total;
-}
+#define READ_THREADS 4 /* one thread copies from the page cache at 5-8 GB/s: the largest share of the wall time of a 3 GB assembly */
 
 #define TRACE(what)                                                                                      \
     do {                                                                                                 \
@@ -427,7 +375,7 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
             }
             if (raw_fd >= 0 && have < piece && !eof) {
                 const int64_t want = piece - have;
-                const int64_t r = pread_parallel(raw_fd, buf + have, want, raw_off);
+                const int64_t r = cli_pread_parallel(raw_fd, buf + have, want, raw_off, READ_THREADS);
                 if (r < 0) {
                     CLI_ERROR("reading %s failed", path);
                     exit(EXIT_FAILURE);

@@ -225,3 +225,63 @@ void cli_order_by_length_desc(const int64_t *lens64, const int32_t *lens32, int3
     for (int32_t i = 0; i < n; ++i) order[i] = (int32_t)(key[i] & 0xFFFFFFFFu);
     free(key);
 }
+
+/* ---------------- pread() with a few threads ----------------
+ * an uncompressed regular file is read straight into a pinned piece: one thread copies from the page cache at 5-8 GB/s, which is
+ * the largest share of the wall time of a 3 GB assembly or of a pair of per-base bedgraphs */
+#include <errno.h>
+#include <unistd.h>
+#define CLI_PREAD_MAX 16
+typedef struct {
+    int fd;
+    char *dst;
+    int64_t off, want, got;
+    int failed; /* a pread() returned < 0 (EIO, ESTALE ...): not an end of file */
+} pread_job_t;
+
+static void *pread_thread(void *p)
+{
+    pread_job_t *j = (pread_job_t *)p;
+    j->got = 0;
+    j->failed = 0;
+    while (j->got < j->want) {
+        const ssize_t r = pread(j->fd, j->dst + j->got, (size_t)(j->want - j->got), (off_t)(j->off + j->got));
+        if (r < 0 && errno == EINTR) continue;
+        if (r < 0) j->failed = 1;
+        if (r <= 0) break; /* r == 0: end of the file */
+        j->got += r;
+    }
+    return NULL;
+}
+
+/* bytes read at file offset `off` (short only at the end of the file); -1 when a read failed */
+int64_t cli_pread_parallel(int fd, char *dst, int64_t want, int64_t off, int n_threads)
+{
+    pread_job_t job[CLI_PREAD_MAX];
+    pthread_t th[CLI_PREAD_MAX];
+    int started[CLI_PREAD_MAX];
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > CLI_PREAD_MAX) n_threads = CLI_PREAD_MAX;
+    int64_t part = ((want + n_threads - 1) / n_threads + 4095) & ~4095LL;
+    if (part < (1 << 20)) part = 1 << 20; /* small reads: fewer threads */
+    int nj = 0;
+    for (int64_t o = 0; o < want; o += part, ++nj) {
+        job[nj].fd = fd;
+        job[nj].dst = dst + o;
+        job[nj].off = off + o;
+        job[nj].want = want - o < part ? want - o : part;
+        started[nj] = nj > 0 && pthread_create(&th[nj], NULL, pread_thread, &job[nj]) == 0;
+    }
+    int64_t total = 0;
+    int open_end = 1;
+    for (int i = 0; i < nj; ++i) {
+        if (i == 0 || !started[i]) pread_thread(&job[i]);
+    }
+    for (int i = 0; i < nj; ++i) {
+        if (started[i]) pthread_join(th[i], NULL);
+        if (open_end) total += job[i].got;
+        if (open_end && job[i].failed) return -1; /* an error inside the bytes that count, not behind the end of the file */
+        if (job[i].got < job[i].want) open_end = 0;
+    }
+    return total;
+}

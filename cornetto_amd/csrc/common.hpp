@@ -38,6 +38,12 @@ struct cornetto_accel {
     int sd_slots = 0;   // sdust: waves the device holds at once (occupancy query, cached)
     int sd_cus = 0;
     int sift_per_cu = 0; // sdust sift: workgroups per CU by the occupancy query (cached)
+    // cornetto_accel_set_lazy(): the large result copies of a call go out on a stream of their own and the call returns when its kernels are
+    // through; cornetto_accel_wait() before the results are read
+    int lazy = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_cp = nullptr;
+    bool copies_pending = false;
     volatile int boost = 0;  // cornetto_accel_boost(): the other users of the device are through (set from another host thread)
     hipEvent_t ev3 = nullptr;
     int share = 100;    // percent of every CU the resident sdust kernel may take (cornetto_accel_set_share)
@@ -119,6 +125,31 @@ static inline int cn_fail(cornetto_accel_t *h, int status, const char *fmt, ...)
         int rc_ = (expr);                                                                                    \
         if (rc_ != CORNETTO_OK) return rc_;                                                                  \
     } while (0)
+
+// device -> host copy of a call's RESULT array.  Default: on the handle's stream (the call's final synchronisation covers it).  Lazy handles:
+// on the copy stream, behind everything the handle's stream holds so far — the caller's next kernels run beside it.
+static inline hipError_t cn_result_d2h(cornetto_accel_t *h, void *dst, const void *src, size_t bytes)
+{
+    if (!h->lazy) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream);
+    hipError_t e = hipSuccess;
+    if (!h->copy_stream) {
+        e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_cp, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    e = hipEventRecord(h->ev_cp, h->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(h->copy_stream, h->ev_cp, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->copy_stream);
+    h->copies_pending = true;
+    return e;
+}
+
+// before a result array with a copy in flight is given up on an error path
+static inline void cn_result_quiesce(cornetto_accel_t *h)
+{
+    if (h->copies_pending && h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+    h->copies_pending = false;
+}
 
 // ---- event timing ---------------------------------------------------------------------------------
 static inline hipEvent_t cn_event(cornetto_accel_t *h)

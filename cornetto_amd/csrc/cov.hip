@@ -566,15 +566,16 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
         // packed: the first record of every contig = the ordered offset of its first tile (1 MB beside the records)
         std::vector<uint32_t> ooff;
         if (packed) ooff.resize(nt);
-        if (!keep_on_device && (hipMemcpyAsync(o, d_dst, (size_t)cnt * rec_bytes, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        if (!keep_on_device && (cn_result_d2h(h, o, d_dst, (size_t)cnt * rec_bytes) != hipSuccess ||
                                 (packed && hipMemcpyAsync(ooff.data(), d_ooff, nt * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess) ||
                                 hipStreamSynchronize(h->stream) != hipSuccess)) {
+            cn_result_quiesce(h);
             cornetto_free(o);
             return cn_fail(h, CORNETTO_E_HIP, "cov_select: copy back failed");
         }
         if (packed) {
             int64_t *cf = (int64_t *)malloc(((size_t)c->n + 1) * sizeof(int64_t));
-            if (!cf) { cornetto_free(o); return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: host allocation failed"); }
+            if (!cf) { cn_result_quiesce(h); cornetto_free(o); return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: host allocation failed"); }
             size_t ti = 0;
             for (int32_t i = 0; i < c->n; ++i) {                 // tiles are in contig order; contigs without tiles have no records
                 while (ti < nt && c->cw_tiles[ti].x < i) ++ti;

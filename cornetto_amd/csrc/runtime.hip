@@ -86,6 +86,11 @@ void cornetto_accel_close(cornetto_accel_t *h)
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
     if (h->ev3) (void)hipEventDestroy(h->ev3);
+    if (h->copy_stream) {
+        (void)hipStreamSynchronize(h->copy_stream);
+        (void)hipStreamDestroy(h->copy_stream);
+    }
+    if (h->ev_cp) (void)hipEventDestroy(h->ev_cp);
     if (h->stream2) {
         (void)hipStreamSynchronize(h->stream2);       // (a dense kernel of a call that failed half-way may still be writing workspaces)
         (void)hipStreamDestroy(h->stream2);
@@ -138,6 +143,28 @@ int cornetto_accel_set_share(cornetto_accel_t *h, int percent)
     if (!h) return CORNETTO_E_ARG;
     if (percent < 10 || percent > 100) return cn_fail(h, CORNETTO_E_ARG, "set_share: %d outside 10..100", percent);
     h->share = percent;
+    return CORNETTO_OK;
+}
+
+int cornetto_accel_set_lazy(cornetto_accel_t *h, int on)
+{
+    if (!h) return CORNETTO_E_ARG;
+    if (!on && h->copies_pending) {
+        CN_HIP(h, hipStreamSynchronize(h->copy_stream));
+        h->copies_pending = false;
+    }
+    h->lazy = on ? 1 : 0;
+    return CORNETTO_OK;
+}
+
+int cornetto_accel_wait(cornetto_accel_t *h)
+{
+    if (!h) return CORNETTO_E_ARG;
+    if (h->copies_pending) {
+        CN_HIP(h, hipSetDevice(h->device));
+        CN_HIP(h, hipStreamSynchronize(h->copy_stream));
+        h->copies_pending = false;
+    }
     return CORNETTO_OK;
 }
 

@@ -137,7 +137,7 @@ __device__ __forceinline__ int sd_wave_find_start(const SdChunk ch, const uint8_
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(64 * SIFT_WPB) void sd_sift(SiftArgs A, SdArgs O)
+__global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6))) void sd_sift(SiftArgs A, SdArgs O)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sift_lds[];
     const int lane = threadIdx.x & 63;

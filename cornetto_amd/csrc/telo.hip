@@ -707,9 +707,10 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
                 h->recs.push_back(cornetto_accel::Rec{"tf_pair", ea, eb});
                 bool ok = hipGetLastError() == hipSuccess;
                 ok = ok && hipMemcpyAsync(p_cnt, d_cnt, 64, hipMemcpyDeviceToHost, h->stream) == hipSuccess;
-                if (tot) ok = ok && hipMemcpyAsync(out, d_hits, tot * sizeof(cornetto_hit_t), hipMemcpyDeviceToHost, h->stream) == hipSuccess;
+                if (tot) ok = ok && cn_result_d2h(h, out, d_hits, tot * sizeof(cornetto_hit_t)) == hipSuccess;
                 ok = ok && hipStreamSynchronize(h->stream) == hipSuccess;
                 if (!ok || (p_cnt[4] >> 32) != 0) {
+                    cn_result_quiesce(h);
                     cornetto_free(out);
                     return cn_fail(h, CORNETTO_E_HIP, "telofind: pairing run heads with tails failed%s", ok ? " (a contig has unequal heads and tails)" : "");
                 }

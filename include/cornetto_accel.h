@@ -114,6 +114,14 @@ int cornetto_accel_set_share(cornetto_accel_t *h, int percent);
  * switches it on when the telofind + coverage thread of a step is through and off when the next step begins.  Scheduling only. */
 int cornetto_accel_boost(cornetto_accel_t *h, int on);
 
+/* Lazy result copies (off by default).  While on, cornetto_telo_scan() / cornetto_telofind() and cornetto_cov_select*() return as soon as their
+ * kernels are through; the device-to-host copy of the large result array (telomere runs; selected windows) is still in flight on a stream of its
+ * own, beside whatever the caller launches next on this handle.  The returned pointers are valid at once, their CONTENT after
+ * cornetto_accel_wait().  Wait before reading, before cornetto_free() of such an array and before calling the same entry point again on the
+ * handle (its device staging is reused).  Counts and every small output are final when the call returns. */
+int cornetto_accel_set_lazy(cornetto_accel_t *h, int on);
+int cornetto_accel_wait(cornetto_accel_t *h);
+
 /* Statistics of the production sdust kernel (development / bench aid).  `enable` != 0 makes the following
  * cornetto_sdust_asm() calls on this handle run the counting build of the kernel (a few percent slower); `out`, if not
  * NULL, receives up to `cap` (<= 256) counters of the most recent such call: [2] wave steps, [3] find_perfect calls,

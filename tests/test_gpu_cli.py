@@ -4,6 +4,7 @@ import gzip
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 import cornetto_amd
@@ -142,6 +143,61 @@ def test_panel_streamed_in_small_pieces(cli, golden_dir, plain, piece):
     rc, out, err = run(cli, args, env={"CORNETTO_BG_PIECE": piece})
     assert rc == 0, err.decode()
     assert out == golden(golden_dir, "bg.fun_t2.exp")
+
+
+@pytest.mark.parametrize("piece", ["97", "5000"])
+def test_panel_sequential_reader_and_fifos(cli, golden_dir, plain, piece, tmp_path):
+    """the fread() loop that anything but two regular files takes (CORNETTO_BG_THREADS=0 asks for it by hand; FIFOs get it by themselves)"""
+    import threading
+    args = ["noboringbits", "-H", "2.5", "-L", "0.5", "-Q", "0.5", plain["cov-total.bg"], "-q", plain["cov-mq20.bg"], "-m", "10000", "-e", "1000"]
+    rc, out, err = run(cli, args, env={"CORNETTO_BG_PIECE": piece, "CORNETTO_BG_THREADS": "0"})
+    assert rc == 0, err.decode()
+    assert out == golden(golden_dir, "bg.fun_t2.exp")
+    fifos = [str(tmp_path / "t.fifo"), str(tmp_path / "q.fifo")]
+    for f in fifos:
+        os.mkfifo(f)
+
+    def pump(src, dst):
+        with open(dst, "wb") as o:
+            o.write(open(src, "rb").read())
+    th = [threading.Thread(target=pump, args=(plain[k], f)) for k, f in zip(("cov-total.bg", "cov-mq20.bg"), fifos)]
+    for t in th:
+        t.start()
+    args[7], args[9] = fifos
+    rc, out, err = run(cli, args, env={"CORNETTO_BG_PIECE": piece})
+    for t in th:
+        t.join()
+    assert rc == 0, err.decode()
+    assert out == golden(golden_dir, "bg.fun_t2.exp")
+
+
+@pytest.mark.parametrize("piece", ["4099", "70001", "1048576"])
+def test_panel_threaded_reader_with_unequal_line_lengths(cli, piece, tmp_path):
+    """two regular files are read by pread() threads one round ahead of the parser; the files spend different numbers of bytes per
+    line (5-digit depths against 1-digit ones), so equal byte counts per round would let one file run ahead without bound: the
+    reader sizes the rounds by what is pending.  Same bytes on stdout as the sequential loop."""
+    rng = np.random.default_rng(int(piece))
+    lens = [40_000, 1, 25_000, 130_000, 7]
+    rows_t, rows_q = [], []
+    for ci, n in enumerate(lens):
+        d = rng.integers(10_000, 60_000, size=n)
+        d[rng.integers(0, n, size=n // 50 + 1)] = 3
+        q = rng.integers(0, 10, size=n)
+        name = "ctg%d_a_rather_long_contig_name" % ci
+        pos = np.arange(n)
+        rows_t.append("".join("%s\t%d\t%d\t%d\n" % (name, p, p + 1, v) for p, v in zip(pos, d)))
+        rows_q.append("".join("%s\t%d\t%d\t%d\n" % (name, p, p + 1, v) for p, v in zip(pos, q)))
+    a, b = tmp_path / "t.bg", tmp_path / "q.bg"
+    a.write_text("".join(rows_t))
+    b.write_text("".join(rows_q))
+    args = ["noboringbits", str(a), "-q", str(b), "-m", "20000", "-e", "1000", "-w", "500", "-i", "50"]
+    rc0, out0, err0 = run(cli, args, env={"CORNETTO_BG_THREADS": "0"})
+    assert rc0 == 0, err0.decode()
+    for threads in ("1", "3", "8"):
+        rc, out, err = run(cli, args, env={"CORNETTO_BG_PIECE": piece, "CORNETTO_BG_THREADS": threads})
+        assert rc == 0, err.decode()
+        assert out == out0 and len(out0) > 1000
+        assert [l for l in err.splitlines() if l.startswith(b"Average")] == [l for l in err0.splitlines() if l.startswith(b"Average")]
 
 
 @pytest.mark.parametrize("devices", ["0,0", "0,0,0"])

@@ -759,3 +759,46 @@ def test_timing_levels(acc):
     assert names0 == set() and names1 == {"sdust_kernel"} and "sdust_scan" in names2 and "sdust_kernel" in names2
     with pytest.raises(Exception):
         acc.set_timing(3)
+
+
+def test_lazy_result_copies_equal_the_synchronous_ones(acc):
+    """cornetto_accel_set_lazy / cornetto_accel_wait: the telomere runs and the selected windows are copied on a stream of their own while the
+    next calls of the handle run; after the wait the arrays hold what the synchronous calls return"""
+    rng = np.random.default_rng(77)
+    lens = [1_200_000, 300_000, 2_000_000, 70_000, 1_000_001]
+    seqs = []
+    for n in lens:
+        s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)].copy()
+        for _ in range(40):                                              # telomere runs, both strands
+            p = int(rng.integers(0, n - 700))
+            unit = np.frombuffer(b"TTAGGG" if rng.integers(0, 2) else b"CCCTAA", dtype=np.uint8)
+            s[p:p + 600] = np.tile(unit, 100)
+        seqs.append(s)
+    depths = [rng.integers(0, 80, size=n).astype(np.uint16) for n in lens]
+    mqs = [np.minimum(depths[i], rng.integers(0, 80, size=n)).astype(np.uint16) for i, n in enumerate(lens)]
+    asm, cov = acc.asm_upload(seqs), acc.cov_upload(depths, mqs)
+    thr = acc.telowin_threshold(0.4, 99.9)
+
+    def run():
+        hits, wins = acc.telo_scan(asm, b"TTAGGG", thr)
+        acc.cov_prepare(cov, 2500, 50)
+        pk, first = acc.cov_select_packed(cov, 16, 100, 0.4, 100000, 1000000, False)
+        return hits, wins, pk, first
+    try:
+        ref = [x.copy() for x in run()]
+        acc.set_lazy(True)
+        for _ in range(3):
+            got = run()
+            acc.wait()
+            for g, r in zip(got, ref):
+                assert np.array_equal(g, r)
+        acc.wait()                                                       # nothing pending: returns at once
+        got = run()
+        acc.set_lazy(False)                                              # turning it off waits as well
+        for g, r in zip(got, ref):
+            assert np.array_equal(g, r)
+    finally:
+        acc.set_lazy(False)
+        asm.close()
+        cov.close()
+    assert len(ref[0]) > 100 and len(ref[2]) > 1000

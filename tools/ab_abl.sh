@@ -1,0 +1,10 @@
+# bash tools/ab_abl.sh "<abl values>" "<gbases values>": sdust alone (bench --serial) with CORNETTO_SIFT_ABL bits set
+B="--serial --no-cpu --no-profiles --no-e2e --no-reads --no-second --emulate-ranks= --steps 20 --warmup 3"
+for abl in ${1:-0}; do for gb in ${2:-3.16}; do
+  CORNETTO_SIFT_ABL=$abl timeout 200 python bench.py $B --gbases $gb 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        j=json.loads(l); print('abl=$abl gbases=$gb', j['ms_per_step'], j['kernels']['sdust_kernel'])
+"
+done; done

@@ -14,8 +14,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <errno.h>
 #include <pthread.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include "cli.h"
 
@@ -144,6 +146,316 @@ static void panel_print(const char *asm_bed, const char *lowq_bed, char **cov_na
     free(line);
 }
 
+/* ---------------- one round of the threaded reader: `want` bytes of each of the two files at their offsets ---------------- */
+typedef struct {
+    int fd[2], n_threads, started;
+    char *dst[2];
+    int64_t off[2], want[2], got[2];
+    pthread_t th;
+} bg_round_t;
+
+static void *bg_round_thread(void *p)
+{
+    bg_round_t *r = (bg_round_t *)p;
+    for (int f = 0; f < 2; ++f) r->got[f] = r->want[f] > 0 ? cli_pread_parallel(r->fd[f], r->dst[f], r->want[f], r->off[f], r->n_threads) : 0;
+    return NULL;
+}
+
+static void bg_round_post(bg_round_t *r)
+{
+    r->started = pthread_create(&r->th, NULL, bg_round_thread, r) == 0;
+    if (!r->started) bg_round_thread(r); /* no thread to be had: read here */
+}
+
+static void bg_round_join(bg_round_t *r)
+{
+    if (r->started) pthread_join(r->th, NULL);
+    r->started = 0;
+}
+
+/* ---------------- get_depths over a byte range of each of two regular files (src/boringbits_main.c:180-301) ----------------
+ * pread() threads fill one pair of pinned pieces while the device takes the other.  The whole files on one device, or one share of
+ * them per device (bg_split): nothing here prints or exits — what went wrong comes back in the job. */
+typedef struct {
+    /* in */
+    cornetto_accel_t *h;
+    int fd_t, fd_q, n_rd;
+    int64_t t0, t1, q0, q1, piece; /* [t0, t1) of the total-depth file, [q0, q1) of the mapq file */
+    /* out */
+    cornetto_cov_t *cov;
+    int32_t n_ctg;
+    char **names;
+    int64_t n_clamped;
+    int fmt_kind, fmt_a, fmt_b; /* a check of the reference failed (cornetto_bgerr_t) */
+    int rc;                     /* anything else: CORNETTO_E_*; -1000 - f: reading file f failed */
+    char err[600];
+} bg_job_t;
+
+static void bg_job_fail(bg_job_t *g, int rc, const char *what)
+{
+    g->rc = rc;
+    snprintf(g->err, sizeof(g->err), "%s failed: %s (%s)", what, cornetto_accel_last_error(g->h), cornetto_accel_strerror(rc));
+}
+
+static void bg_ingest(bg_job_t *g)
+{
+    const int64_t piece = g->piece;
+    char *buf[2][2] = {{NULL, NULL}, {NULL, NULL}};
+    cornetto_bgin_t *bg = NULL;
+    bg_round_t rd[2];
+    memset(rd, 0, sizeof(rd));
+    g->rc = CORNETTO_OK;
+    g->fmt_kind = 0;
+    for (int i = 0; i < 2; ++i)
+        for (int f = 0; f < 2; ++f)
+            if (!(buf[i][f] = (char *)cornetto_pinned_alloc((size_t)piece))) {
+                g->rc = CORNETTO_E_NOMEM;
+                snprintf(g->err, sizeof(g->err), "cannot allocate pinned read buffers");
+                goto out;
+            }
+    for (int i = 0; i < 2; ++i) {
+        rd[i].fd[0] = g->fd_t;
+        rd[i].fd[1] = g->fd_q;
+        rd[i].dst[0] = buf[i][0];
+        rd[i].dst[1] = buf[i][1];
+        rd[i].n_threads = g->n_rd;
+    }
+    int64_t off[2] = {g->t0, g->q0};
+    const int64_t end[2] = {g->t1, g->q1};
+    for (int f = 0; f < 2; ++f) {
+        rd[0].off[f] = off[f];
+        rd[0].want[f] = end[f] - off[f] < piece ? end[f] - off[f] : piece;
+    }
+    bg_round_post(&rd[0]); /* (the first round is on its way while the parser's state is set up) */
+    int rc = cornetto_bgin_open(g->h, &bg);
+    if (rc != CORNETTO_OK) {
+        bg_job_fail(g, rc, "bedgraph ingest");
+        goto out;
+    }
+    int eof[2] = {0, 0};
+    for (int k = 0; !cornetto_bgin_done(bg); ++k) {
+        int64_t pend[2] = {0, 0};
+        cornetto_bgin_pending(bg, &pend[0], &pend[1]);
+        bg_round_t *r = &rd[k & 1], *nx = &rd[(k + 1) & 1];
+        bg_round_join(r);
+        for (int f = 0; f < 2; ++f) {
+            if (r->got[f] < 0) {
+                g->rc = -1000 - f;
+                goto out;
+            }
+            off[f] += r->got[f];
+            if (r->got[f] < r->want[f] || off[f] >= end[f]) eof[f] = 1;
+        }
+        if (!(eof[0] && eof[1])) {
+            /* the next round is sized before this one is parsed: the bytes of either file that will be pending after it, if both
+             * files spend the same number of bytes per line (they nearly do), differ by `ahead`; the file that is ahead reads less */
+            const int64_t ahead = (pend[0] + r->got[0]) - (pend[1] + r->got[1]);
+            const int64_t least = piece < 4096 ? piece : 4096;
+            int64_t w[2] = {piece - (ahead > 0 ? ahead : 0), piece - (ahead < 0 ? -ahead : 0)};
+            for (int f = 0; f < 2; ++f) {
+                if (w[f] < least) w[f] = least;
+                if (w[f] > end[f] - off[f]) w[f] = end[f] - off[f];
+                nx->want[f] = eof[f] ? 0 : w[f];
+                nx->off[f] = off[f];
+            }
+            bg_round_post(nx);
+        }
+        rc = cornetto_bgin_feed(g->h, bg, r->dst[0], r->got[0], r->dst[1], r->got[1], eof[0] | (eof[1] << 1));
+        if (rc == CORNETTO_E_FORMAT) {
+            const cornetto_bgerr_t *e = cornetto_bgin_error(bg);
+            g->fmt_kind = e->kind ? e->kind : 5;
+            g->fmt_a = e->a;
+            g->fmt_b = e->b;
+            goto out;
+        }
+        if (rc != CORNETTO_OK) {
+            bg_job_fail(g, rc, "bedgraph ingest");
+            goto out;
+        }
+        if (eof[0] && eof[1] && !cornetto_bgin_done(bg)) { /* cannot happen: the final feed either finishes or fails */
+            g->rc = CORNETTO_E_ARG;
+            snprintf(g->err, sizeof(g->err), "bedgraph ingest did not finish");
+            goto out;
+        }
+    }
+    rc = cornetto_bgin_finish(g->h, bg, &g->cov, &g->n_ctg, &g->names, &g->n_clamped);
+    if (rc != CORNETTO_OK) bg_job_fail(g, rc, "bedgraph ingest");
+out:
+    for (int i = 0; i < 2; ++i)
+        if (rd[i].started) bg_round_join(&rd[i]); /* never leave a reader behind */
+    if (bg) cornetto_bgin_close(g->h, bg);
+    for (int i = 0; i < 2; ++i)
+        for (int f = 0; f < 2; ++f) cornetto_pinned_free(buf[i][f]);
+}
+
+/* the reference's messages and exit code for what bg_ingest() brought back (:209-227, :249-259) */
+static void bg_job_check(const bg_job_t *g, const char *name_t, const char *name_q)
+{
+    if (g->fmt_kind) {
+        if (g->fmt_kind == 1 || g->fmt_kind == 2) {
+            CLI_ERROR("The depth files should have 4 columns. Had %d.", g->fmt_a);
+        } else if (g->fmt_kind == 3) {
+            CLI_ERROR("%s", "The two files are not in the same order");
+        } else if (g->fmt_kind == 4) {
+            CLI_ERROR("The depth files should be incremantal at one base resolution. Found %d to %d", g->fmt_a, g->fmt_b);
+        } else {
+            CLI_ERROR("The depth files should have end=start+1. Found %d to %d", g->fmt_a, g->fmt_b);
+        }
+        exit(EXIT_FAILURE);
+    }
+    if (g->rc <= -1000) {
+        CLI_ERROR("reading %s failed", g->rc == -1000 ? name_t : name_q);
+        exit(EXIT_FAILURE);
+    }
+    if (g->rc != CORNETTO_OK) {
+        CLI_ERROR("%s", g->err);
+        exit(EXIT_FAILURE);
+    }
+}
+
+/* ---------------- where to cut two per-base bedgraphs into shares of whole contigs ----------------
+ * Both files hold the same lines (contig, position) in the same order, at different byte offsets.  A cut is a line start where the
+ * contig name changes; it is the same cut in both files when the line in front of it (name, position) and the line behind it are the
+ * same in both.  Found with a few 8 KB pread() probes per cut: the lines of a contig are one block, so "still the contig of the probe"
+ * is a predicate a binary search can use. */
+#define BG_NAME_MAX 1024
+typedef struct {
+    int64_t at;          /* line start behind the cut (the file's size: no line) */
+    char prev[BG_NAME_MAX], next[BG_NAME_MAX];
+    int64_t prev_pos, next_pos;
+} bg_cut_t;
+
+/* the first line that starts at or behind `off`: 1 and its start / name / first number; 0: there is none; -1: not a line this code reads */
+static int bg_line_at(int fd, int64_t size, int64_t off, int64_t *ls, char *name, int64_t *pos)
+{
+    char buf[8192];
+    if (off >= size) return 0;
+    const int64_t from = off > 0 ? off - 1 : 0;
+    ssize_t n;
+    do n = pread(fd, buf, sizeof(buf), (off_t)from);
+    while (n < 0 && errno == EINTR);
+    if (n <= 0) return -1;
+    ssize_t i = 0;
+    if (off > 0) {
+        while (i < n && buf[i] != '\n') ++i;
+        if (i == n) return from + n >= size ? 0 : -1;
+        ++i;
+    }
+    if (from + i >= size) return 0;
+    ssize_t j = i;
+    while (j < n && buf[j] != '\t' && buf[j] != ' ' && buf[j] != '\n') ++j;
+    if (j == n || buf[j] == '\n' || j == i || j - i >= BG_NAME_MAX) return -1;
+    ssize_t k = j + 1;
+    int64_t v = 0;
+    if (k >= n || buf[k] < '0' || buf[k] > '9') return -1;
+    for (; k < n && buf[k] >= '0' && buf[k] <= '9'; ++k) v = v * 10 + (buf[k] - '0');
+    if (k == n) return -1;
+    memcpy(name, buf + i, (size_t)(j - i));
+    name[j - i] = 0;
+    *ls = from + i;
+    *pos = v;
+    return 1;
+}
+
+/* the line that ends right in front of the line start `at` (> 0) */
+static int bg_line_before(int fd, int64_t size, int64_t at, char *name, int64_t *pos)
+{
+    char buf[8192];
+    const int64_t from = at > (int64_t)sizeof(buf) ? at - (int64_t)sizeof(buf) : 0;
+    ssize_t n;
+    do n = pread(fd, buf, (size_t)(at - from), (off_t)from);
+    while (n < 0 && errno == EINTR);
+    if (n != at - from || n < 2 || buf[n - 1] != '\n') return -1;
+    ssize_t i = n - 2;
+    while (i >= 0 && buf[i] != '\n') --i;
+    if (i < 0 && from > 0) return -1; /* a line of more than 8 KB */
+    int64_t ls;
+    return bg_line_at(fd, size, from + i + 1, &ls, name, pos) == 1 && ls == from + i + 1 ? 1 : -1;
+}
+
+/* lo: a line start of contig X.  -> the start of the first line behind it that belongs to another contig (size: none); -1: give up */
+static int64_t bg_block_end(int fd, int64_t size, int64_t lo, const char *X)
+{
+    char nm[BG_NAME_MAX];
+    int64_t hi = size, ls, p;
+    for (int64_t step = 1 << 20; lo + step < size; step *= 2) { /* gallop */
+        const int r = bg_line_at(fd, size, lo + step, &ls, nm, &p);
+        if (r < 0) return -1;
+        if (r == 0) break;
+        if (strcmp(nm, X)) {
+            hi = ls;
+            break;
+        }
+        lo = ls;
+    }
+    int64_t cap = hi; /* no line starts in [cap, hi) */
+    while (cap - lo > 4096) {
+        const int64_t mid = lo + (cap - lo) / 2;
+        const int r = bg_line_at(fd, size, mid, &ls, nm, &p);
+        if (r < 0) return -1;
+        if (r == 0 || ls >= hi) cap = mid;
+        else if (strcmp(nm, X)) hi = cap = ls;
+        else lo = ls;
+    }
+    for (;;) { /* line by line */
+        const int r = bg_line_at(fd, size, lo + 1, &ls, nm, &p);
+        if (r < 0) return -1;
+        if (r == 0 || ls >= hi) return hi;
+        if (strcmp(nm, X)) return ls;
+        lo = ls;
+    }
+}
+
+static int bg_cut_describe(int fd, int64_t size, int64_t at, bg_cut_t *c)
+{
+    int64_t ls;
+    c->at = at;
+    c->next[0] = 0;
+    c->next_pos = -1;
+    if (at < size && !(bg_line_at(fd, size, at, &ls, c->next, &c->next_pos) == 1 && ls == at)) return -1;
+    return at > 0 ? bg_line_before(fd, size, at, c->prev, &c->prev_pos) : -1;
+}
+
+/* up to n_want shares -> their number (1: no cut found that is provably the same in both files); cut[k] = start of share k + 1 */
+static int bg_split(int fd_t, int64_t size_t_, int fd_q, int64_t size_q, int n_want, int64_t *cut_t, int64_t *cut_q)
+{
+    int n = 0;
+    char nm[BG_NAME_MAX];
+    for (int d = 1; d < n_want; ++d) {
+        int64_t ls, p;
+        bg_cut_t ct, cq;
+        if (bg_line_at(fd_t, size_t_, size_t_ / n_want * d, &ls, nm, &p) != 1) continue;
+        const int64_t at_t = bg_block_end(fd_t, size_t_, ls, nm);
+        if (at_t <= 0 || at_t >= size_t_ || (n && at_t <= cut_t[n - 1])) continue;
+        if (bg_cut_describe(fd_t, size_t_, at_t, &ct) != 1) continue;
+        /* the same cut in the other file: near the same fraction of its bytes */
+        const int64_t est = (int64_t)((double)at_t / (double)size_t_ * (double)size_q);
+        if (bg_line_at(fd_q, size_q, est < size_q ? est : size_q - 1, &ls, nm, &p) != 1) continue;
+        int64_t at_q = -1;
+        if (!strcmp(nm, ct.prev)) {
+            at_q = bg_block_end(fd_q, size_q, ls, ct.prev);
+        } else if (!strcmp(nm, ct.next)) { /* behind the cut: back to a line of the contig in front of it */
+            for (int64_t step = 1 << 20, at = ls;; step *= 2) {
+                at = at > step ? at - step : 0;
+                const int r = bg_line_at(fd_q, size_q, at, &ls, nm, &p);
+                if (r != 1) break;
+                if (!strcmp(nm, ct.prev)) {
+                    at_q = bg_block_end(fd_q, size_q, ls, ct.prev);
+                    break;
+                }
+                if (strcmp(nm, ct.next) || at == 0) break; /* a third contig: the estimate was off by more than a contig */
+            }
+        }
+        if (at_q <= 0 || at_q >= size_q || bg_cut_describe(fd_q, size_q, at_q, &cq) != 1) continue;
+        if (strcmp(ct.prev, cq.prev) || strcmp(ct.next, cq.next) || ct.prev_pos != cq.prev_pos || ct.next_pos != cq.next_pos) continue;
+        if (n && at_q <= cut_q[n - 1]) continue;
+        cut_t[n] = at_t;
+        cut_q[n] = at_q;
+        ++n;
+    }
+    return n + 1;
+}
+
 /* ---------------- several GPUs (CORNETTO_DEVICES): the window stage sharded by contig ----------------
  * get_regs() is independent per contig (src/boringbits_main.c:331); the thresholds depend on the assembly-wide mean
  * (:283-294 -> :518-519).  The text is parsed on the first device; its contigs are then dealt to the devices (longest first,
@@ -166,6 +478,7 @@ typedef struct {
     int64_t n_recs;
     int rc;
     char err[600];
+    bg_job_t *ing; /* the device parses its own share of the text first (sharded ingest) */
 } bb_dev_t;
 
 static void *bb_worker(void *p)
@@ -179,6 +492,16 @@ static void *bb_worker(void *p)
                 snprintf(d->err, sizeof(d->err), "cannot open HIP device %d: %s", d->dev, cornetto_accel_strerror(d->rc));
                 return NULL;
             }
+        }
+        if (d->ing) {
+            d->ing->h = d->h;
+            bg_ingest(d->ing);
+            if (d->ing->rc != CORNETTO_OK || d->ing->fmt_kind) return NULL; /* (reported in the order of the shares by the caller) */
+            d->part = d->ing->cov;
+            d->n = d->ing->n_ctg;
+            if (d->n > 0) d->rc = cornetto_cov_prepare(d->h, d->part, d->opt->window_size, d->opt->window_inc, d->sums);
+            if (d->rc != CORNETTO_OK) snprintf(d->err, sizeof(d->err), "device %d: %s (%s)", d->dev, cornetto_accel_last_error(d->h), cornetto_accel_strerror(d->rc));
+            return NULL;
         }
         if (d->n == 0) return NULL; /* more devices than contigs: nothing to do here */
         d->rc = cornetto_cov_shard(d->h_src, d->src, d->h, d->ctgs, d->n, &d->part);
@@ -274,36 +597,69 @@ static void bb_multi(cornetto_accel_t *h0, const cornetto_cov_t *cov, int32_t n_
     *n_recs = at;
 }
 
-/* ---------------- one round of the threaded reader: `want` bytes of each of the two files at their offsets ---------------- */
-typedef struct {
-    int fd[2], n_threads, started;
-    char *dst[2];
-    int64_t off[2], want[2], got[2];
-    pthread_t th;
-} bg_round_t;
-
-static void *bg_round_thread(void *p)
+/* Sharded ingest: device d parses share d of the text (whole contigs: bg_split), sums and classifies the contigs it parsed — the text of
+ * 3 Gbp is 2 x 100 GB: every device reads its part of the files over its own PCIe link, and no depth array moves between devices.
+ * The host adds the three totals up for the common thresholds.  -> names / lengths / selected windows of all contigs in file order */
+static void bb_sharded(cornetto_accel_t *h0, bg_job_t *jobs, const int *devs, int n_sh, const optp_t *opt, int8_t boring, const char *name_t, const char *name_q,
+                       uint64_t sums[3], int32_t *mean_depth, int32_t *mean_mq, int32_t *n_ctg_out, char ***names_out, int32_t **lens_out,
+                       cornetto_regrec_t **recs, int64_t *n_recs)
 {
-    bg_round_t *r = (bg_round_t *)p;
-    for (int f = 0; f < 2; ++f) r->got[f] = r->want[f] > 0 ? cli_pread_parallel(r->fd[f], r->dst[f], r->want[f], r->off[f], r->n_threads) : 0;
-    return NULL;
-}
-
-static void bg_round_post(bg_round_t *r)
-{
-    r->started = pthread_create(&r->th, NULL, bg_round_thread, r) == 0;
-    if (!r->started) bg_round_thread(r); /* no thread to be had: read here */
-}
-
-static void bg_round_join(bg_round_t *r, const char *name_t, const char *name_q)
-{
-    if (r->started) pthread_join(r->th, NULL);
-    r->started = 0;
-    for (int f = 0; f < 2; ++f)
-        if (r->got[f] < 0) {
-            CLI_ERROR("reading %s failed", f ? name_q : name_t);
-            exit(EXIT_FAILURE);
+    bb_dev_t dv[CLI_MAX_DEV];
+    memset(dv, 0, sizeof(dv));
+    for (int d = 0; d < n_sh; ++d) {
+        dv[d].dev = devs[d];
+        dv[d].h = d == 0 ? h0 : NULL;
+        dv[d].opt = opt;
+        dv[d].boring = boring;
+        dv[d].ing = &jobs[d];
+    }
+    bb_run(dv, n_sh, 0);
+    int64_t clamped = 0;
+    int32_t n_ctg = 0;
+    for (int d = 0; d < n_sh; ++d) { /* what the sequential parse would have met first */
+        bg_job_check(&jobs[d], name_t, name_q);
+        clamped += jobs[d].n_clamped;
+        n_ctg += jobs[d].n_ctg;
+    }
+    if (clamped) CLI_WARNING("%lld depth values were truncated to 65535", (long long)clamped);
+    sums[0] = sums[1] = sums[2] = 0;
+    for (int d = 0; d < n_sh; ++d)
+        for (int k = 0; k < 3; ++k) sums[k] += dv[d].sums[k];            /* the one exchange: 3 x u64 per device */
+    *mean_depth = (int32_t)round((double)sums[0] / (double)sums[2]);     /* :293 */
+    *mean_mq = (int32_t)round((double)sums[1] / (double)sums[2]);        /* :294 */
+    for (int d = 0; d < n_sh; ++d) {
+        dv[d].lo = cornetto_cov_threshold(opt->low_cov_thresh, *mean_depth);   /* :518 */
+        dv[d].hi = cornetto_cov_threshold(opt->high_cov_thresh, *mean_depth);  /* :519 */
+    }
+    bb_run(dv, n_sh, 1);
+    int64_t total = 0;
+    for (int d = 0; d < n_sh; ++d) total += dv[d].n_recs;
+    cornetto_regrec_t *all = (cornetto_regrec_t *)cli_xmalloc(((size_t)total + 1) * sizeof(*all));
+    char **names = (char **)cli_xmalloc(((size_t)n_ctg + 1) * sizeof(char *));
+    int32_t *lens = (int32_t *)cli_xmalloc(((size_t)n_ctg + 1) * sizeof(int32_t));
+    int64_t at = 0;
+    int32_t base = 0;
+    for (int d = 0; d < n_sh; ++d) {
+        const int32_t *l = jobs[d].n_ctg ? cornetto_cov_lens(jobs[d].cov) : NULL;
+        for (int32_t i = 0; i < jobs[d].n_ctg; ++i) {
+            names[base + i] = jobs[d].names[i];
+            lens[base + i] = l[i];
         }
+        for (int64_t k = 0; k < dv[d].n_recs; ++k) {
+            all[at] = dv[d].recs[k];
+            all[at++].ctg += base;
+        }
+        base += jobs[d].n_ctg;
+        cornetto_free(dv[d].recs);
+        free(jobs[d].names);
+        if (jobs[d].cov) cornetto_cov_free(dv[d].h, jobs[d].cov);
+        if (d > 0 && dv[d].h) cornetto_accel_close(dv[d].h);
+    }
+    *n_ctg_out = n_ctg;
+    *names_out = names;
+    *lens_out = lens;
+    *recs = all;
+    *n_recs = at;
 }
 
 int boringbits_main(int argc, char *argv[], int8_t boring)
@@ -414,131 +770,125 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
         setenv("CORNETTO_DEVICE", one, 1);
     }
     /* Two regular files: pread() threads fill one pair of pinned pieces while the device takes the other (a single fread() stream copies
-     * from the page cache at 5-8 GB/s: 0.85 of the 1.3 s of a 6.8 GB pair).  Anything else (FIFOs, process substitution): the sequential
-     * loop below.  $CORNETTO_BG_THREADS=0 asks for the sequential loop, $CORNETTO_BG_PIECE sets the bytes of each file per round (tests). */
+     * from the page cache at 5-8 GB/s: 0.85 of the 1.3 s of a 6.8 GB pair), and with several devices every device parses its own share
+     * of the text (bb_sharded).  Anything else (FIFOs, process substitution): the sequential loop below on the first device.
+     * $CORNETTO_BG_THREADS=0 asks for the sequential loop, $CORNETTO_BG_PIECE sets the bytes of each file per round (tests),
+     * $CORNETTO_BG_SHARD_MIN the bytes a file must have per device before it is cut (64 MB; tests: 1). */
     struct stat st_t, st_q;
     int n_rd = 8;
     if (getenv("CORNETTO_BG_THREADS")) n_rd = atoi(getenv("CORNETTO_BG_THREADS"));
     const int threaded = n_rd > 0 && fstat(fileno(ft), &st_t) == 0 && fstat(fileno(fq), &st_q) == 0 && S_ISREG(st_t.st_mode) && S_ISREG(st_q.st_mode);
     int64_t piece = threaded ? 64ll << 20 : 256ll << 20; /* bytes of each file kept in flight */
     if (getenv("CORNETTO_BG_PIECE") && atoll(getenv("CORNETTO_BG_PIECE")) > 0) piece = atoll(getenv("CORNETTO_BG_PIECE"));
+    int64_t cut_t[CLI_MAX_DEV], cut_q[CLI_MAX_DEV];
+    int n_sh = 1;
+    if (threaded) {
+        int64_t shard_min = 64ll << 20;
+        if (getenv("CORNETTO_BG_SHARD_MIN") && atoll(getenv("CORNETTO_BG_SHARD_MIN")) > 0) shard_min = atoll(getenv("CORNETTO_BG_SHARD_MIN"));
+        if (n_dev >= 2 && !panel_bed && (int64_t)st_t.st_size >= shard_min * n_dev && (int64_t)st_q.st_size >= shard_min * n_dev)
+            n_sh = bg_split(fileno(ft), (int64_t)st_t.st_size, fileno(fq), (int64_t)st_q.st_size, n_dev, cut_t, cut_q);
+        if (getenv("CORNETTO_BG_SPLIT_ONLY")) { /* (tests: the cuts, without a device) */
+            for (int d = 0; d + 1 < n_sh; ++d) printf("%lld\t%lld\n", (long long)cut_t[d], (long long)cut_q[d]);
+            exit(EXIT_SUCCESS);
+        }
+    }
     cli_accel_open_begin();
-    const int n_buf = threaded ? 2 : 1;
-    char *buf_t[2] = {NULL, NULL}, *buf_q[2] = {NULL, NULL};
-    for (int i = 0; i < n_buf; ++i) {
-        buf_t[i] = (char *)cornetto_pinned_alloc((size_t)piece);
-        buf_q[i] = (char *)cornetto_pinned_alloc((size_t)piece);
-        if (!buf_t[i] || !buf_q[i]) {
-            (void)cli_accel_open_end(); /* no usable device: its message and exit(EXIT_FAILURE) */
-            CLI_ERROR("%s", "cannot allocate pinned read buffers");
-            exit(EXIT_FAILURE);
-        }
-    }
-    bg_round_t rd[2];
-    memset(rd, 0, sizeof(rd));
-    if (threaded) { /* the first round is read while the device is being opened */
-        for (int i = 0; i < 2; ++i) {
-            rd[i].fd[0] = fileno(ft);
-            rd[i].fd[1] = fileno(fq);
-            rd[i].dst[0] = buf_t[i];
-            rd[i].dst[1] = buf_q[i];
-            rd[i].n_threads = n_rd;
-        }
-        rd[0].want[0] = rd[0].want[1] = piece;
-        bg_round_post(&rd[0]);
-    }
-    cornetto_accel_t *h = cli_accel_open_end();
-    cornetto_bgin_t *bg = NULL;
-    cli_accel_check(h, cornetto_bgin_open(h, &bg), "bedgraph ingest");
-    int eof_t = 0, eof_q = 0;
-    int64_t off_t_ = 0, off_q_ = 0;
-    for (int k = 0; !cornetto_bgin_done(bg); ++k) {
-        int64_t pend_t = 0, pend_q = 0;
-        cornetto_bgin_pending(bg, &pend_t, &pend_q);
-        size_t got_t, got_q;
-        const char *src_t = buf_t[0], *src_q = buf_q[0];
-        if (threaded) {
-            bg_round_t *r = &rd[k & 1], *nx = &rd[(k + 1) & 1];
-            bg_round_join(r, covtotal, covmq);
-            got_t = (size_t)r->got[0];
-            got_q = (size_t)r->got[1];
-            if (r->got[0] < r->want[0]) eof_t = 1;
-            if (r->got[1] < r->want[1]) eof_q = 1;
-            off_t_ += r->got[0];
-            off_q_ += r->got[1];
-            src_t = r->dst[0];
-            src_q = r->dst[1];
-            if (!(eof_t && eof_q)) {
-                /* the next round is sized before this one is parsed: the bytes of either file that will be pending after it, if both
-                 * files spend the same number of bytes per line (they nearly do), differ by `ahead`; the file that is ahead reads less */
-                const int64_t ahead = (pend_t + r->got[0]) - (pend_q + r->got[1]);
-                int64_t w_t = piece - (ahead > 0 ? ahead : 0), w_q = piece - (ahead < 0 ? -ahead : 0);
-                const int64_t least = piece < 4096 ? piece : 4096;
-                nx->want[0] = eof_t ? 0 : (w_t < least ? least : w_t);
-                nx->want[1] = eof_q ? 0 : (w_q < least ? least : w_q);
-                nx->off[0] = off_t_;
-                nx->off[1] = off_q_;
-                bg_round_post(nx);
-            } else {
-                nx->want[0] = nx->want[1] = 0;
-                nx->got[0] = nx->got[1] = 0;
-            }
-        } else {
-            /* top both files up to the same number of pending bytes, so the unmatched tail of either stays small */
-            const int64_t least = piece < 4096 ? piece : 4096;
-            size_t want_t = eof_t ? 0 : (size_t)(pend_t < piece - least ? piece - pend_t : least);
-            size_t want_q = eof_q ? 0 : (size_t)(pend_q < piece - least ? piece - pend_q : least);
-            got_t = want_t ? fread(buf_t[0], 1, want_t, ft) : 0;
-            got_q = want_q ? fread(buf_q[0], 1, want_q, fq) : 0;
-            if (got_t < want_t) eof_t = 1;
-            if (got_q < want_q) eof_q = 1;
-        }
-        int rc = cornetto_bgin_feed(h, bg, src_t, (int64_t)got_t, src_q, (int64_t)got_q, eof_t | (eof_q << 1));
-        if (rc == CORNETTO_E_FORMAT) {
-            const cornetto_bgerr_t *e = cornetto_bgin_error(bg);
-            if (e->kind == 1 || e->kind == 2) {
-                CLI_ERROR("The depth files should have 4 columns. Had %d.", e->a);
-            } else if (e->kind == 3) {
-                CLI_ERROR("%s", "The two files are not in the same order");
-            } else if (e->kind == 4) {
-                CLI_ERROR("The depth files should be incremantal at one base resolution. Found %d to %d", e->a, e->b);
-            } else {
-                CLI_ERROR("The depth files should have end=start+1. Found %d to %d", e->a, e->b);
-            }
-            exit(EXIT_FAILURE);
-        }
-        cli_accel_check(h, rc, "bedgraph ingest");
-        if (eof_t && eof_q && !cornetto_bgin_done(bg)) { /* cannot happen: the final feed either finishes or fails */
-            CLI_ERROR("%s", "bedgraph ingest did not finish");
-            exit(EXIT_FAILURE);
-        }
-    }
-    if (threaded) /* a round posted behind a feed that ended the ingest early cannot exist (done needs both ends), but never leave a thread behind */
-        for (int i = 0; i < 2; ++i)
-            if (rd[i].started) bg_round_join(&rd[i], covtotal, covmq);
-    fclose(ft);
-    fclose(fq);
-    for (int i = 0; i < n_buf; ++i) {
-        cornetto_pinned_free(buf_t[i]);
-        cornetto_pinned_free(buf_q[i]);
-    }
+    cornetto_accel_t *h = NULL;
     cornetto_cov_t *cov = NULL;
     int32_t n_ctg = 0;
     char **names = NULL;
     int64_t n_clamped = 0;
-    cli_accel_check(h, cornetto_bgin_finish(h, bg, &cov, &n_ctg, &names, &n_clamped), "bedgraph ingest");
-    cornetto_bgin_close(h, bg);
-    if (n_clamped) CLI_WARNING("%lld depth values were truncated to 65535", (long long)n_clamped);
-    const int32_t *lens = cornetto_cov_lens(cov);
-    CLI_VERBOSE("Loaded depth files in %.2f seconds", cli_realtime() - t0);
-
-    /* ---------------- device: totals, windows, selection ---------------- */
+    const int32_t *lens = NULL;
+    int32_t *lens_owned = NULL;
     int32_t mean_depth = 0, mean_mq = 0;
     cornetto_regrec_t *recs = NULL;
     cornetto_ivl_t *fun = NULL;
     int64_t n_recs = 0, n_fun = 0;
-    int recs_are_malloced = 0;
-    if (n_ctg > 0 && n_dev >= 2 && !panel_bed) {
+    int recs_are_malloced = 0, stage_done = 0;
+    if (threaded) {
+        bg_job_t jobs[CLI_MAX_DEV];
+        memset(jobs, 0, sizeof(jobs));
+        for (int d = 0; d < n_sh; ++d) {
+            jobs[d].fd_t = fileno(ft);
+            jobs[d].fd_q = fileno(fq);
+            jobs[d].n_rd = n_sh > 1 ? (n_rd / n_sh > 2 ? n_rd / n_sh : 2) : n_rd;
+            jobs[d].piece = piece;
+            jobs[d].t0 = d ? cut_t[d - 1] : 0;
+            jobs[d].q0 = d ? cut_q[d - 1] : 0;
+            jobs[d].t1 = d + 1 < n_sh ? cut_t[d] : (int64_t)st_t.st_size;
+            jobs[d].q1 = d + 1 < n_sh ? cut_q[d] : (int64_t)st_q.st_size;
+        }
+        h = cli_accel_open_end();
+        if (n_sh > 1) {
+            uint64_t sums[3];
+            bb_sharded(h, jobs, devs, n_sh, &opt, boring, covtotal, covmq, sums, &mean_depth, &mean_mq, &n_ctg, &names, &lens_owned, &recs, &n_recs);
+            lens = lens_owned;
+            recs_are_malloced = 1;
+            stage_done = 1;
+            CLI_VERBOSE("Loaded depth files and found regions on %d devices (sharded ingest) in %.2f seconds", n_sh, cli_realtime() - t0);
+        } else {
+            jobs[0].h = h;
+            bg_ingest(&jobs[0]);
+            bg_job_check(&jobs[0], covtotal, covmq);
+            cov = jobs[0].cov;
+            n_ctg = jobs[0].n_ctg;
+            names = jobs[0].names;
+            n_clamped = jobs[0].n_clamped;
+        }
+    } else {
+        char *buf_t = (char *)cornetto_pinned_alloc((size_t)piece), *buf_q = (char *)cornetto_pinned_alloc((size_t)piece);
+        if (!buf_t || !buf_q) {
+            (void)cli_accel_open_end(); /* no usable device: its message and exit(EXIT_FAILURE) */
+            CLI_ERROR("%s", "cannot allocate pinned read buffers");
+            exit(EXIT_FAILURE);
+        }
+        h = cli_accel_open_end();
+        cornetto_bgin_t *bg = NULL;
+        cli_accel_check(h, cornetto_bgin_open(h, &bg), "bedgraph ingest");
+        int eof_t = 0, eof_q = 0;
+        bg_job_t g;
+        memset(&g, 0, sizeof(g));
+        while (!cornetto_bgin_done(bg)) {
+            int64_t pend_t = 0, pend_q = 0;
+            cornetto_bgin_pending(bg, &pend_t, &pend_q);
+            /* top both files up to the same number of pending bytes, so the unmatched tail of either stays small */
+            const int64_t least = piece < 4096 ? piece : 4096;
+            size_t want_t = eof_t ? 0 : (size_t)(pend_t < piece - least ? piece - pend_t : least);
+            size_t want_q = eof_q ? 0 : (size_t)(pend_q < piece - least ? piece - pend_q : least);
+            size_t got_t = want_t ? fread(buf_t, 1, want_t, ft) : 0, got_q = want_q ? fread(buf_q, 1, want_q, fq) : 0;
+            if (got_t < want_t) eof_t = 1;
+            if (got_q < want_q) eof_q = 1;
+            int rc = cornetto_bgin_feed(h, bg, buf_t, (int64_t)got_t, buf_q, (int64_t)got_q, eof_t | (eof_q << 1));
+            if (rc == CORNETTO_E_FORMAT) {
+                const cornetto_bgerr_t *e = cornetto_bgin_error(bg);
+                g.fmt_kind = e->kind ? e->kind : 5;
+                g.fmt_a = e->a;
+                g.fmt_b = e->b;
+                bg_job_check(&g, covtotal, covmq);
+            }
+            cli_accel_check(h, rc, "bedgraph ingest");
+            if (eof_t && eof_q && !cornetto_bgin_done(bg)) { /* cannot happen: the final feed either finishes or fails */
+                CLI_ERROR("%s", "bedgraph ingest did not finish");
+                exit(EXIT_FAILURE);
+            }
+        }
+        cornetto_pinned_free(buf_t);
+        cornetto_pinned_free(buf_q);
+        cli_accel_check(h, cornetto_bgin_finish(h, bg, &cov, &n_ctg, &names, &n_clamped), "bedgraph ingest");
+        cornetto_bgin_close(h, bg);
+    }
+    fclose(ft);
+    fclose(fq);
+    if (n_clamped) CLI_WARNING("%lld depth values were truncated to 65535", (long long)n_clamped);
+    if (!stage_done) {
+        lens = cornetto_cov_lens(cov);
+        CLI_VERBOSE("Loaded depth files in %.2f seconds", cli_realtime() - t0);
+    }
+
+    /* ---------------- device: totals, windows, selection ---------------- */
+    if (stage_done) {
+        if (n_ctg == 0) mean_depth = mean_mq = (int32_t)0x80000000;
+    } else if (n_ctg > 0 && n_dev >= 2 && !panel_bed) {
         t0 = cli_realtime();
         uint64_t sums[3];
         bb_multi(h, cov, n_ctg, lens, devs, n_dev, &opt, boring, sums, &mean_depth, &mean_mq, &recs, &n_recs);
@@ -622,7 +972,8 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
     else cornetto_free(recs);
     for (int32_t i = 0; i < n_ctg; ++i) free(names[i]);
     free(names);
-    cornetto_cov_free(h, cov);
+    free(lens_owned);
+    if (cov) cornetto_cov_free(h, cov);
     cornetto_accel_close(h);
     return 0;
 }

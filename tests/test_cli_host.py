@@ -156,3 +156,54 @@ def test_text_parsers_in_front_of_the_device_calls(cli, golden_dir, tmp_path):
     assert out == b"@r\tc\nACGT\n+\nIIII\n"
     rc, out, err = run(cli, ["fa2bed", "-"], stdin=b">a b c\r\nAC\r\nGT\r\n>e\n\n>f\nA")
     assert rc == 0 and out == b"a\t0\t4\ne\t0\t0\nf\t0\t1\n"
+
+
+def _bedgraph_pair(tmp_path, lens, seed, digits_t=(10_000, 60_000), digits_q=(0, 10)):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    rows_t, rows_q, first = [], [], []
+    nl = 0
+    for ci, n in enumerate(lens):
+        name = "ptg%06dl" % ci if ci % 3 else "c%d" % ci
+        d = rng.integers(*digits_t, size=n)
+        q = rng.integers(*digits_q, size=n)
+        first.append(nl)
+        nl += n
+        rows_t.append("".join("%s\t%d\t%d\t%d\n" % (name, p, p + 1, v) for p, v in enumerate(d)))
+        rows_q.append("".join("%s\t%d\t%d\t%d\n" % (name, p, p + 1, v) for p, v in enumerate(q)))
+    a, b = tmp_path / "t.bg", tmp_path / "q.bg"
+    a.write_text("".join(rows_t))
+    b.write_text("".join(rows_q))
+    return str(a), str(b), first
+
+
+@pytest.mark.parametrize("lens,devices", [
+    ([30_000, 5, 20_000, 70_000, 1, 1, 40_000, 9_000], "0,1"),
+    ([30_000, 5, 20_000, 70_000, 1, 1, 40_000, 9_000], "0,1,2,3"),
+    ([3_000] * 40, "0,1,2,3,4,5,6,7"),
+    ([200_000], "0,1,2"),                              # one contig: nothing to cut
+    ([100_000, 100_000], "0,1,2,3,4,5,6,7"),           # more devices than contigs
+])
+def test_bedgraph_cuts_for_sharded_ingest(cli, tmp_path, lens, devices):
+    """CORNETTO_DEVICES + two regular files: every device parses its own share of the text.  The cuts (found with a few pread() probes and
+    a binary search per cut, before any device is opened) are line starts where the contig changes, and the SAME line in both files
+    although their bytes per line differ (5-digit depths against 1-digit ones)"""
+    a, b, first = _bedgraph_pair(tmp_path, lens, 5)
+    env = dict(os.environ, CORNETTO_DEVICES=devices, CORNETTO_BG_SHARD_MIN="1", CORNETTO_BG_SPLIT_ONLY="1",
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=99")
+    p = subprocess.run([cli, "noboringbits", a, "-q", b], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert p.returncode == 0 and b"ERROR: AddressSanitizer" not in p.stderr and b"runtime error:" not in p.stderr, p.stderr.decode(errors="replace")[-2000:]
+    cuts = [tuple(int(x) for x in l.split()) for l in p.stdout.decode().splitlines()]
+    ta, tb = open(a, "rb").read(), open(b, "rb").read()
+    assert len(cuts) <= len(devices.split(",")) - 1
+    if len(lens) == 1:
+        assert cuts == []
+    elif sum(lens) > 100_000 and len(lens) > 2:
+        assert len(cuts) >= 1
+    last = (0, 0)
+    for ct, cq in cuts:
+        assert last[0] < ct < len(ta) and last[1] < cq < len(tb)
+        assert ta[ct - 1:ct] == b"\n" and tb[cq - 1:cq] == b"\n"
+        nl = ta[:ct].count(b"\n")
+        assert nl == tb[:cq].count(b"\n") and nl in first          # the same line, and the first of a contig
+        last = (ct, cq)

@@ -200,6 +200,65 @@ def test_panel_threaded_reader_with_unequal_line_lengths(cli, piece, tmp_path):
         assert [l for l in err.splitlines() if l.startswith(b"Average")] == [l for l in err0.splitlines() if l.startswith(b"Average")]
 
 
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0,0"])
+@pytest.mark.parametrize("args,exp", PANEL)
+def test_panel_sharded_ingest_over_several_devices(cli, golden_dir, plain, args, exp, devices):
+    """CORNETTO_DEVICES with two regular files: the text itself is cut into shares of whole contigs (the same line in both files), every
+    device parses, sums and classifies its share; the host adds the three totals up — same bytes as one device.  (CORNETTO_BG_SHARD_MIN=1:
+    the fixtures are far below the 64 MB per device at which the CLI cuts by itself.)"""
+    a = [plain["cov-total.bg"] if x == "T" else plain["cov-mq20.bg"] if x == "Q" else x for x in args]
+    rc, out, err = run(cli, a, {"CORNETTO_DEVICES": devices, "CORNETTO_BG_SHARD_MIN": "1"})
+    assert rc == 0, err.decode()
+    assert out == golden(golden_dir, exp)
+    assert err.count(b"Average depth:") == 1
+    rc1, out1, err1 = run(cli, a)
+    assert [l for l in err.splitlines() if l.startswith((b"Average", b"Number of contigs"))] == [l for l in err1.splitlines() if l.startswith((b"Average", b"Number of contigs"))]
+
+
+def test_panel_sharded_ingest_unequal_line_lengths_and_errors(cli, tmp_path):
+    """shares of a pair whose files spend different numbers of bytes per line; a malformed line in a LATER share is reported like the
+    sequential parse reports it (exit 1), and an error in the first share wins over one in the last"""
+    rng = np.random.default_rng(9)
+    lens = [40_000, 1, 25_000, 130_000, 7, 60_000, 30_000, 2_600]
+    rows_t, rows_q = [], []
+    for ci, n in enumerate(lens):
+        d = rng.integers(10_000, 60_000, size=n)
+        d[rng.integers(0, n, size=n // 50 + 1)] = 3
+        q = rng.integers(0, 10, size=n)
+        name = "ctg%d_a_rather_long_contig_name" % ci
+        rows_t.append(["%s\t%d\t%d\t%d\n" % (name, p, p + 1, v) for p, v in enumerate(d)])
+        rows_q.append(["%s\t%d\t%d\t%d\n" % (name, p, p + 1, v) for p, v in enumerate(q)])
+    a, b = tmp_path / "t.bg", tmp_path / "q.bg"
+
+    def write(rt, rq):
+        a.write_text("".join("".join(r) for r in rt))
+        b.write_text("".join("".join(r) for r in rq))
+    write(rows_t, rows_q)
+    args = ["noboringbits", str(a), "-q", str(b), "-m", "20000", "-e", "1000", "-w", "500", "-i", "50"]
+    rc0, out0, err0 = run(cli, args)
+    assert rc0 == 0 and len(out0) > 1000, err0.decode()
+    for devices in ("0,0", "0,0,0", "0,0,0,0,0,0,0,0"):
+        rc, out, err = run(cli, args, {"CORNETTO_DEVICES": devices, "CORNETTO_BG_SHARD_MIN": "1", "CORNETTO_BG_PIECE": "300000"})
+        assert rc == 0, err.decode()
+        assert out == out0
+        assert b"sharded ingest" in err
+        assert [l for l in err.splitlines() if l.startswith(b"Average")] == [l for l in err0.splitlines() if l.startswith(b"Average")]
+    # a position that repeats in the last contig but one; then also a 3-column line in the first contig
+    bad_t = [list(r) for r in rows_t]
+    bad_t[6][100] = bad_t[6][99]
+    bad_q = [list(r) for r in rows_q]
+    bad_q[6][100] = bad_q[6][99]
+    write(bad_t, bad_q)
+    rc1, out1, err1 = run(cli, args)
+    rc, out, err = run(cli, args, {"CORNETTO_DEVICES": "0,0,0", "CORNETTO_BG_SHARD_MIN": "1"})
+    assert rc1 == 1 and rc == 1 and b"incremantal" in err and b"incremantal" in err1
+    bad_t[0][50] = "ctg0_a_rather_long_contig_name\t50\t51\n"
+    write(bad_t, bad_q)
+    rc1, out1, err1 = run(cli, args)
+    rc, out, err = run(cli, args, {"CORNETTO_DEVICES": "0,0,0", "CORNETTO_BG_SHARD_MIN": "1"})
+    assert rc1 == 1 and rc == 1 and b"4 columns" in err1 and b"4 columns" in err
+
+
 @pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
 @pytest.mark.parametrize("batch", ["", "200000"])
 @pytest.mark.parametrize("args,exp", [
@@ -255,6 +314,9 @@ def test_panel_window_stage_over_distinct_devices(cli, golden_dir, plain, args, 
     a = [plain["cov-total.bg"] if x == "T" else plain["cov-mq20.bg"] if x == "Q" else x for x in args]
     for devices in ("0,1", "1,0", ",".join(str(i) for i in range(min(n, 8)))):
         rc, out, err = run(cli, a, {"CORNETTO_DEVICES": devices})
+        assert rc == 0, err.decode()
+        assert out == golden(golden_dir, exp)
+        rc, out, err = run(cli, a, {"CORNETTO_DEVICES": devices, "CORNETTO_BG_SHARD_MIN": "1"})       # and the sharded ingest
         assert rc == 0, err.decode()
         assert out == golden(golden_dir, exp)
 

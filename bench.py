@@ -799,10 +799,12 @@ def _shm_dir():
     return "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
 
 
-def make_bedgraph_text(torch, dev, n, seed, mq):
-    """n lines `ptg000001l\t%09d\t%09d\t%02d\n` (34 bytes; %d reads the zero-padded numbers the same) on the device: one contig,
-    depth around 30 with a 20 kb dip every 400 kb (mq: a quarter of the depth in a 20 kb segment every 500 kb)"""
-    pos = torch.arange(n, device=dev, dtype=torch.int64)
+def make_bedgraph_text(torch, dev, n, seed, mq, ctg_len=10_000_000):
+    """n lines `ptg%06dl\t%09d\t%09d\t%02d\n` (34 bytes; %d reads the zero-padded numbers the same) on the device: contigs of ctg_len
+    positions (the last one shorter), depth around 30 with a 20 kb dip every 400 kb (mq: a quarter of the depth in a 20 kb segment every 500 kb)"""
+    gpos = torch.arange(n, device=dev, dtype=torch.int64)
+    ctg = gpos // ctg_len + 1
+    pos = gpos - (ctg - 1) * ctg_len
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     depth = 28 + torch.randint(0, 5, (n,), device=dev, generator=g)
@@ -810,7 +812,7 @@ def make_bedgraph_text(torch, dev, n, seed, mq):
     if mq:
         depth = torch.where(((pos + 100000) % 500000) < 20000, depth // 4, depth)
     out = torch.empty((n, 34), dtype=torch.uint8, device=dev)
-    out[:, :10] = torch.tensor(list(b"ptg000001l"), dtype=torch.uint8, device=dev)
+    out[:, :10] = torch.tensor(list(b"ptg000000l"), dtype=torch.uint8, device=dev)
     out[:, 10] = 9
     out[:, 20] = 9
     out[:, 30] = 9
@@ -821,6 +823,7 @@ def make_bedgraph_text(torch, dev, n, seed, mq):
             out[:, col + nd - 1 - k] = (v % 10 + 48).to(torch.uint8)
             v = v // 10
 
+    digits(ctg, 3, 6)
     digits(pos.clone(), 11, 9)
     digits(pos + 1, 21, 9)
     digits(depth.clone(), 31, 2)
@@ -858,7 +861,14 @@ def e2e_noboringbits(R, torch, cornetto_amd, mlines=100.0):
                 return {"error": p.stderr[-300:].decode("replace")}
             so = p.stdout
             best = dt if best is None else min(best, dt)
-        out.update({"positions": n, "text_bytes": nbytes, "wall_s": round(best, 3), "text_GBps": round(nbytes / best / 1e9, 2),
+        # the same with the text cut into two shares of whole contigs (CORNETTO_DEVICES: one host thread, handle and reader pool per listed
+        # device — here the SAME GPU twice: what the cut and the second handle cost; on a node every share has its own PCIe link)
+        t0 = time.perf_counter()
+        p2 = subprocess.run([cornetto_amd.CLI_PATH, "noboringbits", paths[0], "-q", paths[1]], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                            env=dict(os.environ, CORNETTO_DEVICES="%d,%d" % (R.local_dev, R.local_dev)))
+        out["sharded_ingest_same_gpu_twice"] = {"wall_s": round(time.perf_counter() - t0, 3), "same_stdout": p2.returncode == 0 and p2.stdout == so,
+                                                "sharded": b"sharded ingest" in p2.stderr}
+        out.update({"positions": n, "contigs": (n + 9_999_999) // 10_000_000, "text_bytes": nbytes, "wall_s": round(best, 3), "text_GBps": round(nbytes / best / 1e9, 2),
                     "gbases_s": round(n / best / 1e9, 3), "stdout_bytes": len(so), "stdout_lines": so.count(b"\n"),
                     "command": "cornetto noboringbits cov-total.bg -q cov-mq20.bg (defaults: -w 2500 -i 50 -L 0.4 -H 2.5 -Q 0.4)"})
     except Exception as e:                               # an extra: never fail the bench line over it

@@ -128,6 +128,10 @@ int cornetto_accel_wait(cornetto_accel_t *h);
  * [4] groups of 4 steps that took the ungated path, [5] sum and [6] maximum over the waves of their run time in 10 ns ticks, [7] chunks sampled as low-complexity,
  * [10] find_perfect calls with candidates, [11] queue fetch rounds, [12] ticks spent fetching, [16 + 4b ...] per 0.5 ms bin b
  * of wave run time: waves, find_perfect calls with candidates, jobs, find_perfect calls; [254] waves launched, [255] chunks.
+ * The sift / resolve kernel (the default for W <= 66) fills instead: [200] resolve steps inside runs of consecutive positions, [201] resolve steps
+ * behind a gap (window reads), [202] passes with candidates, [203] positions with more than T / 10 equal words in front, [204] of those after the
+ * partial sums over the shortest candidate, [205] after the 16-term sums / the exact walk, [206] tiles of 64 bases, [207] base-by-base steps of
+ * chunks with other bytes.
  * Returns the number of counters copied.  Results of sdust do not depend on it. */
 int cornetto_accel_sdust_stats(cornetto_accel_t *h, int enable, uint64_t *out, int cap);
 

@@ -229,7 +229,8 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
     // word" bit, one accumulated difference to the letters that must be there — 12 instead of 25 vector instructions per dword.  Anything
     // else (another byte anywhere, the contig's first or last chunk) is staged again the general way below.
     bool general = rb <= 0 || rb + ((rlen + 15) & ~15) > len || (A.abl & 32);
-    if (!general) {
+    if (A.abl & 128) general = false;                 // (instruction counting only: no staging at all; with bit 4)
+    if (!general && !(A.abl & 128)) {
         uint32_t acc = 0u;
         for (int b16 = lane * 16, it = 0; b16 < rlen; b16 += 1024, ++it) {
             uint4 q;
@@ -558,7 +559,10 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
     int n_dense = 0;                                  // steps taken in runs of consecutive positions
     bool have = false;
     int wt = 0, wt_tile = -1;                         // words of tile wt_tile of the region, lane <-> position
-    for (int t = 0; t < ntile; ++t) {
+    unsigned long long nzt = sd_ballot(sw != 0ull);    // the tiles that hold a set bit at all (random sequence: 1 in 10)
+    while (nzt) {
+        const int t = __builtin_ctzll(nzt);
+        nzt &= nzt - 1;
         unsigned long long m = rdlane64(sw, t);
         while (m) {
             const int b = __builtin_ctzll(m);

@@ -7,7 +7,7 @@ export CORNETTO_SDUST_SIFT=1
 for abl in ${@:-0 4 1 3}; do
   export CORNETTO_SIFT_ABL=$abl
   rm -rf $R/gpurun_out/pmcabl_$abl
-  timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH -d $R/gpurun_out/pmcabl_$abl --output-format csv -- python3 $R/tools/perf_probe.py sdust --mbases 3160 --features 1 --reps 2 --profile uniform > $R/gpurun_out/pmcabl_$abl.log 2>&1
+  timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH -d $R/gpurun_out/pmcabl_$abl --output-format csv -- python3 $R/tools/perf_probe.py sdust --mbases 3160 --features ${FEATURES:-1} --reps 2 --profile uniform > $R/gpurun_out/pmcabl_$abl.log 2>&1
   python3 - $abl $R <<'PY'
 import csv, glob, sys, collections
 abl, R = sys.argv[1:3]

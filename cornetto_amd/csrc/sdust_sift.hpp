@@ -445,7 +445,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
             const uint32_t sh = (wv & 7u) << 2;
             const uint32_t old = __hip_atomic_fetch_add(&cnt[((wv >> 3) & 7u) * 64 + lane], alive ? 1u << sh : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             rr += alive ? (int)((old >> sh) & 15u) : 0;
-            sc = sc || (alive && a >= 1 && rr * 10 > T * a);
+            sc = sc | (alive & (a >= 1) & (__mul24(rr, 10) > T * a));        // (no short circuit: one compare instead of an exec-mask branch per step; rr <= 120)
         }
         const bool keep = on && (sc || (dmin > 0 && long_ok));
         if (STATS) st_l2 += (unsigned long long)__popcll(sd_ballot(keep));

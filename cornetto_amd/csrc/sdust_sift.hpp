@@ -457,9 +457,17 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
         const int o = on ? (int)tl[lane] : 0;
         const uint8_t *const p = wc + 2 * o;
         int d = 0, dmin = 0x7fffffff;
-        for (int j = 0; j < lmin; ++j) {
-            d += 10 * (int)p[1 - 2 * j] - T;
-            dmin = d < dmin ? d : dmin;
+        if (lmin == 4) {                              // (T = 16 .. 20, the default among them: the four reads in flight together)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                d += 10 * (int)p[1 - 2 * j] - T;
+                dmin = d < dmin ? d : dmin;
+            }
+        } else {
+            for (int j = 0; j < lmin; ++j) {
+                d += 10 * (int)p[1 - 2 * j] - T;
+                dmin = d < dmin ? d : dmin;
+            }
         }
         const bool ok = on && dmin > 0;
         const unsigned long long m = sd_ballot(ok);

@@ -257,6 +257,9 @@ struct cornetto_asm {
     std::vector<int32_t> tf_ctg_tile0;   // telofind: first tile of each contig (+ total)
     int2 *d_tf_tiles = nullptr;
     int64_t tf_n_tiles = -1;
+    int64_t tw_n_words = -1, tw_n_tiles = 0;   // telowin on the marks of a fused scan: words of the bitmap (-1: layout not built yet), window tiles
+    int64_t *d_tw_boff = nullptr;
+    int2 *d_tw_tiles = nullptr;
     int64_t sd_chunk = -1;               // sdust: chunk size the cached chunk table was built for
     std::vector<int32_t> sd_chunk_ctg;   // contig of every chunk
     void *d_sd_chunks = nullptr;

@@ -460,8 +460,10 @@ int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int3
     } else {
         CN_LAUNCH(h, "cov_blocks", cov_blocks<false, 0><<<dim3((unsigned)nt), dim3(CB_THREADS), 0, h->stream>>>(A));
     }
-    CN_TRY(cnscan::exclusive_u32(h, "cov_tilescan", reinterpret_cast<const uint32_t *>(d_t32), (int64_t)nt, 2, d_toff_d, d_part, nullptr));
-    CN_TRY(cnscan::exclusive_u32(h, "cov_tilescan", reinterpret_cast<const uint32_t *>(d_t32) + 1, (int64_t)nt, 2, d_toff_q, d_part, nullptr));
+    {
+        uint32_t *const outs[2] = {d_toff_d, d_toff_q};
+        CN_TRY(cnscan::exclusive_u32_multi(h, "cov_tilescan", reinterpret_cast<const uint32_t *>(d_t32), (int64_t)nt, 2, 2, outs, d_part, nullptr));
+    }
     const unsigned nb64 = (unsigned)std::min<size_t>(1024, (nt + 255) / 256);
     CN_LAUNCH(h, "cov_total64", cov_total64<<<dim3(nb64), dim3(256), 0, h->stream>>>(d_t64, (int64_t)nt, d_grand));
     CN_HIP(h, hipMemcpyAsync(p_grand, d_grand, 16, hipMemcpyDeviceToHost, h->stream));

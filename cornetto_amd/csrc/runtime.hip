@@ -219,6 +219,8 @@ void cornetto_asm_free(cornetto_accel_t *h, cornetto_asm_t *a)
     if (a->d_off) (void)hipFree(a->d_off);
     if (a->d_len) (void)hipFree(a->d_len);
     if (a->d_tf_tiles) (void)hipFree(a->d_tf_tiles);
+    if (a->d_tw_boff) (void)hipFree(a->d_tw_boff);
+    if (a->d_tw_tiles) (void)hipFree(a->d_tw_tiles);
     if (a->d_sd_chunks) (void)hipFree(a->d_sd_chunks);
     if (a->d_sd_walk) (void)hipFree(a->d_sd_walk);
     if (a->d_sd_plan) (void)hipFree(a->d_sd_plan);

@@ -86,6 +86,93 @@ __global__ __launch_bounds__(SC_THREADS) void scan_add(uint32_t *out, int64_t n,
     }
 }
 
+// The same for up to four counters that sit side by side in one record (in[i * stride + q], q < m): blockIdx.y = q, three launches for all
+// of them instead of three each (a 395 Mb share is made of launches: 12 -> 3 in front of telofind's gather).
+struct Outs4 {
+    uint32_t *o[4];
+};
+__global__ __launch_bounds__(SC_THREADS) void scan_local_m(const uint32_t *in, int64_t n, int stride, Outs4 outs, uint32_t *partial, int64_t np)
+{
+    __shared__ uint32_t wtot[SC_THREADS / 64];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, q = blockIdx.y;
+    const int64_t base = (int64_t)blockIdx.x * SC_TILE + (int64_t)t * SC_ITEMS;
+    uint32_t *const out = outs.o[q];
+    uint32_t v[SC_ITEMS], s = 0;
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; ++k) {
+        const int64_t i = base + k;
+        v[k] = i < n ? in[i * stride + q] : 0u;
+        s += v[k];
+    }
+    const uint32_t inc = wave_incl(s, lane);
+    if (lane == 63) wtot[wv] = inc;
+    __syncthreads();
+    uint32_t pre = inc - s;
+#pragma unroll
+    for (int w = 0; w < SC_THREADS / 64; ++w)
+        if (w < wv) pre += wtot[w];
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; ++k) {
+        const int64_t i = base + k;
+        if (i < n) out[i] = pre;
+        pre += v[k];
+    }
+    if (t == SC_THREADS - 1) partial[(int64_t)q * np + blockIdx.x] = pre;
+}
+
+__global__ __launch_bounds__(1024) void scan_partials_m(uint32_t *partial_all, int64_t np, unsigned long long *total)
+{
+    __shared__ uint32_t sh[1024];
+    const int t = threadIdx.x, q = blockIdx.x;
+    uint32_t *const partial = partial_all + (int64_t)q * np;
+    const int64_t per = (np + 1023) / 1024;
+    const int64_t lo = (int64_t)t * per, hi = lo + per < np ? lo + per : np;
+    uint32_t s = 0;
+    for (int64_t i = lo; i < hi; ++i) s += partial[i];
+    sh[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t o = t >= d ? sh[t - d] : 0u;
+        __syncthreads();
+        sh[t] += o;
+        __syncthreads();
+    }
+    uint32_t run = sh[t] - s;
+    for (int64_t i = lo; i < hi; ++i) {
+        const uint32_t x = partial[i];
+        partial[i] = run;
+        run += x;
+    }
+    if (t == 1023 && total) total[q] = sh[t];
+}
+
+__global__ __launch_bounds__(SC_THREADS) void scan_add_m(Outs4 outs, int64_t n, const uint32_t *partial, int64_t np)
+{
+    const int q = blockIdx.y;
+    uint32_t *const out = outs.o[q];
+    const uint32_t add = partial[(int64_t)q * np + blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * SC_TILE;
+    for (int k = threadIdx.x; k < SC_TILE; k += SC_THREADS) {
+        const int64_t i = base + k;
+        if (i < n) out[i] += add;
+    }
+}
+
+// outs[q][i] = exclusive prefix of in[i * stride + q] for q < m (<= 4); d_total (optional): m grand totals (u64 each).
+// `partial` must hold m * ceil(n / 4096) u32.
+static inline int exclusive_u32_multi(cornetto_accel_t *h, const char *name, const uint32_t *in, int64_t n, int stride, int m, uint32_t *const *outs,
+                                      uint32_t *partial, unsigned long long *d_total)
+{
+    if (n <= 0 || m <= 0) return CORNETTO_OK;
+    const int64_t np = (n + SC_TILE - 1) / SC_TILE;
+    Outs4 o{};
+    for (int q = 0; q < m && q < 4; ++q) o.o[q] = outs[q];
+    CN_LAUNCH(h, name, scan_local_m<<<dim3((unsigned)np, (unsigned)m), dim3(SC_THREADS), 0, h->stream>>>(in, n, stride, o, partial, np));
+    CN_LAUNCH(h, name, scan_partials_m<<<dim3((unsigned)m), dim3(1024), 0, h->stream>>>(partial, np, d_total));
+    CN_LAUNCH(h, name, scan_add_m<<<dim3((unsigned)np, (unsigned)m), dim3(SC_THREADS), 0, h->stream>>>(o, n, partial, np));
+    return CORNETTO_OK;
+}
+
 // out[i] (u32) = exclusive prefix of in[i*stride]; d_total (optional, device u64) = grand total.
 // `partial` must hold ceil(n / 4096) u32.
 static inline int exclusive_u32(cornetto_accel_t *h, const char *name, const uint32_t *in, int64_t n, int stride, uint32_t *out,

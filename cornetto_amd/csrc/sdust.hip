@@ -837,7 +837,7 @@ __global__ __launch_bounds__(64) void sdust_dense(SdArgs A, const uint32_t *list
                         const bool fold = __mul24(pr, max_l) > __mul24(max_r, pl);               // :113-117: entries with start >= i + start
                         max_r = fold ? pr : max_r;
                         max_l = fold ? pl : max_l;
-                        const bool ins = livej & (__mul24(r, 10) > T * new_l) & (__mul24(r, max_l) >= __mul24(max_r, new_l));   // :112, :118
+                        const bool ins = (int)livej & (int)(__mul24(r, 10) > T * new_l) & (int)(__mul24(r, max_l) >= __mul24(max_r, new_l));   // :112, :118
                         max_r = ins ? r : max_r;
                         max_l = ins ? new_l : max_l;
                         nb8 |= ins ? 1u << j : 0u;

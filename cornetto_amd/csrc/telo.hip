@@ -466,27 +466,24 @@ WinLayout win_layout_from_lengths(const int32_t *len, int32_t n, const int64_t *
     return L;
 }
 
-int run_tw_scan(cornetto_accel_t *h, const unsigned long long *d_bitmap, const WinLayout &L, const int32_t *d_len,
-                double thr, cornetto_win_t **wins, int64_t *n_wins)
+// the windows over a bitmap of marks; d_boff / d_tiles: the layout on the device (n_tiles window tiles)
+int run_tw_scan_dev(cornetto_accel_t *h, const unsigned long long *d_bitmap, const int64_t *d_boff, const int2 *d_tiles, size_t n_tiles, const int32_t *d_len,
+                    double thr, cornetto_win_t **wins, int64_t *n_wins)
 {
     *wins = nullptr;
     *n_wins = 0;
     std::vector<int4> host;
-    if (!L.tiles.empty()) {
-        int64_t *d_boff = (int64_t *)cn_ws(h, WS_TW_BOFF, L.bit_off.size() * 8);
-        int2 *d_tiles = (int2 *)cn_ws(h, WS_TW_TILES, L.tiles.size() * sizeof(int2));
+    if (n_tiles) {
         unsigned long long *d_cnt = (unsigned long long *)cn_ws(h, WS_TW_CNT, 16);
         unsigned long long *p_cnt = (unsigned long long *)cn_pin(h, PIN_SMALL, 64);
-        if (!d_boff || !d_tiles || !d_cnt || !p_cnt) return cn_fail(h, CORNETTO_E_NOMEM, "telowin: workspace allocation failed");
-        CN_HIP(h, hipMemcpyAsync(d_boff, L.bit_off.data(), L.bit_off.size() * 8, hipMemcpyHostToDevice, h->stream));
-        CN_HIP(h, hipMemcpyAsync(d_tiles, L.tiles.data(), L.tiles.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+        if (!d_cnt || !p_cnt) return cn_fail(h, CORNETTO_E_NOMEM, "telowin: workspace allocation failed");
         size_t cap = std::max<size_t>(1u << 16, h->dev[WS_TW_OUT].bytes / sizeof(int4));
         for (int attempt = 0; attempt < 2; ++attempt) {
             int4 *d_out = (int4 *)cn_ws(h, WS_TW_OUT, cap * sizeof(int4));
             if (!d_out) return cn_fail(h, CORNETTO_E_NOMEM, "telowin: workspace allocation failed");
             CN_HIP(h, hipMemsetAsync(d_cnt, 0, 8, h->stream));
             TwArgs A{d_bitmap, d_boff, d_len, d_tiles, thr, d_out, d_cnt, (uint32_t)std::min<size_t>(cap, 0x7fffffff)};
-            CN_LAUNCH(h, "tw_scan", tw_scan<<<dim3((unsigned)L.tiles.size()), dim3(256), 0, h->stream>>>(A));
+            CN_LAUNCH(h, "tw_scan", tw_scan<<<dim3((unsigned)n_tiles), dim3(256), 0, h->stream>>>(A));
             CN_HIP(h, hipMemcpyAsync(p_cnt, d_cnt, 8, hipMemcpyDeviceToHost, h->stream));
             CN_HIP(h, hipStreamSynchronize(h->stream));
             const unsigned long long cnt = p_cnt[0];
@@ -509,6 +506,22 @@ int run_tw_scan(cornetto_accel_t *h, const unsigned long long *d_bitmap, const W
     *wins = w;
     *n_wins = (int64_t)host.size();
     return CORNETTO_OK;
+}
+
+// the same with the layout still on the host (uploaded into the handle's workspaces)
+int run_tw_scan(cornetto_accel_t *h, const unsigned long long *d_bitmap, const WinLayout &L, const int32_t *d_len,
+                double thr, cornetto_win_t **wins, int64_t *n_wins)
+{
+    int64_t *wb = nullptr;
+    int2 *wt = nullptr;
+    if (!L.tiles.empty()) {
+        wb = (int64_t *)cn_ws(h, WS_TW_BOFF, L.bit_off.size() * 8);
+        wt = (int2 *)cn_ws(h, WS_TW_TILES, L.tiles.size() * sizeof(int2));
+        if (!wb || !wt) return cn_fail(h, CORNETTO_E_NOMEM, "telowin: workspace allocation failed");
+        CN_HIP(h, hipMemcpyAsync(wb, L.bit_off.data(), L.bit_off.size() * 8, hipMemcpyHostToDevice, h->stream));
+        CN_HIP(h, hipMemcpyAsync(wt, L.tiles.data(), L.tiles.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    }
+    return run_tw_scan_dev(h, d_bitmap, wb, wt, L.tiles.size(), d_len, thr, wins, n_wins);   // (synchronises before it returns: `L` outlives the uploads)
 }
 
 int telowin_from_hits(cornetto_accel_t *h, const cornetto_hit_t *hits, int64_t n_hits, const int32_t *ctg_len,
@@ -600,7 +613,7 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
     cornetto_hit_t *out = nullptr;
     int64_t n_out = 0;
     if (nt > 0) {
-        const size_t np = (nt + 4095) / 4096 + 1;
+        const size_t np = 4 * ((nt + 4095) / 4096) + 4;   // (scan partials of the four counters)
         uint2 *d_lut = (uint2 *)cn_ws(h, WS_TF_LUT, 256 * sizeof(uint2) + 2 * (size_t)k + 16);
         uint8_t *d_mot = reinterpret_cast<uint8_t *>(d_lut + 256);
         // small device block: totals[4] u64, ovf u32, err u32
@@ -655,8 +668,7 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
         if (bitmap_valid) *bitmap_valid = want_bitmap;
         if (hits) {
             // place of every tile in the dense, contig-ordered lists + list totals
-            for (int q = 0; q < 4; ++q)
-                CN_TRY(cnscan::exclusive_u32(h, "tf_order", reinterpret_cast<const uint32_t *>(d_tc) + q, (int64_t)nt, 4, d_offq[q], d_part, d_cnt + q));
+            CN_TRY(cnscan::exclusive_u32_multi(h, "tf_order", reinterpret_cast<const uint32_t *>(d_tc), (int64_t)nt, 4, 4, d_offq, d_part, d_cnt));
             CN_HIP(h, hipMemcpyAsync(p_cnt, d_cnt, 64, hipMemcpyDeviceToHost, h->stream));
             CN_HIP(h, hipStreamSynchronize(h->stream));   // also covers the `lut` upload
             unsigned long long cnt[4] = {p_cnt[0], p_cnt[1], p_cnt[2], p_cnt[3]};
@@ -814,8 +826,23 @@ int cornetto_telo_scan(cornetto_accel_t *h, const cornetto_asm_t *a, const char 
     int rc = telofind_impl(h, a, motif, need_hits ? &hh : nullptr, need_hits ? &nh : nullptr, true, &d_bitmap, &valid);
     if (rc == CORNETTO_OK) {
         if (valid) {
-            WinLayout L = win_layout_from_lengths(a->len.data(), a->n, a->off.data());
-            rc = run_tw_scan(h, d_bitmap, L, a->d_len, thr_adj, wins, n_wins);
+            // the window layout depends on the contig table only: built once, kept on the device with the resident assembly
+            cornetto_asm_t *am = const_cast<cornetto_asm_t *>(a);
+            if (am->tw_n_words < 0) {
+                const WinLayout L = win_layout_from_lengths(a->len.data(), a->n, a->off.data());
+                if (!L.tiles.empty()) {
+                    const bool ok = hipMalloc((void **)&am->d_tw_boff, L.bit_off.size() * 8) == hipSuccess && hipMalloc((void **)&am->d_tw_tiles, L.tiles.size() * sizeof(int2)) == hipSuccess &&
+                                    hipMemcpyAsync(am->d_tw_boff, L.bit_off.data(), L.bit_off.size() * 8, hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+                                    hipMemcpyAsync(am->d_tw_tiles, L.tiles.data(), L.tiles.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+                                    hipStreamSynchronize(h->stream) == hipSuccess;
+                    if (!ok) rc = cn_fail(h, CORNETTO_E_NOMEM, "telo_scan: device allocation failed");
+                }
+                if (rc == CORNETTO_OK) {
+                    am->tw_n_tiles = (int64_t)L.tiles.size();
+                    am->tw_n_words = L.n_words;
+                }
+            }
+            if (rc == CORNETTO_OK) rc = run_tw_scan_dev(h, d_bitmap, am->d_tw_boff, am->d_tw_tiles, (size_t)am->tw_n_tiles, a->d_len, thr_adj, wins, n_wins);
         } else {
             rc = telowin_from_hits(h, hh, nh, a->len.data(), a->n, thr_adj, wins, n_wins);
         }

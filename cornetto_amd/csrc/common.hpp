@@ -8,13 +8,21 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <string>
 #include <utility>
 #include <vector>
 
 #include "../../include/cornetto_accel.h"
 
+inline std::atomic<uint64_t> cn_uid_counter{1};    // resident objects are told apart by number, not by address (addresses come back)
+
 struct cornetto_accel {
     int device = 0;
+    // telofind: what the handle's small device blocks hold from the last call (no upload when the next call wants the same)
+    std::string tf_lut_key;
+    const void *tf_lut_ptr = nullptr;
+
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t stream2 = nullptr;     // sdust: the dense kernel runs here, beside the main kernel on `stream`
@@ -89,7 +97,7 @@ enum {   // device workspace slots
     WS_TW_BOFF, WS_TW_TILES, WS_TW_OUT, WS_TW_CNT, WS_TW_HITS, WS_TW_LEN, WS_TW_BITMAP,
     WS_SD_OUT, WS_SD_CNT, WS_SD_OFF, WS_SD_DST, WS_SD_STATS, WS_SD_PERM,
     WS_CB_T32, WS_CB_T64, WS_CB_GRAND,
-    WS_CW_REGS, WS_CW_SEL, WS_CW_CNT, WS_CW_TRES,
+    WS_CW_REGS, WS_CW_SEL, WS_CW_CNT, WS_CW_TRES, WS_CW_CF,
     WS_TF_HITS,
     WS_BG_TEXT_A, WS_BG_TEXT_B, WS_BG_TOK_A, WS_BG_TOK_B, WS_BG_CNT_A, WS_BG_CNT_B, WS_BG_SMALL, WS_BG_BRK,
     WS_TB, WS_TB_SMALL, WS_TB_OUT, WS_CW_MERGE, WS_IVL_MERGE,
@@ -98,7 +106,7 @@ enum {   // device workspace slots
 };
 static_assert(WS_COUNT <= 64, "cornetto_accel::dev has 64 slots");
 enum {   // pinned host slots
-    PIN_A, PIN_B, PIN_C, PIN_D, PIN_E, PIN_F, PIN_SMALL
+    PIN_A, PIN_B, PIN_C, PIN_D, PIN_E, PIN_F, PIN_SMALL, PIN_TW, PIN_CW
 };
 
 static inline int cn_fail(cornetto_accel_t *h, int status, const char *fmt, ...)
@@ -244,6 +252,7 @@ struct DevBuf {
 
 // ---- resident data sets -----------------------------------------------------------------------------
 struct cornetto_asm {
+    const uint64_t uid = cn_uid_counter.fetch_add(1);
     const uint8_t *d_bases = nullptr;  // 1 B/base, every contig starts at a multiple of 64
     void *owned = nullptr;             // hipMalloc'd storage when uploaded by us
     int32_t n = 0;
@@ -256,6 +265,7 @@ struct cornetto_asm {
     // cached work decompositions (depend on the contig table only); device copies owned by the object
     std::vector<int32_t> tf_ctg_tile0;   // telofind: first tile of each contig (+ total)
     int2 *d_tf_tiles = nullptr;
+    int32_t *d_tf_ct0 = nullptr;         //   tf_ctg_tile0 on the device
     int64_t tf_n_tiles = -1;
     int64_t tw_n_words = -1, tw_n_tiles = 0;   // telowin on the marks of a fused scan: words of the bitmap (-1: layout not built yet), window tiles
     int64_t *d_tw_boff = nullptr;
@@ -301,6 +311,7 @@ struct cornetto_cov {
     int32_t *d_n_reg = nullptr;
     int2 *d_cw_tiles = nullptr;          // window tiles of the last selection (mode, min_len)
     std::vector<int2> cw_tiles;
+    int32_t *d_cw_first = nullptr;       //   first of them of every contig (their number: the contig has none)
     int cw_mode = -1;
     int32_t cw_min_len = 0, cw_only = -2;
 };

@@ -358,6 +358,16 @@ __global__ __launch_bounds__(256) void cov_windows(CwArgs A)
     }
 }
 
+// packed selection: the first record of every contig = the ordered offset of its first tile (a contig without tiles: that of the next contig
+// that has one, or the total)
+__global__ void cov_ctg_first(const uint32_t *ooff, const int32_t *first_tile, int32_t n_ctg, uint32_t n_tiles, uint32_t total, uint32_t *out)
+{
+    const int32_t i = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n_ctg) return;
+    const uint32_t t = (uint32_t)first_tile[i];
+    out[i] = t < n_tiles ? ooff[t] : total;
+}
+
 // tile segments (reservation order) -> (contig, window) order: one wavefront per tile; INTS = 4-byte words per record
 template <int INTS>
 __global__ __launch_bounds__(256) void cov_order(const int32_t *raw, const uint2 *tres, const uint32_t *ooff, int64_t n_tiles, int32_t *dst)
@@ -494,10 +504,19 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
             for (int32_t j = 0; j < c->n_reg[i]; j += 256) c->cw_tiles.push_back(make_int2(i, j));
         }
         if (c->d_cw_tiles) { (void)hipFree(c->d_cw_tiles); c->d_cw_tiles = nullptr; }
+        if (c->d_cw_first) { (void)hipFree(c->d_cw_first); c->d_cw_first = nullptr; }
         if (!c->cw_tiles.empty()) {
-            if (hipMalloc((void **)&c->d_cw_tiles, c->cw_tiles.size() * sizeof(int2)) != hipSuccess)
+            std::vector<int32_t> first((size_t)c->n + 1);
+            size_t ti = 0;
+            for (int32_t i = 0; i < c->n; ++i) {                 // tiles are in contig order
+                while (ti < c->cw_tiles.size() && c->cw_tiles[ti].x < i) ++ti;
+                first[i] = (int32_t)ti;                          // (a contig without tiles: the first tile of the next one that has — or their number)
+            }
+            if (hipMalloc((void **)&c->d_cw_tiles, c->cw_tiles.size() * sizeof(int2)) != hipSuccess || hipMalloc((void **)&c->d_cw_first, ((size_t)c->n + 1) * 4) != hipSuccess)
                 return cn_fail(h, CORNETTO_E_NOMEM, "cov: device allocation failed");
             CN_HIP(h, hipMemcpyAsync(c->d_cw_tiles, c->cw_tiles.data(), c->cw_tiles.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+            CN_HIP(h, hipMemcpyAsync(c->d_cw_first, first.data(), (size_t)c->n * 4, hipMemcpyHostToDevice, h->stream));
+            CN_HIP(h, hipStreamSynchronize(h->stream));   // `first` is a local
         }
         c->cw_mode = mode;
         c->cw_min_len = min_len;
@@ -565,12 +584,18 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
         (void)hipEventRecord(eb, h->stream);
         h->recs.push_back(cornetto_accel::Rec{"cov_order", ea, eb});
         if (hipGetLastError() != hipSuccess) return cn_fail(h, CORNETTO_E_HIP, "cov_select: ordering failed");
-        // packed: the first record of every contig = the ordered offset of its first tile (1 MB beside the records)
-        std::vector<uint32_t> ooff;
-        if (packed) ooff.resize(nt);
-        if (!keep_on_device && (cn_result_d2h(h, o, d_dst, (size_t)cnt * rec_bytes) != hipSuccess ||
-                                (packed && hipMemcpyAsync(ooff.data(), d_ooff, nt * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess) ||
-                                hipStreamSynchronize(h->stream) != hipSuccess)) {
+        // packed: the first record of every contig = the ordered offset of its first tile, picked on the device (4 B per contig to the host)
+        uint32_t *p_cf = nullptr;
+        if (packed) {
+            p_cf = (uint32_t *)cn_pin(h, PIN_CW, ((size_t)c->n + 1) * 4);
+            uint32_t *d_cf = (uint32_t *)cn_ws(h, WS_CW_CF, ((size_t)c->n + 1) * 4);
+            if (!p_cf || !d_cf) return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: allocation failed");
+            cov_ctg_first<<<dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, h->stream>>>(d_ooff, c->d_cw_first, c->n, (uint32_t)nt, (uint32_t)cnt, d_cf);
+            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(p_cf, d_cf, (size_t)c->n * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess)
+                return cn_fail(h, CORNETTO_E_HIP, "cov_select: first records of the contigs failed");
+        }
+        if ((!keep_on_device && cn_result_d2h(h, o, d_dst, (size_t)cnt * rec_bytes) != hipSuccess) ||
+            ((!keep_on_device || packed) && hipStreamSynchronize(h->stream) != hipSuccess)) {
             cn_result_quiesce(h);
             cornetto_free(o);
             return cn_fail(h, CORNETTO_E_HIP, "cov_select: copy back failed");
@@ -578,11 +603,7 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
         if (packed) {
             int64_t *cf = (int64_t *)malloc(((size_t)c->n + 1) * sizeof(int64_t));
             if (!cf) { cn_result_quiesce(h); cornetto_free(o); return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: host allocation failed"); }
-            size_t ti = 0;
-            for (int32_t i = 0; i < c->n; ++i) {                 // tiles are in contig order; contigs without tiles have no records
-                while (ti < nt && c->cw_tiles[ti].x < i) ++ti;
-                cf[i] = ti < nt ? (int64_t)ooff[ti] : (int64_t)cnt;
-            }
+            for (int32_t i = 0; i < c->n; ++i) cf[i] = (int64_t)p_cf[i];   // (contigs without tiles have no records: the offset of the next one that has)
             cf[c->n] = (int64_t)cnt;
             *ctg_first = cf;
         }

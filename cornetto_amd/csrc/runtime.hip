@@ -219,6 +219,7 @@ void cornetto_asm_free(cornetto_accel_t *h, cornetto_asm_t *a)
     if (a->d_off) (void)hipFree(a->d_off);
     if (a->d_len) (void)hipFree(a->d_len);
     if (a->d_tf_tiles) (void)hipFree(a->d_tf_tiles);
+    if (a->d_tf_ct0) (void)hipFree(a->d_tf_ct0);
     if (a->d_tw_boff) (void)hipFree(a->d_tw_boff);
     if (a->d_tw_tiles) (void)hipFree(a->d_tw_tiles);
     if (a->d_sd_chunks) (void)hipFree(a->d_sd_chunks);
@@ -315,6 +316,7 @@ void cornetto_cov_free(cornetto_accel_t *h, cornetto_cov_t *c)
     if (c->d_cb_tiles) (void)hipFree(c->d_cb_tiles);
     if (c->d_n_reg) (void)hipFree(c->d_n_reg);
     if (c->d_cw_tiles) (void)hipFree(c->d_cw_tiles);
+    if (c->d_cw_first) (void)hipFree(c->d_cw_first);
     delete c;
 }
 

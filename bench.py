@@ -494,6 +494,9 @@ class Rank:
             self.share = args.sdust_share if args.sdust_share > 0 else 70
             self.acc2.set_share(self.share)
         # the two large result arrays of this thread (telomere runs, selected windows) travel beside its next kernels
+        self.lead_us = float(os.environ.get("CORNETTO_BENCH_LEAD_US", "0"))
+        self.handshake = self.overlap and os.environ.get("CORNETTO_BENCH_HANDSHAKE", "1") != "0"
+        self.lag_us = float(os.environ.get("CORNETTO_BENCH_SDUST_LAG_US", "0"))
         self.lazy = self.overlap and os.environ.get("CORNETTO_BENCH_LAZY", "1") != "0"
         self.acc.set_lazy(self.lazy)
         self.thr = self.acc.telowin_threshold(0.4, 99.9)
@@ -570,6 +573,10 @@ class Rank:
             box = {}
             try:
                 t0 = time.perf_counter()
+                if self.lag_us:                       # (experiment: the other stream's first kernels land on an empty chip first)
+                    t_lag = t0 + self.lag_us * 1e-6
+                    while time.perf_counter() < t_lag:
+                        pass
                 box["ivls"] = self.acc2.sdust(self.asm2, 20, 64)
                 if record:
                     self._note(self.acc2)
@@ -586,7 +593,18 @@ class Rank:
         acc, world = self.acc, self.world
         if self.overlap:
             self.acc2.boost(False)                    # this thread's kernels want their share of the chip again
+            seq = self.acc2.launch_count() if self.handshake else 0
             self.jobs.put(record)
+            if self.handshake:
+                # where the resident sdust waves land decides how much room this thread's kernels find on every CU: let them get there first
+                # (8.2 ms per step when they do, 9.2 when they arrive 30 us behind tf_scan: cornetto_accel_launch_count)
+                t_end = time.perf_counter() + 1e-3
+                while self.acc2.launch_count() == seq and time.perf_counter() < t_end:
+                    pass
+            if self.lead_us:                          # (experiment: extra lead for the sdust waves)
+                t_lead = time.perf_counter() + self.lead_us * 1e-6
+                while time.perf_counter() < t_lead:
+                    pass
         t0 = time.perf_counter()
         hits, wins = acc.telo_scan(self.asm, b"TTAGGG", self.thr)
         if record:

@@ -78,6 +78,7 @@ def lib():
         "cornetto_accel_last_timing": (C.c_int, [vp, C.POINTER(cp), C.POINTER(C.c_float), C.c_int]),
         "cornetto_accel_set_share": (C.c_int, [vp, C.c_int]),
         "cornetto_accel_boost": (C.c_int, [vp, C.c_int]),
+        "cornetto_accel_launch_count": (C.c_uint64, [vp]),
         "cornetto_accel_set_lazy": (C.c_int, [vp, C.c_int]),
         "cornetto_accel_wait": (C.c_int, [vp]),
         "cornetto_accel_set_timing": (C.c_int, [vp, C.c_int]),
@@ -202,6 +203,10 @@ class Accel:
         if rc != 0:
             raise AccelError(rc, self.L.cornetto_accel_last_error(self.h).decode() or
                              self.L.cornetto_accel_strerror(rc).decode())
+
+    def launch_count(self):
+        """launches of resident sdust waves on this handle so far: cornetto_accel_launch_count()"""
+        return int(self.L.cornetto_accel_launch_count(self.h))
 
     def set_lazy(self, on=True):
         """large result copies on a stream of their own; the arrays the calls return hold their content after wait(): cornetto_accel_set_lazy()"""

@@ -52,7 +52,8 @@ struct cornetto_accel {
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_cp = nullptr;
     bool copies_pending = false;
-    volatile int boost = 0;  // cornetto_accel_boost(): the other users of the device are through (set from another host thread)
+    volatile int boost = 0;
+    volatile unsigned long long launch_seq = 0;   // counts the launches of resident sdust waves (cornetto_accel_launch_count)  // cornetto_accel_boost(): the other users of the device are through (set from another host thread)
     hipEvent_t ev3 = nullptr;
     int share = 100;    // percent of every CU the resident sdust kernel may take (cornetto_accel_set_share)
     int sd_stats = 0;   // sdust: run the statistics build of the kernel (cornetto_accel_sdust_stats)

@@ -146,6 +146,11 @@ int cornetto_accel_set_share(cornetto_accel_t *h, int percent)
     return CORNETTO_OK;
 }
 
+unsigned long long cornetto_accel_launch_count(const cornetto_accel_t *h)
+{
+    return h ? __atomic_load_n(&h->launch_seq, __ATOMIC_ACQUIRE) : 0ull;
+}
+
 int cornetto_accel_set_lazy(cornetto_accel_t *h, int on)
 {
     if (!h) return CORNETTO_E_ARG;

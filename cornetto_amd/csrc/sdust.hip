@@ -1873,6 +1873,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                 const unsigned nbk = (unsigned)std::min<size_t>(all_blocks, (size_t)env_int("CORNETTO_SIFT_BLOCKS", per_cu * std::max(h->sd_cus, 1)));
                 if (want_stats) CN_LAUNCH(h, "sdust_kernel", sd_sift<true><<<dim3(nbk), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream>>>(S, R));
                 else CN_LAUNCH(h, "sdust_kernel", sd_sift<false><<<dim3(nbk), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream>>>(S, R));
+                __atomic_fetch_add(&h->launch_seq, 1ull, __ATOMIC_RELEASE);      // (cornetto_accel_launch_count)
                 // The waves left to the other stream: when its owner says it is through (cornetto_accel_boost, from another host thread) while
                 // this kernel still runs, they are launched as a second kernel on a second stream — same arguments, same chunk counters: the two
                 // launches drain them together — and the stream of this call waits for both.

@@ -114,6 +114,12 @@ int cornetto_accel_set_share(cornetto_accel_t *h, int percent);
  * switches it on when the telofind + coverage thread of a step is through and off when the next step begins.  Scheduling only. */
 int cornetto_accel_boost(cornetto_accel_t *h, int on);
 
+/* How many times a cornetto_sdust_asm() call on this handle has put its resident waves on the device so far (readable from any thread while the
+ * call runs).  Where the resident waves land decides how much room the other handle's kernels find on every CU for the rest of the call: a caller
+ * that starts both sides of a step at once should let the count move before it launches the other side's first kernel — measured on the 3.16 Gbp
+ * bench step: 8.2 ms when the sdust waves are there first, 9.2 ms when they arrive 30 us behind the other stream's first kernel. */
+unsigned long long cornetto_accel_launch_count(const cornetto_accel_t *h);
+
 /* Lazy result copies (off by default).  While on, cornetto_telo_scan() / cornetto_telofind() and cornetto_cov_select*() return as soon as their
  * kernels are through; the device-to-host copy of the large result array (telomere runs; selected windows) is still in flight on a stream of its
  * own, beside whatever the caller launches next on this handle.  The returned pointers are valid at once, their CONTENT after

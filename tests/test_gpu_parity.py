@@ -802,3 +802,30 @@ def test_lazy_result_copies_equal_the_synchronous_ones(acc):
         asm.close()
         cov.close()
     assert len(ref[0]) > 100 and len(ref[2]) > 1000
+
+
+def test_launch_count_moves_with_every_resident_sdust_launch(acc, monkeypatch):
+    """cornetto_accel_launch_count: readable from another thread while the call runs; bench.py waits for it to move before the other
+    stream's first kernel (where the resident waves land decides how much room that stream finds on every CU)"""
+    import threading
+    monkeypatch.setenv("CORNETTO_SDUST_SIFT", "1")
+    rng = np.random.default_rng(11)
+    asm = acc.asm_upload([_sift_stress_seq(rng, 8_000_000, 1)])
+    try:
+        c0 = acc.launch_count()
+        seen = []
+        done = threading.Event()
+
+        def watch():
+            while not done.is_set():
+                seen.append(acc.launch_count())
+        t = threading.Thread(target=watch)
+        t.start()
+        a = acc.sdust(asm, 20, 64)
+        b = acc.sdust(asm, 20, 64)
+        done.set()
+        t.join()
+        assert acc.launch_count() == c0 + 2 and np.array_equal(a, b)
+        assert all(c0 <= x <= c0 + 2 for x in seen) and seen == sorted(seen)
+    finally:
+        asm.close()

@@ -491,7 +491,7 @@ class Rank:
         self.overlap = not args.serial
         if self.overlap:
             # the sdust waves stay resident until their queue is empty: leave part of every CU to the other stream
-            self.share = args.sdust_share if args.sdust_share > 0 else 70
+            self.share = args.sdust_share if args.sdust_share > 0 else 72
             self.acc2.set_share(self.share)
         # the two large result arrays of this thread (telomere runs, selected windows) travel beside its next kernels
         self.lead_us = float(os.environ.get("CORNETTO_BENCH_LEAD_US", "0"))
@@ -671,7 +671,7 @@ class Rank:
         if not self.overlap or self.args.sdust_share > 0:
             return
         best = None
-        for sh in (60, 70, 85, 100):
+        for sh in (62, 72, 85, 100):
             self.acc2.set_share(sh)
             self.step(False)
             self.torch.cuda.synchronize()
@@ -1190,7 +1190,7 @@ def main():
     ap.add_argument("--no-second", action="store_true", help="--gpus > 1: skip the second measurement (the other scaling mode with --gather)")
     ap.add_argument("--emulate-ranks", type=str, default="2,4,8", help="N=1: model the strong-scaling curve for these rank counts on this one GPU ('' = skip)")
     ap.add_argument("--allow-shared-device", action="store_true", help="--gpus > 1 with fewer GPUs than ranks (tests): ranks share devices, collectives over gloo")
-    ap.add_argument("--sdust-share", type=int, default=70, help="percent of the wave slots the resident sdust waves could hold on a CU that they take while the other stream runs beside them (70: 14 of 21 per CU; the rest joins in when the other thread of the step is through: cornetto_accel_boost); 0: probed during warm-up (60 / 70 / 85 / 100)")
+    ap.add_argument("--sdust-share", type=int, default=72, help="percent of the wave slots the resident sdust waves could hold on a CU that they take while the other stream runs beside them (72: 15 of 21 per CU — 14: 8.2 ms per step, 15: 8.0, 16: 8.8, 17: the other stream starves; the rest joins in when the other thread of the step is through: cornetto_accel_boost); 0: probed during warm-up (62 / 72 / 85 / 100)")
     ap.add_argument("--timing", type=int, default=1, help="HIP events in the timed steps around: 1 the three main kernels only (roofline), 2 every launch, 0 none; the extra serial pass that fills the kernel table always uses 2")
     ap.add_argument("--gather", action="store_true", help="also gather every result record to rank 0 inside the step (not part of the path: each rank owns the output of its contigs)")
     ap.add_argument("--allreduce-always", action="store_true", help="weak scaling: all-reduce the depth totals as well (treats the N assemblies as one)")

@@ -1098,19 +1098,34 @@ def emulate_ranks(R, ns, steps, t1_ms):
     (small launches, event pairs, host hand-offs, result copies) scale down with the share — the part of the curve one GPU can show."""
     from cornetto_amd.dist import lpt_partition
     out = {"modelled": True, "t1_ms": round(t1_ms, 3), "steps_per_share": steps,
-           "what": "per-rank shares of the LPT contig partition run one after the other on one GPU; step = slowest share; the 3 x int64 all-reduce is not modelled"}
+           "what": "per-rank shares of the LPT contig partition run one after the other on one GPU (the better of two batches of steps_per_share steps each); step = slowest share; the 3 x int64 all-reduce is not modelled"}
     full = list(range(len(R.lens)))
     for n in ns:
         parts = lpt_partition(R.lens, n)
-        per, bases = [], []
-        for own in parts:
+        per, bases, stages, nctg = [], [], [], []
+        order = list(range(len(parts)))
+        if os.environ.get("CORNETTO_BENCH_EMU_REVERSE"):      # (diagnosis: is a slow share slow, or just measured first?)
+            order.reverse()
+        for ri in order:
+            own = parts[ri]
             R.wrap(own)
-            el = R.timed(steps, 1)
+            # (two warm-up steps: the second sdust call of a chunk table is the first with its long chunks ordered first.  The better of two
+            # batches: whichever shares are measured first after the full-size run come out 0.15-0.2 ms slower than the same shares measured
+            # later — the order of measurement, not the share; a rank of a real run is in its steady state)
+            el = min(R.timed(steps, 2), R.timed(steps, 0))
             per.append(round(el / steps * 1e3, 3))
             bases.append(R.my_bases)
+            nctg.append(len(own))
+            stages.append({k: round(float(np.mean(v)), 3) for k, v in R.wall.items()})
+        # (the share measured first once more at the end: it is the one that pays for the change from 8 ms steps to 1 ms steps)
+        R.wrap(parts[order[0]])
+        again = round(min(R.timed(steps, 2), R.timed(steps, 0)) / steps * 1e3, 3)
+        if again < per[0]:
+            per[0] = again
+            stages[0] = {k: round(float(np.mean(v)), 3) for k, v in R.wall.items()}
         mx = max(per)
-        out[str(n)] = {"per_rank_ms": per, "bases_per_rank": bases, "step_ms": mx, "efficiency": round(t1_ms / (n * mx), 4),
-                       "gbases_s": round(sum(bases) / (mx * 1e-3) / 1e9, 2)}
+        out[str(n)] = {"per_rank_ms": per, "bases_per_rank": bases, "contigs_per_rank": nctg, "step_ms": mx, "efficiency": round(t1_ms / (n * mx), 4),
+                       "gbases_s": round(sum(bases) / (mx * 1e-3) / 1e9, 2), "stage_wall_ms_slowest": stages[per.index(mx)], "stage_wall_ms_fastest": stages[per.index(min(per))]}
     R.wrap(full)
     return out
 

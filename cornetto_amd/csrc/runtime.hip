@@ -418,13 +418,17 @@ int cornetto_cov_shard(cornetto_accel_t *h_src, const cornetto_cov_t *src, corne
     if (hipSetDevice(h_dst->device) != hipSuccess) rc = CORNETTO_E_HIP;
     if (rc == CORNETTO_OK && (hipMemsetAsync(c->owned_d, 0, bytes, h_dst->stream) != hipSuccess || hipMemsetAsync(c->owned_q, 0, bytes, h_dst->stream) != hipSuccess))
         rc = CORNETTO_E_HIP;
-    for (int32_t i = 0; i < n && rc == CORNETTO_OK; ++i) {
-        const size_t nb = (size_t)src->len[ctgs[i]] * sizeof(uint16_t);
-        if (nb == 0) continue;
+    for (int32_t i = 0; i < n && rc == CORNETTO_OK;) {
+        // a run of contigs that follow each other in the source, laid out there by the same rule as here (next offset = this one + length, rounded up
+        // to 64), is one copy: a read-level coverage set has 1e5 .. 1e6 contigs, a device's share of it thousands of runs, not hundreds of thousands
+        int32_t j = i;
+        while (j + 1 < n && ctgs[j + 1] == ctgs[j] + 1 && src->off[ctgs[j + 1]] == cn_align_up(src->off[ctgs[j]] + src->len[ctgs[j]], 64)) ++j;
+        const size_t nb = (size_t)(src->off[ctgs[j]] + src->len[ctgs[j]] - src->off[ctgs[i]]) * sizeof(uint16_t);
         // xGMI peer copy (staged through the host by the runtime where peer access is not available); the same device is a plain copy
-        if (hipMemcpyPeerAsync((uint16_t *)c->owned_d + c->off[i], h_dst->device, src->d_depth + src->off[ctgs[i]], h_src->device, nb, h_dst->stream) != hipSuccess ||
-            hipMemcpyPeerAsync((uint16_t *)c->owned_q + c->off[i], h_dst->device, src->d_mq + src->off[ctgs[i]], h_src->device, nb, h_dst->stream) != hipSuccess)
+        if (nb && (hipMemcpyPeerAsync((uint16_t *)c->owned_d + c->off[i], h_dst->device, src->d_depth + src->off[ctgs[i]], h_src->device, nb, h_dst->stream) != hipSuccess ||
+                   hipMemcpyPeerAsync((uint16_t *)c->owned_q + c->off[i], h_dst->device, src->d_mq + src->off[ctgs[i]], h_src->device, nb, h_dst->stream) != hipSuccess))
             rc = CORNETTO_E_HIP;
+        i = j + 1;
     }
     if (rc == CORNETTO_OK) rc = cov_finish_table(h_dst, c);
     if (rc == CORNETTO_OK && hipStreamSynchronize(h_dst->stream) != hipSuccess) rc = CORNETTO_E_HIP;

@@ -231,7 +231,7 @@ void cli_order_by_length_desc(const int64_t *lens64, const int32_t *lens32, int3
  * the largest share of the wall time of a 3 GB assembly or of a pair of per-base bedgraphs */
 #include <errno.h>
 #include <unistd.h>
-#define CLI_PREAD_MAX 16
+#define CLI_PREAD_MAX 64
 typedef struct {
     int fd;
     char *dst;

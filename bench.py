@@ -1322,7 +1322,10 @@ def main():
             "results_per_rank": dict(zip(("telomere_runs", "telomere_windows", "sdust_intervals", "selected_cov_windows"), R.counts)),
             "cached_across_steps": ["tile / chunk / window decomposition tables of the resident assembly and coverage (functions of the contig lengths only; built by the first "
                                     "step, %0.1f ms against %0.1f ms for a timed step)" % (first_step_ms, ms_per_step),
-                                    "device workspaces and pinned result buffers (no allocation in a timed step)"],
+                                    "device workspaces and pinned result buffers (no allocation in a timed step)",
+                                    "sdust: which chunks of the chunk table run long (inside repeat arrays, with other bytes) — noted by the first call for a table, "
+                                    "handed out first from the second call on (a function of the resident bases, which must not change)",
+                                    "telofind: the motif's match tables on the device while the motif stays the same"],
             "first_step_ms": round(first_step_ms, 3),
         }
         if coll:

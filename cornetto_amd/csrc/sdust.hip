@@ -2030,6 +2030,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                 uint8_t *g_ring = reinterpret_cast<uint8_t *>(g_slot + (size_t)rc * NL);
                 CN_LAUNCH(h, "sdust_kernel", sdust_kernel_g<<<dim3(nb), dim3(64), 0, h->stream>>>(A, g_ring, g_cw, g_cv, g_slot, rc));
             }
+            if (!sift_on) __atomic_fetch_add(&h->launch_seq, 1ull, __ATOMIC_RELEASE);   // (cornetto_accel_launch_count: the other kernel families count as well)
             if (dense_pending) {
                 CN_HIP(h, hipStreamWaitEvent(h->stream, h->ev2, 0));
                 dense_pending = false;                 // (joined on the device: the stream's later work waits for it)

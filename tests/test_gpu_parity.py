@@ -804,11 +804,12 @@ def test_lazy_result_copies_equal_the_synchronous_ones(acc):
     assert len(ref[0]) > 100 and len(ref[2]) > 1000
 
 
-def test_launch_count_moves_with_every_resident_sdust_launch(acc, monkeypatch):
+@pytest.mark.parametrize("sift", ["1", "0"])
+def test_launch_count_moves_with_every_resident_sdust_launch(acc, monkeypatch, sift):
     """cornetto_accel_launch_count: readable from another thread while the call runs; bench.py waits for it to move before the other
     stream's first kernel (where the resident waves land decides how much room that stream finds on every CU)"""
     import threading
-    monkeypatch.setenv("CORNETTO_SDUST_SIFT", "1")
+    monkeypatch.setenv("CORNETTO_SDUST_SIFT", sift)
     rng = np.random.default_rng(11)
     asm = acc.asm_upload([_sift_stress_seq(rng, 8_000_000, 1)])
     try:

@@ -970,88 +970,177 @@ def make_fastq_piece(torch, dev, target_bases, seed):
     return text, L, off
 
 
-def reads_leg(R, torch, cornetto_amd, gbases):
-    """BASELINE config 5 on one GPU: FASTQ text in pinned host memory -> records framed on the device with the length test of
+def reads_shares(piece_lens, n_pieces, world):
+    """Config 5's read-level shard: the stream is `n_pieces` pieces (piece j = the generated piece j % len(piece_lens)), cut into
+    `world` contiguous shares at READ boundaries by cumulative bases (share r holds the reads whose first base has a cumulative
+    index in [r B / world, (r + 1) B / world)).  -> per rank a list of (piece slot, first read, one past the last read), no empty
+    segments; every read of the stream is in exactly one segment and the segments of the ranks, in rank order, are the stream."""
+    k = len(piece_lens)
+    tot = [int(np.sum(l)) for l in piece_lens]
+    B = sum(tot[j % k] for j in range(n_pieces))
+    shares = [[] for _ in range(world)]
+    base = 0
+    for j in range(n_pieces):
+        lens = np.asarray(piece_lens[j % k], dtype=np.int64)
+        start = base + np.concatenate([[0], np.cumsum(lens)[:-1]])          # cumulative index of every read's first base
+        owner = np.minimum(world - 1, (start * world) // B)                  # non-decreasing
+        for r in range(int(owner[0]), int(owner[-1]) + 1):
+            lo, hi = int(np.searchsorted(owner, r, "left")), int(np.searchsorted(owner, r, "right"))
+            if hi > lo:
+                shares[r].append((j % k, lo, hi))
+        base += tot[j % k]
+    return shares
+
+
+def reads_leg(R, torch, dist, cornetto_amd, gbases):
+    """BASELINE config 5: FASTQ text in pinned host memory -> records framed on the device with the length test of
     `seq -m 10000` (src/seq.c:120) -> reads packed in HBM -> sdust per read (src/sdust/sdust.c:196-203) -> intervals on the host.
-    Two host threads with a handle (= HIP stream) each take the pieces alternately, so the H2D copy of one piece runs beside
-    the kernels of the other.  The first ~200 Mbases are also run through the reference's own `seq -m 10000 | sdust` (oracle/_ref)
-    on one core and compared line for line."""
+    Two host threads with a handle (= HIP stream) each take the work items alternately, so the H2D copy of one item runs beside
+    the kernels of the other.  One rank: the items are the pieces of the stream.  N ranks: the SAME stream cut into N shares at
+    read boundaries by cumulative bases (reads_shares; no data-path collective: every rank owns the output of its reads), each
+    rank streams its share over its own PCIe link, wall = barrier to barrier, max over the ranks; the ranks' counts must add up
+    to what rank 0 gets for the whole pieces.  Rank 0 also runs the first ~200 Mbases through the reference's own
+    `seq -m 10000 | sdust` (oracle/_ref) on one core and compares line for line.  Every rank calls this; rank 0 gets the dict."""
     import ctypes as C
     import subprocess
     import threading
+    world, rank = R.world, R.rank
     out = {"min_len": 10000, "sdust": "-w 64 -t 20"}
     L = cornetto_amd.lib()
     pins = []
+
+    def everyone(flag):
+        """True when `flag` holds on every rank (a rank that cannot go on must not leave the others in a barrier)"""
+        if world == 1:
+            return bool(flag)
+        fl = [None] * world
+        dist.all_gather_object(fl, bool(flag))
+        return all(fl)
+
     try:
-        piece_bases = 1.0e9
+        piece_bases = min(1.0e9, max(1.0e6, gbases * 1e9 / 2))     # (small --reads-gbases: tests)
         pieces = []
         for pi in range(2):
             text, lens, off = make_fastq_piece(torch, R.dev, piece_bases, 500 + pi)
             n = int(text.numel())
             pin = L.cornetto_pinned_alloc(n + 64)
-            if not pin:
-                return {"skipped": "no pinned host memory for a %d-byte piece" % n}
-            pins.append(pin)
-            host = text.cpu().numpy()
-            C.memmove(pin, host.ctypes.data, n)
-            pieces.append({"pin": pin, "n": n, "lens": lens, "off": off, "host": host if pi == 0 else None})
+            if pin:
+                pins.append(pin)
+                host = text.cpu().numpy()
+                C.memmove(pin, host.ctypes.data, n)
+                pieces.append({"pin": pin, "n": n, "lens": lens, "off": np.concatenate([off, [n]]).astype(np.int64), "host": host if (pi == 0 and rank == 0) else None})
             del text
+            if not everyone(bool(pin)):
+                return {"skipped": "no pinned host memory for a %d-byte piece" % n}
         torch.cuda.empty_cache()
         n_pieces = max(2, int(np.ceil(gbases * 1e9 / piece_bases)))
+        if world > 1:
+            n_pieces = max(n_pieces, 2 * world)        # at least two pieces' worth of text per rank
         accs = [cornetto_amd.Accel(R.local_dev), cornetto_amd.Accel(R.local_dev)]
         for a in accs:
             a.set_timing(1)
-        res = [None] * n_pieces
+
+        def item(slot, lo, hi):
+            p = pieces[slot]
+            return (p["pin"] + int(p["off"][lo]), int(p["off"][hi] - p["off"][lo]), hi - lo, int(p["lens"][lo:hi].sum()))
+
+        whole = [item(s, 0, len(pieces[s]["lens"])) for s in range(2)]
+        if world == 1:
+            items = [whole[j % 2] for j in range(n_pieces)]
+        else:
+            segs = reads_shares([p["lens"] for p in pieces], n_pieces, world)[rank]
+            # (a share of one or two long segments is cut once more so that both host threads have items of similar size)
+            items = []
+            for s, lo, hi in segs:
+                if hi - lo >= 2 and len(segs) < 4:
+                    mid = lo + int(np.searchsorted(np.cumsum(pieces[s]["lens"][lo:hi]), int(pieces[s]["lens"][lo:hi].sum()) // 2)) + 1
+                    mid = min(max(mid, lo + 1), hi - 1)
+                    items += [item(s, lo, mid), item(s, mid, hi)]
+                else:
+                    items.append(item(s, lo, hi))
         ktime = [0.0, 0.0]
         err = []
 
-        def work(w):
+        def work(w, todo, res):
             try:
-                for j in range(w, n_pieces, 2):
-                    p = pieces[j % 2]
-                    recs, used, plain, reads = accs[w].fastq_split((p["pin"], p["n"]), final=True, min_len=10000, want_reads=True)
+                for j in range(w, len(todo), 2):
+                    addr, nb, nreads, _ = todo[j]
+                    recs, used, plain, reads = accs[w].fastq_split((addr, nb), final=True, min_len=10000, want_reads=True)
                     iv = accs[w].sdust(reads, 20, 64)
                     ktime[w] += sum(ms for k, ms in accs[w].last_timing() if k == "sdust_kernel")
                     reads.close()
-                    if not plain or used != p["n"] or len(recs) != len(p["lens"]):
-                        raise RuntimeError("piece %d: framing fell back (plain %r, used %d of %d, %d of %d records)" % (j, plain, used, p["n"], len(recs), len(p["lens"])))
+                    if not plain or used != nb or len(recs) != nreads:
+                        raise RuntimeError("item %d: framing fell back (plain %r, used %d of %d, %d of %d records)" % (j, plain, used, nb, len(recs), nreads))
                     res[j] = (int(recs["keep"].sum()), int(recs["len"][recs["keep"] == 1].sum()), len(iv), digest([iv]))
             except BaseException as e:
                 err.append(repr(e))
 
-        for rep in range(2):                          # the first pass warms the workspaces up
-            np_run = 2 if rep == 0 else n_pieces
-            keep_n = n_pieces
-            n_pieces = np_run
+        def run(todo):
+            res = [None] * len(todo)
             ktime[0] = ktime[1] = 0.0
-            th = [threading.Thread(target=work, args=(w,)) for w in range(2)]
+            th = [threading.Thread(target=work, args=(w, todo, res)) for w in range(2)]
+            if world > 1:
+                dist.barrier()
             t0 = time.perf_counter()
             for t in th:
                 t.start()
             for t in th:
                 t.join()
-            wall = time.perf_counter() - t0
-            n_pieces = keep_n
-            if err:
-                return {"error": err[0]}
-        done = [r for r in res if r is not None]
-        text_bytes = sum(pieces[j % 2]["n"] for j in range(n_pieces))
-        bases_in = sum(int(pieces[j % 2]["lens"].sum()) for j in range(n_pieces))
-        same = all(res[j][3] == res[j % 2][3] for j in range(n_pieces))
-        out.update({"pieces": n_pieces, "text_bytes": text_bytes, "reads_in": sum(len(pieces[j % 2]["lens"]) for j in range(n_pieces)), "bases_in": bases_in,
-                    "reads_kept": sum(r[0] for r in done), "bases_kept": sum(r[1] for r in done), "sdust_intervals": sum(r[2] for r in done),
-                    "wall_s": round(wall, 3), "gbases_s_text_in": round(bases_in / wall / 1e9, 3), "gbases_s_kept": round(sum(r[1] for r in done) / wall / 1e9, 3),
-                    "pcie_GBps": round(text_bytes / wall / 1e9, 2), "sdust_kernel_ms_sum": round(ktime[0] + ktime[1], 2), "repeats_identical": bool(same),
-                    "how": "2 host threads x 1 handle each, pieces of ~1 Gbase (2 GB of text) from pinned memory: cornetto_fastq_split(min_len = 10000) + cornetto_sdust_asm; "
-                           "the two distinct pieces are streamed alternately"})
+            if world > 1:
+                dist.barrier()
+            return time.perf_counter() - t0, res
+
+        # the first pass warms the workspaces up; on rank 0 of a sharded run it is also what the whole pieces give (the check below)
+        _, res_whole = run(whole)
+        if not everyone(not err):
+            return {"error": err[0] if err else "another rank failed"}
+        wall, res = run(items)
+        if not everyone(not err):
+            return {"error": err[0] if err else "another rank failed"}
+        mine = {"items": len(items), "text_bytes": sum(i[1] for i in items), "reads_in": sum(i[2] for i in items), "bases_in": sum(i[3] for i in items),
+                "reads_kept": sum(r[0] for r in res), "bases_kept": sum(r[1] for r in res), "sdust_intervals": sum(r[2] for r in res),
+                "wall_s": wall, "sdust_kernel_ms_sum": ktime[0] + ktime[1]}
+        allr = [mine]
+        if world > 1:
+            allr = [None] * world
+            dist.all_gather_object(allr, mine)
         for a in accs:
             a.close()
+        if rank != 0:
+            return None
+        wall = max(x["wall_s"] for x in allr)
+        tot = {k: sum(x[k] for x in allr) for k in ("text_bytes", "reads_in", "bases_in", "reads_kept", "bases_kept", "sdust_intervals")}
+        exp = {"reads_in": sum(whole[j % 2][2] for j in range(n_pieces)), "bases_in": sum(whole[j % 2][3] for j in range(n_pieces)),
+               "reads_kept": sum(res_whole[j % 2][0] for j in range(n_pieces)), "bases_kept": sum(res_whole[j % 2][1] for j in range(n_pieces)),
+               "sdust_intervals": sum(res_whole[j % 2][2] for j in range(n_pieces))}
+        if world == 1:
+            same = all(res[j][3] == res_whole[j % 2][3] for j in range(n_pieces))
+        else:
+            same = all(tot[k] == exp[k] for k in exp)
+        out.update({"pieces": n_pieces, "ranks": world})
+        out.update(tot)
+        out.update({"wall_s": round(wall, 3), "gbases_s_text_in": round(tot["bases_in"] / wall / 1e9, 3), "gbases_s_kept": round(tot["bases_kept"] / wall / 1e9, 3),
+                    "pcie_GBps": round(tot["text_bytes"] / wall / 1e9, 2), "sdust_kernel_ms_sum": round(sum(x["sdust_kernel_ms_sum"] for x in allr), 2)})
+        if world == 1:
+            out["repeats_identical"] = bool(same)
+            out["how"] = ("2 host threads x 1 handle each, pieces of ~%.2g Gbase from pinned memory" % (piece_bases / 1e9) + " (2 B of text per base): cornetto_fastq_split(min_len = 10000) + cornetto_sdust_asm; "
+                          "the two distinct pieces are streamed alternately")
+        else:
+            out["shares_add_up"] = bool(same)
+            out["per_rank"] = [{"bases_in": x["bases_in"], "reads_in": x["reads_in"], "items": x["items"], "wall_s": round(x["wall_s"], 3)} for x in allr]
+            out["how"] = ("one stream of %d pieces of ~1 Gbase (less with a small --reads-gbases) cut into %d shares at read boundaries by cumulative bases (src/seq.c:116-129 per read; reads_shares); every rank: "
+                          "2 host threads x 1 handle, its share from its own pinned memory over its own PCIe link: cornetto_fastq_split(min_len = 10000) + cornetto_sdust_asm; "
+                          "no collective in the data path; wall = barrier to barrier, the slowest rank; the ranks' read / kept / interval counts are compared with "
+                          "those of the whole pieces on rank 0" % (n_pieces, world))
+        if not same:
+            out["parity"] = {"ok": False, "what": "the shares do not add up to the whole pieces" if world > 1 else "a repeated piece gave other intervals", "got": tot, "expected": exp}
+            return out
         # ---- the reference on a sample: seq -m 10000 | sdust, one core ------------------------------------------
         ref_cli = os.path.join(ROOT, "oracle", "_ref", "cornetto")
         if os.path.exists(ref_cli):
             p0 = pieces[0]
             j = int(np.searchsorted(np.cumsum(p0["lens"]), 200e6)) + 1
-            cut = int(p0["off"][j]) if j < len(p0["off"]) else p0["n"]
+            cut = int(p0["off"][j]) if j < len(p0["lens"]) else p0["n"]
             shm = _shm_dir()
             f1 = os.path.join(shm, "cornetto_bench_reads.%d.fq" % os.getpid())
             f2 = os.path.join(shm, "cornetto_bench_reads_m.%d.fq" % os.getpid())
@@ -1083,6 +1172,8 @@ def reads_leg(R, torch, cornetto_amd, gbases):
                     except OSError:
                         pass
     except Exception as e:                               # an extra: never fail the bench line over it (a parity mismatch does)
+        if world > 1:
+            raise                                        # (a rank that drops out of the collectives would hang the others)
         out["error"] = repr(e)
     finally:
         for pin in pins:
@@ -1183,6 +1274,43 @@ def measure(R, args, scaling, profile, steps, warmup, gather):
     return el
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (`python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <the same arguments>`), pass rank 0's JSON
+    line through, return the launcher's exit status.  This process never touches a GPU (counting devices does not initialise one)
+    and never replaces itself (no exec).  Fewer visible GPUs than ranks: exit status 3 and no line, unless --allow-shared-device."""
+    import socket
+    import subprocess
+    try:
+        import torch
+        ndev = torch.cuda.device_count()
+    except Exception:
+        ndev = 0
+    if ndev < args.gpus and not args.allow_shared_device:
+        sys.stderr.write("bench.py: --gpus %d but %d GPU(s) visible: refusing to report a multi-GPU number (--allow-shared-device is for tests)\n" % (args.gpus, ndev))
+        return 3
+    if ndev < 1:
+        sys.stderr.write("bench.py needs a GPU (there is no CPU fallback of the product path)\n")
+        return 1
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    for raw in p.stdout:
+        txt = raw.decode(errors="replace")
+        if txt.startswith("{"):
+            sys.stdout.write(txt)
+            sys.stdout.flush()
+        else:                                            # anything else the ranks print is not the line
+            sys.stderr.write(txt)
+    return p.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1213,6 +1341,8 @@ def main():
     args = ap.parse_args()
     if args.scaling is None:
         args.scaling = "strong" if args.gpus > 1 else "weak"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))                     # plain `python bench.py --gpus N`: this process only starts the ranks and relays their line
 
     import torch
     import torch.distributed as dist
@@ -1382,10 +1512,12 @@ def main():
     R.unload()
     if rank == 0 and world == 1 and not args.no_e2e:
         line["e2e"]["noboringbits"] = e2e_noboringbits(R, torch, cornetto_amd)
-    if rank == 0 and world == 1 and not args.no_reads:
-        line["reads"] = reads_leg(R, torch, cornetto_amd, args.reads_gbases)
-        if line["reads"].get("parity") is not None and not line["reads"]["parity"].get("ok", True):
-            ok = False
+    if not args.no_reads:                               # every rank: N > 1 streams one FASTQ stream sharded by cumulative bases (config 5)
+        rd = reads_leg(R, torch, dist, cornetto_amd, args.reads_gbases)
+        if rank == 0:
+            line["reads"] = rd
+            if rd.get("parity") is not None and not rd["parity"].get("ok", True):
+                ok = False
     if rank == 0:
         print(json.dumps(line), flush=True)
     R.close()

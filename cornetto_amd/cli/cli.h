@@ -132,6 +132,35 @@ void cli_batch_take(cli_batch_t *b, const char *name, cli_str_t *seq); /* takes 
 void cli_batch_clear(cli_batch_t *b);
 int64_t cli_batch_limit(void); /* $CORNETTO_BATCH_BASES, default 4e9 */
 
+/* ---- the host path (cli/host_backend.c): plain sequential C99 for every scan, chosen with --accel=no (noboringbits / boringbits, the
+ * reference's own switch: src/boringbits_main.c:627-632) or CORNETTO_ACCEL=no (every sub-command) — never by itself ---- */
+int cli_host_mode(void);
+void cli_host_set(int on);
+/* the hits / intervals of record `ctg` are appended to a growing array (n, cap in records) */
+void cli_host_telofind(const uint8_t *seq, int64_t len, const char *motif, int32_t ctg, cornetto_hit_t **hits, int64_t *n_hits, int64_t *cap_hits);
+int cli_host_sdust(const uint8_t *seq, int64_t len, int T, int W, int32_t ctg, cornetto_ivl_t **ivls, int64_t *n_ivls, int64_t *cap_ivls); /* -1: -w / -t out of range */
+/* same contract as cornetto_telowin(); results are malloc memory */
+void cli_host_telowin(const cornetto_hit_t *hits, int64_t n_hits, const int32_t *lens, int32_t n_ctg, double thr_adj, cornetto_win_t **wins, int64_t *n_wins);
+/* get_depths(): what the two bedgraphs hold; exits with the reference's messages on malformed input */
+typedef struct {
+    int32_t n_ctg;
+    char **names;
+    int32_t *lens;
+    int64_t *first;          /* [n_ctg + 1]: contig i is depth[first[i] .. first[i + 1]) */
+    uint16_t *depth, *mq;
+    int64_t n_pos, n_clamped;
+    double sum_depth, sum_mq, positions; /* the reference's double accumulators (:283-285) */
+} cli_host_cov_t;
+void cli_host_get_depths(FILE *ft, FILE *fq, cli_host_cov_t *out);
+void cli_host_cov_free(cli_host_cov_t *c);
+/* get_regs() + the predicate of print_fun_bits (boring = 0) / print_boring_bits (1): the rows to print, malloc memory */
+void cli_host_cov_select(const cli_host_cov_t *c, int w, int inc, int32_t lo, int32_t hi, float low_mq, int32_t edge_len, int32_t min_ctg_len, int boring,
+                         cornetto_regrec_t **recs, int64_t *n_recs);
+void cli_host_merge_windows(const cornetto_regrec_t *recs, int64_t n_recs, int32_t dist, int32_t min_len, cornetto_ivl_t **ivls, int64_t *n_ivls);
+/* same contract as cornetto_telobreaks(); -1: a coordinate outside its contig */
+int cli_host_telobreaks(const int32_t *ctg_len, int32_t n_ctg, const cornetto_ivl_t *sd, int64_t n_sd, const cornetto_telrow_t *tel, int64_t n_tel,
+                        cornetto_ivl_t **out, int64_t *n_out);
+
 /* ---- sub-commands: int xxx_main(int argc, char *argv[]) with argv[0] = sub-command (src/main.c:40-54) ---- */
 int depth_main(int argc, char *argv[]);
 int boringbits_main(int argc, char *argv[], int8_t boring);

@@ -467,6 +467,49 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
     TRACE("done");
 }
 
+/* the host path (--accel=no / CORNETTO_ACCEL=no): the sequential reader, one record at a time, printed as it is scanned */
+static void host_stream(const char *path, int must_open, const multi_what_t *what)
+{
+    cli_fastx_t *fx = cli_fastx_open(path);
+    if (!fx) {
+        if (must_open) {
+            CLI_ERROR("Failed to open %s : No such file or directory.", path); /* F_CHK, src/error.h:114-119 */
+            exit(EXIT_FAILURE);
+        }
+        return;
+    }
+    cli_str_t name = {0, 0, 0}, comment = {0, 0, 0}, seq = {0, 0, 0}, qual = {0, 0, 0};
+    cornetto_hit_t *hits = NULL;
+    cornetto_ivl_t *ivls = NULL;
+    int64_t n = 0, cap = 0, l;
+    while ((l = cli_fastx_read(fx, &name, &comment, &seq, &qual)) >= 0) {
+        if (l > 0x7fffffffLL) {
+            CLI_ERROR("record %s has %lld bases; the reference's reader is limited to 2^31-1 (src/kseq.h:185)", name.s, (long long)l);
+            exit(EXIT_FAILURE);
+        }
+        const uint8_t *s = (const uint8_t *)(seq.s ? seq.s : "");
+        n = 0;
+        if (what->kind == 0) {
+            cli_host_telofind(s, l, what->motif, 0, &hits, &n, &cap);
+            for (int64_t i = 0; i < n; ++i) print_hit(name.s, name.l, l, &hits[i]);
+        } else {
+            if (cli_host_sdust(s, l, what->T, what->W, 0, &ivls, &n, &cap) != 0) {
+                CLI_ERROR("sdust: -w %d / -t %d outside 3..1026 / 0..2^20", what->W, what->T);
+                exit(EXIT_FAILURE);
+            }
+            for (int64_t i = 0; i < n; ++i) print_ivl(name.s, name.l, &ivls[i]);
+        }
+    }
+    cli_out_flush();
+    free(hits);
+    free(ivls);
+    free(name.s);
+    free(comment.s);
+    free(seq.s);
+    free(qual.s);
+    cli_fastx_close(fx);
+}
+
 int find_telomere_main(int argc, char *argv[])
 {
     if (argc < 2) { /* src/find_telomere.c:84-88 */
@@ -478,6 +521,11 @@ int find_telomere_main(int argc, char *argv[])
     if (motif[0] == 0) {
         CLI_ERROR("%s", "empty search sequence");
         exit(EXIT_FAILURE);
+    }
+    if (cli_host_mode()) {
+        const multi_what_t what = {0, motif, 0, 0};
+        host_stream(argv[1], 1, &what);
+        return EXIT_SUCCESS;
     }
     int devs[CLI_MAX_DEV];
     const int n_dev = cli_device_list(devs);
@@ -525,6 +573,11 @@ int sdust_main(int argc, char *argv[])
     if (optind == argc) {
         fprintf(stderr, "Usage: sdust [-w %d] [-t %d] <in.fa>\n", o.W, o.T);
         exit(1);
+    }
+    if (cli_host_mode()) {
+        const multi_what_t what = {1, NULL, o.T, o.W};
+        host_stream(argv[optind], 0, &what);
+        return 0;
     }
     int devs[CLI_MAX_DEV];
     const int n_dev = cli_device_list(devs);

@@ -186,7 +186,12 @@ int telomere_breaks_main(int argc, char *argv[])
     /* ---- bitset stage on the device, :79-128 ---- */
     cornetto_ivl_t *runs = NULL;
     int64_t n_runs = 0;
-    if (n_ids > 0 && n_sd > 0 && n_tel > 0) {
+    if (n_ids > 0 && n_sd > 0 && n_tel > 0 && cli_host_mode()) {
+        if (cli_host_telobreaks(id_len, n_ids, sd, n_sd, tel, n_tel, &runs, &n_runs) != 0) {
+            CLI_ERROR("%s", "telobreaks failed: an interval or telomere row lies outside its contig");
+            exit(EXIT_FAILURE);
+        }
+    } else if (n_ids > 0 && n_sd > 0 && n_tel > 0) {
         cornetto_accel_t *h = cli_accel_open();
         cli_accel_check(h, cornetto_telobreaks(h, id_len, n_ids, sd, n_sd, tel, n_tel, &runs, &n_runs), "telobreaks");
         /* (the handle lives until exit: the result may sit in its pinned pool) */

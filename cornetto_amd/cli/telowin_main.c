@@ -83,17 +83,20 @@ int telomere_windows_main(int argc, char *argv[])
     fclose(fp);
 
     if (n_ctg > 0) {
-        cornetto_accel_t *h = cli_accel_open();
+        const int host = cli_host_mode();
+        cornetto_accel_t *h = host ? NULL : cli_accel_open();
         cornetto_win_t *wins = NULL;
         int64_t n_wins = 0;
-        cli_accel_check(h, cornetto_telowin(h, hits, n_hits, lens, n_ctg, thr_adj, &wins, &n_wins), "telowin");
+        if (host) cli_host_telowin(hits, n_hits, lens, n_ctg, thr_adj, &wins, &n_wins);
+        else cli_accel_check(h, cornetto_telowin(h, hits, n_hits, lens, n_ctg, thr_adj, &wins, &n_wins), "telowin");
         for (int64_t i = 0; i < n_wins; ++i) { /* :38 */
             const int den = wins[i].end - wins[i].start;
             printf("Window\t%s\t%d\t%d\t%d\t%.3g\n", names[wins[i].ctg], lens[wins[i].ctg], wins[i].start, wins[i].end,
                    (double)wins[i].car / den);
         }
-        cornetto_free(wins);
-        cornetto_accel_close(h);
+        if (host) free(wins);
+        else cornetto_free(wins);
+        if (h) cornetto_accel_close(h);
     }
     for (int32_t i = 0; i < n_ctg; ++i) free(names[i]);
     free(names);

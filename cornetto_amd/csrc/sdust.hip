@@ -1871,14 +1871,13 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                 const int per_cu = free_now ? per_cu_all : std::max(1, per_cu_all * h->share / 100);
                 const size_t all_blocks = (nc + SIFT_WPB - 1) / SIFT_WPB;
                 const unsigned nbk = (unsigned)std::min<size_t>(all_blocks, (size_t)env_int("CORNETTO_SIFT_BLOCKS", per_cu * std::max(h->sd_cus, 1)));
-                if (want_stats) CN_LAUNCH(h, "sdust_kernel", sd_sift<true><<<dim3(nbk), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream>>>(S, R));
-                else CN_LAUNCH(h, "sdust_kernel", sd_sift<false><<<dim3(nbk), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream>>>(S, R));
-                __atomic_fetch_add(&h->launch_seq, 1ull, __ATOMIC_RELEASE);      // (cornetto_accel_launch_count)
                 // The waves left to the other stream: when its owner says it is through (cornetto_accel_boost, from another host thread) while
                 // this kernel still runs, they are launched as a second kernel on a second stream — same arguments, same chunk counters: the two
-                // launches drain them together — and the stream of this call waits for both.
+                // launches drain them together — and the stream of this call waits for both.  The helper must not start before the counters,
+                // the counts and the walk list of THIS call are reset: it waits for an event recorded behind those memsets, in front of the main launch.
                 const unsigned extra = (unsigned)std::min<size_t>(all_blocks > nbk ? all_blocks - nbk : 0, (size_t)(per_cu_all - per_cu) * std::max(h->sd_cus, 1));
-                if (extra > 0 && !want_stats) {
+                const bool may_help = extra > 0 && !want_stats;
+                if (may_help) {
                     if (!h->stream2) {
                         int pr_least = 0, pr_greatest = 0;
                         (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
@@ -1887,11 +1886,19 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                         CN_HIP(h, hipEventCreateWithFlags(&h->ev1, hipEventDisableTiming));
                     }
                     if (!h->ev3) CN_HIP(h, hipEventCreateWithFlags(&h->ev3, hipEventDisableTiming));
+                    CN_HIP(h, hipEventRecord(h->ev1, h->stream));               // the state of this call is set up
+                }
+                if (want_stats) CN_LAUNCH(h, "sdust_kernel", sd_sift<true><<<dim3(nbk), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream>>>(S, R));
+                else CN_LAUNCH(h, "sdust_kernel", sd_sift<false><<<dim3(nbk), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream>>>(S, R));
+                __atomic_fetch_add(&h->launch_seq, 1ull, __ATOMIC_RELEASE);      // (cornetto_accel_launch_count)
+                if (may_help) {
                     CN_HIP(h, hipEventRecord(h->ev3, h->stream));
                     bool helped = false;
                     while (hipEventQuery(h->ev3) == hipErrorNotReady) {
                         if (!helped && __atomic_load_n(&h->boost, __ATOMIC_ACQUIRE) != 0) {
+                            CN_HIP(h, hipStreamWaitEvent(h->stream2, h->ev1, 0));
                             sd_sift<false><<<dim3(extra), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream2>>>(S, R);
+                            dense_pending = true;                                // (every exit from here on joins the second stream: DenseJoin)
                             CN_HIP(h, hipGetLastError());
                             CN_HIP(h, hipEventRecord(h->ev2, h->stream2));
                             helped = true;

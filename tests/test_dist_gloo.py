@@ -94,3 +94,53 @@ def test_single_process_gather_is_identity_order():
     out = gather_records(recs, [7, 3])
     assert out.tolist() == [(3, 5, 9), (3, 20, 30), (7, 1, 2)]
     assert allreduce_sums((1, 2, 3)) == (1, 2, 3)
+
+
+def _bench_module():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("cornetto_bench", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_reads_shares_cut_the_stream_at_read_boundaries(world):
+    """config 5 (src/seq.c:116-129 per read): the shares of the ranks, in rank order, are the stream; no read is split,
+    none is in two shares, and the shares are balanced by bases to within one read"""
+    bench = _bench_module()
+    rng = np.random.default_rng(7)
+    pieces = [np.clip(rng.lognormal(9.2, 0.9, size=n), 200, 200000).astype(np.int64) for n in (700, 650)]
+    n_pieces = 5
+    shares = bench.reads_shares(pieces, n_pieces, world)
+    assert len(shares) == world
+    stream = [(j % 2, i) for j in range(n_pieces) for i in range(len(pieces[j % 2]))]
+    got = [(s, i) for sh in shares for (s, lo, hi) in sh for i in range(lo, hi)]
+    assert got == stream
+    B = sum(int(pieces[j % 2].sum()) for j in range(n_pieces))
+    per = [sum(int(pieces[s][lo:hi].sum()) for s, lo, hi in sh) for sh in shares]
+    assert sum(per) == B
+    assert max(abs(p - B / world) for p in per) <= 2 * 200000
+    assert all(hi > lo for sh in shares for _, lo, hi in sh)
+
+
+def test_reads_shares_with_more_ranks_than_reads():
+    bench = _bench_module()
+    shares = bench.reads_shares([np.array([1000, 10], dtype=np.int64)], 1, 4)
+    assert [(s, i) for sh in shares for (s, lo, hi) in sh for i in range(lo, hi)] == [(0, 0), (0, 1)]
+
+
+def test_plain_bench_with_several_gpus_starts_its_own_ranks_or_refuses():
+    """`python bench.py --gpus 2` (the shape of the driver's command) never needs a launcher around it: without two visible
+    GPUs it prints no line and exits 3 (here: no GPU at all); the launch itself is covered on the GPU box
+    (tests/test_gpu_bench_ranks.py::test_plain_command_starts_its_own_ranks)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the launch is tested by tests/test_gpu_bench_ranks.py")
+    assert p.returncode == 3, p.stderr.decode(errors="replace")[-2000:]
+    assert p.stdout == b"" and b"refusing" in p.stderr

@@ -109,3 +109,35 @@ def test_two_ranks_weak_scaling_equals_two_one_rank_runs():
     assert a0["gathered_digests"] != a1["gathered_digests"]
     assert two["gathered_digests"] == a0["gathered_digests"] + a1["gathered_digests"]
     assert two["config"]["bases_job"] == 2 * a0["config"]["bases_job"]
+
+
+@pytest.mark.timeout(1800)
+def test_plain_command_starts_its_own_ranks():
+    """the shape of the command the driver runs — `python bench.py --gpus N ...`, no torch.distributed.run around it: bench.py starts
+    the ranks itself as child processes and relays ONE line: config 4 (`second`: the other scaling mode with the gather) and config 5
+    (`reads`: one FASTQ stream sharded over the ranks by cumulative bases) are in it"""
+    shared = [] if _n_gpus() >= 2 else ["--allow-shared-device"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--gbases", "0.05", "--steps", "2", "--warmup", "1", "--check-steps", "2",
+           "--reads-gbases", "0.08"] + shared
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=1500, cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout.decode()[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["collectives"]["world"] == 2
+    assert line["second"]["scaling"] == "weak" and line["second"]["gather"] is True
+    rd = line["reads"]
+    assert rd["ranks"] == 2 and rd["shares_add_up"] is True and len(rd["per_rank"]) == 2
+    assert sum(x["bases_in"] for x in rd["per_rank"]) == rd["bases_in"] and rd["sdust_intervals"] > 0
+    assert abs(rd["per_rank"][0]["bases_in"] - rd["per_rank"][1]["bases_in"]) <= 400000
+    assert rd.get("parity", {"ok": True})["ok"]
+
+
+@pytest.mark.timeout(600)
+def test_plain_command_refuses_shared_devices():
+    if _n_gpus() >= 2:
+        pytest.skip("needs a box with fewer GPUs than ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=500, cwd=ROOT)
+    assert p.returncode == 3 and p.stdout == b"" and b"refusing" in p.stderr

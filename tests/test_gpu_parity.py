@@ -413,27 +413,31 @@ def test_sdust_boost_from_another_thread_does_not_change_results(acc, monkeypatc
     assert len(ref) > 5000
 
 
-def test_sdust_kernel_family_is_chosen_by_the_sequence(acc, monkeypatch):
-    """CORNETTO_SDUST_SIFT=-1: one 64-byte sample per 2048 bases decides once per resident assembly — sift / resolve when at least
-    1 sample in 256 lies inside a repeat array, the per-lane recurrence otherwise; the intervals are the same either way"""
+def test_sdust_family_choice_by_sample_keeps_small_assemblies_on_the_sift_stages(acc, monkeypatch):
+    """CORNETTO_SDUST_SIFT=-1 (the choice by a sample of the bases): an assembly below 2 Gbases takes the sift stages whatever its
+    composition (the per-lane kernel has a 4 ms floor); the intervals are the oracle's, plain or repeat-rich, call after call"""
     monkeypatch.setenv("CORNETTO_SDUST_SIFT", "-1")
     monkeypatch.delenv("CORNETTO_SDUST_CHUNK", raising=False)
-    pytest.skip("assemblies below 2 Gbases always take the sift stages (the per-lane kernel has a 4 ms floor); the choice by sample is "
-                "exercised at full size: tests/test_gpu_fullsize.py, bench.py")
     rng = np.random.default_rng(5)
     plain = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=1_000_000)].copy()
     rich = plain.copy()
-    rich[200_000:400_000] = np.tile(np.frombuffer(b"CATTC", dtype=np.uint8), 40_000)        # (97 of 488 samples; at least 64 are asked for)
+    rich[200_000:400_000] = np.tile(np.frombuffer(b"CATTC", dtype=np.uint8), 40_000)
+    rich[600_000:600_300] = ord("N")
     acc.set_timing(2)
-    for seq, sift in ((plain, False), (rich, True)):
-        asm = acc.asm_upload([seq])
-        iv = acc.sdust(asm, 20, 64)
-        names = {n for n, _ in acc.last_timing()}
-        assert ("sdust_prep" not in names) == sift, names          # (only the per-lane kernel plans its queue)
-        iv2 = acc.sdust(asm, 20, 64)
-        asm.close()
-        assert np.array_equal(iv, iv2)
-        assert [(int(x["start"]), int(x["finish"])) for x in iv] == [(int(r) >> 32, int(r) & 0xFFFFFFFF) for r in ob.sdust(seq, 20, 64)]
+    try:
+        for seq in (plain, rich):
+            asm = acc.asm_upload([seq])
+            iv = acc.sdust(asm, 20, 64)
+            names = {n for n, _ in acc.last_timing()}
+            assert "sdust_prep" not in names, names                    # (only the per-lane kernel plans its queue)
+            st = acc.sdust_stats(asm, 20, 64)
+            assert st is None or st.get("kernel") == "sd_sift", st
+            iv2 = acc.sdust(asm, 20, 64)
+            asm.close()
+            assert np.array_equal(iv, iv2)
+            assert [(int(x["start"]), int(x["finish"])) for x in iv] == [(int(r) >> 32, int(r) & 0xFFFFFFFF) for r in ob.sdust(seq, 20, 64)]
+    finally:
+        acc.set_timing(0)
 
 
 def test_sdust_largest_window_on_homopolymers(acc):

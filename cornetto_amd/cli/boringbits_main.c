@@ -662,6 +662,97 @@ static void bb_sharded(cornetto_accel_t *h0, bg_job_t *jobs, const int *devs, in
     *n_recs = at;
 }
 
+static void print_params(int32_t n_ctg, int32_t mean_depth, int32_t mean_mq, const optp_t *opt) /* :497-506 */
+{
+    fprintf(stderr, "Number of contigs: %d\n", n_ctg);
+    fprintf(stderr, "Average depth: %d\n", mean_depth);
+    fprintf(stderr, "Average mq depth: %d\n", mean_mq);
+    fprintf(stderr, "Window size: %d\n", opt->window_size);
+    fprintf(stderr, "Window increment: %d\n", opt->window_inc);
+    fprintf(stderr, "Low coverage threshold: %.1fx%d\n", opt->low_cov_thresh, mean_depth);
+    fprintf(stderr, "High coverage threshold: %.1fx%d\n", opt->high_cov_thresh, mean_depth);
+    fprintf(stderr, "Low mapq coverage threshold: %.1f\n", opt->low_mq_cov_thresh);
+    fprintf(stderr, "Min contig length: %d\n", opt->min_ctg_len);
+    fprintf(stderr, "Edge length: %d\n", opt->edge_len);
+}
+
+/* print_fun_bits / print_boring_bits (:425-445 / :463-481) over the selected rows, contig by contig */
+static void print_bits(char **names, const int32_t *lens, int32_t n_ctg, const cornetto_regrec_t *recs, int64_t n_recs, const optp_t *opt, int8_t boring)
+{
+    int64_t k = 0;
+    for (int32_t i = 0; i < n_ctg; ++i) {
+        const char *name = names[i];
+        const size_t name_l = strlen(name);
+        const int len = lens[i];
+        if (!boring) {
+            if (len < opt->min_ctg_len) {
+                cli_out_flush();
+                printf("%s\t%d\t%d\t.\t.\n", name, 0, opt->min_ctg_len); /* :430 prints min_ctg_len, not len */
+            } else {
+                cli_out_flush();
+                printf("%s\t%d\t%d\t.\t.\n", name, 0, opt->edge_len);
+                printf("%s\t%d\t%d\t.\t.\n", name, len - opt->edge_len, len);
+            }
+        }
+        for (; k < n_recs && recs[k].ctg == i; ++k)
+            { /* name, st, end, depth, mq_depth: :441 / :475 */
+                cli_out_bytes(name, name_l);
+                cli_out_char('\t');
+                cli_out_int(recs[k].st);
+                cli_out_char('\t');
+                cli_out_int(recs[k].end);
+                cli_out_char('\t');
+                cli_out_int(recs[k].depth);
+                cli_out_char('\t');
+                cli_out_int(recs[k].mq_depth);
+                cli_out_char('\n');
+            }
+    }
+    cli_out_flush();
+}
+
+/* --accel=no / CORNETTO_ACCEL=no: the whole sub-command on the host (cli/host_backend.c), the_boring_bits() :483-536 */
+static int host_bits(FILE *ft, FILE *fq, const optp_t *opt, int8_t boring, const char *panel_bed, const char *lowq_bed)
+{
+    double t0 = cli_realtime();
+    cli_host_cov_t cov;
+    cli_host_get_depths(ft, fq, &cov);
+    fclose(ft);
+    fclose(fq);
+    if (cov.n_clamped) CLI_WARNING("%lld depth values were truncated to 65535", (long long)cov.n_clamped);
+    CLI_VERBOSE("Loaded depth files in %.2f seconds", cli_realtime() - t0);
+    int32_t mean_depth = (int32_t)0x80000000, mean_mq = (int32_t)0x80000000;   /* (no record at all: the reference rounds 0 / 0) */
+    if (cov.n_ctg > 0) {
+        mean_depth = (int32_t)round(cov.sum_depth / cov.positions);           /* :293 */
+        mean_mq = (int32_t)round(cov.sum_mq / cov.positions);                 /* :294 */
+    }
+    print_params(cov.n_ctg, mean_depth, mean_mq, opt);
+    t0 = cli_realtime();
+    cornetto_regrec_t *recs = NULL;
+    int64_t n_recs = 0;
+    if (cov.n_ctg > 0) {
+        const int32_t lo_t = cornetto_cov_threshold(opt->low_cov_thresh, mean_depth);   /* :518 */
+        const int32_t hi_t = cornetto_cov_threshold(opt->high_cov_thresh, mean_depth);  /* :519 */
+        cli_host_cov_select(&cov, opt->window_size, opt->window_inc, lo_t, hi_t, opt->low_mq_cov_thresh, opt->edge_len, opt->min_ctg_len, panel_bed ? 0 : boring,
+                            &recs, &n_recs);
+    }
+    CLI_VERBOSE("Found regions in %.2f seconds", cli_realtime() - t0);
+    if (panel_bed) {
+        cornetto_ivl_t *fun = NULL;
+        int64_t n_fun = 0;
+        cli_host_merge_windows(recs, n_recs, pn_par[0], pn_par[1], &fun, &n_fun);       /* create-cornetto.sh:41-47 */
+        panel_print(panel_bed, lowq_bed, cov.names, cov.n_ctg, fun, n_fun);
+        free(fun);
+    } else {
+        t0 = cli_realtime();
+        print_bits(cov.names, cov.lens, cov.n_ctg, recs, n_recs, opt, boring);
+        CLI_VERBOSE("Printed the bits in %.2f seconds", cli_realtime() - t0);
+    }
+    free(recs);
+    cli_host_cov_free(&cov);
+    return 0;
+}
+
 int boringbits_main(int argc, char *argv[], int8_t boring)
 {
     static const struct option lo[] = {
@@ -729,9 +820,10 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
             }
         } else if (c == 0 && li == 9) { /* --accel: the seam the reference left (src/boringbits_main.c:627-632) */
             if (strcmp(optarg, "no") == 0 || strcmp(optarg, "n") == 0) {
-                CLI_ERROR("%s", "--accel=no: this build has no CPU path for the window stage; use the reference binary");
-                exit(EXIT_FAILURE);
-            } else if (!(strcmp(optarg, "yes") == 0 || strcmp(optarg, "y") == 0)) {
+                cli_host_set(1);       /* the host path of cli/host_backend.c: sequential parse, window sums, selection */
+            } else if (strcmp(optarg, "yes") == 0 || strcmp(optarg, "y") == 0) {
+                cli_host_set(0);
+            } else {
                 fprintf(stderr, "option '--accel' only accepts 'yes' or 'no'.\n");
             }
         }
@@ -762,6 +854,7 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
         CLI_ERROR("Failed to open %s : No such file or directory.", covmq);
         exit(EXIT_FAILURE);
     }
+    if (cli_host_mode()) return host_bits(ft, fq, &opt, boring, panel_bed, lowq_bed);
     int devs[CLI_MAX_DEV];
     const int n_dev = cli_device_list(devs);
     if (n_dev >= 1) { /* the text is parsed on the first listed device */
@@ -914,16 +1007,7 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
         /* the reference divides 0/0 here: round(NaN) -> INT_MIN; nothing is printed either way */
         mean_depth = mean_mq = (int32_t)0x80000000;
     }
-    fprintf(stderr, "Number of contigs: %d\n", n_ctg); /* :497-506 */
-    fprintf(stderr, "Average depth: %d\n", mean_depth);
-    fprintf(stderr, "Average mq depth: %d\n", mean_mq);
-    fprintf(stderr, "Window size: %d\n", opt.window_size);
-    fprintf(stderr, "Window increment: %d\n", opt.window_inc);
-    fprintf(stderr, "Low coverage threshold: %.1fx%d\n", opt.low_cov_thresh, mean_depth);
-    fprintf(stderr, "High coverage threshold: %.1fx%d\n", opt.high_cov_thresh, mean_depth);
-    fprintf(stderr, "Low mapq coverage threshold: %.1f\n", opt.low_mq_cov_thresh);
-    fprintf(stderr, "Min contig length: %d\n", opt.min_ctg_len);
-    fprintf(stderr, "Edge length: %d\n", opt.edge_len);
+    print_params(n_ctg, mean_depth, mean_mq, &opt);
 
     if (panel_bed) {
         panel_print(panel_bed, lowq_bed, names, n_ctg, fun, n_fun);
@@ -937,36 +1021,7 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
 
     /* ---------------- print (:425-445 / :463-481) ---------------- */
     t0 = cli_realtime();
-    int64_t k = 0;
-    for (int32_t i = 0; i < n_ctg; ++i) {
-        const char *name = names[i];
-        const size_t name_l = strlen(name);
-        const int len = lens[i];
-        if (!boring) {
-            if (len < opt.min_ctg_len) {
-                cli_out_flush();
-                printf("%s\t%d\t%d\t.\t.\n", name, 0, opt.min_ctg_len); /* :430 prints min_ctg_len, not len */
-            } else {
-                cli_out_flush();
-                printf("%s\t%d\t%d\t.\t.\n", name, 0, opt.edge_len);
-                printf("%s\t%d\t%d\t.\t.\n", name, len - opt.edge_len, len);
-            }
-        }
-        for (; k < n_recs && recs[k].ctg == i; ++k)
-            { /* name, st, end, depth, mq_depth: :441 / :475 */
-                cli_out_bytes(name, name_l);
-                cli_out_char('\t');
-                cli_out_int(recs[k].st);
-                cli_out_char('\t');
-                cli_out_int(recs[k].end);
-                cli_out_char('\t');
-                cli_out_int(recs[k].depth);
-                cli_out_char('\t');
-                cli_out_int(recs[k].mq_depth);
-                cli_out_char('\n');
-            }
-    }
-    cli_out_flush();
+    print_bits(names, lens, n_ctg, recs, n_recs, &opt, boring);
     CLI_VERBOSE("Printed the bits in %.2f seconds", cli_realtime() - t0);
     if (recs_are_malloced) free(recs);
     else cornetto_free(recs);

@@ -228,3 +228,41 @@ def tricky_fastx(rng, n_rec, strict=False, lowc=0.0):
     if text.endswith(b"\n") and rng.random() < 0.3:
         text = text[:-1]
     return text
+
+
+# ---- the CLI goldens (stdout of the unmodified reference: tests/golden/make_golden.py), shared by the device tests
+# (tests/test_gpu_cli.py) and the host-path tests (tests/test_cli_accel_no.py)
+FASTA_SIDE = [
+    (["telofind", "probe.fa"], "probe.telofind.exp"),
+    (["telofind", "mix.fa.gz"], "mix.telofind.exp"),
+    (["telofind", "mix.fa.gz", "ttaggg"], "mix.lower_motif.telofind.exp"),
+    (["telofind", "mix.fa.gz", "TTAGGGTTAGGG"], "mix.k12.telofind.exp"),
+    (["telofind", "mix.fa.gz", "TTAGGG" * 6], "mix.k36.telofind.exp"),
+    (["telofind", "mix.fa.gz", "GGGTTA" * 11 + "G"], "mix.k67.telofind.exp"),
+    (["telofind", "mix.fa.gz", "AAAA"], "mix.AAAA.telofind.exp"),
+    (["telofind", "mix.fa.gz", "GNG"], "mix.GNG.telofind.exp"),
+    (["telofind", "probe_selfoverlap.fa", "ACACA"], "probe_selfoverlap.ACACA.telofind.exp"),
+    (["sdust", "probe.fa"], "probe.sdust.exp"),
+    (["sdust", "probe_sdust.fa"], "probe_sdust.sdust.exp"),
+    (["sdust", "-w", "32", "-t", "10", "probe_sdust.fa"], "probe_sdust.w32t10.sdust.exp"),
+    (["sdust", "mix.fa.gz"], "mix.sdust.exp"),
+    (["sdust", "mix.fa.gz", "-w", "32", "-t", "10"], "mix.w32t10.sdust.exp"),
+    (["sdust", "-w", "100", "-t", "25", "mix.fa.gz"], "mix.w100t25.sdust.exp"),
+    (["sdust", "reads.fq"], "reads.sdust.exp"),
+    (["telowin", "probe.telomere", "99.9", "0.4"], "probe.telowin.exp"),
+    (["telowin", "probe.telomere", "100", "0.5"], "probe.i100t05.telowin.exp"),
+    (["telowin", "probe.telomere", "95"], "probe.i95.telowin.exp"),
+    (["telowin", "mix.telofind.exp", "99.9", "0.4"], "mix.telowin.exp"),
+    (["telowin", "mix.telofind.exp", "99.9", "0.1"], "mix.t01.telowin.exp"),
+]
+
+# "T" / "Q" stand for the uncompressed cov-total.bg / cov-mq20.bg
+PANEL = [
+    (["boringbits", "T", "-q", "Q", "-m", "10000", "-e", "1000", "-L", "0.6", "-Q", "0.6", "-H", "1.6"], "bg.boring_t1.exp"),
+    (["noboringbits", "-H", "2.5", "-L", "0.5", "-Q", "0.5", "T", "-q", "Q", "-m", "10000", "-e", "1000"], "bg.fun_t2.exp"),
+    (["noboringbits", "T", "-q", "Q"], "bg.fun_default.exp"),
+    (["boringbits", "T", "-q", "Q"], "bg.boring_default.exp"),
+    (["noboringbits", "T", "-q", "Q", "-w", "300", "-i", "7", "-L", "0.33", "-H", "1.45", "-Q", "0.9", "-m", "5000", "-e", "500"], "bg.fun_w300i7.exp"),
+    (["boringbits", "T", "-q", "Q", "-w", "300", "-i", "7", "-L", "0.33", "-H", "1.45", "-Q", "0.9", "-m", "5000", "-e", "500"], "bg.boring_w300i7.exp"),
+    (["noboringbits", "T", "-q", "Q", "-w", "1000", "-i", "1000", "-m", "2000", "-e", "10000"], "bg.fun_w1000i1000.exp"),
+]

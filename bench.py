@@ -78,11 +78,93 @@ def _plant(torch, dev, bases, starts, lengths, units, unit_ids):
         bases[idx[ok]] = val[ok]
 
 
+def _revcomp_np(a):
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[list(b"ACGT")] = list(b"TGCA")
+    return comp[a[::-1]]
+
+
+def _humanlike_base(torch, dev, total, seed, g):
+    """the background of the humanlike profile: isochores of 100 kb - 1 Mb (log-uniform) whose GC content is drawn from 35-55 %,
+    bases independent inside an isochore, then CpG taken down to ~20 % of its expectation the way genomes lose it (80 % of the CpG
+    dinucleotides deaminated: CG -> TG or, for the other strand, CG -> CA) — which also gives the TpG / CpA excess of a real genome"""
+    rs = np.random.default_rng(seed ^ 0x150C40)
+    n_iso = int(total / 2.0e5) + 16
+    iso_len = (10 ** rs.uniform(5.0, 6.0, size=n_iso)).astype(np.int64)
+    while int(iso_len.sum()) < total:
+        iso_len = np.concatenate([iso_len, (10 ** rs.uniform(5.0, 6.0, size=n_iso)).astype(np.int64)])
+    bounds = torch.from_numpy(np.cumsum(iso_len)).to(dev)
+    gc = torch.from_numpy(rs.uniform(0.35, 0.55, size=len(iso_len)).astype(np.float32)).to(dev)
+    bases = torch.empty(total, dtype=torch.uint8, device=dev)
+    step = 1 << 27
+    at = torch.tensor(list(b"AT"), dtype=torch.uint8, device=dev)
+    cg = torch.tensor(list(b"CG"), dtype=torch.uint8, device=dev)
+    for s0 in range(0, total, step):
+        e0 = min(total, s0 + step)
+        pos = torch.arange(s0, e0, device=dev)
+        p_gc = gc[torch.bucketize(pos, bounds, right=True).clamp_(max=len(iso_len) - 1)]
+        del pos
+        is_gc = torch.rand(e0 - s0, device=dev, generator=g) < p_gc
+        del p_gc
+        bit = torch.randint(0, 2, (e0 - s0,), device=dev, generator=g)
+        bases[s0:e0] = torch.where(is_gc, cg[bit], at[bit])
+        del is_gc, bit
+    for s0 in range(0, total - 1, step):                # CpG depletion (a chunk's last base pairs with the next chunk's first)
+        e0 = min(total - 1, s0 + step)
+        cpg = (bases[s0:e0] == 67) & (bases[s0 + 1:e0 + 1] == 71)
+        r = torch.rand(e0 - s0, device=dev, generator=g)
+        c2t = cpg & (r < 0.4)
+        g2a = cpg & (r >= 0.4) & (r < 0.8)
+        del cpg, r
+        bases[s0:e0][c2t] = 84
+        bases[s0 + 1:e0 + 1][g2a] = 65
+        del c2t, g2a
+    return bases
+
+
+def _plant_copies(torch, dev, bases, starts, lens_, cons_off, cons, flip, div, g):
+    """diverged copies of (a part of) a consensus: copy j = cons[cons_off[j] : cons_off[j] + lens_[j]] (its reverse complement when
+    flip[j]), every base substituted with probability div[j], written at bases[starts[j] ...] (ragged, batched on the device)"""
+    if len(starts) == 0:
+        return
+    cons_f = torch.from_numpy(np.ascontiguousarray(cons)).to(dev)
+    cons_r = torch.from_numpy(np.ascontiguousarray(_revcomp_np(cons))).to(dev)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    n_cons = len(cons)
+    starts, lens_, cons_off = np.asarray(starts, np.int64), np.asarray(lens_, np.int64), np.asarray(cons_off, np.int64)
+    flip, div = np.asarray(flip, bool), np.asarray(div, np.float32)
+    csum = np.concatenate([[0], np.cumsum(lens_)])
+    budget, i = 1 << 25, 0                               # elements per batch
+    while i < len(starts):
+        j = int(np.searchsorted(csum, csum[i] + budget, "right")) - 1
+        j = max(j, i + 1)
+        ln = torch.from_numpy(lens_[i:j]).to(dev)
+        tot = int(csum[j] - csum[i])
+        rep = torch.repeat_interleave(torch.arange(j - i, device=dev), ln, output_size=tot)
+        within = torch.arange(tot, device=dev) - torch.from_numpy(csum[i:j] - csum[i]).to(dev)[rep]
+        dst = torch.from_numpy(starts[i:j]).to(dev)[rep] + within
+        co = torch.from_numpy(cons_off[i:j]).to(dev)[rep]
+        fl = torch.from_numpy(flip[i:j]).to(dev)[rep]
+        # a flipped copy reads the reverse complement of the same stretch of the consensus
+        src_f = co + within
+        src_r = (n_cons - co - ln[rep]) + within
+        val = torch.where(fl, cons_r[src_r.clamp_(0, n_cons - 1)], cons_f[src_f.clamp_(0, n_cons - 1)])
+        mut = torch.rand(tot, device=dev, generator=g) < torch.from_numpy(div[i:j]).to(dev)[rep]
+        val = torch.where(mut, lut[torch.randint(0, 4, (tot,), device=dev, generator=g)], val)
+        bases[dst] = val
+        del rep, within, dst, co, fl, src_f, src_r, val, mut
+        i = j
+
+
 def make_assembly(torch, dev, lens, seed, profile="uniform"):
     """bases (uint8 ASCII, contigs at 64-byte aligned offsets) with planted features — SURVEY 8d, C2.
     profile "satellite" additionally plants what a real human assembly is full of: HSat2/3-like (CATTC)n / (GGAAT)n
     arrays of 0.1-5 Mb (half of them exact, half with 2 % substitutions) over >= 3 % of the bases, (AT)n / (AAAG)n
-    microsatellites every ~20 kb and poly-A / poly-T runs every ~10 kb."""
+    microsatellites every ~20 kb and poly-A / poly-T runs every ~10 kb.
+    profile "humanlike" has those on a background with the COMPOSITION of a human assembly instead of uniform bases (what the
+    position-parallel sieve of sd_sift is sensitive to): isochores with 35-55 % GC, CpG at ~20 % of its expectation, ~10 % of the
+    bases in 85-95 %-identity copies of a 300-bp Alu-like consensus with 10-40-base poly-A tails, ~15 % in 5'-truncated
+    80-95 %-identity copies of an AT-rich 6 kb L1-like consensus."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     offs, pos = [], 0
@@ -90,21 +172,51 @@ def make_assembly(torch, dev, lens, seed, profile="uniform"):
         offs.append(pos)
         pos = (pos + n + 63) // 64 * 64
     total = pos + 256
-    codes = torch.randint(0, 4, (total,), dtype=torch.uint8, device=dev, generator=g)
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    bases = lut[codes.long()] if total < (1 << 28) else None
-    if bases is None:                                  # chunked lookup keeps the int64 index temporary small
-        bases = torch.empty_like(codes)
-        step = 1 << 28
-        for s in range(0, total, step):
-            bases[s:s + step] = lut[codes[s:s + step].long()]
-    del codes
+    if profile == "humanlike":
+        bases = _humanlike_base(torch, dev, total, seed, g)
+    else:
+        codes = torch.randint(0, 4, (total,), dtype=torch.uint8, device=dev, generator=g)
+        bases = lut[codes.long()] if total < (1 << 28) else None
+        if bases is None:                                  # chunked lookup keeps the int64 index temporary small
+            bases = torch.empty_like(codes)
+            step = 1 << 28
+            for s in range(0, total, step):
+                bases[s:s + step] = lut[codes[s:s + step].long()]
+        del codes
     rng = np.random.default_rng(seed)
 
     def put(p, b):
         bases[p:p + len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
 
-    if profile == "satellite":
+    if profile == "humanlike":
+        rh = np.random.default_rng(seed ^ 0xA1B2C3)
+        acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+        # L1-like: 6 kb, 58 % AT, ends in a poly-A tail; copies are 5'-truncated (they keep the 3' end), 80-95 % identity
+        l1 = acgt[rh.choice(4, size=6000, p=[0.33, 0.21, 0.21, 0.25])].copy()
+        l1[-30:] = ord("A")
+        # Alu-like: two GC-rich arms around an A-rich linker, then the poly-A tail (drawn per copy: 10-40)
+        alu = acgt[rh.choice(4, size=340, p=[0.21, 0.30, 0.31, 0.18])].copy()
+        alu[120:135] = np.frombuffer(b"AAAAATACAAAAAAT"[:15], dtype=np.uint8)
+        alu[300:] = ord("A")
+        big = [(o, n) for o, n in zip(offs, lens) if n >= 20000]
+        wts = np.array([n for _, n in big], dtype=np.float64)
+        wts /= wts.sum()
+        nb = float(sum(n for _, n in big))
+
+        def scatter(count, max_len):
+            ci = rh.choice(len(big), size=count, p=wts)
+            o = np.array([big[i][0] for i in ci], dtype=np.int64)
+            n = np.array([big[i][1] for i in ci], dtype=np.int64)
+            return o + 2000 + (rh.random(count) * (n - max_len - 4000)).astype(np.int64)
+
+        n_l1 = int(0.15 * nb / 1050.0)                     # mean fragment ~1.05 kb (log-uniform 100 .. 6000)
+        ln = np.minimum(6000, (10 ** rh.uniform(2.0, np.log10(6000.0), size=n_l1)).astype(np.int64))
+        _plant_copies(torch, dev, bases, scatter(n_l1, 6000), ln, 6000 - ln, l1, rh.random(n_l1) < 0.5, rh.uniform(0.05, 0.20, size=n_l1), g)
+        n_alu = int(0.10 * nb / 325.0)
+        ln = 300 + rh.integers(10, 41, size=n_alu)
+        _plant_copies(torch, dev, bases, scatter(n_alu, 340), ln, np.zeros(n_alu, np.int64), alu, rh.random(n_alu) < 0.5, rh.uniform(0.05, 0.15, size=n_alu), g)
+    if profile in ("satellite", "humanlike"):
         rs = np.random.default_rng(seed ^ 0x5A7E111)
         # microsatellites and homopolymer runs, everywhere
         st, ln, ui = [], [], []
@@ -492,6 +604,7 @@ class Rank:
         if self.overlap:
             # the sdust waves stay resident until their queue is empty: leave part of every CU to the other stream
             self.share = args.sdust_share if args.sdust_share > 0 else 72
+            self.share_tuned_for = None
             self.acc2.set_share(self.share)
         # the two large result arrays of this thread (telomere runs, selected windows) travel beside its next kernels
         self.lead_us = float(os.environ.get("CORNETTO_BENCH_LEAD_US", "0"))
@@ -670,6 +783,13 @@ class Rank:
         tunes for itself."""
         if not self.overlap or self.args.sdust_share > 0:
             return
+        if self.args.sdust_share < 0 and self.profile == "uniform":
+            self.share = 72
+            self.acc2.set_share(self.share)
+            return
+        if self.share_tuned_for == (self.profile, self.scaling, self.my_bases):
+            return                                       # (probed once per resident workload)
+        self.share_tuned_for = (self.profile, self.scaling, self.my_bases)
         best = None
         for sh in (62, 72, 85, 100):
             self.acc2.set_share(sh)
@@ -1321,7 +1441,7 @@ def main():
                     help="strong (default for --gpus > 1: BASELINE's metric is ONE 3 Gbp assembly at 1/2/4/8 GPUs): one assembly, contigs split "
                          "over the ranks (LPT), one all-reduce per step; weak: one assembly per rank, no collective.  With --gpus > 1 the other one "
                          "is measured too (with the gather of all records to rank 0) and reported under 'second'")
-    ap.add_argument("--profile", choices=("uniform", "satellite"), default="uniform", help="main workload (the other one is reported under 'profiles' at N=1)")
+    ap.add_argument("--profile", choices=("uniform", "satellite", "humanlike"), default="uniform", help="main workload (the other ones are reported under 'profiles' at N=1)")
     ap.add_argument("--assembly-index", type=int, default=0, help="seed offset of the (first) assembly: rank r of a weak run uses index + r")
     ap.add_argument("--cpu-sample-mbases", type=float, default=500.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU leg (cpu_baseline and parity)")
@@ -1333,7 +1453,7 @@ def main():
     ap.add_argument("--no-second", action="store_true", help="--gpus > 1: skip the second measurement (the other scaling mode with --gather)")
     ap.add_argument("--emulate-ranks", type=str, default="2,4,8", help="N=1: model the strong-scaling curve for these rank counts on this one GPU ('' = skip)")
     ap.add_argument("--allow-shared-device", action="store_true", help="--gpus > 1 with fewer GPUs than ranks (tests): ranks share devices, collectives over gloo")
-    ap.add_argument("--sdust-share", type=int, default=72, help="percent of the wave slots the resident sdust waves could hold on a CU that they take while the other stream runs beside them (72: 15 of 21 per CU — 14: 8.2 ms per step, 15: 8.0, 16: 8.8, 17: the other stream starves; the rest joins in when the other thread of the step is through: cornetto_accel_boost); 0: probed during warm-up (62 / 72 / 85 / 100)")
+    ap.add_argument("--sdust-share", type=int, default=-1, help="percent of the wave slots the resident sdust waves could hold on a CU that they take while the other stream runs beside them; -1 (default): 72 on the uniform profile (15 of 21 per CU — 14: 8.2 ms per step, 15: 8.0, 16: 8.8, 17: the other stream starves), probed during warm-up (62 / 72 / 85 / 100) on the repeat-rich profiles, where sdust is a larger part of the step; 0: always probed.  The rest of the slots joins in when the other thread of the step is through (cornetto_accel_boost)")
     ap.add_argument("--timing", type=int, default=1, help="HIP events in the timed steps around: 1 the three main kernels only (roofline), 2 every launch, 0 none; the extra serial pass that fills the kernel table always uses 2")
     ap.add_argument("--gather", action="store_true", help="also gather every result record to rank 0 inside the step (not part of the path: each rank owns the output of its contigs)")
     ap.add_argument("--allreduce-always", action="store_true", help="weak scaling: all-reduce the depth totals as well (treats the N assemblies as one)")
@@ -1431,7 +1551,7 @@ def main():
         wl = "%s over %s synthetic HG002-like hifiasm assembly%s (%d contigs, %.3f Gbp%s, planted telomeres/STRs/N runs%s; per-base u16 depth+mq)" % (
             "telowin+sdust+noboringbits", "one" if args.scaling == "strong" or world == 1 else "%d" % world,
             "" if args.scaling == "strong" or world == 1 else " (one per GPU)", len(R.lens), sum(R.lens) / 1e9,
-            " each" if args.scaling == "weak" and world > 1 else "", ", satellite arrays, microsatellites, poly-A" if args.profile == "satellite" else "")
+            " each" if args.scaling == "weak" and world > 1 else "", {"satellite": ", satellite arrays, microsatellites, poly-A", "humanlike": "; isochores 35-55 % GC, CpG depleted, 10 % Alu-like + 15 % L1-like copies, microsatellites, 3 % satellite arrays"}.get(args.profile, ""))
         line = {
             "metric": "Gbases/s scanned (telowin+sdust+boringbits)", "value": round(value, 4), "unit": "Gbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -1504,10 +1624,12 @@ def main():
         st = R.acc2.sdust_stats(R.asm2, 20, 64) if hasattr(R.acc2, "sdust_stats") else None
         if st:
             profs[args.profile]["sdust_stats"] = st
-        other = "satellite" if args.profile == "uniform" else "uniform"
-        R.unload()
-        R.load(other)
-        profs[other] = profile_leg(R, min(args.steps, 5))
+        for other in ("uniform", "satellite", "humanlike"):
+            if other == args.profile:
+                continue
+            R.unload()
+            R.load(other)
+            profs[other] = profile_leg(R, min(args.steps, 5))
         line["profiles"] = profs
     R.unload()
     if rank == 0 and world == 1 and not args.no_e2e:

@@ -1853,7 +1853,8 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                 uint32_t *d_wflag = a->d_sd_walk + 2 + nc, *d_wrank = d_wflag + nc, *d_worder = d_wrank + nc, *d_wpart = d_worder + nc;
                 SiftArgs S{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, lds_wave, reg_cap,
                            walk_known ? d_worder : nullptr, walk_known ? nullptr : a->d_sd_walk, walk_known ? nullptr : d_wflag,
-                           reinterpret_cast<uint32_t *>(d_tot + 256), T / 10 + 1, lmin, env_int("CORNETTO_SIFT_ABL", 0)};
+                           reinterpret_cast<uint32_t *>(d_tot + 256), T / 10 + 1, lmin, env_int("CORNETTO_SIFT_ABL", 0),
+                           std::min(65, std::max(1, env_int("CORNETTO_SIFT_DP", 16)))};
                 sift_walk_pending = !walk_known;
                 SdArgs R = A;
                 R.stats = want_stats ? d_tot + 200 : nullptr;
@@ -2060,8 +2061,8 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                         fprintf(stderr, "[sdust stats]   waves that ran %4.1f-%4.1f ms: %6llu, job fetches %llu, find_perfect calls %llu (%llu with candidates)\n", b * 0.5, b * 0.5 + 0.5,
                                 p_tot[16 + 4 * b], p_tot[18 + 4 * b], p_tot[19 + 4 * b], p_tot[17 + 4 * b]);
             if (env_stats && sift_on)
-                fprintf(stderr, "[sdust stats] sift: tiles %llu, positions with ct > T/10 %llu, after L1 %llu, after L2 %llu; resolve: steps %llu, window reads %llu; passes with candidates %llu; base-by-base steps of chunks with other bytes %llu\n",
-                        p_tot[206], p_tot[203], p_tot[204], p_tot[205], p_tot[200], p_tot[201], p_tot[202], p_tot[207]);
+                fprintf(stderr, "[sdust stats] sift: tiles %llu, positions with ct > T/10 %llu, after L1 %llu, after L2 %llu; resolve: steps %llu, window reads %llu, dp tiles %llu; passes with candidates %llu; base-by-base steps of chunks with other bytes %llu\n",
+                        p_tot[206], p_tot[203], p_tot[204], p_tot[205], p_tot[200], p_tot[201], p_tot[208], p_tot[202], p_tot[207]);
             if (env_stats)
                 fprintf(stderr, "[sdust stats] flagged low-complexity %llu; chunks %zu waves %u wave-steps %llu find_perfect calls %llu (%llu with candidates) plain groups %llu; wave time avg %.1f us max %.1f us; queue: %.1f fetch rounds and %.1f us per wave\n", p_tot[7], nc, nb,
                         p_tot[2], p_tot[3], p_tot[10], p_tot[4], nb ? (double)p_tot[5] / nb / 100.0 : 0.0, (double)p_tot[6] / 100.0, nb ? (double)p_tot[11] / nb : 0.0, nb ? (double)p_tot[12] / nb / 100.0 : 0.0);

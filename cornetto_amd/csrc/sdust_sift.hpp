@@ -54,6 +54,7 @@ struct SiftArgs {
     uint32_t *counter;        // [SIFT_NCTR * 16], zero before the launch: counter c (at index 16 c) hands out the chunks c + j SIFT_NCTR
     int32_t thr, lmin;        // equal words a last word needs (T / 10 + 1); shortest l with 10 l (l + 1) / 2 > T l, capped at 16
     int32_t abl;              // development aid (CORNETTO_SIFT_ABL): 1 no resolve, 2 no L1 / L2, 4 no tiles: timing only, results are wrong
+    int32_t dp_min;           // a tile with at least this many sifted positions is resolved end-parallel (dp tile); 65: never (CORNETTO_SIFT_DP)
 };
 
 #ifndef SIFT_WPB
@@ -65,7 +66,8 @@ constexpr int SIFT_LS = 15;      // L2 walks the suffixes with l <= SIFT_LS
 // fixed part of the LDS of a wave: tables 4 x 64 x u32 | lists 2 x 128 x u16 | counters 8 x 64 x u32; then bits (cap / 8) and the
 // word / count buffer, two bytes per position (word, count)
 constexpr int SIFT_FIXED = 1024 + 512 + 2048;
-__host__ __device__ constexpr uint32_t sift_lds_bytes(uint32_t cap) { return (SIFT_FIXED + cap / 8 + 2 * (SIFT_PAD + cap) + 15) / 16 * 16; }
+// (bits: the sifted positions, then the coverage of the region, cap / 8 bytes each)
+__host__ __device__ constexpr uint32_t sift_lds_bytes(uint32_t cap) { return (SIFT_FIXED + cap / 4 + 2 * (SIFT_PAD + cap) + 15) / 16 * 16; }
 
 
 // four bytes -> four codes: bits 0-1 the base (A0 C1 G2 T3), bit 2 set for anything that is not A/C/G/T/a/c/g/t
@@ -137,7 +139,7 @@ __device__ __forceinline__ int sd_wave_find_start(const SdChunk ch, const uint8_
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6))) void sd_sift(SiftArgs A, SdArgs O)
+__global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(5))) void sd_sift(SiftArgs A, SdArgs O)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sift_lds[];
     const int lane = threadIdx.x & 63;
@@ -151,8 +153,13 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
     uint32_t *const cnt = reinterpret_cast<uint32_t *>(L + 1536);
     uint32_t *const sb = reinterpret_cast<uint32_t *>(L + SIFT_FIXED);
     const uint32_t cap = A.reg_cap;
+    uint32_t *const cb = sb + (cap >> 5);             // coverage of the region, one bit per base: what the chunk's rows are made of
+    // the dp tiles reuse the L2 counters (idle by then): the column of the position in front of a tile (c, B per length), the best
+    // perfect interval per start inside the tile
+    uint2 *const col = reinterpret_cast<uint2 *>(cnt);
+    uint32_t *const ring = cnt + 128;
     // wc[2 p] = the word that ends at offset p of the region (bit 6: none), wc[2 p + 1] = ct(p): one address serves both
-    uint8_t *const wc = L + SIFT_FIXED + cap / 8 + 2 * SIFT_PAD;
+    uint8_t *const wc = L + SIFT_FIXED + cap / 4 + 2 * SIFT_PAD;
     const int T = A.T, W = A.W, CAPW = W - 2;
 
     // ---- per-lane constants -----------------------------------------------------------------------------------------
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
     const int Tl = T * lane;
     const uint32_t m_recip = sd_recip_tab[lane];
     // statistics build: counted per wave, added up once at the end
-    unsigned long long st_steps = 0, st_jumps = 0, st_cand = 0, st_trig = 0, st_l1 = 0, st_l2 = 0, st_walk = 0, st_tiles = 0;
+    unsigned long long st_steps = 0, st_jumps = 0, st_cand = 0, st_trig = 0, st_l1 = 0, st_l2 = 0, st_walk = 0, st_tiles = 0, st_dp = 0;
 
     struct Meta {
         SdChunk ch;
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
     tab[64 + lane] = 0;
     tab[128 + lane] = 0;
     tab[192 + lane] = 0;
-    for (int i = lane; i < (int)(cap >> 5); i += 64) sb[i] = 0;
+    for (int i = lane; i < (int)(cap >> 4); i += 64) sb[i] = 0;          // (the sifted positions and the coverage)
     if (lane < SIFT_PAD) reinterpret_cast<uint16_t *>(wc)[lane - SIFT_PAD] = halo ? 0xFF40 : 0x0040;   // no word; count unknown (large) / none
     bool bad = false;
     // Nearly every chunk holds letters only and lies inside its contig: the codes without the "not a base" flags, the words without the "no
@@ -550,6 +557,48 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
     SD_LDS_ORDER();
 
     // ---- resolve: the set bits in order ---------------------------------------------------------------------------------
+    // What a clean chunk records: the inserted intervals whose start lies in [start - W, end - W) (the contig's first chunk: from 0, its
+    // last: all) — the starts that leave the window at times inside the chunk, the rule of the walked chunks and of the stitch.  They
+    // are marked in the coverage bits of the region when they are inserted (the result is the union of the inserted intervals: header);
+    // the runs of the coverage are the chunk's rows.  No entry has to be followed until it leaves the window.
+    const int s_lo = ch.start > 0 ? ch.start - W : -0x40000000, s_hi = islast ? 0x7fffffff : ch.end - W;
+    auto mark64 = [&](int o, int nbits) {             // bits [o, o + nbits) of the region, 1 <= nbits <= 64
+        const uint32_t d = (uint32_t)o >> 5, b = (uint32_t)o & 31u;
+        const unsigned long long mk = nbits >= 64 ? ~0ull : (1ull << nbits) - 1ull;
+        const unsigned long long lo64 = mk << b;
+        const uint32_t w1 = (uint32_t)(lo64 >> 32), w2 = b ? (uint32_t)(mk >> (64u - b)) : 0u;
+        (void)__hip_atomic_fetch_or(&cb[d], (uint32_t)lo64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (w1) (void)__hip_atomic_fetch_or(&cb[d + 1], w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (w2) (void)__hip_atomic_fetch_or(&cb[d + 2], w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto mark = [&](int s, int nbits) {               // the interval [s, s + nbits) of the contig, if this chunk records its start
+        if (s < s_lo || s >= s_hi) return;
+        if (nbits > 64) {                             // (W = 65, 66 only)
+            mark64(s - rb, 64);
+            mark64(s - rb + 64, nbits - 64);
+        } else {
+            mark64(s - rb, nbits);
+        }
+    };
+    // find_perfect as `pass` above; an inserted interval is marked at once
+    auto pass_m = [&](int amax) {
+        const unsigned long long cm = sd_ballot(__mul24(r, 10) > Tl) & ~(~1ull << amax) & ~1ull;
+        if (cm) {
+            const bool cand = (cm >> lane) & 1ull;
+            if (STATS) ++st_cand;
+            uint32_t key_c = 0u;
+            if (cand) key_c = lane == 1 ? ((uint32_t)r & 0x7FFu) << 13 : __umulhi(((uint32_t)r & 0x7FFu) << 13, m_recip);
+            const uint32_t key_e = (uint32_t)slot & 0xFFFFFFu;
+            const uint32_t xs = sd_scan_max_dpp(key_e > key_c ? key_e : key_c);
+            const uint32_t sk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)xs, 0x138, 0xF, 0xF, true);
+            const uint32_t km = sk > key_e ? sk : key_e;           // :113-117: entries with start >= this one
+            if (cand && key_c >= km) {                              // :118
+                slot = (int)(key_c | ((uint32_t)lane << 24));
+                mark(sv0 - lane, lane + 3);
+            }
+        }
+    };
+
     unsigned long long sw = 0;
     if (lane < ntile) sw = (unsigned long long)sb[2 * lane] | (unsigned long long)sb[2 * lane + 1] << 32;
     // steps in front of start - W + 2 (of 2 at a contig start) are not taken: offsets below 128 - W + 2 (2)
@@ -565,20 +614,116 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
 
     int cur = 0;                                      // (a position of the contig)
     int n_dense = 0;                                  // steps taken in runs of consecutive positions
-    bool have = false;
+    bool have = false;                                // the slots are those of position cur
+    bool fresh = false;                               // ... and so are w and r (not behind a dp tile)
+    int dp_at = -1;                                   // the columns in LDS are those of this position
     int wt = 0, wt_tile = -1;                         // words of tile wt_tile of the region, lane <-> position
+    // the state at position i, read from the staged words (a gap behind cur: the slots age by it); no pass
+    auto jump = [&](int i) {
+        const int o = i - rb;
+        const int amax = i - 2 < CAPW - 1 ? i - 2 : CAPW - 1;
+        if (STATS) ++st_jumps;
+        if (have) {
+            const int g = i - cur;
+            if (g > 0) {
+                const int moved = __builtin_amdgcn_ds_bpermute(((lane - g) & 63) << 2, slot);
+                slot = (g < CAPW && lane >= g) ? moved : 0;
+            }
+        } else {
+            slot = 0;
+        }
+        // ---- the window at i; equal words at younger ages through the LDS table
+        const bool ok = lane <= amax;
+        w = ok ? (int)wc[2 * (o - lane)] : 0;
+        if (ok) (void)__hip_atomic_fetch_or(&tab_mine[w], mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        SD_LDS_ORDER();
+        const unsigned long long e = (unsigned long long)tab[w] | (unsigned long long)tab[64 + w] << 32;
+        SD_LDS_ORDER();
+        if (ok) tab_mine[w] = 0;
+        SD_LDS_ORDER();
+        r = wave_scan_add(ok ? sd_mbcnt64(e) : 0);
+        cur = i;
+        sv0 = i - 2;
+        have = true;
+        fresh = true;
+    };
+    // ---- dp tile: the 64 positions of tile t at once, lane <-> END of the interval, one step per length l (tools/sim/sdust_dp_sim.c):
+    //   c(l, i) = equal words behind the first of the l + 1 words that end at i = c(l - 1, i - 1) + [word(i) == word(i - l)]
+    //   r(l, i) = r(l - 1, i) + c(l, i);  key = the ratio r / l of a candidate (10 r > T l), 0 otherwise
+    //   B(l, i) = max(key, B(l - 1, i), B(l - 1, i - 1)): the best candidate inside, itself included;  perfect <=> key >= the other two
+    // Lane 0 takes its neighbour's values from the column of the position in front of the tile (ages there <-> lengths here);
+    // lane 63 leaves the column of the tile's last position behind.  Against one pass per position (11 vector instructions per
+    // length and 64 positions instead of ~30 vector + ~30 scalar per position) this pays from a dozen sifted positions per tile on.
+    auto dp_tile = [&](int t) {
+        const int o0 = 64 * t + lane;
+        const uint8_t *const pw = wc + 2 * o0;
+        const uint32_t w_own = pw[0];
+        int c = 0, rr = 0;
+        uint32_t B = 0u, lbest = 0u;
+        ring[lane] = 0;
+        SD_LDS_ORDER();
+        uint2 in = col[0];
+        for (int l = 1; l < CAPW; ++l) {
+            const uint2 nin = col[l];                 // (one step ahead of its use: lane 63 overwrites it below)
+            const uint32_t wv = pw[-2 * l];
+            c = __builtin_amdgcn_update_dpp((int)in.x, c, 0x138, 0xF, 0xF, false) + (wv == w_own ? 1 : 0);
+            rr += c;
+            const bool cand = __mul24(rr, 10) > T * l;
+            uint32_t key = 0u;
+            if (cand) key = l == 1 ? (uint32_t)rr << 13 : __umulhi((uint32_t)rr << 13, sd_recip_tab[l]);
+            const uint32_t Bn = (uint32_t)__builtin_amdgcn_update_dpp((int)in.y, (int)B, 0x138, 0xF, 0xF, false);
+            const uint32_t mx = B > Bn ? B : Bn;
+            if (cand && key >= mx) {
+                lbest = (uint32_t)l;
+                if (l <= lane) ring[lane - l] = key | (uint32_t)l << 24;    // the newest (longest) per start inside the tile
+            }
+            B = mx > key ? mx : key;
+            SD_LDS_ORDER();
+            if (lane == 63) col[l] = make_uint2((uint32_t)c, B);
+            in = nin;
+        }
+        if (lbest) mark(rb + o0 - 2 - (int)lbest, (int)lbest + 3);
+        SD_LDS_ORDER();
+        // what a stepping stage behind the tile needs: the slots at the tile's last position (age a <-> start at lane 63 - a)
+        slot = lane < CAPW ? (int)ring[63 - lane] : 0;
+        SD_LDS_ORDER();
+    };
+    const int dp_t1 = rlen >> 6;                       // whole tiles; the first two hold the steps with a short window
     unsigned long long nzt = sd_ballot(sw != 0ull);    // the tiles that hold a set bit at all (random sequence: 1 in 10)
     while (nzt) {
         const int t = __builtin_ctzll(nzt);
         nzt &= nzt - 1;
         unsigned long long m = rdlane64(sw, t);
+        if (__popcll(m) >= A.dp_min && t >= 2 && t < dp_t1) {
+            const int e = rb + 64 * t - 1;
+            if (dp_at != e) {
+                if (!(have && fresh && cur == e)) jump(e);
+                // the columns at e: c(a) = r(a) - r(a - 1); B(a) = the best entry among the starts of age <= a
+                // (the subtraction as written out: hipcc 7.2 folds `r - dpp(r)` into a v_sub_u32_dpp with its operands the wrong way round)
+                const int rprev = sd_dpp_shr1(0, r, true);
+                int cc;
+                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(cc) : "v"(r), "v"(rprev));
+                const uint32_t bb = sd_scan_max_dpp((uint32_t)slot & 0xFFFFFFu);
+                col[lane] = make_uint2((uint32_t)cc, bb);
+                SD_LDS_ORDER();
+            }
+            if (lane == 0) col[0] = make_uint2(0u, 0u);
+            SD_LDS_ORDER();
+            dp_tile(t);
+            if (STATS) ++st_dp;
+            n_dense += 64;
+            cur = e + 64;
+            dp_at = cur;
+            have = true;
+            fresh = false;
+            continue;
+        }
         while (m) {
             const int b = __builtin_ctzll(m);
             const int o = 64 * t + b;                 // offset in the region
             const int i = rb + o;
-            if (have && i - cur == 1) {
-                // ---- a run of consecutive positions (inside a repeat array: every position): one step each — the oldest start
-                // leaves the window (:147), the words age by one, the new word comes in
+            if (have && fresh && i - cur == 1) {
+                // ---- a run of consecutive positions: one step each — the words age by one, the new word comes in
                 const unsigned long long inv = ~(m >> b);
                 const int run = inv ? __builtin_ctzll(inv) : 64 - b;          // set bits from b on
                 m &= run + b >= 64 ? ~(~0ull << b) : ~(~(~0ull << run) << b);
@@ -591,78 +736,16 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
                     if (STATS) ++st_steps;
                     const int ii = i + j;
                     const int amax = ii - 2 < CAPW - 1 ? ii - 2 : CAPW - 1;
-                    const uint32_t so = (uint32_t)rdlane(slot, CAPW - 1);
-                    if (so) {
-                        const int s = sv0 - (CAPW - 1);
-                        emit(s, s + (int)(so >> 24) + 3, s + W);
-                    }
                     push_word(rdlane(wt, b + j), amax, true);
                     sv0 = ii - 2;
-                    pass(amax);
+                    pass_m(amax);
                 }
                 cur = i + run - 1;
                 continue;
             }
             m &= m - 1;
-            const int amax = i - 2 < CAPW - 1 ? i - 2 : CAPW - 1;
-            {
-                if (STATS) ++st_jumps;
-                if (have) {
-                    // ---- a gap: the starts that leave the window meanwhile, oldest first; the others age by the gap
-                    const int g = i - cur;
-                    // (a start s leaves at time s + W)
-                    unsigned long long em = sd_ballot(slot != 0 && lane >= (CAPW - g > 0 ? CAPW - g : 0) && lane < CAPW);
-                    while (em) {
-                        const int a = 63 - __builtin_clzll(em);
-                        em &= ~(1ull << a);
-                        const uint32_t so = (uint32_t)rdlane(slot, a);
-                        const int s = sv0 - a;
-                        emit(s, s + (int)(so >> 24) + 3, s + W);
-                    }
-                    const int moved = __builtin_amdgcn_ds_bpermute(((lane - g) & 63) << 2, slot);
-                    slot = (g < CAPW && lane >= g) ? moved : 0;
-                } else {
-                    slot = 0;
-                }
-                // ---- the window at i, read from the staged words; equal words at younger ages through the LDS table
-                const bool ok = lane <= amax;
-                w = ok ? (int)wc[2 * (o - lane)] : 0;
-                if (ok) (void)__hip_atomic_fetch_or(&tab_mine[w], mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                SD_LDS_ORDER();
-                const unsigned long long e = (unsigned long long)tab[w] | (unsigned long long)tab[64 + w] << 32;
-                SD_LDS_ORDER();
-                if (ok) tab_mine[w] = 0;
-                SD_LDS_ORDER();
-                r = wave_scan_add(ok ? sd_mbcnt64(e) : 0);
-            }
-            cur = i;
-            sv0 = i - 2;
-            have = true;
-            pass(amax);
-        }
-    }
-    // ---- the end of the chunk: what has left the window by then; the end of the contig flushes everything (:152-153)
-    if (have) {
-        if (islast) {
-            // (a start that would have left before the contig's end was saved then; the others at the sentinel step)
-            unsigned long long em = sd_ballot(slot != 0 && lane < CAPW);
-            while (em) {
-                const int a = 63 - __builtin_clzll(em);
-                em &= ~(1ull << a);
-                const uint32_t so = (uint32_t)rdlane(slot, a);
-                const int s = sv0 - a, tm = s + W;
-                emit(s, s + (int)(so >> 24) + 3, tm < len ? tm : len);
-            }
-        } else {
-            const int g = ch.end - 1 - cur;            // as if the walk went on to the chunk's last step
-            unsigned long long em = sd_ballot(slot != 0 && lane >= (CAPW - g > 0 ? CAPW - g : 0) && lane < CAPW);
-            while (em) {
-                const int a = 63 - __builtin_clzll(em);
-                em &= ~(1ull << a);
-                const uint32_t so = (uint32_t)rdlane(slot, a);
-                const int s = sv0 - a;
-                emit(s, s + (int)(so >> 24) + 3, s + W);
-            }
+            jump(i);
+            pass_m(i - 2 < CAPW - 1 ? i - 2 : CAPW - 1);
         }
     }
     // (a chunk inside a repeat array is a long sequential piece of work too: noted like the walked ones, handed out first next time)
@@ -670,7 +753,49 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
         A.iswalk_out[k] = 1u;
         A.walk_out[2 + atomicAdd(&A.walk_out[0], 1u)] = (uint32_t)k;
     }
-    finish();
+    // ---- the chunk's rows: the runs of the coverage (a run starts at a set bit behind a clear one, it ends in front of the next clear one)
+    {
+        SD_LDS_ORDER();
+        const int nd = (rlen + 31) >> 5;
+        uint32_t *const row = reinterpret_cast<uint32_t *>(out);
+        uint32_t n_s = 0, n_e = 0;
+        int carry = 0;                                // the dword in front of this round's first
+        for (int base = 0; base <= nd; base += 64) {   // (one dword beyond the last: a run that reaches the region's end closes there)
+            const int d = base + lane;
+            const uint32_t v = d < nd ? cb[d] : 0u;
+            const unsigned long long nz = sd_ballot(v != 0u);
+            if (!nz && carry >= 0) {
+                carry = 0;
+                continue;
+            }
+            const uint32_t pm = (uint32_t)__builtin_amdgcn_update_dpp(carry, (int)v, 0x138, 0xF, 0xF, false) >> 31;
+            const uint32_t sh = (v << 1) | pm;
+            uint32_t st = v & ~sh, en = ~v & sh;
+            const int ns = __popc(st), ne = __popc(en);
+            const int xs = wave_scan_add(ns), xe = wave_scan_add(ne);
+            uint32_t is = n_s + (uint32_t)(xs - ns), ie = n_e + (uint32_t)(xe - ne);
+            while (st) {
+                const int b = __builtin_ctz(st);
+                st &= st - 1;
+                if (is < O.cap) row[2 * is] = (uint32_t)(rb + 32 * d + b);
+                ++is;
+            }
+            while (en) {
+                const int b = __builtin_ctz(en);
+                en &= en - 1;
+                if (ie < O.cap) row[2 * ie + 1] = (uint32_t)(rb + 32 * d + b);
+                ++ie;
+            }
+            n_s += (uint32_t)rdlane(xs, 63);
+            n_e += (uint32_t)rdlane(xe, 63);
+            carry = rdlane((int)v, 63);
+        }
+        if (lane == 0) {
+            O.out_n[k] = n_s;
+            if (n_s > O.cap) atomicMax(O.ovf, n_s);
+            if (STATS) st_tiles += (unsigned long long)ntile;
+        }
+    }
   };
 
     // The waves stay (as many as the caller lets this kernel hold of the chip: the other stream needs its share) and take
@@ -708,5 +833,6 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
         atomicAdd(&O.stats[5], st_l2);
         atomicAdd(&O.stats[6], st_tiles);
         atomicAdd(&O.stats[7], st_walk);
+        atomicAdd(&O.stats[8], st_dp);
     }
 }

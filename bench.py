@@ -127,12 +127,24 @@ def _plant_copies(torch, dev, bases, starts, lens_, cons_off, cons, flip, div, g
     flip[j]), every base substituted with probability div[j], written at bases[starts[j] ...] (ragged, batched on the device)"""
     if len(starts) == 0:
         return
+    # copies that would overlap an earlier one (by start) are dropped: a scatter with colliding destinations has no defined winner,
+    # and the assembly must be the same bytes in every process
+    starts, lens_, cons_off = np.asarray(starts, np.int64), np.asarray(lens_, np.int64), np.asarray(cons_off, np.int64)
+    flip, div = np.asarray(flip, bool), np.asarray(div, np.float32)
+    order = np.argsort(starts, kind="stable")
+    starts, lens_, cons_off, flip, div = starts[order], lens_[order], cons_off[order], flip[order], div[order]
+    keep = np.ones(len(starts), bool)
+    end = -1
+    for j in range(len(starts)):
+        if starts[j] < end:
+            keep[j] = False
+        else:
+            end = starts[j] + lens_[j]
+    starts, lens_, cons_off, flip, div = starts[keep], lens_[keep], cons_off[keep], flip[keep], div[keep]
     cons_f = torch.from_numpy(np.ascontiguousarray(cons)).to(dev)
     cons_r = torch.from_numpy(np.ascontiguousarray(_revcomp_np(cons))).to(dev)
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
     n_cons = len(cons)
-    starts, lens_, cons_off = np.asarray(starts, np.int64), np.asarray(lens_, np.int64), np.asarray(cons_off, np.int64)
-    flip, div = np.asarray(flip, bool), np.asarray(div, np.float32)
     csum = np.concatenate([[0], np.cumsum(lens_)])
     budget, i = 1 << 25, 0                               # elements per batch
     while i < len(starts):
@@ -210,10 +222,10 @@ def make_assembly(torch, dev, lens, seed, profile="uniform"):
             n = np.array([big[i][1] for i in ci], dtype=np.int64)
             return o + 2000 + (rh.random(count) * (n - max_len - 4000)).astype(np.int64)
 
-        n_l1 = int(0.15 * nb / 1050.0)                     # mean fragment ~1.05 kb (log-uniform 100 .. 6000)
+        n_l1 = int(0.17 * nb / 1050.0)                     # (about a tenth of them overlap an earlier one and are dropped)                     # mean fragment ~1.05 kb (log-uniform 100 .. 6000)
         ln = np.minimum(6000, (10 ** rh.uniform(2.0, np.log10(6000.0), size=n_l1)).astype(np.int64))
         _plant_copies(torch, dev, bases, scatter(n_l1, 6000), ln, 6000 - ln, l1, rh.random(n_l1) < 0.5, rh.uniform(0.05, 0.20, size=n_l1), g)
-        n_alu = int(0.10 * nb / 325.0)
+        n_alu = int(0.11 * nb / 325.0)
         ln = 300 + rh.integers(10, 41, size=n_alu)
         _plant_copies(torch, dev, bases, scatter(n_alu, 340), ln, np.zeros(n_alu, np.int64), alu, rh.random(n_alu) < 0.5, rh.uniform(0.05, 0.15, size=n_alu), g)
     if profile in ("satellite", "humanlike"):

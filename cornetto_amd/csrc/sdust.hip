@@ -39,6 +39,7 @@ namespace {
 __device__ __forceinline__ int nt4_code(uint32_t c);
 struct SdArgs;
 struct SdChunk;
+template <bool LEAN = false>
 __device__ int sd_find_start(const SdArgs &A, const SdChunk ch, const uint8_t *seq);
 
 struct SdChunk {
@@ -1372,6 +1373,9 @@ __device__ __forceinline__ uint32_t sd_not_acgt(uint32_t word)
 // ---- where a lane starts for a chunk: W-2 word emissions before (chunk start - 2W), found by scanning backwards (see
 // the header comment); the common case — the W bases there are plain letters — is checked with 16-byte loads, the scan
 // gives up after SD_SCAN_CAP bases of N-dense sequence and uses the word-count table, or asks the host for it (-1).
+// LEAN (the walk of sd_sift, where this is a rare fallback of one wave): without the five 16-byte loads in flight — inlined there
+// they were the kernel's highest register pressure and the one place that spilled
+template <bool LEAN>
 __device__ int sd_find_start(const SdArgs &A, const SdChunk ch, const uint8_t *seq)
 {
     const int W = A.W, CAPW = W - 2;
@@ -1387,7 +1391,7 @@ __device__ int sd_find_start(const SdArgs &A, const SdChunk ch, const uint8_t *s
             if (plain) {
                 uint32_t bad = 0;
                 const int q0 = (y - W) & ~15;                                  // 16-byte loads, all issued before use
-                if (y - q0 <= 80) {
+                if (!LEAN && y - q0 <= 80) {
                     uint4 v[5];
 #pragma unroll
                     for (int i = 0; i < 5; ++i) v[i] = q0 + 16 * i < y ? *reinterpret_cast<const uint4 *>(seq + q0 + 16 * i) : make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
@@ -1632,13 +1636,14 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
         // there is nothing to test.  What was tightened meanwhile: the P-slot hand-off between lanes waits for the wave's
         // outstanding stores in front of EVERY slot load.  The guard covers both instantiations that can be launched;
         // CORNETTO_SDUST_ALLOW_SCRATCH=1 lifts it.
-        for (int inst = 0; inst < 2; ++inst) {
+        for (int inst = 0; inst < 3; ++inst) {           // (sd_sift: the production build; its counting build may keep a register in scratch)
             hipFuncAttributes fa;
-            const void *fn = inst ? reinterpret_cast<const void *>(&sdust_w64<true>) : reinterpret_cast<const void *>(&sdust_w64<false>);
+            const void *fn = inst == 2 ? reinterpret_cast<const void *>(&sd_sift<false>)
+                             : inst ? reinterpret_cast<const void *>(&sdust_w64<true>) : reinterpret_cast<const void *>(&sdust_w64<false>);
             if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return cn_fail(h, CORNETTO_E_HIP, "sdust: hipFuncGetAttributes failed");
             if (fa.localSizeBytes != 0 && !env_int("CORNETTO_SDUST_ALLOW_SCRATCH", 0))
                 return cn_fail(h, CORNETTO_E_HIP, "sdust: kernel%s built with %zu bytes of scratch per lane (register spills): refusing to run it",
-                               inst ? " (statistics build)" : "", (size_t)fa.localSizeBytes);
+                               inst == 1 ? " (statistics build)" : inst == 2 ? " sd_sift" : "", (size_t)fa.localSizeBytes);
         }
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sdust_w64<false>, 64 * SD_WPB, 0) != hipSuccess || per_cu < 1) per_cu = 16;
@@ -1854,7 +1859,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                 SiftArgs S{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, lds_wave, reg_cap,
                            walk_known ? d_worder : nullptr, walk_known ? nullptr : a->d_sd_walk, walk_known ? nullptr : d_wflag,
                            reinterpret_cast<uint32_t *>(d_tot + 256), T / 10 + 1, lmin, env_int("CORNETTO_SIFT_ABL", 0),
-                           std::min(65, std::max(1, env_int("CORNETTO_SIFT_DP", 16)))};
+                           std::min(65, std::max(1, env_int("CORNETTO_SIFT_DP", 24))), std::min(65, std::max(1, env_int("CORNETTO_SIFT_L2SKIP", 48)))};
                 sift_walk_pending = !walk_known;
                 SdArgs R = A;
                 R.stats = want_stats ? d_tot + 200 : nullptr;

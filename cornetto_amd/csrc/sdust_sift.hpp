@@ -55,6 +55,7 @@ struct SiftArgs {
     int32_t thr, lmin;        // equal words a last word needs (T / 10 + 1); shortest l with 10 l (l + 1) / 2 > T l, capped at 16
     int32_t abl;              // development aid (CORNETTO_SIFT_ABL): 1 no resolve, 2 no L1 / L2, 4 no tiles: timing only, results are wrong
     int32_t dp_min;           // a tile with at least this many sifted positions is resolved end-parallel (dp tile); 65: never (CORNETTO_SIFT_DP)
+    int32_t l2_skip;          // an L1 batch with at least this many survivors skips L2 (65: never; CORNETTO_SIFT_L2SKIP)
 };
 
 #ifndef SIFT_WPB
@@ -139,7 +140,7 @@ __device__ __forceinline__ int sd_wave_find_start(const SdChunk ch, const uint8_
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(5))) void sd_sift(SiftArgs A, SdArgs O)
+__global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6))) void sd_sift(SiftArgs A, SdArgs O)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sift_lds[];
     const int lane = threadIdx.x & 63;
@@ -154,11 +155,8 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(5
     uint32_t *const sb = reinterpret_cast<uint32_t *>(L + SIFT_FIXED);
     const uint32_t cap = A.reg_cap;
     uint32_t *const cb = sb + (cap >> 5);             // coverage of the region, one bit per base: what the chunk's rows are made of
-    // the dp tiles reuse the L2 counters (idle by then): the column of the position in front of a tile (c, B per length), the best
-    // perfect interval per start inside the tile
-    uint2 *const col = reinterpret_cast<uint2 *>(cnt);
-    uint32_t *const ring = cnt + 128;
-    // wc[2 p] = the word that ends at offset p of the region (bit 6: none), wc[2 p + 1] = ct(p): one address serves both
+    // the dp tiles reuse the L2 counters (idle by then): the column of the position in front of a tile, per length
+    uint4 *const col = reinterpret_cast<uint4 *>(cnt);   // [length l]: c and B of the position in front of the tile, ceil(2^32 / l), floor(T l / 10)
     uint8_t *const wc = L + SIFT_FIXED + cap / 4 + 2 * SIFT_PAD;
     const int T = A.T, W = A.W, CAPW = W - 2;
 
@@ -175,9 +173,6 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(5
     const int thr = A.thr, lmin = A.lmin;             // c > T / 10; the partial sums of L1 have lmin terms
     const int LS = CAPW - 1 < SIFT_LS ? CAPW - 1 : SIFT_LS;
     const bool long_ok = CAPW - 1 > LS;               // suffixes longer than the walk exist
-    // stepping stages: lane = l
-    const int Tl = T * lane;
-    const uint32_t m_recip = sd_recip_tab[lane];
     // statistics build: counted per wave, added up once at the end
     unsigned long long st_steps = 0, st_jumps = 0, st_cand = 0, st_trig = 0, st_l1 = 0, st_l2 = 0, st_walk = 0, st_tiles = 0, st_dp = 0;
 
@@ -350,7 +345,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(5
         if (age_slots) slot = sd_dpp_shr1(0, slot, true);
     };
     // find_perfect (:104-128) over every suffix: lane = l; the running maximum of :113-118 is a scan of exact ratio keys
-    auto pass = [&](int amax) {
+    auto pass = [&](int amax, const int Tl, const uint32_t m_recip) {
         // (lanes 1 .. amax: a scalar mask)
         const unsigned long long cm = sd_ballot(__mul24(r, 10) > Tl) & ~(~1ull << amax) & ~1ull;
         if (cm) {
@@ -378,13 +373,16 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(5
     };
 
     if (unclean) {
+        // stepping stages: lane = l (computed per chunk: two registers less across the tile loop)
+        const int Tl = T * lane;
+        const uint32_t m_recip = sd_recip_tab[lane];
         if (A.walk_out && lane == 0) {
             A.iswalk_out[k] = 1u;
             A.walk_out[2 + atomicAdd(&A.walk_out[0], 1u)] = (uint32_t)k;
         }
         // ---- walk: the reference's loop (:139-157), one base per step, from the warm-up start --------------------------
         int u = sd_wave_find_start(ch, seq, W, lane);
-        if (u == -2) u = __builtin_amdgcn_readfirstlane(sd_find_start(O, ch, seq));
+        if (u == -2) u = __builtin_amdgcn_readfirstlane(sd_find_start<true>(O, ch, seq));
         if (u < 0) return;                            // (the word-count table is needed: the host builds it and runs again)
         const int stop = islast ? len + 1 : ch.end;   // the contig's last chunk also takes the sentinel step i == len
         int l = 0, size = 0, cv = 4, ctile = -1;
@@ -416,7 +414,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(5
                     size = full ? CAPW : size + 1;
                     push_word((int)t, size - 1, !full || moves);                // shift_window (:66-86)
                     sv0 = start + size - 1;
-                    pass(size - 1);
+                    pass(size - 1, Tl, m_recip);
                 }
             } else {
                 emit_slots(0, i);                                               // :152-153
@@ -478,7 +476,13 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(5
         }
         const bool ok = on && dmin > 0;
         const unsigned long long m = sd_ballot(ok);
-        if (m) {
+        if (__popcll(m) >= A.l2_skip) {
+            // most of a full batch passed: a repeat, where L2 keeps nearly everything as well and the dp tiles take any superset
+            // at the same price — the survivors are sifted positions at once (any superset of the inserting positions is exact)
+            if (STATS) st_l1 += (unsigned long long)__popcll(m);
+            if (STATS) st_l2 += (unsigned long long)__popcll(m);
+            if (ok) (void)__hip_atomic_fetch_or(&sb[o >> 5], 1u << (o & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (m) {
             if (STATS) st_l1 += (unsigned long long)__popcll(m);
             if (ok) tl2[ntl2 + sd_mbcnt64(m)] = (uint16_t)o;
             ntl2 += __popcll(m);
@@ -562,6 +566,8 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(5
     // are marked in the coverage bits of the region when they are inserted (the result is the union of the inserted intervals: header);
     // the runs of the coverage are the chunk's rows.  No entry has to be followed until it leaves the window.
     const int s_lo = ch.start > 0 ? ch.start - W : -0x40000000, s_hi = islast ? 0x7fffffff : ch.end - W;
+    const int Tl = T * lane;                          // stepping stages: lane = l
+    const uint32_t m_recip = sd_recip_tab[lane];
     auto mark64 = [&](int o, int nbits) {             // bits [o, o + nbits) of the region, 1 <= nbits <= 64
         const uint32_t d = (uint32_t)o >> 5, b = (uint32_t)o & 31u;
         const unsigned long long mk = nbits >= 64 ? ~0ull : (1ull << nbits) - 1ull;
@@ -588,12 +594,12 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(5
             if (STATS) ++st_cand;
             uint32_t key_c = 0u;
             if (cand) key_c = lane == 1 ? ((uint32_t)r & 0x7FFu) << 13 : __umulhi(((uint32_t)r & 0x7FFu) << 13, m_recip);
-            const uint32_t key_e = (uint32_t)slot & 0xFFFFFFu;
+            const uint32_t key_e = (uint32_t)slot;                 // (here a slot is the key alone: nothing follows an entry to its exit)
             const uint32_t xs = sd_scan_max_dpp(key_e > key_c ? key_e : key_c);
             const uint32_t sk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)xs, 0x138, 0xF, 0xF, true);
             const uint32_t km = sk > key_e ? sk : key_e;           // :113-117: entries with start >= this one
             if (cand && key_c >= km) {                              // :118
-                slot = (int)(key_c | ((uint32_t)lane << 24));
+                slot = (int)key_c;
                 mark(sv0 - lane, lane + 3);
             }
         }
@@ -652,40 +658,64 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(5
     //   r(l, i) = r(l - 1, i) + c(l, i);  key = the ratio r / l of a candidate (10 r > T l), 0 otherwise
     //   B(l, i) = max(key, B(l - 1, i), B(l - 1, i - 1)): the best candidate inside, itself included;  perfect <=> key >= the other two
     // Lane 0 takes its neighbour's values from the column of the position in front of the tile (ages there <-> lengths here);
-    // lane 63 leaves the column of the tile's last position behind.  Against one pass per position (11 vector instructions per
-    // length and 64 positions instead of ~30 vector + ~30 scalar per position) this pays from a dozen sifted positions per tile on.
+    // lane 63 leaves the column of the tile's last position behind.  B starts at 1 (below every candidate's key), so that a key of
+    // 0 never passes the test.  What a stepping stage behind the tile needs of P is the running maximum of :113-117 only — the best
+    // entry among the starts of age <= a, for every a — and that is B of the last position: the slots are set to it.
+    // Against one pass per position (~13 vector instructions per length and 64 positions instead of ~30 vector + ~30 scalar per
+    // position) this pays from a dozen sifted positions per tile on.
     auto dp_tile = [&](int t) {
         const int o0 = 64 * t + lane;
         const uint8_t *const pw = wc + 2 * o0;
         const uint32_t w_own = pw[0];
         int c = 0, rr = 0;
-        uint32_t B = 0u, lbest = 0u;
-        ring[lane] = 0;
-        SD_LDS_ORDER();
-        uint2 in = col[0];
-        for (int l = 1; l < CAPW; ++l) {
-            const uint2 nin = col[l];                 // (one step ahead of its use: lane 63 overwrites it below)
+        uint32_t B = 1u, lbest = 0u;
+        const bool last = lane == 63;
+        // one length: `cin` = the column entry of length l - 1 (lane 0's neighbour), `cl` = that of length l (its constants; lane 63 leaves c and B there)
+        auto step = [&](const int l, const uint4 cin, const uint4 cl) __attribute__((always_inline)) {
             const uint32_t wv = pw[-2 * l];
-            c = __builtin_amdgcn_update_dpp((int)in.x, c, 0x138, 0xF, 0xF, false) + (wv == w_own ? 1 : 0);
+            c = __builtin_amdgcn_update_dpp((int)cin.x, c, 0x138, 0xF, 0xF, false) + (wv == w_own ? 1 : 0);
             rr += c;
-            const bool cand = __mul24(rr, 10) > T * l;
-            uint32_t key = 0u;
-            if (cand) key = l == 1 ? (uint32_t)rr << 13 : __umulhi((uint32_t)rr << 13, sd_recip_tab[l]);
-            const uint32_t Bn = (uint32_t)__builtin_amdgcn_update_dpp((int)in.y, (int)B, 0x138, 0xF, 0xF, false);
+            const uint32_t kq = __umulhi((uint32_t)rr << 13, cl.z);
+            const uint32_t key = rr > (int)cl.w ? kq : 0u;
+            const uint32_t Bn = (uint32_t)__builtin_amdgcn_update_dpp((int)cin.y, (int)B, 0x138, 0xF, 0xF, false);
             const uint32_t mx = B > Bn ? B : Bn;
-            if (cand && key >= mx) {
-                lbest = (uint32_t)l;
-                if (l <= lane) ring[lane - l] = key | (uint32_t)l << 24;    // the newest (longest) per start inside the tile
-            }
+            lbest = key >= mx ? (uint32_t)l : lbest;
+            asm volatile("" : "+v"(lbest));           // (decided here: unrolled, the scheduler would keep key and mx of every length alive to the end)
             B = mx > key ? mx : key;
             SD_LDS_ORDER();
-            if (lane == 63) col[l] = make_uint2((uint32_t)c, B);
-            in = nin;
+            if (last) *reinterpret_cast<uint2 *>(&col[l]) = make_uint2((uint32_t)c, B);
+        };
+        // (every column entry is read one step ahead of its use: lane 63 overwrites its c and B)
+        uint4 ca = col[0], cb_ = col[1];
+        {   // l = 1: the key is r itself (2^32 / 1 has no 32-bit reciprocal)
+            const uint4 cn = col[2];
+            const uint32_t wv = pw[-2];
+            c = __builtin_amdgcn_update_dpp((int)ca.x, c, 0x138, 0xF, 0xF, false) + (wv == w_own ? 1 : 0);
+            rr += c;
+            const uint32_t key = rr > (int)cb_.w ? (uint32_t)rr << 13 : 0u;
+            const uint32_t Bn = (uint32_t)__builtin_amdgcn_update_dpp((int)ca.y, (int)B, 0x138, 0xF, 0xF, false);
+            const uint32_t mx = B > Bn ? B : Bn;
+            lbest = key >= mx ? 1u : lbest;
+            B = mx > key ? mx : key;
+            SD_LDS_ORDER();
+            if (last) *reinterpret_cast<uint2 *>(&col[1]) = make_uint2((uint32_t)c, B);
+            ca = cb_;
+            cb_ = cn;
         }
+        // two lengths per turn: an entry is loaded into the register whose entry has just had its last use (no copies); ca = entry
+        // l - 1, cb_ = entry l on entering
+        int l = 2;
+        for (; l + 1 < CAPW; l += 2) {
+            step(l, ca, cb_);
+            ca = col[l + 1];
+            step(l + 1, cb_, ca);
+            cb_ = col[l + 2 < 64 ? l + 2 : 63];
+        }
+        if (l < CAPW) step(l, ca, cb_);
         if (lbest) mark(rb + o0 - 2 - (int)lbest, (int)lbest + 3);
         SD_LDS_ORDER();
-        // what a stepping stage behind the tile needs: the slots at the tile's last position (age a <-> start at lane 63 - a)
-        slot = lane < CAPW ? (int)ring[63 - lane] : 0;
+        slot = lane >= 1 && lane < CAPW ? (int)col[lane].y : 0;
+        slot = slot == 1 ? 0 : slot;
         SD_LDS_ORDER();
     };
     const int dp_t1 = rlen >> 6;                       // whole tiles; the first two hold the steps with a short window
@@ -703,11 +733,12 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(5
                 const int rprev = sd_dpp_shr1(0, r, true);
                 int cc;
                 asm volatile("v_sub_u32 %0, %1, %2" : "=v"(cc) : "v"(r), "v"(rprev));
-                const uint32_t bb = sd_scan_max_dpp((uint32_t)slot & 0xFFFFFFu);
-                col[lane] = make_uint2((uint32_t)cc, bb);
+                const uint32_t bb = sd_scan_max_dpp((uint32_t)slot);
+                // (with the constants of length `lane`: lane 63 rewrites c and B only)
+                col[lane] = make_uint4((uint32_t)cc, bb > 1u ? bb : 1u, m_recip, (uint32_t)(Tl / 10));
                 SD_LDS_ORDER();
             }
-            if (lane == 0) col[0] = make_uint2(0u, 0u);
+            if (lane == 0) *reinterpret_cast<uint2 *>(&col[0]) = make_uint2(0u, 1u);
             SD_LDS_ORDER();
             dp_tile(t);
             if (STATS) ++st_dp;

@@ -1464,6 +1464,7 @@ def main():
     ap.add_argument("--reads-gbases", type=float, default=10.0, help="bases of FASTQ streamed through the read-level leg")
     ap.add_argument("--no-second", action="store_true", help="--gpus > 1: skip the second measurement (the other scaling mode with --gather)")
     ap.add_argument("--emulate-ranks", type=str, default="2,4,8", help="N=1: model the strong-scaling curve for these rank counts on this one GPU ('' = skip)")
+    ap.add_argument("--rank-share", type=str, default="", help="N,k (profiling aid, N=1 only): the main workload is the share rank k of an N-rank strong-scaling run would own")
     ap.add_argument("--allow-shared-device", action="store_true", help="--gpus > 1 with fewer GPUs than ranks (tests): ranks share devices, collectives over gloo")
     ap.add_argument("--sdust-share", type=int, default=-1, help="percent of the wave slots the resident sdust waves could hold on a CU that they take while the other stream runs beside them; -1 (default): 72 on the uniform profile (15 of 21 per CU — 14: 8.2 ms per step, 15: 8.0, 16: 8.8, 17: the other stream starves), probed during warm-up (62 / 72 / 85 / 100) on the repeat-rich profiles, where sdust is a larger part of the step; 0: always probed.  The rest of the slots joins in when the other thread of the step is through (cornetto_accel_boost)")
     ap.add_argument("--timing", type=int, default=1, help="HIP events in the timed steps around: 1 the three main kernels only (roofline), 2 every launch, 0 none; the extra serial pass that fills the kernel table always uses 2")
@@ -1484,6 +1485,11 @@ def main():
     rank, world = R.rank, R.world
     t_first = time.perf_counter()
     R.load(args.profile)
+    if args.rank_share and world == 1:
+        from cornetto_amd.dist import lpt_partition
+        n_sh, k_sh = (int(x) for x in args.rank_share.split(","))
+        R.wrap(lpt_partition(R.lens, n_sh)[k_sh])
+        R.job_bases = R.my_bases
     t_first = time.perf_counter()
     R.step(False)                                   # the first step of a resident assembly builds its decomposition tables
     first_step_ms = (time.perf_counter() - t_first) * 1e3

@@ -58,6 +58,9 @@ struct cornetto_accel {
     int share = 100;    // percent of every CU the resident sdust kernel may take (cornetto_accel_set_share)
     int sd_stats = 0;   // sdust: run the statistics build of the kernel (cornetto_accel_sdust_stats)
     unsigned long long sd_last[256] = {0};   // its counters from the most recent such run
+    // scan.hpp: the single-pass scans keep their tile states in WS_SCAN; a state counts only with the epoch of its call (no clearing
+    // between calls), the tiles of a call take their numbers from a ticket counter that is never reset
+    uint32_t scan_epoch = 0, scan_tickets = 0;
     int timing = 2;     // event pairs around: 2 every kernel launch, 1 the three streaming / scanning main kernels only, 0 none (cornetto_accel_set_timing)
 };
 
@@ -103,6 +106,7 @@ enum {   // device workspace slots
     WS_BG_TEXT_A, WS_BG_TEXT_B, WS_BG_TOK_A, WS_BG_TOK_B, WS_BG_CNT_A, WS_BG_CNT_B, WS_BG_SMALL, WS_BG_BRK,
     WS_TB, WS_TB_SMALL, WS_TB_OUT, WS_CW_MERGE, WS_IVL_MERGE,
     WS_FQ_TEXT, WS_FQ_CNT, WS_FQ_NL, WS_FQ_RECS, WS_FQ_ENDS, WS_FQ_SRC,
+    WS_SCAN,
     WS_COUNT
 };
 static_assert(WS_COUNT <= 64, "cornetto_accel::dev has 64 slots");

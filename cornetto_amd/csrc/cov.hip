@@ -273,6 +273,7 @@ struct CwArgs {
     const int32_t *n_reg;      // windows per contig
     const int2 *tiles;         // {ctg, first window}
     int32_t w, inc, q, r;
+    uint32_t w_magic, w_shift;   // floor(n / w) = umulhi(n, w_magic) >> w_shift for 0 <= n < 2^31 (w >= 2; w_magic = 0: divide)
     // selection
     int32_t mode;              // 0 = all windows of one contig into regs; 1 = fun; 2 = boring
     int32_t lo, hi, edge, min_len;
@@ -321,12 +322,22 @@ __global__ __launch_bounds__(256) void cov_windows(CwArgs A)
             sd += hb.y;
             sq += hb.w;
         }
-        depth = (int32_t)sd / (end - st);                // :360  (positions >= len contributed zero)
-        mq = (int32_t)sq / (end - st);                   // :361
+        // :360-361 (positions >= len contributed zero).  Nearly every window is w long and its sums are below 2^31: the division is a
+        // multiplication by a reciprocal the host made for w (exact for 0 <= n < 2^31); anything else divides
+        if (end - st == A.w && A.w_magic && (int32_t)(sd | sq) >= 0) {
+            depth = (int32_t)(__umulhi(sd, A.w_magic) >> A.w_shift);
+            mq = (int32_t)(__umulhi(sq, A.w_magic) >> A.w_shift);
+        } else {
+            depth = (int32_t)sd / (end - st);
+            mq = (int32_t)sq / (end - st);
+        }
         if (A.mode == 0) {
             A.regs[j] = cornetto_reg_t{st, end, depth, mq};
         } else {
-            const bool fun = depth < A.lo || depth > A.hi || ((double)mq / (double)depth) < A.low_mq;   // :439
+            // :439.  mq >= depth > 0 gives a quotient >= 1, which is not below a threshold <= 1: no division for those (the test is
+            // the reference's IEEE double division wherever it can decide)
+            bool fun = depth < A.lo || depth > A.hi;
+            if (!fun && !(A.low_mq <= 1.0 && depth > 0 && mq >= depth)) fun = ((double)mq / (double)depth) < A.low_mq;
             if (A.mode == 1) sel = len >= A.min_len && fun;                                               // :428 else-branch
             else sel = len > A.min_len && st > A.edge && end < len - A.edge && !fun;                      // :467,:473-474
         }
@@ -536,6 +547,12 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
     CwArgs A{};
     A.blk = d_blk; A.toff_d = d_toff_d; A.toff_q = d_toff_q; A.blk_off = c->d_blk_off; A.ctg_len = c->d_len; A.n_reg = c->d_n_reg;
     A.tiles = c->d_cw_tiles; A.w = w; A.inc = inc; A.q = q; A.r = r; A.mode = mode; A.lo = lo; A.hi = hi; A.edge = edge;
+    if (w >= 2) {                                   // floor(n / w) for 0 <= n < 2^31: M = floor(2^(31 + L) / w) + 1, L = ceil(log2 w)
+        int L = 0;
+        while ((1ll << L) < (long long)w) ++L;
+        A.w_magic = (uint32_t)(((1ull << (31 + L)) / (unsigned long long)w) + 1ull);
+        A.w_shift = (uint32_t)(L - 1);
+    }
     A.min_len = min_len; A.low_mq = (double)low_mq;   // float promoted exactly as in `x < low_mq_cov_thresh`
     A.counter = d_cnt; A.tile_res = d_tres;
     if (mode == 0) {

@@ -122,6 +122,7 @@ def lib():
         "cornetto_bgin_close": (None, [vp, vp]),
         "cornetto_bgin_feed": (C.c_int, [vp, vp, cp, i64, cp, i64, C.c_int]),
         "cornetto_bgin_pending": (None, [vp, C.POINTER(i64), C.POINTER(i64)]),
+        "cornetto_bgin_unmatched_mq": (i64, [vp]),
         "cornetto_bgin_error": (C.POINTER(BgErr), [vp]),
         "cornetto_bgin_done": (C.c_int, [vp]),
         "cornetto_bgin_finish": (C.c_int, [vp, vp, pp, C.POINTER(i32), C.POINTER(C.POINTER(cp)), C.POINTER(i64)]),

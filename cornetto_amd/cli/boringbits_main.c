@@ -180,6 +180,7 @@ typedef struct {
     /* in */
     cornetto_accel_t *h;
     int fd_t, fd_q, n_rd;
+    int not_last;                  /* a share in front of another one: cov-mq bytes left over are the next share's partners (see bg_ingest) */
     int64_t t0, t1, q0, q1, piece; /* [t0, t1) of the total-depth file, [q0, q1) of the mapq file */
     /* out */
     cornetto_cov_t *cov;
@@ -277,6 +278,12 @@ static void bg_ingest(bg_job_t *g)
             snprintf(g->err, sizeof(g->err), "bedgraph ingest did not finish");
             goto out;
         }
+    }
+    if (g->not_last && cornetto_bgin_unmatched_mq(bg) > 0) {
+        /* the sequential loop pairs the cov-total record after this share with those tokens (:214-227): a cut is only the same line in
+         * both files when every record in front of it has its partner */
+        g->fmt_kind = 3;
+        goto out;
     }
     rc = cornetto_bgin_finish(g->h, bg, &g->cov, &g->n_ctg, &g->names, &g->n_clamped);
     if (rc != CORNETTO_OK) bg_job_fail(g, rc, "bedgraph ingest");
@@ -908,6 +915,7 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
             jobs[d].piece = piece;
             jobs[d].t0 = d ? cut_t[d - 1] : 0;
             jobs[d].q0 = d ? cut_q[d - 1] : 0;
+            jobs[d].not_last = d + 1 < n_sh;
             jobs[d].t1 = d + 1 < n_sh ? cut_t[d] : (int64_t)st_t.st_size;
             jobs[d].q1 = d + 1 < n_sh ? cut_q[d] : (int64_t)st_q.st_size;
         }

@@ -330,6 +330,54 @@ static int read_threads(void)
         if (trace) fprintf(stderr, "[cli trace] %-28s %8.1f ms\n", (what), (cli_realtime() - t_begin) * 1e3); \
     } while (0)
 
+/* ---- read-ahead for an uncompressed FASTA file: while piece k is on the device (upload, framing, scan, printing), a thread finds where
+ * piece k + 1 begins — at the '>' of the last record of piece k, which a piece that is not the file's last leaves unconsumed
+ * (cornetto_fasta_split) — and reads it into a second pinned buffer (the unconsumed bytes come from the page cache once more:
+ * cheaper than carrying tens of megabytes of a contig over).  The device's `consumed` is the authority: if it differs from the
+ * prediction (text that is not plain FASTA), what was read ahead is dropped and the caller goes on as without it. */
+typedef struct {
+    int fd, n_threads, started;
+    const char *cur;      /* piece k */
+    int64_t cur_n, cur_off; /* its bytes and the file offset of its first byte */
+    char *dst;            /* buffer of piece k + 1 (allocated by the thread on first use) */
+    int64_t cap;
+    int64_t pred;         /* out: predicted consumed bytes of piece k (-1: no prediction: nothing was read) */
+    int64_t got;          /* out: bytes of piece k + 1 (-1: read error) */
+    int eof;              /* out: the file ends inside piece k + 1 */
+    pthread_t th;
+} fa_ahead_t;
+
+static void *fa_ahead_thread(void *p)
+{
+    fa_ahead_t *a = (fa_ahead_t *)p;
+    a->pred = -1;
+    a->got = 0;
+    a->eof = 0;
+    /* the last '>' that begins a line */
+    int64_t at = a->cur_n;
+    while (at > 0) {
+        const char *q = (const char *)memrchr(a->cur, '>', (size_t)at);
+        if (!q) break;
+        at = (int64_t)(q - a->cur);
+        if (at > 0 && a->cur[at - 1] == '\n') {
+            a->pred = at;
+            break;
+        }
+    }
+    if (a->pred <= 0) {
+        a->pred = -1;
+        return NULL;
+    }
+    if (!a->dst) a->dst = (char *)cornetto_pinned_alloc((size_t)a->cap);
+    if (!a->dst) {
+        a->pred = -1;
+        return NULL;
+    }
+    a->got = cli_pread_parallel(a->fd, a->dst, a->cap, a->cur_off + a->pred, a->n_threads);
+    if (a->got >= 0 && a->got < a->cap) a->eof = 1;
+    return NULL;
+}
+
 static void stream_records(const char *path, int must_open, scan_fn scan, void *arg)
 {
     const int trace = getenv("CORNETTO_CLI_TRACE") != NULL;
@@ -374,7 +422,19 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
         }
         buf[0] = first;
         TRACE("pinned piece allocated");
+        /* read-ahead (uncompressed FASTA file; CORNETTO_CLI_AHEAD=0 switches it off) */
+        const char *ahead_env = getenv("CORNETTO_CLI_AHEAD");
+        const int use_ahead = fasta && raw_fd >= 0 && !(ahead_env && !atoi(ahead_env));
+        fa_ahead_t ah;
+        memset(&ah, 0, sizeof(ah));
+        char *other = NULL;          /* the second buffer, once the thread has made it */
+        int64_t buf_off = 0;         /* file offset of buf[0] (raw files) */
+        int ahead_ready = 0;         /* buf already holds the next piece (have, eof set) */
         for (;;) {
+            if (ahead_ready) {
+                ahead_ready = 0;
+                goto piece_in_place;
+            }
             if (start) {
                 memmove(buf, buf + start, (size_t)(have - start));
                 have -= start;
@@ -402,7 +462,18 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
                 if (r < want) eof = 1;
             }
             if (have == 0) break;
+        piece_in_place:
             TRACE("piece read");
+            if (use_ahead && !eof && start == 0) {        /* the next piece, beside everything below */
+                ah.fd = raw_fd;
+                ah.n_threads = READ_THREADS;
+                ah.cur = buf;
+                ah.cur_n = have;
+                ah.cur_off = buf_off;
+                ah.dst = other;
+                ah.cap = piece;
+                ah.started = pthread_create(&ah.th, NULL, fa_ahead_thread, &ah) == 0;
+            }
             if (!h) h = cli_accel_open_end();
             TRACE("device open");
             cornetto_asm_t *a = NULL;
@@ -436,7 +507,30 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
             free(r);
             cornetto_asm_free(h, a);
             start = used;
+            if (ah.started) {
+                pthread_join(ah.th, NULL);
+                ah.started = 0;
+                other = ah.dst;
+                if (plain && !eof && ah.pred == used && ah.got > 0) {
+                    /* the piece that was read ahead begins where this one stopped: swap the buffers */
+                    char *t = buf;
+                    buf = other;
+                    other = t;
+                    buf_off += used;
+                    raw_off = buf_off + ah.got;
+                    have = ah.got;
+                    eof = ah.eof;
+                    start = 0;
+                    ahead_ready = 1;
+                    continue;
+                }
+                if (ah.got < 0) {
+                    CLI_ERROR("reading %s failed", path);
+                    exit(EXIT_FAILURE);
+                }
+            }
             if (!plain || eof) break;              /* not plain from buf + start on / the input is finished */
+            buf_off += start;                      /* (the bytes in front of `start` are dropped by the memmove above) */
             if (used == 0 && have == piece) { /* one record larger than the piece: a larger one, as long as the index allows */
                 if (piece >= piece_max) break;
                 const int64_t bigger = piece * 2 > piece_max ? piece_max : piece * 2;
@@ -446,6 +540,8 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
                 cornetto_pinned_free(buf);
                 buf = nb;
                 piece = bigger;
+                if (other) cornetto_pinned_free(other);   /* (the read-ahead buffer is made again at the new size) */
+                other = NULL;
             }
         }
         if (!h) h = cli_accel_open_end();

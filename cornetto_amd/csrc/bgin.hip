@@ -252,6 +252,7 @@ struct cornetto_bgin {
     unsigned long long n_clamp = 0;
     cornetto_bgerr_t err{0, 0, 0, 0};
     bool finished = false;
+    int64_t left_mq = 0;      // tokens of cov-mq behind the last record when cov-total ended (the reference never looks at them: :204-207)
 };
 
 namespace {
@@ -317,6 +318,8 @@ void cornetto_bgin_pending(const cornetto_bgin_t *b, int64_t *pend_tot, int64_t 
     if (pend_tot) *pend_tot = b ? (int64_t)b->pend[0].size() : 0;
     if (pend_mq) *pend_mq = b ? (int64_t)b->pend[1].size() : 0;
 }
+
+int64_t cornetto_bgin_unmatched_mq(const cornetto_bgin_t *b) { return b && b->finished ? b->left_mq : 0; }
 
 const cornetto_bgerr_t *cornetto_bgin_error(const cornetto_bgin_t *b) { return b ? &b->err : nullptr; }
 
@@ -462,6 +465,7 @@ int cornetto_bgin_feed(cornetto_accel_t *h, cornetto_bgin_t *b, const char *tot,
                 return CORNETTO_E_FORMAT;
             }
             b->finished = true;
+            b->left_mq = left_b > 0 ? left_b : 0;
         }
     }
     // carry: context records + everything not consumed

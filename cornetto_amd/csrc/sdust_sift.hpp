@@ -506,9 +506,12 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
         constexpr int PAR = decltype(par_c)::value;
         constexpr bool GENERAL = decltype(general_c)::value, TABLE_ONLY = decltype(only_c)::value;
         constexpr int CUR = PAR * 128, PREV = (PAR ^ 1) * 128;
+        // (the tile in front of a chunk as well: its first two words reach in front of the region, and a byte there that is not a
+        // letter — it does not make the chunk unclean — leaves them without a word: bit 6)
+        constexpr bool CHECK = GENERAL || TABLE_ONLY;
         const uint32_t wv = pq[0];
-        const bool valid = !GENERAL || (wv < 64u && q * 64 + lane < rlen);
-        const uint32_t wi = GENERAL ? wv & 63u : wv;
+        const bool valid = !CHECK || (wv < 64u && q * 64 + lane < rlen);
+        const uint32_t wi = CHECK ? wv & 63u : wv;
         if (valid) (void)__hip_atomic_fetch_or(&tab_mine[CUR + wi], mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         SD_LDS_ORDER();
         const uint32_t ec_lo = tab[CUR + wi], ec_hi = tab[CUR + 64 + wi], ep_lo = tab[PREV + wi], ep_hi = tab[PREV + 64 + wi];
@@ -640,7 +643,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
         }
         // ---- the window at i; equal words at younger ages through the LDS table
         const bool ok = lane <= amax;
-        w = ok ? (int)wc[2 * (o - lane)] : 0;
+        w = ok ? (int)(wc[2 * (o - lane)] & 63u) : 0;      // (& 63: W = 65, 66 read the region's first two words at their first step, see above)
         if (ok) (void)__hip_atomic_fetch_or(&tab_mine[w], mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         SD_LDS_ORDER();
         const unsigned long long e = (unsigned long long)tab[w] | (unsigned long long)tab[64 + w] << 32;

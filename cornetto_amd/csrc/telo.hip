@@ -877,7 +877,9 @@ int cornetto_telo_scan(cornetto_accel_t *h, const cornetto_asm_t *a, const char 
     }
     cn_timing_end(h);
     if (rc != CORNETTO_OK || !hits) {
-        free(hh);
+        // (a lazy handle may still be copying into hh on its copy stream; hh is library memory — the pinned pool for large results)
+        cn_result_quiesce(h);
+        cornetto_free(hh);
     } else {
         *hits = hh;
         *n_hits = nh;

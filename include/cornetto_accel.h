@@ -319,6 +319,10 @@ int cornetto_bgin_feed(cornetto_accel_t *h, cornetto_bgin_t *b, const char *tot,
 /* bytes of each file handed over but not consumed yet (records without a partner in the other file): a
  * caller that tops both up to the same amount keeps them bounded */
 void cornetto_bgin_pending(const cornetto_bgin_t *b, int64_t *pend_tot, int64_t *pend_mq);
+/* once the ingest is done: white-space separated tokens of cov-mq behind its last consumed record.  The reference stops reading
+ * when cov-total ends (src/boringbits_main.c:204-207) and never sees them; a caller that cuts the files into shares needs the
+ * count: leftover tokens in a share that is not the last would have been the partners of the next share's cov-total records. */
+int64_t cornetto_bgin_unmatched_mq(const cornetto_bgin_t *b);
 const cornetto_bgerr_t *cornetto_bgin_error(const cornetto_bgin_t *b);
 int cornetto_bgin_done(const cornetto_bgin_t *b);
 

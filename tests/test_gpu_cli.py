@@ -226,6 +226,14 @@ def test_panel_sharded_ingest_unequal_line_lengths_and_errors(cli, tmp_path):
     rc1, out1, err1 = run(cli, args)
     rc, out, err = run(cli, args, {"CORNETTO_DEVICES": "0,0,0", "CORNETTO_BG_SHARD_MIN": "1"})
     assert rc1 == 1 and rc == 1 and b"4 columns" in err1 and b"4 columns" in err
+    # one contig's block twice in cov-mq (the same last line in front of every cut): the sequential loop pairs the surplus lines with
+    # the next contig's cov-total records and stops with "not in the same order"; a share must not drop them silently
+    dup_q = [list(r) for r in rows_q]
+    dup_q[1] = dup_q[1] + dup_q[1]
+    write(rows_t, dup_q)
+    rc1, out1, err1 = run(cli, args)
+    rc, out, err = run(cli, args, {"CORNETTO_DEVICES": "0,0,0,0,0", "CORNETTO_BG_SHARD_MIN": "1"})
+    assert rc1 == 1 and rc == 1 and b"not in the same order" in err1 and b"not in the same order" in err
 
 
 @pytest.mark.parametrize("devices", ["0,0", "0,0,0"])

@@ -37,8 +37,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_FILE = os.path.join("profiles", "r03_pmc_traffic_%s.json")      # % kernel symbol
-SQ_FILE = os.path.join("profiles", "r03_sq_%s.json")
+PMC_FILE = os.path.join("profiles", "r04_%s_pmc_traffic_%s.json")   # % (workload profile, kernel symbol)
+SQ_FILE = os.path.join("profiles", "r04_%s_sq_%s.json")
 
 
 def contig_lengths(total_target):
@@ -1554,7 +1554,7 @@ def main():
         # HBM/fabric bytes per launch of the dominant kernel and its instruction mix: NOT measured in this run — taken from the
         # committed rocprofv3 PMC passes of this workload (profiles/README.md), scaled to the bases of this run
         traffic, traffic_source, issue = None, None, None
-        for cand in (PMC_FILE % symbol, os.path.join("profiles", "r02_pmc_traffic.json")):
+        for cand in (PMC_FILE % (args.profile, symbol), os.path.join("profiles", "r03_pmc_traffic_%s.json" % symbol), os.path.join("profiles", "r02_pmc_traffic.json")):
             try:
                 pmcs = json.load(open(os.path.join(ROOT, cand)))
                 pmc = pmcs.get(symbol) or pmcs["sdust_w64"]
@@ -1563,10 +1563,14 @@ def main():
             except Exception:
                 continue
         try:
-            sq = json.load(open(os.path.join(ROOT, SQ_FILE % symbol)))
+            sq_name = SQ_FILE % (args.profile, symbol)
+            if not os.path.exists(os.path.join(ROOT, sq_name)):
+                sq_name = os.path.join("profiles", "r03_sq_%s.json" % symbol)
+            sq = json.load(open(os.path.join(ROOT, sq_name)))
             pl = sq["per_launch"]
             issue = {"valu_insts": pl["SQ_INSTS_VALU"], "salu_insts": pl["SQ_INSTS_SALU"], "lds_insts": pl["SQ_INSTS_LDS"],
-                     "valu_busy": sq.get("valu_busy_of_kernel_time"), "per_64_bases": sq.get("per_64_bases"), "source": SQ_FILE % symbol,
+                     "valu_busy": sq.get("valu_busy_of_kernel_time"), "per_64_bases": sq.get("per_64_bases"), "source": sq_name,
+                     "counting_build_ms": sq.get("counting_build_ms", sq.get("kernel_ms")), "production_ms": sq.get("production_ms"),
                      "note": "a wave-64 vector instruction holds its SIMD's ALU for 4 cycles: valu_busy = 4 x SQ_INSTS_VALU / (SIMDs x cycles of the kernel); "
                              "not measured in this run: the committed rocprofv3 --pmc passes of the same workload"}
         except Exception:
@@ -1588,7 +1592,7 @@ def main():
                            "2 HIP streams (sdust || telofind+coverage), sdust on %d %% of the wave slots" % getattr(R, "share", 100) if nst == 2 else "stages serial on one stream")},
             "roofline": {"bound": "valu-issue", "kernel": dom, "kernel_symbol": symbol, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source, "issue": issue,
-                         "note": "sdust is integer work per base, bound by instruction issue, not by HBM (profiles/r03_sq_<kernel>.json); achieved / peak / frac are "
+                         "note": "sdust is integer work per base, bound by instruction issue, not by HBM (profiles/r04_<profile>_sq_<kernel>.json); achieved / peak / frac are "
                                  "against the HBM roofline as the contract asks (1 B/base algorithmic). traffic and issue are not measured in this run: "
                                  "the committed rocprofv3 PMC figures scaled by bases"},
             "kernels": kern,

@@ -47,8 +47,8 @@ void cli_order_by_length_desc(const int64_t *lens64, const int32_t *lens32, int3
 void *cli_xrealloc(void *p, size_t n);
 char *cli_xstrdup(const char *s);
 
-/* Open the accelerator ($CORNETTO_DEVICE, default 0) or print the reason and exit(EXIT_FAILURE): this
- * build has no CPU path. */
+/* Open the accelerator ($CORNETTO_DEVICE, default 0) or print the reason and exit(EXIT_FAILURE): the
+ * host path (host_backend.c) is only ever chosen explicitly. */
 cornetto_accel_t *cli_accel_open(void);
 /* the same, with the HIP initialisation running on a helper thread between _begin() and _end() (while the input is read);
  * _cancel() drops it when no device work turned up */

@@ -73,7 +73,7 @@ cornetto_accel_t *cli_accel_open(void)
     cornetto_accel_t *h = NULL;
     int rc = cornetto_accel_open(&h, d ? atoi(d) : 0, NULL);
     if (rc != CORNETTO_OK) {
-        CLI_ERROR("cannot open HIP device %d: %s. This build runs the scans on an AMD GPU only; there is no CPU path.",
+        CLI_ERROR("cannot open HIP device %d: %s. The scans run on an AMD GPU; the sequential host path is a choice (--accel=no / CORNETTO_ACCEL=no), never a fallback.",
                   d ? atoi(d) : 0, cornetto_accel_strerror(rc));
         exit(EXIT_FAILURE);
     }
@@ -111,7 +111,7 @@ cornetto_accel_t *cli_accel_open_end(void)
     pthread_join(g_open.th, NULL);
     g_open.started = 0;
     if (g_open.rc != CORNETTO_OK) {
-        CLI_ERROR("cannot open HIP device %d: %s. This build runs the scans on an AMD GPU only; there is no CPU path.",
+        CLI_ERROR("cannot open HIP device %d: %s. The scans run on an AMD GPU; the sequential host path is a choice (--accel=no / CORNETTO_ACCEL=no), never a fallback.",
                   g_open.dev, cornetto_accel_strerror(g_open.rc));
         exit(EXIT_FAILURE);
     }

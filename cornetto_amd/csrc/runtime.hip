@@ -11,8 +11,10 @@ namespace {
 std::mutex g_pool_mu;
 std::unordered_map<void *, size_t> g_pool_live;      // pinned buffers currently owned by callers
 std::multimap<size_t, void *> g_pool_free;           // pinned buffers ready for reuse, by capacity
+std::unordered_map<void *, uint64_t> g_pool_age;     // when a free buffer was handed back (the oldest one makes room)
+uint64_t g_pool_clock = 0;
 constexpr size_t POOL_MIN = 1u << 20;                // below this, plain malloc
-constexpr size_t POOL_KEEP = 8;                      // free buffers kept before releasing to the driver
+constexpr size_t POOL_KEEP = 12;                     // free buffers kept; beyond that the one that has waited longest goes back to the driver
 }  // namespace
 
 void *cn_result_alloc(size_t bytes)
@@ -27,6 +29,7 @@ void *cn_result_alloc(size_t bytes)
             void *p = it->second;
             g_pool_live[p] = it->first;
             g_pool_free.erase(it);
+            g_pool_age.erase(p);
             return p;
         }
     }
@@ -125,17 +128,36 @@ void cornetto_free(void *p)
         if (it == g_pool_live.end()) {
             drop = nullptr;
         } else {
+            // keep what was used last: when the list is full the buffer that has waited longest leaves (a list full of the sizes of
+            // an earlier workload made every step of the next one pin and unpin its result buffers: +7 ms per step, round 4)
             const size_t cap = it->second;
             g_pool_live.erase(it);
-            if (g_pool_free.size() < POOL_KEEP) {
-                g_pool_free.emplace(cap, p);
-                return;
+            if (g_pool_free.size() >= POOL_KEEP) {
+                auto oldest = g_pool_free.end();
+                uint64_t best = ~0ull;
+                for (auto f = g_pool_free.begin(); f != g_pool_free.end(); ++f) {
+                    const uint64_t age = g_pool_age[f->second];
+                    if (age < best) {
+                        best = age;
+                        oldest = f;
+                    }
+                }
+                if (oldest != g_pool_free.end()) {
+                    drop = oldest->second;
+                    g_pool_age.erase(drop);
+                    g_pool_free.erase(oldest);
+                }
             }
-            drop = p;
+            g_pool_free.emplace(cap, p);
+            g_pool_age[p] = ++g_pool_clock;
+            if (drop) {
+                // (released outside the lock below)
+            }
+            p = nullptr;
         }
     }
     if (drop) (void)hipHostFree(drop);
-    else free(p);
+    else if (p) free(p);
 }
 
 int cornetto_accel_set_share(cornetto_accel_t *h, int percent)

@@ -56,14 +56,7 @@ int main(int argc, char **argv)
         for (int seed = 1; seed <= seeds; ++seed) {
             rng_s = 0x9E3779B97F4A7C15ull * (uint64_t)(seed + 100 * tw);
             make_seq(s, n, seed % 3);
-            for (int p = 0; p < n; ++p) {
-                int c0 = "\0\1\2\3"[0];
-                (void)c0;
-                int b = s[p] & 0xDF;
-                int code = b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : 3;
-                word[p] = p >= 2 ? ((word[p - 1] << 2) | code) & 63 : code | (p ? (word[p - 1] << 2) & 63 : 0);
-            }
-            /* fix the first two (not words): rebuild properly */
+            /* word(p) = the 3-mer that ends at p (a word for p >= 2) */
             {
                 unsigned t = 0;
                 for (int p = 0; p < n; ++p) {

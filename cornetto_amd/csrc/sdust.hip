@@ -2066,8 +2066,8 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                         fprintf(stderr, "[sdust stats]   waves that ran %4.1f-%4.1f ms: %6llu, job fetches %llu, find_perfect calls %llu (%llu with candidates)\n", b * 0.5, b * 0.5 + 0.5,
                                 p_tot[16 + 4 * b], p_tot[18 + 4 * b], p_tot[19 + 4 * b], p_tot[17 + 4 * b]);
             if (env_stats && sift_on)
-                fprintf(stderr, "[sdust stats] sift: tiles %llu, positions with ct > T/10 %llu, after L1 %llu, after L2 %llu; resolve: steps %llu, window reads %llu, dp tiles %llu; passes with candidates %llu; base-by-base steps of chunks with other bytes %llu\n",
-                        p_tot[206], p_tot[203], p_tot[204], p_tot[205], p_tot[200], p_tot[201], p_tot[208], p_tot[202], p_tot[207]);
+                fprintf(stderr, "[sdust stats] sift: tiles %llu, positions with ct > T/10 %llu, after L1 %llu, after L2 %llu; resolve: steps %llu, window reads %llu (behind a gap of 2 / 3-4 / 5-8: %llu / %llu / %llu), dp tiles %llu; passes with candidates %llu; base-by-base steps of chunks with other bytes %llu\n",
+                        p_tot[206], p_tot[203], p_tot[204], p_tot[205], p_tot[200], p_tot[201], p_tot[209], p_tot[210], p_tot[211], p_tot[208], p_tot[202], p_tot[207]);
             if (env_stats)
                 fprintf(stderr, "[sdust stats] flagged low-complexity %llu; chunks %zu waves %u wave-steps %llu find_perfect calls %llu (%llu with candidates) plain groups %llu; wave time avg %.1f us max %.1f us; queue: %.1f fetch rounds and %.1f us per wave\n", p_tot[7], nc, nb,
                         p_tot[2], p_tot[3], p_tot[10], p_tot[4], nb ? (double)p_tot[5] / nb / 100.0 : 0.0, (double)p_tot[6] / 100.0, nb ? (double)p_tot[11] / nb : 0.0, nb ? (double)p_tot[12] / nb / 100.0 : 0.0);

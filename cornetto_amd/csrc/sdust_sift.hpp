@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
     const int LS = CAPW - 1 < SIFT_LS ? CAPW - 1 : SIFT_LS;
     const bool long_ok = CAPW - 1 > LS;               // suffixes longer than the walk exist
     // statistics build: counted per wave, added up once at the end
-    unsigned long long st_steps = 0, st_jumps = 0, st_cand = 0, st_trig = 0, st_l1 = 0, st_l2 = 0, st_walk = 0, st_tiles = 0, st_dp = 0;
+    unsigned long long st_steps = 0, st_jumps = 0, st_cand = 0, st_trig = 0, st_l1 = 0, st_l2 = 0, st_walk = 0, st_tiles = 0, st_dp = 0, st_g2 = 0, st_g4 = 0, st_g8 = 0;
 
     struct Meta {
         SdChunk ch;
@@ -778,6 +778,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
                 continue;
             }
             m &= m - 1;
+            if (STATS && have && fresh) { if (i - cur <= 2) ++st_g2; else if (i - cur <= 4) ++st_g4; else if (i - cur <= 8) ++st_g8; }
             jump(i);
             pass_m(i - 2 < CAPW - 1 ? i - 2 : CAPW - 1);
         }
@@ -868,5 +869,8 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
         atomicAdd(&O.stats[6], st_tiles);
         atomicAdd(&O.stats[7], st_walk);
         atomicAdd(&O.stats[8], st_dp);
+        atomicAdd(&O.stats[9], st_g2);
+        atomicAdd(&O.stats[10], st_g4);
+        atomicAdd(&O.stats[11], st_g8);
     }
 }

@@ -369,6 +369,44 @@ def test_sdust_sift_vs_oracle(acc, monkeypatch, T, W, chunk, kind):
     assert got == exp, (T, W, chunk)
 
 
+@pytest.mark.parametrize("dp,l2skip", [("1", "65"), ("1", "1"), ("24", "48"), ("65", "1"), ("65", "65"), ("8", "32")])
+@pytest.mark.parametrize("T,W,chunk", [(20, 64, "0"), (20, 66, "448"), (20, 65, "640"), (12, 40, "256"), (5, 7, "256"), (30, 16, "1024"), (2, 64, "0")])
+def test_sdust_dp_tiles_and_l2_skip_vs_oracle(acc, monkeypatch, T, W, chunk, dp, l2skip):
+    """round 4: tiles resolved end-parallel (CORNETTO_SIFT_DP: from how many sifted positions per tile — 1: every tile that
+    holds one, 65: none) and L1 batches that skip the second filter (CORNETTO_SIFT_L2SKIP) are scheduling choices: any
+    superset of the inserting positions and either resolve stage give the reference's intervals.  Exact and diverged
+    repeats of periods 1-7, chunk borders and contig ends inside them, hand-overs stepping -> dp -> dp -> stepping."""
+    monkeypatch.setenv("CORNETTO_SDUST_CHUNK", chunk)
+    monkeypatch.setenv("CORNETTO_SDUST_SIFT", "1")
+    monkeypatch.setenv("CORNETTO_SIFT_DP", dp)
+    monkeypatch.setenv("CORNETTO_SIFT_L2SKIP", l2skip)
+    rng = np.random.default_rng(99 + T * 7 + W)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = []
+    for k, n in enumerate((60_000, 20_011, 4096, 1537, 600, 129)):
+        s = acgt[rng.integers(0, 4, size=n)].copy()
+        for _ in range(max(1, n // 2000)):
+            L = int(rng.integers(8, min(1500, n)))
+            p = int(rng.integers(0, n - L + 1))
+            u = int(rng.integers(1, 8))
+            rep = np.tile(acgt[rng.integers(0, 4, size=u)], L // u + 1)[:L].copy()
+            if k % 3:
+                mm = rng.random(L) < 0.02 * (k % 3)
+                rep[mm] = acgt[rng.integers(0, 4, size=int(mm.sum()))]
+            s[p:p + L] = rep
+        if k == 1:
+            s[-700:] = np.tile(np.frombuffer(b"TTAGGG", dtype=np.uint8), 117)[:700]      # the contig ends inside an array
+        if k == 2:
+            s[1000:1003] = ord("N")                                                      # one walked chunk among the others
+        seqs.append(s)
+    asm = acc.asm_upload(seqs)
+    iv = acc.sdust(asm, T, W)
+    asm.close()
+    got = [(int(x["ctg"]), int(x["start"]), int(x["finish"])) for x in iv]
+    exp = [(ci, int(r) >> 32, int(r) & 0xFFFFFFFF) for ci, q in enumerate(seqs) for r in ob.sdust(q, T, W)]
+    assert got == exp, (T, W, chunk, dp, l2skip)
+
+
 def test_sdust_sift_off_equals_on(acc, monkeypatch):
     """CORNETTO_SDUST_SIFT=0 (the per-lane recurrence of sdust_w64 for every chunk) and the default give the same intervals"""
     rng = np.random.default_rng(77)

@@ -615,7 +615,7 @@ class Rank:
         self.overlap = not args.serial
         if self.overlap:
             # the sdust waves stay resident until their queue is empty: leave part of every CU to the other stream
-            self.share = args.sdust_share if args.sdust_share > 0 else 72
+            self.share = args.sdust_share if args.sdust_share > 0 else 85
             self.share_tuned_for = None
             self.acc2.set_share(self.share)
         # the two large result arrays of this thread (telomere runs, selected windows) travel beside its next kernels
@@ -730,11 +730,13 @@ class Rank:
                 t_lead = time.perf_counter() + self.lead_us * 1e-6
                 while time.perf_counter() < t_lead:
                     pass
-        t0 = time.perf_counter()
-        hits, wins = acc.telo_scan(self.asm, b"TTAGGG", self.thr)
-        if record:
-            self._note(acc)
-            self._lap("telo_scan", t0)
+        cov_first = os.environ.get("CORNETTO_BENCH_COV_FIRST", "1") != "0"
+        if not cov_first:
+            t0 = time.perf_counter()
+            hits, wins = acc.telo_scan(self.asm, b"TTAGGG", self.thr)
+            if record:
+                self._note(acc)
+                self._lap("telo_scan", t0)
         t0 = time.perf_counter()
         sums = acc.cov_prepare(self.cov, 2500, 50)
         if record:
@@ -755,6 +757,14 @@ class Rank:
         if record:
             self._note(acc)
             self._lap("cov_select", t0)
+        if cov_first:
+            # the coverage stage goes first: its large result copy (8 B per selected window: 60 MB of the 3.16 Gbp assembly) travels beside
+            # the telomere kernels instead of being waited for at the end of the step
+            t0 = time.perf_counter()
+            hits, wins = acc.telo_scan(self.asm, b"TTAGGG", self.thr)
+            if record:
+                self._note(acc)
+                self._lap("telo_scan", t0)
         if self.overlap and os.environ.get("CORNETTO_BENCH_BOOST", "1") != "0":
             self.acc2.boost(True)                     # this thread's kernels are through: the waves sdust had left to it join in (cornetto_accel_boost)
         if self.lazy:
@@ -795,17 +805,13 @@ class Rank:
         tunes for itself."""
         if not self.overlap or self.args.sdust_share > 0:
             return
-        if self.args.sdust_share < 0 and self.profile == "uniform":
-            self.share = 72
-            self.acc2.set_share(self.share)
-            return
         if self.share_tuned_for == (self.profile, self.scaling, self.my_bases):
             return                                       # (probed once per resident workload)
         self.share_tuned_for = (self.profile, self.scaling, self.my_bases)
         for _ in range(2):                             # (the result pools of a new workload grow in its first steps: not the share's doing)
             self.step(False)
         best, seen = None, {}
-        for sh in (72, 62, 85, 100, 72):               # (72 twice: the first candidate measured is the one that pays for what is still warming up)
+        for sh in (85, 72, 92, 100, 85):               # (the first one twice: the first candidate measured is the one that pays for what is still warming up)
             self.acc2.set_share(sh)
             self.step(False)
             self.torch.cuda.synchronize()
@@ -1472,7 +1478,7 @@ def main():
     ap.add_argument("--emulate-ranks", type=str, default="2,4,8", help="N=1: model the strong-scaling curve for these rank counts on this one GPU ('' = skip)")
     ap.add_argument("--rank-share", type=str, default="", help="N,k (profiling aid, N=1 only): the main workload is the share rank k of an N-rank strong-scaling run would own")
     ap.add_argument("--allow-shared-device", action="store_true", help="--gpus > 1 with fewer GPUs than ranks (tests): ranks share devices, collectives over gloo")
-    ap.add_argument("--sdust-share", type=int, default=-1, help="percent of the wave slots the resident sdust waves could hold on a CU that they take while the other stream runs beside them; -1 (default): 72 on the uniform profile (15 of 21 per CU — 14: 8.2 ms per step, 15: 8.0, 16: 8.8, 17: the other stream starves), probed during warm-up (62 / 72 / 85 / 100) on the repeat-rich profiles, where sdust is a larger part of the step; 0: always probed.  The rest of the slots joins in when the other thread of the step is through (cornetto_accel_boost)")
+    ap.add_argument("--sdust-share", type=int, default=-1, help="percent of the wave slots the resident sdust waves could hold on a CU that they take while the other stream runs beside them; -1 / 0 (default): probed during warm-up (72 / 85 / 92 / 100, four untimed steps each) for every resident workload — with the coverage stage in front of the telomere scan the two host threads of a step balance at 85-92 on the uniform profile (7.6-7.8 ms per step; 72: 8.1), repeat-rich profiles want 85-100.  The rest of the slots joins in when the other thread of the step is through (cornetto_accel_boost)")
     ap.add_argument("--timing", type=int, default=1, help="HIP events in the timed steps around: 1 the three main kernels only (roofline), 2 every launch, 0 none; the extra serial pass that fills the kernel table always uses 2")
     ap.add_argument("--gather", action="store_true", help="also gather every result record to rank 0 inside the step (not part of the path: each rank owns the output of its contigs)")
     ap.add_argument("--allreduce-always", action="store_true", help="weak scaling: all-reduce the depth totals as well (treats the N assemblies as one)")
@@ -1605,6 +1611,7 @@ def main():
                                     "handed out first from the second call on (a function of the resident bases, which must not change)",
                                     "telofind: the motif's match tables on the device while the motif stays the same"],
             "first_step_ms": round(first_step_ms, 3),
+            "sdust_share_percent": getattr(R, "share", None), "sdust_share_probe_ms": getattr(R, "share_probe_ms", None),
         }
         if coll:
             line["collectives"] = coll

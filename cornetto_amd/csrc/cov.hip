@@ -106,7 +106,7 @@ __global__ __launch_bounds__(CB_THREADS) void cov_blocks(CbArgs A)
         // INC known (<= 64: at most 4 vectors per thread and part): the loads of all four phases (2 arrays x 2 parts: the whole
         // tile, 4 x 12.8 KB at INC = 50) are issued before the first LDS store — beside another stream's resident kernel only
         // one or two of these workgroups fit on a CU, and what bounds the kernel then is the bytes it keeps in flight.
-        constexpr int NVI = 4;
+        constexpr int NVI = INC ? (PB * INC / 8 + CB_THREADS - 1) / CB_THREADS : 4;
         cb_u4 pre[2][CB_PARTS][NVI];
         if (INC) {
 #pragma unroll

@@ -37,6 +37,7 @@ struct CbArgs {
     const int2 *tiles;         // {ctg, first block of the tile within the contig}
     int32_t inc, r;            // block size, head size (w % inc)
     uint4 *blk;                // [tile*256 + b] = {local inclusive prefix depth, head depth, prefix mq, head mq}
+    int64_t n_tiles;
     uint2 *tile_tot32;         // wrapping tile totals {depth, mq}
     ulonglong2 *tile_tot64;    // exact tile totals
 };
@@ -73,8 +74,10 @@ __device__ __forceinline__ uint32_t add_u16x2(uint32_t acc, uint32_t pair)
 
 typedef unsigned int cb_u4 __attribute__((ext_vector_type(4)));
 
-// INC: the block size when it is known at compile time (50, the default step), else 0
-template <bool STAGE, int INC>
+// INC: the block size when it is known at compile time (50, the default step), else 0.  NT (INC known only): tiles per workgroup — the
+// loads of ALL of them are issued before the first one is summed: beside another stream's resident kernel one workgroup fits on a CU, and
+// with one tile its load and its sum phases alternate with nothing in flight meanwhile
+template <bool STAGE, int INC, int NT = 1>
 __global__ __launch_bounds__(CB_THREADS) void cov_blocks(CbArgs A)
 {
     __builtin_amdgcn_s_setprio(3);   // short streaming kernel: issue ahead of a long compute-bound kernel of another stream
@@ -84,10 +87,41 @@ __global__ __launch_bounds__(CB_THREADS) void cov_blocks(CbArgs A)
     __shared__ unsigned long long wsum64[2][CB_THREADS / 64];
 
     const int t = threadIdx.x;
-    const int2 tile = A.tiles[blockIdx.x];
+    const int inc = INC ? INC : A.inc, r = A.r;
+    constexpr int PBc = CB_THREADS / CB_PARTS;
+    constexpr int NVIc = INC ? (PBc * INC / 8 + CB_THREADS - 1) / CB_THREADS : 4;
+    cb_u4 pre_all[NT][2][CB_PARTS][NVIc];
+    if (STAGE && INC) {
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            const int64_t tix = (int64_t)blockIdx.x * NT + ti;
+            if (tix >= A.n_tiles) continue;
+            const int2 tl = A.tiles[tix];
+            const int ln = A.ctg_len[tl.x];
+            const int64_t of = A.ctg_off[tl.x];
+            const int64_t e0l = (int64_t)tl.y * inc;
+            const int nvec = PBc * inc / 8;
+#pragma unroll
+            for (int which = 0; which < 2; ++which)
+#pragma unroll
+                for (int part = 0; part < CB_PARTS; ++part) {
+                    const int64_t pe0 = e0l + (int64_t)part * PBc * inc;
+                    const int64_t left = ((int64_t)ln - pe0) * 2;
+                    const uint32_t nrec = left <= 0 ? 0u : (uint32_t)(left < (int64_t)nvec * 16 ? (left + 15) & ~15LL : (int64_t)nvec * 16);
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((which ? A.mq : A.depth) + of + pe0), 0, (int)nrec, 0x00020000);
+#pragma unroll
+                    for (int k = 0; k < NVIc; ++k) pre_all[ti][which][part][k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (t + k * CB_THREADS) * 16, 0, 0);
+                }
+        }
+    }
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti) {
+    const int64_t tix = (int64_t)blockIdx.x * NT + ti;
+    if (tix >= A.n_tiles) break;
+    if (ti) __syncthreads();                            // (the tile before is through with the staging buffer and the wave sums)
+    const int2 tile = A.tiles[tix];
     const int len = A.ctg_len[tile.x];
     const int64_t off = A.ctg_off[tile.x];
-    const int inc = INC ? INC : A.inc, r = A.r;
     const int64_t e0 = (int64_t)tile.y * inc;           // first element of the tile within the contig
     const int64_t p0 = e0 + (int64_t)t * inc;           // first element of my block
 
@@ -106,21 +140,8 @@ __global__ __launch_bounds__(CB_THREADS) void cov_blocks(CbArgs A)
         // INC known (<= 64: at most 4 vectors per thread and part): the loads of all four phases (2 arrays x 2 parts: the whole
         // tile, 4 x 12.8 KB at INC = 50) are issued before the first LDS store — beside another stream's resident kernel only
         // one or two of these workgroups fit on a CU, and what bounds the kernel then is the bytes it keeps in flight.
-        constexpr int NVI = INC ? (PB * INC / 8 + CB_THREADS - 1) / CB_THREADS : 4;
-        cb_u4 pre[2][CB_PARTS][NVI];
-        if (INC) {
-#pragma unroll
-            for (int which = 0; which < 2; ++which)
-#pragma unroll
-                for (int part = 0; part < CB_PARTS; ++part) {
-                    const int64_t pe0 = e0 + (int64_t)part * PB * inc;
-                    const int64_t left = ((int64_t)len - pe0) * 2;
-                    const uint32_t nrec = left <= 0 ? 0u : (uint32_t)(left < (int64_t)nvec * 16 ? (left + 15) & ~15LL : (int64_t)nvec * 16);
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((which ? A.mq : A.depth) + off + pe0), 0, (int)nrec, 0x00020000);
-#pragma unroll
-                    for (int k = 0; k < NVI; ++k) pre[which][part][k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (t + k * CB_THREADS) * 16, 0, 0);
-                }
-        }
+        constexpr int NVI = NVIc;
+        auto &pre = pre_all[ti];
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
 #pragma unroll
@@ -224,9 +245,9 @@ __global__ __launch_bounds__(CB_THREADS) void cov_blocks(CbArgs A)
             pd += wsum[0][i];
             pq += wsum[1][i];
         }
-    A.blk[(size_t)blockIdx.x * CB_THREADS + t] = make_uint4(sdv + pd, hd, sqv + pq, hq);
+    A.blk[(size_t)tix * CB_THREADS + t] = make_uint4(sdv + pd, hd, sqv + pq, hq);
     if (t == CB_THREADS - 1) {
-        A.tile_tot32[blockIdx.x] = make_uint2(sdv + pd, sqv + pq);
+        A.tile_tot32[tix] = make_uint2(sdv + pd, sqv + pq);
         ulonglong2 x;
         if (STAGE) {
             x.x = sdv + pd;
@@ -235,8 +256,9 @@ __global__ __launch_bounds__(CB_THREADS) void cov_blocks(CbArgs A)
             x.x = wsum64[0][0] + wsum64[0][1] + wsum64[0][2] + wsum64[0][3];
             x.y = wsum64[1][0] + wsum64[1][1] + wsum64[1][2] + wsum64[1][3];
         }
-        A.tile_tot64[blockIdx.x] = x;
+        A.tile_tot64[tix] = x;
     }
+  }
 }
 
 // exact grand totals of depth / mq for the mean: one 64-bit atomic pair per workgroup
@@ -467,13 +489,19 @@ int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int3
     uint4 *d_blk = reinterpret_cast<uint4 *>(c->d_blk);
     uint32_t *d_toff_d = reinterpret_cast<uint32_t *>(d_blk + c->n_blk), *d_toff_q = d_toff_d + nt;
     CN_HIP(h, hipMemsetAsync(d_grand, 0, 16, h->stream));
-    CbArgs A{c->d_depth, c->d_mq, c->d_off, c->d_len, c->d_cb_tiles, inc, r, d_blk, d_t32, d_t64};
+    CbArgs A{c->d_depth, c->d_mq, c->d_off, c->d_len, c->d_cb_tiles, inc, r, d_blk, (int64_t)nt, d_t32, d_t64};
     if (inc <= CB_MAX_INC_LDS) {
         const size_t lds = (size_t)CB_THREADS / CB_PARTS * inc * sizeof(uint16_t);
         static_assert(CB_THREADS / CB_PARTS * 50 / 8 <= 4 * CB_THREADS, "cov_blocks<true, INC>: at most 4 vectors per thread and part");
         if (A.inc == 50) {                               // the default step (-i 50)
-            CN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&cov_blocks<true, 50>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            CN_LAUNCH(h, "cov_blocks", cov_blocks<true, 50><<<dim3((unsigned)nt), dim3(CB_THREADS), lds, h->stream>>>(A));
+            static const int cb_nt = [] { const char *e = getenv("CORNETTO_COV_TILES"); return e ? atoi(e) : 1; }();   // (2: two tiles per workgroup, all loads up front — 138 registers: does not fit beside the resident sdust waves, 8.4 instead of 3.9 ms in the step)
+            if (cb_nt == 2) {
+                CN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&cov_blocks<true, 50, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                CN_LAUNCH(h, "cov_blocks", cov_blocks<true, 50, 2><<<dim3((unsigned)((nt + 1) / 2)), dim3(CB_THREADS), lds, h->stream>>>(A));
+            } else {
+                CN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&cov_blocks<true, 50>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                CN_LAUNCH(h, "cov_blocks", cov_blocks<true, 50><<<dim3((unsigned)nt), dim3(CB_THREADS), lds, h->stream>>>(A));
+            }
         } else {
             CN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&cov_blocks<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             CN_LAUNCH(h, "cov_blocks", cov_blocks<true, 0><<<dim3((unsigned)nt), dim3(CB_THREADS), lds, h->stream>>>(A));

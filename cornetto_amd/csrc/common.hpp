@@ -61,6 +61,7 @@ struct cornetto_accel {
     // scan.hpp: the single-pass scans keep their tile states in WS_SCAN; a state counts only with the epoch of its call (no clearing
     // between calls), the tiles of a call take their numbers from a ticket counter that is never reset
     uint32_t scan_epoch = 0, scan_tickets = 0;
+    uint32_t st_epoch = 0, st_tickets = 0;          // the same for the single-pass interval merge (ivlmerge.hpp, WS_STITCH)
     int timing = 2;     // event pairs around: 2 every kernel launch, 1 the three streaming / scanning main kernels only, 0 none (cornetto_accel_set_timing)
 };
 
@@ -106,7 +107,7 @@ enum {   // device workspace slots
     WS_BG_TEXT_A, WS_BG_TEXT_B, WS_BG_TOK_A, WS_BG_TOK_B, WS_BG_CNT_A, WS_BG_CNT_B, WS_BG_SMALL, WS_BG_BRK,
     WS_TB, WS_TB_SMALL, WS_TB_OUT, WS_CW_MERGE, WS_IVL_MERGE,
     WS_FQ_TEXT, WS_FQ_CNT, WS_FQ_NL, WS_FQ_RECS, WS_FQ_ENDS, WS_FQ_SRC,
-    WS_SCAN,
+    WS_SCAN, WS_STITCH,
     WS_COUNT
 };
 static_assert(WS_COUNT <= 64, "cornetto_accel::dev has 64 slots");
@@ -285,6 +286,9 @@ struct cornetto_asm {
     int64_t sd_tail0 = 0;                // sdust: first chunk of the part of the table that is made of short chunks
     uint32_t *d_sd_walk = nullptr;       // sdust sift: [0] = n, [1 ..] the chunks that hold other bytes than letters (found by the first call: handed out first afterwards), then a byte per chunk
     int64_t sd_walk_key = -1;            //   chunk table it belongs to; -1: none yet
+    // sdust: what the last call for (chunk table, T, W) gave: rows of all chunks / merged intervals.  The next call sizes its gather,
+    // merge and result copy by them and checks afterwards (no round trip for the count inside the call); -1: none yet
+    int64_t sd_est_key = -1, sd_est_rows = -1, sd_est_out = -1;
     int sd_auto = -1;                    // sdust: which kernel family takes this assembly (-1 not decided, 0 the per-lane recurrence, 1 sift / resolve)
     int64_t sd_flagged = -1;             // sdust: chunks of this table that sd_prep samples as low-complexity (-1: not known yet)
     // sdust: per-256-base-block word-emission prefix table, built only if a lane needs it (N-dense input)

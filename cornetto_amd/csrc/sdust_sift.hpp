@@ -63,7 +63,10 @@ struct SiftArgs {
 #endif
 constexpr int SIFT_NCTR = 64;    // chunk counters, 64 bytes apart
 constexpr int SIFT_PAD = 16;     // positions in front of the word / count buffer (look-back of L1 / L2 below offset 0)
-constexpr int SIFT_LS = 15;      // L2 walks the suffixes with l <= SIFT_LS
+#ifndef SIFT_K
+#define SIFT_K 16                // L2: partial sums over this many counts, the exact walk over the suffixes of up to this many words
+#endif
+constexpr int SIFT_LS = SIFT_K - 1;   // L2 walks the suffixes with l <= SIFT_LS
 // fixed part of the LDS of a wave: tables 4 x 64 x u32 | lists 2 x 128 x u16 | counters 8 x 64 x u32; then bits (cap / 8) and the
 // word / count buffer, two bytes per position (word, count)
 constexpr int SIFT_FIXED = 1024 + 512 + 2048;
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
         for (int j = 0; j < 8; ++j) cnt[j * 64 + lane] = 0;
         int d = 0, dmin = 0x7fffffff;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < SIFT_K; ++j) {
             d += 10 * (int)p[1 - 2 * j] - T;
             dmin = d < dmin ? d : dmin;
         }

@@ -442,7 +442,10 @@ def cpu_reference_leg(bases, depth, mq, offs, lens, own, budget_bases):
             t0 = time.perf_counter()
             r = R.so.sdust(None, seq.ctypes.data, n, 20, 64, C.byref(cnt))
             t["sdust"] += time.perf_counter() - t0
-            res["sdust"] = np.ctypeslib.as_array(C.cast(r, C.POINTER(C.c_uint64)), shape=(max(cnt.value, 1),))[:cnt.value].copy()
+            if r and cnt.value > 0:
+                res["sdust"] = np.ctypeslib.as_array(C.cast(r, C.POINTER(C.c_uint64)), shape=(cnt.value,)).copy()
+            else:                                                          # sdust.c:194-198: nothing found = no buffer at all
+                res["sdust"] = np.zeros(0, np.uint64)
             R.libc.free(r)
             ctg = R.CtgDepth(b"c", n, n, d.ctypes.data, q.ctypes.data)
             asm = R.AsmDepth(1, 1, C.pointer(ctg), 30, 30)

@@ -22,6 +22,9 @@ struct cornetto_accel {
     // telofind: what the handle's small device blocks hold from the last call (no upload when the next call wants the same)
     std::string tf_lut_key;
     const void *tf_lut_ptr = nullptr;
+    uint64_t tf_bm_uid = 0;              // telofind: the assembly whose padding words the mark bitmap block (tf_bm_ptr, tf_bm_words) holds as zeros
+    const void *tf_bm_ptr = nullptr;
+    size_t tf_bm_words = 0;
 
     hipStream_t stream = nullptr;
     bool own_stream = false;

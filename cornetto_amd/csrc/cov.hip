@@ -393,20 +393,22 @@ __global__ __launch_bounds__(256) void cov_windows(CwArgs A)
 
 // packed selection: the first record of every contig = the ordered offset of its first tile (a contig without tiles: that of the next contig
 // that has one, or the total)
-__global__ void cov_ctg_first(const uint32_t *ooff, const int32_t *first_tile, int32_t n_ctg, uint32_t n_tiles, uint32_t total, uint32_t *out)
+__global__ void cov_ctg_first(const uint32_t *ooff, const int32_t *first_tile, int32_t n_ctg, uint32_t n_tiles, const unsigned long long *total, uint32_t *out)
 {
     const int32_t i = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n_ctg) return;
     const uint32_t t = (uint32_t)first_tile[i];
-    out[i] = t < n_tiles ? ooff[t] : total;
+    out[i] = t < n_tiles ? ooff[t] : (uint32_t)*total;
 }
 
 // tile segments (reservation order) -> (contig, window) order: one wavefront per tile; INTS = 4-byte words per record
 template <int INTS>
-__global__ __launch_bounds__(256) void cov_order(const int32_t *raw, const uint2 *tres, const uint32_t *ooff, int64_t n_tiles, int32_t *dst)
+__global__ __launch_bounds__(256) void cov_order(const int32_t *raw, const uint2 *tres, const uint32_t *ooff, int64_t n_tiles, int32_t *dst, const unsigned long long *total,
+                                                 uint32_t cap)
 {
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= n_tiles) return;
+    if (*total > cap) return;   // the selection outgrew the block (the host reruns at the exact size): segments beyond it were never written
     const uint2 r = tres[t];
     const int32_t *src = raw + (size_t)r.x * INTS;
     int32_t *d = dst + (size_t)ooff[t] * INTS;
@@ -598,6 +600,14 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
     cap = std::max(cap, h->dev[WS_CW_SEL].bytes / (2 * rec_bytes));   // keep what an earlier call grew to
     unsigned long long cnt = 0;
     cornetto_regrec_t *d_raw = nullptr, *d_dst = nullptr;
+    uint32_t *p_cf = nullptr, *d_cf = nullptr;
+    if (packed) {
+        p_cf = (uint32_t *)cn_pin(h, PIN_CW, ((size_t)c->n + 1) * 4);
+        d_cf = (uint32_t *)cn_ws(h, WS_CW_CF, ((size_t)c->n + 1) * 4);
+        if (!p_cf || !d_cf) return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: allocation failed");
+    }
+    // selection, ordering and (packed) the first record of every contig are queued in one go: the ordering kernels read the count on the
+    // device, so the host meets it once — together with the per-contig offsets — and only then sizes the result
     for (int attempt = 0; attempt < 2; ++attempt) {
         cap = std::min<size_t>(cap, 0x7fffffff);
         d_raw = (cornetto_regrec_t *)cn_ws(h, WS_CW_SEL, 2 * cap * rec_bytes);
@@ -608,6 +618,22 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
         A.cap = (uint32_t)cap;
         CN_HIP(h, hipMemsetAsync(d_cnt, 0, 8, h->stream));
         CN_LAUNCH(h, "cov_windows", cov_windows<<<dim3((unsigned)nt), dim3(256), 0, h->stream>>>(A));
+        // tiles are in (contig, window) order: exclusive scan of their counts = final position of each segment
+        CN_TRY(cnscan::exclusive_u32(h, "cov_order", reinterpret_cast<const uint32_t *>(d_tres) + 1, (int64_t)nt, 2, d_ooff, d_part, nullptr));
+        const unsigned nb = (unsigned)((nt + 3) / 4);
+        hipEvent_t ea = cn_event(h), eb = cn_event(h);
+        (void)hipEventRecord(ea, h->stream);
+        if (packed) cov_order<2><<<dim3(nb), dim3(256), 0, h->stream>>>(reinterpret_cast<const int32_t *>(d_raw), d_tres, d_ooff, (int64_t)nt, reinterpret_cast<int32_t *>(d_dst), d_cnt, (uint32_t)cap);
+        else cov_order<5><<<dim3(nb), dim3(256), 0, h->stream>>>(reinterpret_cast<const int32_t *>(d_raw), d_tres, d_ooff, (int64_t)nt, reinterpret_cast<int32_t *>(d_dst), d_cnt, (uint32_t)cap);
+        (void)hipEventRecord(eb, h->stream);
+        h->recs.push_back(cornetto_accel::Rec{"cov_order", ea, eb});
+        if (hipGetLastError() != hipSuccess) return cn_fail(h, CORNETTO_E_HIP, "cov_select: ordering failed");
+        if (packed) {
+            // the first record of every contig = the ordered offset of its first tile, picked on the device (4 B per contig to the host)
+            cov_ctg_first<<<dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, h->stream>>>(d_ooff, c->d_cw_first, c->n, (uint32_t)nt, d_cnt, d_cf);
+            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(p_cf, d_cf, (size_t)c->n * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess)
+                return cn_fail(h, CORNETTO_E_HIP, "cov_select: first records of the contigs failed");
+        }
         CN_HIP(h, hipMemcpyAsync(p_cnt, d_cnt, 8, hipMemcpyDeviceToHost, h->stream));
         CN_HIP(h, hipStreamSynchronize(h->stream));
         cnt = p_cnt[0];
@@ -618,29 +644,7 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
     cornetto_regrec_t *o = keep_on_device ? d_dst : (cornetto_regrec_t *)cn_result_alloc((cnt ? cnt : 1) * rec_bytes);
     if (!o) return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: host allocation failed");
     if (cnt) {
-        // tiles are in (contig, window) order: exclusive scan of their counts = final position of each segment
-        int rc = cnscan::exclusive_u32(h, "cov_order", reinterpret_cast<const uint32_t *>(d_tres) + 1, (int64_t)nt, 2, d_ooff, d_part, nullptr);
-        if (rc != CORNETTO_OK) { if (!keep_on_device) cornetto_free(o); return rc; }
-        const unsigned nb = (unsigned)((nt + 3) / 4);
-        hipEvent_t ea = cn_event(h), eb = cn_event(h);
-        (void)hipEventRecord(ea, h->stream);
-        if (packed) cov_order<2><<<dim3(nb), dim3(256), 0, h->stream>>>(reinterpret_cast<const int32_t *>(d_raw), d_tres, d_ooff, (int64_t)nt, reinterpret_cast<int32_t *>(d_dst));
-        else cov_order<5><<<dim3(nb), dim3(256), 0, h->stream>>>(reinterpret_cast<const int32_t *>(d_raw), d_tres, d_ooff, (int64_t)nt, reinterpret_cast<int32_t *>(d_dst));
-        (void)hipEventRecord(eb, h->stream);
-        h->recs.push_back(cornetto_accel::Rec{"cov_order", ea, eb});
-        if (hipGetLastError() != hipSuccess) return cn_fail(h, CORNETTO_E_HIP, "cov_select: ordering failed");
-        // packed: the first record of every contig = the ordered offset of its first tile, picked on the device (4 B per contig to the host)
-        uint32_t *p_cf = nullptr;
-        if (packed) {
-            p_cf = (uint32_t *)cn_pin(h, PIN_CW, ((size_t)c->n + 1) * 4);
-            uint32_t *d_cf = (uint32_t *)cn_ws(h, WS_CW_CF, ((size_t)c->n + 1) * 4);
-            if (!p_cf || !d_cf) return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: allocation failed");
-            cov_ctg_first<<<dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, h->stream>>>(d_ooff, c->d_cw_first, c->n, (uint32_t)nt, (uint32_t)cnt, d_cf);
-            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(p_cf, d_cf, (size_t)c->n * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess)
-                return cn_fail(h, CORNETTO_E_HIP, "cov_select: first records of the contigs failed");
-        }
-        if ((!keep_on_device && cn_result_d2h(h, o, d_dst, (size_t)cnt * rec_bytes) != hipSuccess) ||
-            ((!keep_on_device || packed) && hipStreamSynchronize(h->stream) != hipSuccess)) {
+        if (!keep_on_device && (cn_result_d2h(h, o, d_dst, (size_t)cnt * rec_bytes) != hipSuccess || (!h->lazy && hipStreamSynchronize(h->stream) != hipSuccess))) {
             cn_result_quiesce(h);
             cornetto_free(o);
             return cn_fail(h, CORNETTO_E_HIP, "cov_select: copy back failed");

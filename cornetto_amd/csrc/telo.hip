@@ -46,6 +46,7 @@ struct TfArgs {
     int32_t bordered;    // 0: heads/tails + bitmap; 1: all matches (lists 0 and 2)
     int32_t mode;        // 0: count only; 1: write at tile_off (dense lists); 2: write into fixed rows of TF_ROW
     unsigned long long *bitmap;
+    const int64_t *bm_off;   // first bit of every contig in the bitmap (multiples of 64: the contigs back to back, whatever lies between them in memory)
     int32_t *list0, *list1, *list2, *list3;   // mode 1: dense lists; mode 2: [tile][TF_ROW] rows
     const uint32_t *off0, *off1, *off2, *off3;   // mode 1: exclusive scan of the per-tile counts
     uint4 *tile_cnt;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
             q2 = Mr & ~((Mr << k) | (pR >> (64 - k)));
             q3 = Mr & ~((Mr >> k) | (nR << (64 - k)));
             if (A.bitmap && s0 >= 0 && s0 < len)
-                A.bitmap[(off + s0) >> 6] = smear(Mf, pF, k) | smear(Mr, pR, k);
+                A.bitmap[(A.bm_off[ctg] + s0) >> 6] = smear(Mf, pF, k) | smear(Mr, pR, k);
         }
     }
     // packed 4 x 16-bit exclusive scan over the workgroup (a tile holds < 2^15 heads per list)
@@ -574,6 +575,24 @@ int telowin_from_hits(cornetto_accel_t *h, const cornetto_hit_t *hits, int64_t n
 }
 
 // the whole telofind pass; optionally leaves the mark bitmap on the device (unbordered motifs)
+// the window layout of a resident assembly (it depends on the contig table only): built once, kept on the device with the object.  The marks of
+// the contigs lie back to back in the bitmap (a wrapped subset of a larger buffer — one rank's share — costs its own bases, not the span)
+int ensure_tw_layout(cornetto_accel_t *h, cornetto_asm_t *am)
+{
+    if (am->tw_n_words >= 0) return CORNETTO_OK;
+    const WinLayout L = win_layout_from_lengths(am->len.data(), am->n, nullptr);
+    if (!L.bit_off.empty()) {
+        const bool ok = hipMalloc((void **)&am->d_tw_boff, L.bit_off.size() * 8) == hipSuccess && hipMalloc((void **)&am->d_tw_tiles, (L.tiles.size() + 1) * sizeof(int2)) == hipSuccess &&
+                        hipMemcpyAsync(am->d_tw_boff, L.bit_off.data(), L.bit_off.size() * 8, hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+                        (L.tiles.empty() || hipMemcpyAsync(am->d_tw_tiles, L.tiles.data(), L.tiles.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream) == hipSuccess) &&
+                        hipStreamSynchronize(h->stream) == hipSuccess;
+        if (!ok) return cn_fail(h, CORNETTO_E_NOMEM, "telo_scan: device allocation failed");
+    }
+    am->tw_n_tiles = (int64_t)L.tiles.size();
+    am->tw_n_words = L.n_words;
+    return CORNETTO_OK;
+}
+
 int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *motif_c, cornetto_hit_t **hits,
                   int64_t *n_hits, bool want_bitmap_req, unsigned long long **bitmap_out, bool *bitmap_valid)
 {
@@ -657,16 +676,21 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
         const bool want_bitmap = want_bitmap_req && !bordered;
         unsigned long long *d_bitmap = nullptr;
         if (want_bitmap) {
-            int64_t last_end = 0;
-            for (int32_t c = 0; c < a->n; ++c) last_end = std::max(last_end, a->off[c] + a->len[c]);
-            const size_t words = (size_t)(cn_align_up(last_end, 64) / 64 + 4);
+            CN_TRY(ensure_tw_layout(h, a));
+            const size_t words = (size_t)a->tw_n_words;
             d_bitmap = (unsigned long long *)cn_ws(h, WS_TF_BITMAP, words * 8);
             if (!d_bitmap) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: bitmap allocation failed");
-            // every word of a contig is written by the kernel; the memset only covers padding between contigs.  (Skipping it when the block
-            // still holds this assembly's padding from the last call was measured: the bench step got 0.9 ms SLOWER, 9.1 against 8.2 ms — with
-            // the memset in front, the coverage kernels of this stream run 1.3 ms faster beside the resident sdust waves.  What the 49 MB fill
-            // changes is where those waves land while it runs; kept.)
-            CN_HIP(h, hipMemsetAsync(d_bitmap, 0, words * 8, h->stream));
+            // every word of a contig is written by the kernel; the memset only covers padding between contigs, and the padding of THIS
+            // assembly's layout stays zero in the block from one call to the next.  Skipped then for blocks up to 64 MB (round 4: the
+            // 1/8 share of the bench assembly, 49 MB, -0.07 ms of 0.39 per call).  Larger blocks keep the fill: measured twice (rounds 3
+            // and 4), the 3.16 Gbp bench step is 0.1-0.9 ms SLOWER without it — with the fill in front, the kernels of this stream find
+            // more room beside the resident sdust waves; what it changes is where those waves land while it runs.
+            static const int64_t keep_mb = [] { const char *v = getenv("CORNETTO_TF_BITMAP_KEEP_MB"); return v ? atoll(v) : 64ll; }();
+            if (!((int64_t)(words * 8) <= (keep_mb << 20) && h->tf_bm_uid == a->uid && h->tf_bm_ptr == d_bitmap && h->tf_bm_words == words)) {
+                h->tf_bm_uid = 0;
+                CN_HIP(h, hipMemsetAsync(d_bitmap, 0, words * 8, h->stream));
+                h->tf_bm_uid = a->uid; h->tf_bm_ptr = d_bitmap; h->tf_bm_words = words;
+            }
             if (bitmap_out) *bitmap_out = d_bitmap;
         }
         auto launch = [&](const TfArgs &A) -> int {
@@ -678,7 +702,7 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
         };
         TfArgs A{};
         A.bases = a->d_bases; A.ctg_off = a->d_off; A.ctg_len = a->d_len; A.tiles = a->d_tf_tiles; A.lut = d_lut; A.k = k; A.mot = d_mot;
-        A.bordered = bordered ? 1 : 0; A.bitmap = want_bitmap ? d_bitmap : nullptr; A.tile_cnt = d_tc; A.ovf = d_ovf;
+        A.bordered = bordered ? 1 : 0; A.bitmap = want_bitmap ? d_bitmap : nullptr; A.bm_off = a->d_tw_boff; A.tile_cnt = d_tc; A.ovf = d_ovf;
         // pass 1: single pass into fixed rows (unbordered motif, hits wanted), or counts only
         const bool rows_mode = hits && !bordered;
         int32_t *d_rows[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -854,22 +878,7 @@ int cornetto_telo_scan(cornetto_accel_t *h, const cornetto_asm_t *a, const char 
     int rc = telofind_impl(h, a, motif, need_hits ? &hh : nullptr, need_hits ? &nh : nullptr, true, &d_bitmap, &valid);
     if (rc == CORNETTO_OK) {
         if (valid) {
-            // the window layout depends on the contig table only: built once, kept on the device with the resident assembly
-            cornetto_asm_t *am = const_cast<cornetto_asm_t *>(a);
-            if (am->tw_n_words < 0) {
-                const WinLayout L = win_layout_from_lengths(a->len.data(), a->n, a->off.data());
-                if (!L.tiles.empty()) {
-                    const bool ok = hipMalloc((void **)&am->d_tw_boff, L.bit_off.size() * 8) == hipSuccess && hipMalloc((void **)&am->d_tw_tiles, L.tiles.size() * sizeof(int2)) == hipSuccess &&
-                                    hipMemcpyAsync(am->d_tw_boff, L.bit_off.data(), L.bit_off.size() * 8, hipMemcpyHostToDevice, h->stream) == hipSuccess &&
-                                    hipMemcpyAsync(am->d_tw_tiles, L.tiles.data(), L.tiles.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
-                                    hipStreamSynchronize(h->stream) == hipSuccess;
-                    if (!ok) rc = cn_fail(h, CORNETTO_E_NOMEM, "telo_scan: device allocation failed");
-                }
-                if (rc == CORNETTO_OK) {
-                    am->tw_n_tiles = (int64_t)L.tiles.size();
-                    am->tw_n_words = L.n_words;
-                }
-            }
+            cornetto_asm_t *am = const_cast<cornetto_asm_t *>(a);   // (its window layout was built with the bitmap: ensure_tw_layout)
             if (rc == CORNETTO_OK) rc = run_tw_scan_dev(h, d_bitmap, am->d_tw_boff, am->d_tw_tiles, (size_t)am->tw_n_tiles, a->d_len, thr_adj, wins, n_wins);
         } else {
             rc = telowin_from_hits(h, hh, nh, a->len.data(), a->n, thr_adj, wins, n_wins);

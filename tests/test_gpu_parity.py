@@ -505,6 +505,62 @@ def test_sdust_largest_window_on_homopolymers(acc):
     asm.close()
 
 
+def test_telo_scan_repeated_on_one_handle_with_changing_assemblies(acc):
+    """the mark bitmap block of a handle keeps the zero padding of the last assembly's layout from one call to the next (no fill
+    in front of the second scan of the same assembly): alternate two layouts, change a contig's bytes in place between calls, change
+    the motif — the windows and the runs follow the oracle every time"""
+    rng = np.random.default_rng(404)
+    thr = acc.telowin_threshold(0.4, 99.9)
+
+    def make(n_seq, top):
+        seqs = []
+        for _ in range(n_seq):
+            n = int(rng.integers(1, top))
+            s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].copy()
+            for motif in (b"TTAGGG", b"CCCTAA", b"AAAA"):
+                if n > 4000:
+                    p = int(rng.integers(0, n - 3000))
+                    rep = np.frombuffer(motif * int(rng.integers(50, 400)), dtype=np.uint8)[: n - p]
+                    s[p:p + len(rep)] = rep
+            seqs.append(s)
+        return seqs
+
+    def check(asm, seqs, motif):
+        hits, wins = acc.telo_scan(asm, motif, thr)
+        exp_h, exp_w = [], []
+        for ci, s in enumerate(seqs):
+            oh = ob.telofind(s, motif)
+            exp_h += [(ci, int(h["strand"]), int(h["start"]), int(h["end"])) for h in oh]
+            exp_w += [(ci, int(w["start"]), int(w["end"]), int(w["car"])) for w in ob.telowin(oh, len(s), thr)]
+        assert [tuple(map(int, h)) for h in hits] == exp_h, motif
+        assert [tuple(map(int, w)) for w in wins] == exp_w, motif
+
+    big, small = make(12, 60000), make(30, 9000)
+    a_big, a_small = acc.asm_upload(big), acc.asm_upload(small)
+    for asm, seqs, motif in ((a_big, big, b"TTAGGG"), (a_big, big, b"TTAGGG"), (a_big, big, b"AAAA"), (a_small, small, b"TTAGGG"), (a_small, small, b"CCCTAA"),
+                             (a_big, big, b"CCCTAA"), (a_big, big, b"TTAGGG"), (a_small, small, b"TTAGGG"), (a_small, small, b"TTAGGG")):
+        check(asm, seqs, motif)
+    a_small.close()
+    # the same resident object, other bytes: fewer marks than the call before left in the block
+    import torch
+    flat = torch.zeros(sum((len(s) + 63) // 64 * 64 for s in big), dtype=torch.uint8, device="cuda")
+    offs, o = [], 0
+    for s in big:
+        offs.append(o)
+        flat[o:o + len(s)] = torch.from_numpy(s).cuda()
+        o += (len(s) + 63) // 64 * 64
+    w = acc.asm_wrap(flat.data_ptr(), np.array(offs, dtype=np.int64), np.array([len(s) for s in big], dtype=np.int64))
+    check(w, big, b"TTAGGG")
+    check(w, big, b"TTAGGG")
+    plain = [np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=len(s))].copy() for s in big]
+    for s, o in zip(plain, offs):
+        flat[o:o + len(s)] = torch.from_numpy(s).cuda()
+    torch.cuda.synchronize()
+    check(w, plain, b"TTAGGG")
+    w.close()
+    a_big.close()
+
+
 def test_telofind_random_vs_oracle(acc):
     rng = np.random.default_rng(99)
     for motif in (b"TTAGGG", b"CCCTAA", b"TTTAGGG", b"AC", b"A", b"ACGTACGTACGTACGTACGTACGTACGTACGT", b"TTAGGGTTAGGGTTAGG",

@@ -30,6 +30,8 @@ asm = acc.asm_wrap(bases.data_ptr(), o, ln)
 cov = acc.cov_wrap(depth.data_ptr(), mq.data_ptr(), o, ln.astype(np.int32))
 thr = acc.telowin_threshold(0.4, 99.9)
 print("share: %d contigs, %.1f Mbases" % (len(own), ln.sum() / 1e6))
+if os.environ.get("PERF_LAZY") == "1":        # result copies on the handle's copy stream, met at wait() (what the bench's second thread does)
+    acc.set_lazy(True)
 
 
 def timed(name, fn):
@@ -39,6 +41,7 @@ def timed(name, fn):
     t0 = time.perf_counter()
     for _ in range(reps):
         fn()
+        acc.wait()
     wall = (time.perf_counter() - t0) / reps * 1e3
     acc.set_timing(2)
     fn()

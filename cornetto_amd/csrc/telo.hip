@@ -680,13 +680,12 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
             const size_t words = (size_t)a->tw_n_words;
             d_bitmap = (unsigned long long *)cn_ws(h, WS_TF_BITMAP, words * 8);
             if (!d_bitmap) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: bitmap allocation failed");
-            // every word of a contig is written by the kernel; the memset only covers padding between contigs, and the padding of THIS
-            // assembly's layout stays zero in the block from one call to the next.  Skipped then for blocks up to 64 MB (round 4: the
-            // 1/8 share of the bench assembly, 49 MB, -0.07 ms of 0.39 per call).  Larger blocks keep the fill: measured twice (rounds 3
-            // and 4), the 3.16 Gbp bench step is 0.1-0.9 ms SLOWER without it — with the fill in front, the kernels of this stream find
-            // more room beside the resident sdust waves; what it changes is where those waves land while it runs.
-            static const int64_t keep_mb = [] { const char *v = getenv("CORNETTO_TF_BITMAP_KEEP_MB"); return v ? atoll(v) : 64ll; }();
-            if (!((int64_t)(words * 8) <= (keep_mb << 20) && h->tf_bm_uid == a->uid && h->tf_bm_ptr == d_bitmap && h->tf_bm_words == words)) {
+            // every word of a contig is written by the kernel; the memset only covers the padding behind the last contig, and that stays zero in
+            // the block from one call for THIS assembly's layout to the next: filled once per (assembly, block).  (Round 4, five bench runs each
+            // way: 7.84-7.90 ms per 3.16 Gbp step without the 395 MB fill, 7.87-7.94 with it, one slow run of 8.2 in either; the 1/8 share of the
+            // assembly 0.31 instead of 0.39 ms per call.  Round 3 had measured the opposite with the telomere scan first in the step.)
+            static const int refill = [] { const char *v = getenv("CORNETTO_TF_BITMAP_REFILL"); return v ? atoi(v) : 0; }();
+            if (refill || !(h->tf_bm_uid == a->uid && h->tf_bm_ptr == d_bitmap && h->tf_bm_words == words)) {
                 h->tf_bm_uid = 0;
                 CN_HIP(h, hipMemsetAsync(d_bitmap, 0, words * 8, h->stream));
                 h->tf_bm_uid = a->uid; h->tf_bm_ptr = d_bitmap; h->tf_bm_words = words;

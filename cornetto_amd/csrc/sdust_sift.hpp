@@ -170,9 +170,15 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
     const unsigned long long below = lane ? ~0ull >> (64 - lane) : 0ull;
     const unsigned long long mc = lo > 0 ? below & (~0ull << lo) : below;
     const unsigned long long mp = lo < 0 ? ~0ull << (64 + lo) : 0ull;
-    const uint32_t mc_lo = (uint32_t)mc, mc_hi = (uint32_t)(mc >> 32), mp_lo = (uint32_t)mp, mp_hi = (uint32_t)(mp >> 32);
+    // A lane of the lower half never needs the upper half of this tile's table (those lanes lie behind it), a lane of the upper half never
+    // the lower half of the table before (W - 3 <= 63 positions back ends above lane 32 there): three gathers per tile, not four.  The four
+    // 64-entry tables lie as [T0 lo][T1 lo][T1 hi][T0 hi] (T0 = the tiles of parity 0), which puts the "middle" table of a lane — the lower
+    // half before / the upper half now — at one per-lane base plus a constant for either parity.
+    const uint32_t m_a = (uint32_t)mc, m_d = (uint32_t)(mp >> 32), m_m = lane < 32 ? (uint32_t)mp : (uint32_t)(mc >> 32);
     const uint32_t mybit = 1u << (lane & 31);
-    uint32_t *const tab_mine = tab + ((lane >> 5) << 6);     // the table of this lane's half (of parity 0)
+    uint32_t *const mine0 = tab + (lane < 32 ? 0 : 192), *const mine1 = tab + (lane < 32 ? 64 : 128);   // tiles: this tile's table of this lane's half, parity 0 / 1
+    uint32_t *const tab_mine = mine0;                         // resolve (window reads): the table of this lane's half, [T0 lo] / [T0 hi]
+    const uint32_t *const mid1 = tab + (lane < 32 ? 0 : 128);   // the middle table at parity 1; at parity 0: + 64
     const int thr = A.thr, lmin = A.lmin;             // c > T / 10; the partial sums of L1 have lmin terms
     const int LS = CAPW - 1 < SIFT_LS ? CAPW - 1 : SIFT_LS;
     const bool long_ok = CAPW - 1 > LS;               // suffixes longer than the walk exist
@@ -508,20 +514,21 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
     auto tile = [&](auto par_c, auto general_c, auto only_c, const int q) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_c)::value;
         constexpr bool GENERAL = decltype(general_c)::value, TABLE_ONLY = decltype(only_c)::value;
-        constexpr int CUR = PAR * 128, PREV = (PAR ^ 1) * 128;
+        constexpr int A_AT = PAR ? 64 : 0, D_AT = PAR ? 192 : 128, M_AT = PAR ? 0 : 64;     // this tile's lower half, the upper half before, the middle
+        constexpr int Z0 = PAR ? 0 : 64, Z1 = PAR ? 192 : 128;                              // the two tables of the tile before
         // (the tile in front of a chunk as well: its first two words reach in front of the region, and a byte there that is not a
         // letter — it does not make the chunk unclean — leaves them without a word: bit 6)
         constexpr bool CHECK = GENERAL || TABLE_ONLY;
         const uint32_t wv = pq[0];
         const bool valid = !CHECK || (wv < 64u && q * 64 + lane < rlen);
         const uint32_t wi = CHECK ? wv & 63u : wv;
-        if (valid) (void)__hip_atomic_fetch_or(&tab_mine[CUR + wi], mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (valid) (void)__hip_atomic_fetch_or(&(PAR ? mine1 : mine0)[wi], mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         SD_LDS_ORDER();
-        const uint32_t ec_lo = tab[CUR + wi], ec_hi = tab[CUR + 64 + wi], ep_lo = tab[PREV + wi], ep_hi = tab[PREV + 64 + wi];
+        const uint32_t e_a = tab[A_AT + wi], e_m = mid1[M_AT + wi], e_d = tab[D_AT + wi];
         SD_LDS_ORDER();
-        tab[PREV + lane] = 0;                          // the tables of the tile before become the tables of the next tile
-        tab[PREV + 64 + lane] = 0;
-        const int ct = __popc(ec_lo & mc_lo) + __popc(ec_hi & mc_hi) + __popc(ep_lo & mp_lo) + __popc(ep_hi & mp_hi);
+        tab[Z0 + lane] = 0;                            // the tables of the tile before become the tables of the next tile
+        tab[Z1 + lane] = 0;
+        const int ct = __popc(e_a & m_a) + __popc(e_m & m_m) + __popc(e_d & m_d);
         pq[1] = (uint8_t)(TABLE_ONLY ? 255 : (valid ? ct : 0));      // (no word there: nothing to count)
         pq += 128;
         if (!TABLE_ONLY) {
@@ -620,8 +627,8 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
     } else if (lane == 0) {
         sw &= ~3ull;
     }
-    tab[lane] = 0;                                    // (the equal-word table of the window reads: the first pair)
-    tab[64 + lane] = 0;
+    tab[lane] = 0;                                    // (the equal-word table of the window reads: the pair of parity 0)
+    tab[192 + lane] = 0;
     SD_LDS_ORDER();
 
     int cur = 0;                                      // (a position of the contig)
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
         w = ok ? (int)(wc[2 * (o - lane)] & 63u) : 0;      // (& 63: W = 65, 66 read the region's first two words at their first step, see above)
         if (ok) (void)__hip_atomic_fetch_or(&tab_mine[w], mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         SD_LDS_ORDER();
-        const unsigned long long e = (unsigned long long)tab[w] | (unsigned long long)tab[64 + w] << 32;
+        const unsigned long long e = (unsigned long long)tab[w] | (unsigned long long)tab[192 + w] << 32;
         SD_LDS_ORDER();
         if (ok) tab_mine[w] = 0;
         SD_LDS_ORDER();

@@ -826,7 +826,7 @@ class Rank:
         for _ in range(2):                             # (the result pools of a new workload grow in its first steps: not the share's doing)
             self.step(False)
         best, seen = None, {}
-        for sh in (85, 72, 92, 100, 85):               # (the first one twice: the first candidate measured is the one that pays for what is still warming up)
+        for sh in (85, 80, 76, 72, 92, 100, 85):       # (the first one twice: the first candidate measured is the one that pays for what is still warming up)
             self.acc2.set_share(sh)
             self.step(False)
             self.torch.cuda.synchronize()

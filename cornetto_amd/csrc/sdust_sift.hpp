@@ -442,26 +442,65 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
         const bool on = lane < nb;
         const int o = on ? (int)tl2[lane] : 0;
         const uint8_t *const p = wc + 2 * o;
+        // the reference-shaped form: every term with its own tests (windows of less than SIFT_K + 1 words; batches in which a walk meets a
+        // position without a word — the first words of a contig, another byte in the halo)
+        auto exact = [&]() {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) cnt[j * 64 + lane] = 0;
-        int d = 0, dmin = 0x7fffffff;
+            for (int j = 0; j < 8; ++j) cnt[j * 64 + lane] = 0;
+            int d = 0, dmin = 0x7fffffff;
 #pragma unroll
-        for (int j = 0; j < SIFT_K; ++j) {
-            d += 10 * (int)p[1 - 2 * j] - T;
-            dmin = d < dmin ? d : dmin;
+            for (int j = 0; j < SIFT_K; ++j) {
+                d += 10 * (int)p[1 - 2 * j] - T;
+                dmin = d < dmin ? d : dmin;
+            }
+            SD_LDS_ORDER();
+            int rr = 0;
+            bool alive = on, sc = false;
+            for (int a = 0; a <= LS; ++a) {
+                const uint32_t wv = p[-2 * a];
+                alive = alive && wv < 64u;
+                const uint32_t sh = (wv & 7u) << 2;
+                const uint32_t old = __hip_atomic_fetch_add(&cnt[((wv >> 3) & 7u) * 64 + lane], alive ? 1u << sh : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                rr += alive ? (int)((old >> sh) & 15u) : 0;
+                sc = sc | (alive & (a >= 1) & (__mul24(rr, 10) > T * a));        // (no short circuit: one compare instead of an exec-mask branch per step; rr <= 120)
+            }
+            return on && (sc || (dmin > 0 && long_ok));
+        };
+        bool keep;
+        if (LS == SIFT_LS) {
+            // Every window but the shortest: the sums and the walk look at the same SIFT_K positions, word and count come in one 16-bit
+            // read, and the tests are compares against floor(k T / 10) (10 S > k T  <=>  S > floor(k T / 10)), made by the scalar unit
+            // for this batch.  Positions without a word are not tested per term: their bits are collected, and a batch that met one runs again
+            // in the exact form (a dozen VALU per term here, nineteen there).
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cnt[j * 64 + lane] = 0;
+            const uint16_t *const p16 = reinterpret_cast<const uint16_t *>(p);
+            uint8_t *const cl = reinterpret_cast<uint8_t *>(cnt + lane);
+            uint32_t S = 0, rr = 0, seen = 0;
+            bool pos = true, sc = false;
+            uint32_t tt = (uint32_t)T;
+            asm volatile("" : "+s"(tt));               // (the thresholds are made here, per batch: kept across the chunk loop they cost spilled scalar registers)
+            SD_LDS_ORDER();
+#pragma unroll 4
+            for (int a = 0; a < SIFT_K; ++a) {         // (four terms in flight: all sixteen returns at once do not fit the registers)
+                const uint32_t x = p16[-a];
+                seen |= x;
+                S += x >> 8;
+                pos = pos & (S > (tt * (uint32_t)(a + 1)) / 10u);
+                const uint32_t old = __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(cl + (__builtin_amdgcn_ubfe(x, 3, 3) << 8)), 1u << ((x << 2) & 31u), __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_WORKGROUP);
+                rr += __builtin_amdgcn_ubfe(old, x << 2, 4);
+                if (a >= 1) sc = sc | (rr > (tt * (uint32_t)a) / 10u);
+            }
+            if (sd_any(on && (seen & 0xC0u) != 0u)) {
+                SD_LDS_ORDER();
+                keep = exact();
+            } else {
+                keep = on && (sc || (pos && long_ok));
+            }
+        } else {
+            keep = exact();
         }
-        SD_LDS_ORDER();
-        int rr = 0;
-        bool alive = on, sc = false;
-        for (int a = 0; a <= LS; ++a) {
-            const uint32_t wv = p[-2 * a];
-            alive = alive && wv < 64u;
-            const uint32_t sh = (wv & 7u) << 2;
-            const uint32_t old = __hip_atomic_fetch_add(&cnt[((wv >> 3) & 7u) * 64 + lane], alive ? 1u << sh : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            rr += alive ? (int)((old >> sh) & 15u) : 0;
-            sc = sc | (alive & (a >= 1) & (__mul24(rr, 10) > T * a));        // (no short circuit: one compare instead of an exec-mask branch per step; rr <= 120)
-        }
-        const bool keep = on && (sc || (dmin > 0 && long_ok));
         if (STATS) st_l2 += (unsigned long long)__popcll(sd_ballot(keep));
         if (keep) (void)__hip_atomic_fetch_or(&sb[o >> 5], 1u << (o & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };

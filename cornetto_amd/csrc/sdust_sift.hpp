@@ -550,6 +550,16 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
     // PAR: parity of the tile (which pair of tables is "this tile").  GENERAL: lanes without a word (the first two positions of
     // a contig, behind its end) stay out of the tables.  TABLE_ONLY: the first tile in front of a chunk.
     uint8_t *pq = wc + 2 * lane;                      // this lane's position in the current tile
+    // the three table addresses of a tile, one shift-add each (written out: the compiler shares the shift and pays an add per base, one of them
+    // the addition of the block's LDS offset, which is zero)
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    const uint32_t tab_a = (uint32_t)(uintptr_t)(lds_u32 *)tab, mine0_a = (uint32_t)(uintptr_t)(lds_u32 *)mine0, mine1_a = (uint32_t)(uintptr_t)(lds_u32 *)mine1,
+                   mid1_a = (uint32_t)(uintptr_t)(lds_u32 *)mid1;
+    auto lds_at = [](uint32_t wi, uint32_t base) __attribute__((always_inline)) {
+        uint32_t a;
+        asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a) : "v"(wi), "v"(base));
+        return (lds_u32 *)(uintptr_t)a;
+    };
     auto tile = [&](auto par_c, auto general_c, auto only_c, const int q) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_c)::value;
         constexpr bool GENERAL = decltype(general_c)::value, TABLE_ONLY = decltype(only_c)::value;
@@ -561,13 +571,17 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
         const uint32_t wv = pq[0];
         const bool valid = !CHECK || (wv < 64u && q * 64 + lane < rlen);
         const uint32_t wi = CHECK ? wv & 63u : wv;
-        if (valid) (void)__hip_atomic_fetch_or(&(PAR ? mine1 : mine0)[wi], mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lds_u32 *const t_mine = lds_at(wi, PAR ? mine1_a : mine0_a), *const t_all = lds_at(wi, tab_a), *const t_mid = lds_at(wi, mid1_a);
+        if (valid) (void)__hip_atomic_fetch_or(t_mine, mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         SD_LDS_ORDER();
-        const uint32_t e_a = tab[A_AT + wi], e_m = mid1[M_AT + wi], e_d = tab[D_AT + wi];
+        const uint32_t e_a = t_all[A_AT], e_m = t_mid[M_AT], e_d = t_all[D_AT];
         SD_LDS_ORDER();
         tab[Z0 + lane] = 0;                            // the tables of the tile before become the tables of the next tile
         tab[Z1 + lane] = 0;
-        const int ct = __popc(e_a & m_a) + __popc(e_m & m_m) + __popc(e_d & m_d);
+        uint32_t ctu = (uint32_t)__popc(e_a & m_a);
+        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(ctu) : "v"(e_m & m_m));      // (the count's own adder: the compiler sums three counts with a fourth instruction)
+        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(ctu) : "v"(e_d & m_d));
+        const int ct = (int)ctu;
         pq[1] = (uint8_t)(TABLE_ONLY ? 255 : (valid ? ct : 0));      // (no word there: nothing to count)
         pq += 128;
         if (!TABLE_ONLY) {

@@ -436,6 +436,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
         return;
     }
 
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
     int ntl = 0, ntl2 = 0;                            // (uniform) entries in the two lists
     // L2: the 16-term sums (every candidate of more than 16 words needs them positive), the exact walk over the shorter suffixes
     auto run_l2 = [&](int nb) {
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
 #pragma unroll
             for (int j = 0; j < 8; ++j) cnt[j * 64 + lane] = 0;
             const uint16_t *const p16 = reinterpret_cast<const uint16_t *>(p);
-            uint8_t *const cl = reinterpret_cast<uint8_t *>(cnt + lane);
+            const uint32_t cl_a = (uint32_t)(uintptr_t)(lds_u32 *)(tab + lane);       // (the counters lie 1536 bytes behind the tables: the offset rides in the instruction)
             uint32_t S = 0, rr = 0, seen = 0;
             bool pos = true, sc = false;
             uint32_t tt = (uint32_t)T;
@@ -485,10 +486,11 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
             for (int a = 0; a < SIFT_K; ++a) {         // (four terms in flight: all sixteen returns at once do not fit the registers)
                 const uint32_t x = p16[-a];
                 seen |= x;
-                S += x >> 8;
+                asm("v_add_u32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "+v"(S) : "v"(x));   // S += x >> 8
                 pos = pos & (S > (tt * (uint32_t)(a + 1)) / 10u);
-                const uint32_t old = __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(cl + (__builtin_amdgcn_ubfe(x, 3, 3) << 8)), 1u << ((x << 2) & 31u), __ATOMIC_RELAXED,
-                                                            __HIP_MEMORY_SCOPE_WORKGROUP);
+                uint32_t row;                                              // the counter word of this lane for the word's upper three bits
+                asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(row) : "v"(__builtin_amdgcn_ubfe(x, 3, 3)), "v"(cl_a));
+                const uint32_t old = __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)row + 384, 1u << ((x << 2) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 rr += __builtin_amdgcn_ubfe(old, x << 2, 4);
                 if (a >= 1) sc = sc | (rr > (tt * (uint32_t)a) / 10u);
             }
@@ -511,11 +513,12 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
         const uint8_t *const p = wc + 2 * o;
         int d = 0, dmin = 0x7fffffff;
         if (lmin == 4) {                              // (T = 16 .. 20, the default among them: the four reads in flight together)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                d += 10 * (int)p[1 - 2 * j] - T;
-                dmin = d < dmin ? d : dmin;
-            }
+            // 10 S_j > (j + 1) T  <=>  S_j > floor((j + 1) T / 10): an add and a compare per term, the floors by the scalar unit
+            uint32_t tt = (uint32_t)T;
+            asm volatile("" : "+s"(tt));
+            const uint32_t c0 = p[1], c1 = p[-1], c2 = p[-3], c3 = p[-5];
+            const uint32_t s1 = c0 + c1, s2 = s1 + c2, s3 = s2 + c3;
+            dmin = ((c0 > tt / 10u) & (s1 > (2u * tt) / 10u) & (s2 > (3u * tt) / 10u) & (s3 > (4u * tt) / 10u)) ? 1 : 0;
         } else {
             for (int j = 0; j < lmin; ++j) {
                 d += 10 * (int)p[1 - 2 * j] - T;
@@ -552,7 +555,6 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
     uint8_t *pq = wc + 2 * lane;                      // this lane's position in the current tile
     // the three table addresses of a tile, one shift-add each (written out: the compiler shares the shift and pays an add per base, one of them
     // the addition of the block's LDS offset, which is zero)
-    typedef __attribute__((address_space(3))) uint32_t lds_u32;
     const uint32_t tab_a = (uint32_t)(uintptr_t)(lds_u32 *)tab, mine0_a = (uint32_t)(uintptr_t)(lds_u32 *)mine0, mine1_a = (uint32_t)(uintptr_t)(lds_u32 *)mine1,
                    mid1_a = (uint32_t)(uintptr_t)(lds_u32 *)mid1;
     auto lds_at = [](uint32_t wi, uint32_t base) __attribute__((always_inline)) {
@@ -589,7 +591,11 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
             const unsigned long long m = sd_ballot(trig);
             if (m) {
                 if (STATS) st_trig += (unsigned long long)__popcll(m);
-                if (trig) tl[ntl + sd_mbcnt64(m)] = (uint16_t)(q * 64 + lane);
+                // (every lane stores, the others into one entry behind the list: a select instead of an exec-mask region — three scalar
+                // instructions of a loop that issues more scalar than vector instructions)
+                int idx;                                   // trig ? its rank among the sifted lanes : 64 — entry ntl + 64 lies behind everything the list holds
+                asm("v_cndmask_b32_e64 %0, 64, %1, %2" : "=v"(idx) : "v"(sd_mbcnt64(m)), "s"(m));
+                (tl + ntl)[idx] = (uint16_t)(q * 64 + lane);
                 ntl += __popcll(m);
                 SD_LDS_ORDER();
                 if (ntl >= 64) {

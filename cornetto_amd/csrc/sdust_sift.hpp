@@ -479,7 +479,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
             const uint32_t cl_a = (uint32_t)(uintptr_t)(lds_u32 *)(tab + lane);       // (the counters lie 1536 bytes behind the tables: the offset rides in the instruction)
             uint32_t S = 0, rr = 0, seen = 0;
             bool pos = true, sc = false;
-            uint32_t tt = (uint32_t)T;
+            uint32_t tt = (uint32_t)T, th0 = 0;
             asm volatile("" : "+s"(tt));               // (the thresholds are made here, per batch: kept across the chunk loop they cost spilled scalar registers)
             SD_LDS_ORDER();
 #pragma unroll 4
@@ -487,12 +487,14 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
                 const uint32_t x = p16[-a];
                 seen |= x;
                 asm("v_add_u32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "+v"(S) : "v"(x));   // S += x >> 8
-                pos = pos & (S > (tt * (uint32_t)(a + 1)) / 10u);
+                const uint32_t th1 = (tt * (uint32_t)(a + 1)) / 10u;      // floor((a + 1) T / 10): this term's bound for the sums, the next term's for the walk
+                pos = pos & (S > th1);
                 uint32_t row;                                              // the counter word of this lane for the word's upper three bits
                 asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(row) : "v"(__builtin_amdgcn_ubfe(x, 3, 3)), "v"(cl_a));
                 const uint32_t old = __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)row + 384, 1u << ((x << 2) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 rr += __builtin_amdgcn_ubfe(old, x << 2, 4);
-                if (a >= 1) sc = sc | (rr > (tt * (uint32_t)a) / 10u);
+                if (a >= 1) sc = sc | (rr > th0);
+                th0 = th1;
             }
             if (sd_any(on && (seen & 0xC0u) != 0u)) {
                 SD_LDS_ORDER();

@@ -482,9 +482,12 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
             uint32_t tt = (uint32_t)T, th0 = 0;
             asm volatile("" : "+s"(tt));               // (the thresholds are made here, per batch: kept across the chunk loop they cost spilled scalar registers)
             SD_LDS_ORDER();
+            uint32_t xn = p16[0];
 #pragma unroll 4
             for (int a = 0; a < SIFT_K; ++a) {         // (four terms in flight: all sixteen returns at once do not fit the registers)
-                const uint32_t x = p16[-a];
+                const uint32_t x = xn;
+                xn = p16[-(a + 1)];                    // (the next term's read travels with this term's counter update; the last one reads the pad)
+                asm("" : "+v"(xn));
                 seen |= x;
                 asm("v_add_u32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "+v"(S) : "v"(x));   // S += x >> 8
                 const uint32_t th1 = (tt * (uint32_t)(a + 1)) / 10u;      // floor((a + 1) T / 10): this term's bound for the sums, the next term's for the walk
@@ -564,6 +567,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
         asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a) : "v"(wi), "v"(base));
         return (lds_u32 *)(uintptr_t)a;
     };
+    uint32_t wv_ahead = pq[0];
     auto tile = [&](auto par_c, auto general_c, auto only_c, const int q) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_c)::value;
         constexpr bool GENERAL = decltype(general_c)::value, TABLE_ONLY = decltype(only_c)::value;
@@ -572,7 +576,9 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
         // (the tile in front of a chunk as well: its first two words reach in front of the region, and a byte there that is not a
         // letter — it does not make the chunk unclean — leaves them without a word: bit 6)
         constexpr bool CHECK = GENERAL || TABLE_ONLY;
-        const uint32_t wv = pq[0];
+        const uint32_t wv = wv_ahead;                   // (read one tile ahead: the word bytes do not change while the tiles run, and the
+        wv_ahead = pq[128];                           //  next tile's first LDS round trip overlaps this tile's; behind the region: nobody's bytes)
+        asm("" : "+v"(wv_ahead));                      // (a 32-bit value as it comes from the byte load: no second zero extension)
         const bool valid = !CHECK || (wv < 64u && q * 64 + lane < rlen);
         const uint32_t wi = CHECK ? wv & 63u : wv;
         lds_u32 *const t_mine = lds_at(wi, PAR ? mine1_a : mine0_a), *const t_all = lds_at(wi, tab_a), *const t_mid = lds_at(wi, mid1_a);

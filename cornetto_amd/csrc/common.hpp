@@ -313,7 +313,7 @@ struct cornetto_cov {
     int32_t w = 0, inc = 0;
     std::vector<int64_t> blk_off;      // first block-sum slot of contig i
     int64_t n_blk = 0;
-    uint32_t *d_blk = nullptr;         // [n_blk][4] = full depth, head depth, full mq, head mq
+    uint32_t *d_blk = nullptr;         // prefixes [n_blk] {depth, mq}, heads [n_blk] {depth, mq} (cov.hip: CbArgs), the tile offsets
     int64_t *d_blk_off = nullptr;
     uint64_t sums[3] = {0, 0, 0};
     // cached work decompositions

@@ -36,7 +36,8 @@ struct CbArgs {
     const int32_t *ctg_len;
     const int2 *tiles;         // {ctg, first block of the tile within the contig}
     int32_t inc, r;            // block size, head size (w % inc)
-    uint4 *blk;                // [tile*256 + b] = {local inclusive prefix depth, head depth, prefix mq, head mq}
+    uint2 *pre;                // [tile*256 + b] = local inclusive prefix {depth, mq} of the block sums
+    uint2 *head;               // [tile*256 + b] = {depth, mq} sums of the block's first r positions (r > 0 only: w not a multiple of inc)
     int64_t n_tiles;
     uint2 *tile_tot32;         // wrapping tile totals {depth, mq}
     ulonglong2 *tile_tot64;    // exact tile totals
@@ -245,7 +246,8 @@ __global__ __launch_bounds__(CB_THREADS) void cov_blocks(CbArgs A)
             pd += wsum[0][i];
             pq += wsum[1][i];
         }
-    A.blk[(size_t)tix * CB_THREADS + t] = make_uint4(sdv + pd, hd, sqv + pq, hq);
+    A.pre[(size_t)tix * CB_THREADS + t] = make_uint2(sdv + pd, sqv + pq);
+    if (A.r) A.head[(size_t)tix * CB_THREADS + t] = make_uint2(hd, hq);
     if (t == CB_THREADS - 1) {
         A.tile_tot32[tix] = make_uint2(sdv + pd, sqv + pq);
         ulonglong2 x;
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void cov_total64(const ulonglong2 *tot64, int6
 }
 
 struct CwArgs {
-    const uint4 *blk;
+    const uint2 *pre, *head;   // what cov_blocks left (8 B per block each: a window reads two prefixes, the head only when w % inc != 0)
     const uint32_t *toff_d, *toff_q;   // exclusive prefix of the tile totals (wrapping)
     const int64_t *blk_off;    // first global block of each contig (multiple of 256)
     const int32_t *ctg_len;
@@ -310,8 +312,8 @@ struct CwArgs {
 
 __device__ __forceinline__ uint2 cw_prefix(const CwArgs &A, int64_t x)   // inclusive global prefix at block x
 {
-    const uint4 b = A.blk[x];
-    return make_uint2(b.x + A.toff_d[x >> 8], b.z + A.toff_q[x >> 8]);
+    const uint2 b = A.pre[x];
+    return make_uint2(b.x + A.toff_d[x >> 8], b.y + A.toff_q[x >> 8]);
 }
 
 __global__ __launch_bounds__(256) void cov_windows(CwArgs A)
@@ -340,9 +342,9 @@ __global__ __launch_bounds__(256) void cov_windows(CwArgs A)
         // prefix is continuous across contigs, so G[a+q-1] - G[a-1] is the sum over exactly [a, a+q)
         uint32_t sd = hi.x - lo.x, sq = hi.y - lo.y;
         if (A.r) {
-            const uint4 hb = A.blk[a + A.q];
-            sd += hb.y;
-            sq += hb.w;
+            const uint2 hb = A.head[a + A.q];
+            sd += hb.x;
+            sq += hb.y;
         }
         // :360-361 (positions >= len contributed zero).  Nearly every window is w long and its sums are below 2^31: the division is a
         // multiplication by a reciprocal the host made for w (exact for 0 <= n < 2^31); anything else divides
@@ -469,7 +471,7 @@ int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int3
         if (c->d_n_reg) { (void)hipFree(c->d_n_reg); c->d_n_reg = nullptr; }
         const size_t nt = tiles.size();
         if (nt == 0) { cn_timing_end(h); return CORNETTO_OK; }
-        // blk [n_blk] uint4, then two arrays of tile offsets [nt] u32 each
+        // prefixes [n_blk] uint2, heads [n_blk] uint2, then two arrays of tile offsets [nt] u32 each
         if (hipMalloc((void **)&c->d_blk, (size_t)c->n_blk * sizeof(uint4) + 2 * nt * sizeof(uint32_t)) != hipSuccess ||
             hipMalloc((void **)&c->d_blk_off, (size_t)(c->n + 1) * 8) != hipSuccess ||
             hipMalloc((void **)&c->d_cb_tiles, nt * sizeof(int2)) != hipSuccess ||
@@ -488,10 +490,10 @@ int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int3
     unsigned long long *p_grand = (unsigned long long *)cn_pin(h, PIN_SMALL, 64);
     if (!d_t32 || !d_t64 || !d_grand || !p_grand) return cn_fail(h, CORNETTO_E_NOMEM, "cov_prepare: workspace allocation failed");
     uint32_t *d_part = reinterpret_cast<uint32_t *>(d_t32 + nt);
-    uint4 *d_blk = reinterpret_cast<uint4 *>(c->d_blk);
-    uint32_t *d_toff_d = reinterpret_cast<uint32_t *>(d_blk + c->n_blk), *d_toff_q = d_toff_d + nt;
+    uint2 *d_pre = reinterpret_cast<uint2 *>(c->d_blk), *d_head = d_pre + c->n_blk;
+    uint32_t *d_toff_d = reinterpret_cast<uint32_t *>(d_head + c->n_blk), *d_toff_q = d_toff_d + nt;
     CN_HIP(h, hipMemsetAsync(d_grand, 0, 16, h->stream));
-    CbArgs A{c->d_depth, c->d_mq, c->d_off, c->d_len, c->d_cb_tiles, inc, r, d_blk, (int64_t)nt, d_t32, d_t64};
+    CbArgs A{c->d_depth, c->d_mq, c->d_off, c->d_len, c->d_cb_tiles, inc, r, d_pre, d_head, (int64_t)nt, d_t32, d_t64};
     if (inc <= CB_MAX_INC_LDS) {
         const size_t lds = (size_t)CB_THREADS / CB_PARTS * inc * sizeof(uint16_t);
         static_assert(CB_THREADS / CB_PARTS * 50 / 8 <= 4 * CB_THREADS, "cov_blocks<true, INC>: at most 4 vectors per thread and part");
@@ -566,8 +568,8 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
     const size_t nt = c->cw_tiles.size();
     if (nt == 0) return CORNETTO_OK;
     const size_t nt_blk = (size_t)c->n_cb_tiles;
-    const uint4 *d_blk = reinterpret_cast<const uint4 *>(c->d_blk);
-    const uint32_t *d_toff_d = reinterpret_cast<const uint32_t *>(d_blk + c->n_blk), *d_toff_q = d_toff_d + nt_blk;
+    const uint2 *d_pre = reinterpret_cast<const uint2 *>(c->d_blk), *d_head = d_pre + c->n_blk;
+    const uint32_t *d_toff_d = reinterpret_cast<const uint32_t *>(d_head + c->n_blk), *d_toff_q = d_toff_d + nt_blk;
     unsigned long long *d_cnt = (unsigned long long *)cn_ws(h, WS_CW_CNT, 16);
     // per tile: {base,count} (8 B) + ordered offset (4 B) + scan partials
     uint2 *d_tres = (uint2 *)cn_ws(h, WS_CW_TRES, nt * 12 + ((nt + 4095) / 4096 + 1) * 4);
@@ -575,7 +577,7 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
     if (!d_cnt || !d_tres || !p_cnt) return cn_fail(h, CORNETTO_E_NOMEM, "cov: workspace allocation failed");
     uint32_t *d_ooff = reinterpret_cast<uint32_t *>(d_tres + nt), *d_part = d_ooff + nt;
     CwArgs A{};
-    A.blk = d_blk; A.toff_d = d_toff_d; A.toff_q = d_toff_q; A.blk_off = c->d_blk_off; A.ctg_len = c->d_len; A.n_reg = c->d_n_reg;
+    A.pre = d_pre; A.head = d_head; A.toff_d = d_toff_d; A.toff_q = d_toff_q; A.blk_off = c->d_blk_off; A.ctg_len = c->d_len; A.n_reg = c->d_n_reg;
     A.tiles = c->d_cw_tiles; A.w = w; A.inc = inc; A.q = q; A.r = r; A.mode = mode; A.lo = lo; A.hi = hi; A.edge = edge;
     if (w >= 2) {                                   // floor(n / w) for 0 <= n < 2^31: M = floor(2^(31 + L) / w) + 1, L = ceil(log2 w)
         int L = 0;

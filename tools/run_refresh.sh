@@ -5,6 +5,11 @@ TAG=${1:-r04}
 set -x
 mkdir -p gpurun_out
 R=$PWD
+# the counters first: the bench line quotes them (roofline.issue / roofline.traffic read profiles/${TAG}_<profile>_*.json)
+for P in uniform satellite humanlike; do
+  bash tools/pmc_kernel.sh ${TAG}_$P sd_sift 3160 $P 1 | tail -12
+  cp gpurun_out/${TAG}_${P}_sq_sd_sift.json gpurun_out/${TAG}_${P}_pmc_traffic_sd_sift.json profiles/ 2>/dev/null
+done
 timeout 1800 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/${TAG}_tests.log
 tail -3 gpurun_out/${TAG}_tests.log
 timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/${TAG}_smoke.log 2>&1; tail -1 gpurun_out/${TAG}_smoke.log
@@ -25,6 +30,3 @@ python3 tools/summarize_profile.py stats gpurun_out/prof_${TAG}_sat gpurun_out/$
 python3 tools/summarize_profile.py stats gpurun_out/prof_${TAG}_hum gpurun_out/${TAG}_kernel_stats_humanlike_serial.csv | head -8
 python3 tools/summarize_profile.py stats gpurun_out/prof_${TAG}_share8 gpurun_out/${TAG}_kernel_stats_share8.csv | head -30
 rm -rf gpurun_out/prof_${TAG} gpurun_out/prof_${TAG}_serial gpurun_out/prof_${TAG}_sat gpurun_out/prof_${TAG}_hum gpurun_out/prof_${TAG}_share8
-for P in uniform satellite humanlike; do
-  bash tools/pmc_kernel.sh ${TAG}_$P sd_sift 3160 $P 1 | tail -12
-done

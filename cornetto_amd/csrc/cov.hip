@@ -321,7 +321,6 @@ __global__ __launch_bounds__(256) void cov_windows(CwArgs A)
     __builtin_amdgcn_s_setprio(3);   // short streaming kernel: issue ahead of a long compute-bound kernel of another stream
 
     __shared__ uint32_t wcnt[4];
-    __shared__ unsigned long long sbase;
     const int t = threadIdx.x;
     const int2 tile = A.tiles[blockIdx.x];
     const int ctg = tile.x;
@@ -378,18 +377,13 @@ __global__ __launch_bounds__(256) void cov_windows(CwArgs A)
         if (i < wv) pre += wcnt[i];
         tot += wcnt[i];
     }
-    if (t == 0) {
-        unsigned long long b = tot ? atomicAdd(A.counter, (unsigned long long)tot) : 0ull;
-        sbase = b;
-        A.tile_res[blockIdx.x] = make_uint2((uint32_t)b, tot);
-    }
-    __syncthreads();
+    // a tile's selected windows go to the tile's own 256 entries of the raw array (no reservation: one counter for 250 000 tiles was a third of
+    // the kernel's time — 2 ns per atomic on one address); the ordering pass packs the segments by the scan of their counts
+    if (t == 0) A.tile_res[blockIdx.x] = make_uint2(blockIdx.x * 256u, tot);
     if (sel) {
-        const unsigned long long idx = sbase + pre + __popcll(bal & ((1ull << lane) - 1ull));
-        if (idx < A.cap) {
-            if (A.pk) A.pk[idx] = cornetto_regpk_t{st, (uint16_t)depth, (uint16_t)mq};   // means of uint16 values: they fit
-            else A.sel[idx] = cornetto_regrec_t{ctg, st, end, depth, mq};
-        }
+        const size_t idx = (size_t)blockIdx.x * 256u + pre + __popcll(bal & ((1ull << lane) - 1ull));
+        if (A.pk) A.pk[idx] = cornetto_regpk_t{st, (uint16_t)depth, (uint16_t)mq};   // means of uint16 values: they fit
+        else A.sel[idx] = cornetto_regrec_t{ctg, st, end, depth, mq};
     }
 }
 
@@ -597,9 +591,11 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
         CN_HIP(h, hipStreamSynchronize(h->stream));
         return CORNETTO_OK;
     }
-    // raw (reservation order) and ordered copies share one workspace: [cap] + [cap]
+    // raw (256 entries per tile, a tile's selected windows at the front of its own) and ordered copies share one workspace: [nt * 256] + [cap]
+    const size_t n_raw = nt * 256;
+    if (n_raw > 0xffffff00ull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "cov: %zu window tiles", nt);
     size_t cap = std::max<size_t>(1 << 16, nt * 256 / 8);
-    cap = std::max(cap, h->dev[WS_CW_SEL].bytes / (2 * rec_bytes));   // keep what an earlier call grew to
+    if (h->dev[WS_CW_SEL].bytes / rec_bytes > n_raw) cap = std::max(cap, h->dev[WS_CW_SEL].bytes / rec_bytes - n_raw);   // keep what an earlier call grew to
     unsigned long long cnt = 0;
     cornetto_regrec_t *d_raw = nullptr, *d_dst = nullptr;
     uint32_t *p_cf = nullptr, *d_cf = nullptr;
@@ -612,16 +608,16 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
     // device, so the host meets it once — together with the per-contig offsets — and only then sizes the result
     for (int attempt = 0; attempt < 2; ++attempt) {
         cap = std::min<size_t>(cap, 0x7fffffff);
-        d_raw = (cornetto_regrec_t *)cn_ws(h, WS_CW_SEL, 2 * cap * rec_bytes);
-        if (!d_raw) return cn_fail(h, CORNETTO_E_NOMEM, "cov: workspace allocation of %zu bytes failed", 2 * cap * rec_bytes);
-        d_dst = reinterpret_cast<cornetto_regrec_t *>(reinterpret_cast<uint8_t *>(d_raw) + cap * rec_bytes);
+        d_raw = (cornetto_regrec_t *)cn_ws(h, WS_CW_SEL, (n_raw + cap) * rec_bytes);
+        if (!d_raw) return cn_fail(h, CORNETTO_E_NOMEM, "cov: workspace allocation of %zu bytes failed", (n_raw + cap) * rec_bytes);
+        d_dst = reinterpret_cast<cornetto_regrec_t *>(reinterpret_cast<uint8_t *>(d_raw) + n_raw * rec_bytes);
         A.sel = d_raw;
         A.pk = packed ? reinterpret_cast<cornetto_regpk_t *>(d_raw) : nullptr;
         A.cap = (uint32_t)cap;
         CN_HIP(h, hipMemsetAsync(d_cnt, 0, 8, h->stream));
         CN_LAUNCH(h, "cov_windows", cov_windows<<<dim3((unsigned)nt), dim3(256), 0, h->stream>>>(A));
-        // tiles are in (contig, window) order: exclusive scan of their counts = final position of each segment
-        CN_TRY(cnscan::exclusive_u32(h, "cov_order", reinterpret_cast<const uint32_t *>(d_tres) + 1, (int64_t)nt, 2, d_ooff, d_part, nullptr));
+        // tiles are in (contig, window) order: exclusive scan of their counts = final position of each segment; its total = the number selected
+        CN_TRY(cnscan::exclusive_u32(h, "cov_order", reinterpret_cast<const uint32_t *>(d_tres) + 1, (int64_t)nt, 2, d_ooff, d_part, d_cnt));
         const unsigned nb = (unsigned)((nt + 3) / 4);
         hipEvent_t ea = cn_event(h), eb = cn_event(h);
         (void)hipEventRecord(ea, h->stream);

@@ -679,6 +679,38 @@ def test_cov_regs_vs_oracle(acc, w, inc):
     cov.close()
 
 
+@pytest.mark.parametrize("w,inc", [(2500, 50), (300, 7)])
+def test_cov_select_more_windows_than_the_first_block_holds(w, inc):
+    """a fresh handle sizes the ordered block for an eighth of the windows (at least 65 536): a selection that takes nearly all of 120 000+
+    is detected after the fact and rerun at the exact size — both record forms, then again on the grown block; against the oracle's windows
+    and the reference's predicate (src/boringbits_main.c:467,473-474)"""
+    rng = np.random.default_rng(w + inc)
+    lens = [int(inc * 125_000 + 17), 30_000, 12_345]
+    depths = [rng.integers(20, 41, size=n).astype(np.uint16) for n in lens]
+    mqs = [np.minimum(d, rng.integers(15, 41, size=d.size)).astype(np.uint16) for d in depths]
+    import cornetto_amd
+    a = cornetto_amd.Accel(0)
+    cov = a.cov_upload(depths, mqs)
+    a.cov_prepare(cov, w, inc)
+    lo, hi, Q, edge, min_len = 12, 75, 0.4, 1000, 10_000
+    exp = []
+    for ci, (d, q) in enumerate(zip(depths, mqs)):
+        regs = ob.get_regs(d, q, w, inc)
+        for r in regs:
+            st, end, dep, mq = int(r["st"]), int(r["end"]), int(r["depth"]), int(r["mq_depth"])
+            if len(d) > min_len and st > edge and end < len(d) - edge and not ob.is_fun(dep, mq, lo, hi, Q):
+                exp.append((ci, st, end, dep, mq))
+    assert len(exp) > 100_000
+    for _ in range(2):
+        recs = a.cov_select(cov, lo, hi, Q, edge, min_len, True)
+        assert [tuple(int(x) for x in r) for r in recs] == exp
+        pk, cf = a.cov_select_packed(cov, lo, hi, Q, edge, min_len, True)
+        un = a.unpack_regs(pk, cf, lens, w)
+        assert [tuple(int(x) for x in r) for r in un] == exp
+    cov.close()
+    a.close()
+
+
 def test_sdust_repeatable_with_many_small_chunks(acc, golden_dir, monkeypatch):
     """the chunk queue hands the chunks to different lanes / waves at different times on every run: 24 runs over
     ~100 k tiny chunks must all give the golden answer (a build of the kernel that spilled registers did not)"""

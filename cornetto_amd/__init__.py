@@ -109,6 +109,7 @@ def lib():
         "cornetto_cov_free": (None, [vp, vp]),
         "cornetto_cov_shard": (C.c_int, [vp, vp, vp, vp, i32, pp]),
         "cornetto_n_reg": (i32, [i32, i32, i32]),
+        "cornetto_regs_assert": (i32, [i32, i32, i32]),
         "cornetto_cov_prepare": (C.c_int, [vp, vp, i32, i32, C.POINTER(C.c_uint64)]),
         "cornetto_cov_regs": (C.c_int, [vp, vp, i32, vp]),
         "cornetto_cov_threshold": (i32, [C.c_float, i32]),

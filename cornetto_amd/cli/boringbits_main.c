@@ -484,9 +484,36 @@ typedef struct {
     cornetto_regrec_t *recs;
     int64_t n_recs;
     int rc;
+    int asserted;  /* cornetto_cov_prepare() met an assert of get_regs() (CORNETTO_E_ASSERT): err holds the reference's line; reported by the
+                      caller, behind the format errors of ALL shares (the reference parses everything before get_regs()) */
     char err[600];
     bg_job_t *ing; /* the device parses its own share of the text first (sharded ingest) */
 } bb_dev_t;
+
+/* get_regs() (src/boringbits_main.c:331-369) runs over EVERY contig — it knows no -m — before anything is printed: the first contig whose
+ * last window is empty (:353) or stops short of the end (:368) ends the process the way the reference's assert does */
+static void regs_assert_all(const int32_t *lens, int32_t n_ctg, const optp_t *opt)
+{
+    if (opt->window_inc < 1) return;
+    for (int32_t i = 0; i < n_ctg; ++i) {
+        const int line = cornetto_regs_assert(lens[i], opt->window_size, opt->window_inc);
+        if (!line) continue;
+        char msg[256];
+        snprintf(msg, sizeof(msg), "src/boringbits_main.c:%d: get_regs: Assertion `%s' failed. (contig %d of length %d, -w %d -i %d)", line,
+                 line == 353 ? "st<end" : "end == length", i, lens[i], opt->window_size, opt->window_inc);
+        cli_ref_abort(msg);
+    }
+}
+
+static void bb_prepare(bb_dev_t *d)
+{
+    d->rc = cornetto_cov_prepare(d->h, d->part, d->opt->window_size, d->opt->window_inc, d->sums);
+    if (d->rc == CORNETTO_E_ASSERT) {
+        snprintf(d->err, sizeof(d->err), "%s", cornetto_accel_last_error(d->h));
+        d->asserted = 1;
+        d->rc = CORNETTO_OK;
+    }
+}
 
 static void *bb_worker(void *p)
 {
@@ -506,13 +533,13 @@ static void *bb_worker(void *p)
             if (d->ing->rc != CORNETTO_OK || d->ing->fmt_kind) return NULL; /* (reported in the order of the shares by the caller) */
             d->part = d->ing->cov;
             d->n = d->ing->n_ctg;
-            if (d->n > 0) d->rc = cornetto_cov_prepare(d->h, d->part, d->opt->window_size, d->opt->window_inc, d->sums);
+            if (d->n > 0) bb_prepare(d);
             if (d->rc != CORNETTO_OK) snprintf(d->err, sizeof(d->err), "device %d: %s (%s)", d->dev, cornetto_accel_last_error(d->h), cornetto_accel_strerror(d->rc));
             return NULL;
         }
         if (d->n == 0) return NULL; /* more devices than contigs: nothing to do here */
         d->rc = cornetto_cov_shard(d->h_src, d->src, d->h, d->ctgs, d->n, &d->part);
-        if (d->rc == CORNETTO_OK) d->rc = cornetto_cov_prepare(d->h, d->part, d->opt->window_size, d->opt->window_inc, d->sums);
+        if (d->rc == CORNETTO_OK) bb_prepare(d);
     } else if (d->n > 0) {
         d->rc = cornetto_cov_select(d->h, d->part, d->lo, d->hi, d->opt->low_mq_cov_thresh, d->opt->edge_len, d->opt->min_ctg_len, d->boring, &d->recs, &d->n_recs);
     }
@@ -567,6 +594,8 @@ static void bb_multi(cornetto_accel_t *h0, const cornetto_cov_t *cov, int32_t n_
     }
     for (int32_t i = 0; i < n_ctg; ++i) dv[owner[i]].ctgs[dv[owner[i]].n++] = i; /* ascending: a device's contigs keep their input order */
     bb_run(dv, n_dev, 0);
+    for (int d = 0; d < n_dev; ++d)
+        if (dv[d].asserted) regs_assert_all(lens, n_ctg, opt);           /* (names the first contig in INPUT order, as the reference would) */
     sums[0] = sums[1] = sums[2] = 0;
     for (int d = 0; d < n_dev; ++d)
         for (int k = 0; k < 3; ++k) sums[k] += dv[d].sums[k];            /* the one exchange: 3 x u64 per device */
@@ -629,6 +658,8 @@ static void bb_sharded(cornetto_accel_t *h0, bg_job_t *jobs, const int *devs, in
         n_ctg += jobs[d].n_ctg;
     }
     if (clamped) CLI_WARNING("%lld depth values were truncated to 65535", (long long)clamped);
+    for (int d = 0; d < n_sh; ++d)                                       /* shares are in file order: the first one names the assert */
+        if (dv[d].asserted) cli_ref_abort(dv[d].err);
     sums[0] = sums[1] = sums[2] = 0;
     for (int d = 0; d < n_sh; ++d)
         for (int k = 0; k < 3; ++k) sums[k] += dv[d].sums[k];            /* the one exchange: 3 x u64 per device */
@@ -740,6 +771,8 @@ static int host_bits(FILE *ft, FILE *fq, const optp_t *opt, int8_t boring, const
     if (cov.n_ctg > 0) {
         const int32_t lo_t = cornetto_cov_threshold(opt->low_cov_thresh, mean_depth);   /* :518 */
         const int32_t hi_t = cornetto_cov_threshold(opt->high_cov_thresh, mean_depth);  /* :519 */
+        /* get_regs() (:331-369) runs over EVERY contig — it knows no -m — before anything is printed: its asserts end the process here */
+        regs_assert_all(cov.lens, cov.n_ctg, opt);
         cli_host_cov_select(&cov, opt->window_size, opt->window_inc, lo_t, hi_t, opt->low_mq_cov_thresh, opt->edge_len, opt->min_ctg_len, panel_bed ? 0 : boring,
                             &recs, &n_recs);
     }

@@ -58,6 +58,7 @@ void cli_accel_open_begin(void);
 cornetto_accel_t *cli_accel_open_end(void);
 void cli_accel_open_cancel(void);
 /* print the handle's last error and exit(EXIT_FAILURE) if rc != 0 */
+void cli_ref_abort(const char *msg);   /* stderr line + abort(): where the reference dies on an assert */
 void cli_accel_check(cornetto_accel_t *h, int rc, const char *what);
 
 /* ---- record lines on stdout: a plain buffer + decimal formatter (printf costs ~200 ns per field; the window lists have

@@ -127,9 +127,19 @@ void cli_accel_open_cancel(void)
     if (g_open.rc == CORNETTO_OK && g_open.h) cornetto_accel_close(g_open.h);
 }
 
+/* the reference ends here with SIGABRT (an assert of get_regs(), src/boringbits_main.c:353,368): glibc's one line on stderr, nothing on
+ * stdout (no output buffer is flushed), exit status 134 in a shell — the same here */
+void cli_ref_abort(const char *msg)
+{
+    fprintf(stderr, "cornetto: %s\n", msg);
+    fflush(stderr);
+    abort();
+}
+
 void cli_accel_check(cornetto_accel_t *h, int rc, const char *what)
 {
     if (rc == CORNETTO_OK) return;
+    if (rc == CORNETTO_E_ASSERT) cli_ref_abort(cornetto_accel_last_error(h));
     CLI_ERROR("%s failed: %s (%s)", what, cornetto_accel_last_error(h), cornetto_accel_strerror(rc));
     exit(EXIT_FAILURE);
 }

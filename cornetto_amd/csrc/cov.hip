@@ -303,10 +303,8 @@ struct CwArgs {
     int32_t lo, hi, edge, min_len;
     double low_mq;
     cornetto_reg_t *regs;
-    cornetto_regrec_t *sel;    // selected windows, tile by tile (one reservation per tile)
-    cornetto_regpk_t *pk;      // ... or, if not NULL, their packed form (cornetto_cov_select_packed)
-    unsigned long long *counter;
-    uint32_t cap;
+    cornetto_regrec_t *sel;    // selected windows, each tile's at the front of the tile's own 256 entries of the raw array
+    cornetto_regpk_t *pk;      // ... or, if not NULL, their packed 8-byte form (whenever the means fit: w <= 32768; cov_order expands them)
     uint2 *tile_res;           // per tile {base, count}
 };
 
@@ -334,12 +332,17 @@ __global__ __launch_bounds__(256) void cov_windows(CwArgs A)
         end = st + A.w;
         if (end > len) end = len;                        // :349-351
         const int64_t a = A.blk_off[ctg] + j;
-        const uint2 hi = cw_prefix(A, a + A.q - 1);   // q >= 1 always (inc <= w)
-        uint2 lo = make_uint2(0, 0);
-        if (a > 0) lo = cw_prefix(A, a - 1);
         // blocks of a contig start at a multiple of 256 = a tile boundary of the prefix, and the global
-        // prefix is continuous across contigs, so G[a+q-1] - G[a-1] is the sum over exactly [a, a+q)
-        uint32_t sd = hi.x - lo.x, sq = hi.y - lo.y;
+        // prefix is continuous across contigs, so G[a+q-1] - G[a-1] is the sum over exactly [a, a+q).
+        // q == 0 (inc > w: sparse windows, each inside its own block): the window is the head of block a alone
+        uint32_t sd = 0, sq = 0;
+        if (A.q > 0) {
+            const uint2 hi = cw_prefix(A, a + A.q - 1);
+            uint2 lo = make_uint2(0, 0);
+            if (a > 0) lo = cw_prefix(A, a - 1);
+            sd = hi.x - lo.x;
+            sq = hi.y - lo.y;
+        }
         if (A.r) {
             const uint2 hb = A.head[a + A.q];
             sd += hb.x;
@@ -412,10 +415,41 @@ __global__ __launch_bounds__(256) void cov_order(const int32_t *raw, const uint2
     for (uint32_t i = threadIdx.x & 63; i < nint; i += 64) d[i] = src[i];
 }
 
+// the same with packed segments expanded to full records: the contig is the tile's, end = min(st + w, length) (:348-351)
+__global__ __launch_bounds__(256) void cov_order_expand(const cornetto_regpk_t *raw, const uint2 *tres, const uint32_t *ooff, int64_t n_tiles, cornetto_regrec_t *dst,
+                                                        const unsigned long long *total, uint32_t cap, const int2 *tiles, const int32_t *ctg_len, int32_t w)
+{
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tiles) return;
+    if (*total > cap) return;
+    const uint2 r = tres[t];
+    const int32_t ctg = tiles[t].x, len = ctg_len[ctg];
+    const cornetto_regpk_t *src = raw + r.x;
+    cornetto_regrec_t *d = dst + ooff[t];
+    for (uint32_t i = threadIdx.x & 63; i < r.y; i += 64) {
+        const cornetto_regpk_t p = src[i];
+        const int64_t e = (int64_t)p.st + w;
+        d[i] = cornetto_regrec_t{ctg, p.st, e > len ? len : (int32_t)e, (int32_t)p.depth, (int32_t)p.mq_depth};
+    }
+}
+
 int32_t n_reg_host(int32_t length, int32_t w, int32_t inc)
 {
     int32_t n = (length - w + inc - 1) / inc + 1;   // src/boringbits_main.c:338, C truncation
     return n < 1 ? 1 : n;                           // :339
+}
+
+// The two asserts of get_regs() that can fire (src/boringbits_main.c:353 inside the loop, :368 behind it; :369 repeats :353 for the last window).
+// Every window but the last starts in front of the last one, so only the last window decides: 0 = the reference computes, 353 / 368 = the
+// line of the assert that ends it.  With 1 <= inc <= w and length >= 1 neither fires; with inc > w the windows are sparse and the last one
+// must still reach the contig's end.
+int32_t regs_assert_host(int32_t length, int32_t w, int32_t inc)
+{
+    const int64_t st = (int64_t)(n_reg_host(length, w, inc) - 1) * inc;
+    int64_t end = st + w;
+    if (end > length) end = length;
+    if (!(st < end)) return 353;
+    return end == length ? 0 : 368;
 }
 
 }  // namespace
@@ -428,6 +462,12 @@ int32_t cornetto_n_reg(int32_t length, int32_t window_size, int32_t window_inc)
     return n_reg_host(length, window_size, window_inc);
 }
 
+int32_t cornetto_regs_assert(int32_t length, int32_t window_size, int32_t window_inc)
+{
+    if (window_inc <= 0) return 353;
+    return regs_assert_host(length, window_size, window_inc);
+}
+
 int32_t cornetto_cov_threshold(float factor, int32_t mean)
 {
     return (int32_t)round(factor * mean);   // float product promoted to double by round(): src/boringbits_main.c:518-519
@@ -436,7 +476,15 @@ int32_t cornetto_cov_threshold(float factor, int32_t mean)
 int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int32_t inc, uint64_t sums[3])
 {
     if (!h || !c || !sums) return cn_fail(h, CORNETTO_E_ARG, "cov_prepare: bad argument");
-    if (inc < 1 || w < inc) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "cov_prepare: needs 1 <= window_inc <= window_size (got -w %d -i %d; the reference aborts on its assert)", w, inc);
+    if (inc < 1) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "cov_prepare: needs window_inc >= 1 (got -i %d: the reference divides by it)", inc);
+    // get_regs() runs over every contig before anything is printed, and its asserts (:353, :368) end the process: the first contig, in input
+    // order, whose last window is empty or stops short of the contig's end (possible only with w < inc or w < 1) decides
+    for (int32_t i = 0; i < c->n; ++i) {
+        const int32_t line = c->len[i] < 1 ? 0 : regs_assert_host(c->len[i], w, inc);
+        if (line)
+            return cn_fail(h, CORNETTO_E_ASSERT, "src/boringbits_main.c:%d: get_regs: Assertion `%s' failed. (contig %d of length %d, -w %d -i %d)", line,
+                           line == 353 ? "st<end" : "end == length", i, c->len[i], w, inc);
+    }
     CN_HIP(h, hipSetDevice(h->device));
     cn_timing_begin(h);
     const int32_t q = w / inc, r = w % inc;
@@ -532,6 +580,12 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
     const size_t rec_bytes = packed ? sizeof(cornetto_regpk_t) : sizeof(cornetto_regrec_t);
     if (!c->d_blk) return cn_fail(h, CORNETTO_E_ARG, "cov: cornetto_cov_prepare() has not been called");
     const int32_t w = c->w, inc = c->inc, q = w / inc, r = w % inc;
+    // A window mean fits 16 bits as long as the reference's `int` sums cannot wrap: w x 65535 < 2^31.  Then the raw array (256 entries per
+    // window tile: 250 000 tiles for 3 Gbp) holds the 8-byte form for either record type — 0.5 GB instead of 1.3 GB of workspace for the
+    // full records — and the ordering pass expands them.  Larger windows keep full records; the packed interface refuses them.
+    const bool raw_packed = w <= 32768;
+    if (packed && !raw_packed) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "cov_select_packed: window size %d > 32768 (a wrapped sum's mean does not fit 16 bits)", w);
+    const size_t raw_bytes = raw_packed ? sizeof(cornetto_regpk_t) : sizeof(cornetto_regrec_t);
     if (c->cw_mode != mode || c->cw_min_len != min_len || c->cw_only != only_ctg) {   // window tiles, cached
         c->cw_tiles.clear();
         for (int32_t i = 0; i < c->n; ++i) {
@@ -580,7 +634,7 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
         A.w_shift = (uint32_t)(L - 1);
     }
     A.min_len = min_len; A.low_mq = (double)low_mq;   // float promoted exactly as in `x < low_mq_cov_thresh`
-    A.counter = d_cnt; A.tile_res = d_tres;
+    A.tile_res = d_tres;
     if (mode == 0) {
         const size_t nr = (size_t)c->n_reg[only_ctg];
         cornetto_reg_t *d_regs = (cornetto_reg_t *)cn_ws(h, WS_CW_REGS, nr * sizeof(cornetto_reg_t));
@@ -595,7 +649,7 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
     const size_t n_raw = nt * 256;
     if (n_raw > 0xffffff00ull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "cov: %zu window tiles", nt);
     size_t cap = std::max<size_t>(1 << 16, nt * 256 / 8);
-    if (h->dev[WS_CW_SEL].bytes / rec_bytes > n_raw) cap = std::max(cap, h->dev[WS_CW_SEL].bytes / rec_bytes - n_raw);   // keep what an earlier call grew to
+    if (h->dev[WS_CW_SEL].bytes > n_raw * raw_bytes) cap = std::max(cap, (h->dev[WS_CW_SEL].bytes - n_raw * raw_bytes) / rec_bytes);   // keep what an earlier call grew to
     unsigned long long cnt = 0;
     cornetto_regrec_t *d_raw = nullptr, *d_dst = nullptr;
     uint32_t *p_cf = nullptr, *d_cf = nullptr;
@@ -608,13 +662,11 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
     // device, so the host meets it once — together with the per-contig offsets — and only then sizes the result
     for (int attempt = 0; attempt < 2; ++attempt) {
         cap = std::min<size_t>(cap, 0x7fffffff);
-        d_raw = (cornetto_regrec_t *)cn_ws(h, WS_CW_SEL, (n_raw + cap) * rec_bytes);
-        if (!d_raw) return cn_fail(h, CORNETTO_E_NOMEM, "cov: workspace allocation of %zu bytes failed", (n_raw + cap) * rec_bytes);
-        d_dst = reinterpret_cast<cornetto_regrec_t *>(reinterpret_cast<uint8_t *>(d_raw) + n_raw * rec_bytes);
+        d_raw = (cornetto_regrec_t *)cn_ws(h, WS_CW_SEL, n_raw * raw_bytes + cap * rec_bytes);
+        if (!d_raw) return cn_fail(h, CORNETTO_E_NOMEM, "cov: workspace allocation of %zu bytes failed", n_raw * raw_bytes + cap * rec_bytes);
+        d_dst = reinterpret_cast<cornetto_regrec_t *>(reinterpret_cast<uint8_t *>(d_raw) + n_raw * raw_bytes);
         A.sel = d_raw;
-        A.pk = packed ? reinterpret_cast<cornetto_regpk_t *>(d_raw) : nullptr;
-        A.cap = (uint32_t)cap;
-        CN_HIP(h, hipMemsetAsync(d_cnt, 0, 8, h->stream));
+        A.pk = raw_packed ? reinterpret_cast<cornetto_regpk_t *>(d_raw) : nullptr;
         CN_LAUNCH(h, "cov_windows", cov_windows<<<dim3((unsigned)nt), dim3(256), 0, h->stream>>>(A));
         // tiles are in (contig, window) order: exclusive scan of their counts = final position of each segment; its total = the number selected
         CN_TRY(cnscan::exclusive_u32(h, "cov_order", reinterpret_cast<const uint32_t *>(d_tres) + 1, (int64_t)nt, 2, d_ooff, d_part, d_cnt));
@@ -622,6 +674,7 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
         hipEvent_t ea = cn_event(h), eb = cn_event(h);
         (void)hipEventRecord(ea, h->stream);
         if (packed) cov_order<2><<<dim3(nb), dim3(256), 0, h->stream>>>(reinterpret_cast<const int32_t *>(d_raw), d_tres, d_ooff, (int64_t)nt, reinterpret_cast<int32_t *>(d_dst), d_cnt, (uint32_t)cap);
+        else if (raw_packed) cov_order_expand<<<dim3(nb), dim3(256), 0, h->stream>>>(reinterpret_cast<const cornetto_regpk_t *>(d_raw), d_tres, d_ooff, (int64_t)nt, d_dst, d_cnt, (uint32_t)cap, c->d_cw_tiles, c->d_len, w);
         else cov_order<5><<<dim3(nb), dim3(256), 0, h->stream>>>(reinterpret_cast<const int32_t *>(d_raw), d_tres, d_ooff, (int64_t)nt, reinterpret_cast<int32_t *>(d_dst), d_cnt, (uint32_t)cap);
         (void)hipEventRecord(eb, h->stream);
         h->recs.push_back(cornetto_accel::Rec{"cov_order", ea, eb});

@@ -148,7 +148,12 @@ __global__ __launch_bounds__(ST_THREADS) void st_fused(StArgs A)
     if (t == 0) s_tile = atomicAdd(A.ticket, 1u) - A.ticket_base;
     __syncthreads();
     const int64_t tile = s_tile;
+    if (tile >= (A.n_cap + ST_TILE - 1) / ST_TILE) return;   // (a ticket base out of step with the counter: never an index)
     const int64_t n = (int64_t)__hip_atomic_load(A.d_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // More rows than the caller sized the grid, the input and the output for: NO tile touches anything (rows beyond n_cap were never
+    // gathered, heads would land beyond the output block); *d_count keeps the caller's marker and the caller takes the long way.
+    // Every tile has drawn its ticket above, so the host's ticket base stays in step with the device's counter.
+    if (n > A.n_cap) return;
     if (tile * ST_TILE >= n) return;                 // (nothing in front of a tile that works waits for one that does not)
     const int64_t j0 = tile * ST_TILE + (int64_t)t * ST_ITEMS;
     cornetto_ivl_t x[ST_ITEMS + 1];
@@ -299,17 +304,22 @@ static inline int merge_fused(cornetto_accel_t *h, const char *name, const corne
     const bool fresh = h->dev[WS_STITCH].bytes < need;
     uint8_t *ws = (uint8_t *)cn_ws(h, WS_STITCH, need);
     if (!ws) return cn_fail(h, CORNETTO_E_NOMEM, "merge: workspace allocation failed");
-    if (fresh) {
-        CN_HIP(h, hipMemsetAsync(ws, 0, h->dev[WS_STITCH].bytes, h->stream));
-        h->st_tickets = 0;
-        h->st_epoch = 0;
-    }
-    h->st_epoch = (h->st_epoch + 1) & 0x3FFFFFFFu;
-    if (h->st_epoch == 0) h->st_epoch = 1;
-    StArgs A{d_in, d_n, n_cap, dist, reinterpret_cast<unsigned long long *>(ws + 64), reinterpret_cast<uint32_t *>(ws), h->st_tickets, h->st_epoch, d_out, d_count};
-    h->st_tickets += (uint32_t)nt;
-    CN_LAUNCH(h, name, st_fused<<<dim3((unsigned)nt), dim3(ST_THREADS), 0, h->stream>>>(A));
-    return CORNETTO_OK;
+    const int rc = [&]() -> int {
+        if (fresh) {
+            CN_HIP(h, hipMemsetAsync(ws, 0, h->dev[WS_STITCH].bytes, h->stream));
+            h->st_tickets = 0;
+            h->st_epoch = 0;
+        }
+        uint32_t epoch = (h->st_epoch + 1) & 0x3FFFFFFFu;
+        if (epoch == 0) epoch = 1;
+        StArgs A{d_in, d_n, n_cap, dist, reinterpret_cast<unsigned long long *>(ws + 64), reinterpret_cast<uint32_t *>(ws), h->st_tickets, epoch, d_out, d_count};
+        CN_LAUNCH(h, name, st_fused<<<dim3((unsigned)nt), dim3(ST_THREADS), 0, h->stream>>>(A));
+        h->st_epoch = epoch;                         // (the device's ticket counter advances iff the kernel was queued)
+        h->st_tickets += (uint32_t)nt;
+        return CORNETTO_OK;
+    }();
+    if (rc != CORNETTO_OK) h->dev[WS_STITCH].bytes = 0;   // the next call gets new, cleared memory and counters that start again
+    return rc;
 }
 
 // bytes of device workspace merge() needs for n intervals

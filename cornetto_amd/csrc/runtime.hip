@@ -14,6 +14,8 @@ std::multimap<size_t, void *> g_pool_free;           // pinned buffers ready for
 std::unordered_map<void *, uint64_t> g_pool_age;     // when a free buffer was handed back (the oldest one makes room)
 uint64_t g_pool_clock = 0;
 constexpr size_t POOL_MIN = 1u << 20;                // below this, plain malloc
+size_t g_pool_free_bytes = 0;                        // capacity of the free list
+constexpr size_t POOL_KEEP_BYTES = 4ull << 30;       // ... and its byte budget (the newest buffer always stays: the next step wants it again)
 constexpr size_t POOL_KEEP = 12;                     // free buffers kept; beyond that the one that has waited longest goes back to the driver
 }  // namespace
 
@@ -28,6 +30,7 @@ void *cn_result_alloc(size_t bytes)
         if (it != g_pool_free.end() && it->first <= 2 * cap) {
             void *p = it->second;
             g_pool_live[p] = it->first;
+            g_pool_free_bytes -= it->first;
             g_pool_free.erase(it);
             g_pool_age.erase(p);
             return p;
@@ -114,6 +117,7 @@ const char *cornetto_accel_strerror(int status)
     case CORNETTO_E_NOMEM: return "out of memory";
     case CORNETTO_E_UNSUPPORTED: return "parameter outside the supported range";
     case CORNETTO_E_FORMAT: return "malformed input text";
+    case CORNETTO_E_ASSERT: return "the reference aborts on an assert here";
     default: return "unknown status";
     }
 }
@@ -121,43 +125,41 @@ const char *cornetto_accel_strerror(int status)
 void cornetto_free(void *p)
 {
     if (!p) return;
-    void *drop = nullptr;
+    std::vector<void *> drop;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         auto it = g_pool_live.find(p);
-        if (it == g_pool_live.end()) {
-            drop = nullptr;
-        } else {
-            // keep what was used last: when the list is full the buffer that has waited longest leaves (a list full of the sizes of
-            // an earlier workload made every step of the next one pin and unpin its result buffers: +7 ms per step, round 4)
+        if (it != g_pool_live.end()) {
+            // keep what was used last: while the list is over its count or its byte budget the buffer that has waited longest leaves (a
+            // list full of the sizes of an earlier workload made every step of the next one pin and unpin its result buffers: +7 ms per
+            // step, round 4; a process that once returned multi-GB results must not keep them page-locked for good either)
             const size_t cap = it->second;
             g_pool_live.erase(it);
-            if (g_pool_free.size() >= POOL_KEEP) {
+            g_pool_free.emplace(cap, p);
+            g_pool_age[p] = ++g_pool_clock;
+            g_pool_free_bytes += cap;
+            while (g_pool_free.size() > 1 && (g_pool_free.size() > POOL_KEEP || g_pool_free_bytes > POOL_KEEP_BYTES)) {
                 auto oldest = g_pool_free.end();
                 uint64_t best = ~0ull;
                 for (auto f = g_pool_free.begin(); f != g_pool_free.end(); ++f) {
-                    const uint64_t age = g_pool_age[f->second];
+                    const auto a = g_pool_age.find(f->second);
+                    const uint64_t age = a == g_pool_age.end() ? 0 : a->second;
                     if (age < best) {
                         best = age;
                         oldest = f;
                     }
                 }
-                if (oldest != g_pool_free.end()) {
-                    drop = oldest->second;
-                    g_pool_age.erase(drop);
-                    g_pool_free.erase(oldest);
-                }
-            }
-            g_pool_free.emplace(cap, p);
-            g_pool_age[p] = ++g_pool_clock;
-            if (drop) {
-                // (released outside the lock below)
+                if (oldest == g_pool_free.end()) break;
+                drop.push_back(oldest->second);
+                g_pool_free_bytes -= oldest->first;
+                g_pool_age.erase(oldest->second);
+                g_pool_free.erase(oldest);
             }
             p = nullptr;
         }
     }
-    if (drop) (void)hipHostFree(drop);
-    else if (p) free(p);
+    for (void *d : drop) (void)hipHostFree(d);       // (outside the lock)
+    if (p) free(p);
 }
 
 int cornetto_accel_set_share(cornetto_accel_t *h, int percent)

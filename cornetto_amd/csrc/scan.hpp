@@ -190,6 +190,7 @@ __global__ __launch_bounds__(SC_THREADS) void scan_lookback(LbArgs A)
     if (t == 0) s_gid = atomicAdd(A.ticket, 1u) - A.ticket_base;
     __syncthreads();
     const int64_t gid = s_gid;
+    if (gid >= (int64_t)A.m * A.np) return;          // (a ticket base out of step with the counter — the host resets both on any error: never an index)
     const int q = (int)(gid / A.np);
     const int64_t tile = gid - (int64_t)q * A.np;
     const int64_t base = tile * SC_TILE + (int64_t)t * SC_ITEMS;
@@ -268,17 +269,22 @@ static inline int lookback_launch(cornetto_accel_t *h, const char *name, const u
     const bool fresh = h->dev[WS_SCAN].bytes < need;
     uint8_t *ws = (uint8_t *)cn_ws(h, WS_SCAN, need);
     if (!ws) return cn_fail(h, CORNETTO_E_NOMEM, "scan: workspace allocation failed");
-    if (fresh) {                                     // new memory: no state of any epoch in it, the ticket counter starts again
-        CN_HIP(h, hipMemsetAsync(ws, 0, h->dev[WS_SCAN].bytes, h->stream));
-        h->scan_tickets = 0;
-        h->scan_epoch = 0;
-    }
-    h->scan_epoch = (h->scan_epoch + 1) & 0x3FFFFFFFu;
-    if (h->scan_epoch == 0) h->scan_epoch = 1;
-    LbArgs A{in, n, np, stride, m, o, reinterpret_cast<unsigned long long *>(ws + 64), reinterpret_cast<uint32_t *>(ws), h->scan_tickets, h->scan_epoch, d_total};
-    h->scan_tickets += (uint32_t)(m * np);
-    CN_LAUNCH(h, name, scan_lookback<<<dim3((unsigned)(m * np)), dim3(SC_THREADS), 0, h->stream>>>(A));
-    return CORNETTO_OK;
+    const int rc = [&]() -> int {
+        if (fresh) {                                 // new memory: no state of any epoch in it, the ticket counter starts again
+            CN_HIP(h, hipMemsetAsync(ws, 0, h->dev[WS_SCAN].bytes, h->stream));
+            h->scan_tickets = 0;
+            h->scan_epoch = 0;
+        }
+        uint32_t epoch = (h->scan_epoch + 1) & 0x3FFFFFFFu;
+        if (epoch == 0) epoch = 1;
+        LbArgs A{in, n, np, stride, m, o, reinterpret_cast<unsigned long long *>(ws + 64), reinterpret_cast<uint32_t *>(ws), h->scan_tickets, epoch, d_total};
+        CN_LAUNCH(h, name, scan_lookback<<<dim3((unsigned)(m * np)), dim3(SC_THREADS), 0, h->stream>>>(A));
+        h->scan_epoch = epoch;                       // the device's ticket counter advances iff the kernel was queued: the host's copy only then
+        h->scan_tickets += (uint32_t)(m * np);
+        return CORNETTO_OK;
+    }();
+    if (rc != CORNETTO_OK) h->dev[WS_SCAN].bytes = 0;   // counters possibly out of step: the next call gets new, cleared memory (cn_ws frees the block)
+    return rc;
 }
 
 // outs[q][i] = exclusive prefix of in[i * stride + q] for q < m (<= 4); d_total (optional): m grand totals (u64 each).

@@ -2058,7 +2058,8 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
             // the counts are checked afterwards — anything that does not fit takes the steps below as before
             const int64_t est_key = key * 131 + T * 1031 + W;
             if (sift_on && !want_stats && a->sd_est_key == est_key && a->sd_est_rows >= 0 && env_int("CORNETTO_SDUST_FUSED", 1)) {
-                const size_t n_cap = (size_t)(a->sd_est_rows + a->sd_est_rows / 8 + 4096);
+                size_t n_cap = (size_t)(a->sd_est_rows + a->sd_est_rows / 8 + 4096);
+                if (env_int("CORNETTO_SDUST_EST_FORCE", 0) > 0) n_cap = (size_t)env_int("CORNETTO_SDUST_EST_FORCE", 0);   // (tests: an estimate that does not hold)
                 const size_t m_cap = (size_t)(a->sd_est_out + a->sd_est_out / 16 + 1024);
                 uint8_t *ws = (uint8_t *)cn_ws(h, WS_SD_DST, 2 * n_cap * sizeof(cornetto_ivl_t) + cnivl::ws_bytes(n_cap));
                 cornetto_ivl_t *of = (cornetto_ivl_t *)cn_result_alloc(m_cap * sizeof(cornetto_ivl_t));

@@ -37,7 +37,9 @@ enum {
     CORNETTO_E_ARG = -3,      /* invalid argument (NULL, negative length, misaligned device offset, ...) */
     CORNETTO_E_NOMEM = -4,    /* host or device allocation failed */
     CORNETTO_E_UNSUPPORTED = -5, /* parameter outside the implemented range (sdust W > 1026, T > 2^20, ...) */
-    CORNETTO_E_FORMAT = -6       /* malformed input text; see cornetto_bgin_error() */
+    CORNETTO_E_FORMAT = -6,      /* malformed input text; see cornetto_bgin_error() */
+    CORNETTO_E_ASSERT = -7       /* the reference ends with SIGABRT on these inputs: an assert of get_regs() fails (src/boringbits_main.c:353,368);
+                                    cornetto_accel_last_error() names it.  A drop-in caller prints that and abort()s */
 };
 
 typedef struct cornetto_accel cornetto_accel_t; /* device + stream + workspaces */
@@ -247,10 +249,17 @@ const int32_t *cornetto_cov_lens(const cornetto_cov_t *c);
 /* number of windows of a contig: src/boringbits_main.c:338-339 */
 int32_t cornetto_n_reg(int32_t length, int32_t window_size, int32_t window_inc);
 
+/* The asserts of get_regs() for one contig (src/boringbits_main.c:353 `st<end`, :368 `end == length`): 0 when the reference computes
+ * the windows, else the line of the assert that aborts it.  With 1 <= window_inc <= window_size and length >= 1 always 0; with
+ * window_inc > window_size the windows are sparse ([j*inc, min(j*inc + w, length))) and the last one has to reach the contig's end. */
+int32_t cornetto_regs_assert(int32_t length, int32_t window_size, int32_t window_inc);
+
 /* Stage 1: per-`window_inc` block sums on the device plus the exact totals the mean needs.
  * sums[0] = sum of depth, sums[1] = sum of mq_depth, sums[2] = number of positions; the caller forms
  * mean = (int)round(sums[0]/sums[2]) (src/boringbits_main.c:283-285,293-294) — across ranks after an
- * all-reduce of sums[].  Needs 1 <= window_inc <= window_size. */
+ * all-reduce of sums[].  Needs window_inc >= 1; window_inc > window_size is computed as the reference computes it (:346-366).
+ * CORNETTO_E_ASSERT when cornetto_regs_assert() is non-zero for any contig: get_regs() runs over EVERY contig before the
+ * reference prints anything, so the process ends there with nothing on stdout. */
 int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t window_size, int32_t window_inc,
                          uint64_t sums[3]);
 

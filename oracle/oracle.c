@@ -259,6 +259,23 @@ int32_t orc_n_reg(int32_t length, int32_t window_size, int32_t window_inc)
     return n < 1 ? 1 : n;                                                    /* :339 */
 }
 
+/* the asserts of get_regs(): the loop of :346-353 and the two lines behind it (:368-369), statement for statement, without the sums.
+ * 0 = the reference gets through, else the line of the assert that raises SIGABRT */
+int orc_regs_assert(int32_t length, int32_t window_size, int32_t window_inc)
+{
+    int32_t n = orc_n_reg(length, window_size, window_inc);
+    int32_t st = 0, end = 0;
+    for (int32_t j = 0; j < n; ++j) {                        /* :346 */
+        st = j * window_inc;                                 /* :347 */
+        end = st + window_size;                              /* :348 */
+        if (end > length) end = length;                      /* :349-351 */
+        if (!(st < end)) return 353;                         /* :353 */
+    }
+    if (!(end == length)) return 368;                        /* :368 */
+    if (!(st < end)) return 369;                             /* :369 */
+    return 0;
+}
+
 void orc_get_regs(const uint16_t *depth, const uint16_t *mq_depth, int32_t length,
                   int32_t window_size, int32_t window_inc, orc_reg_t *regs)
 {

@@ -25,10 +25,11 @@ REF = os.path.join(ROOT, "oracle", "_ref", "cornetto")
 REFSRC = "/root/reference"
 
 
-def run(args, out_path, stdin=None):
-    """run the reference, store stdout at out_path, return exit status"""
+def run(args, out_path, stdin=None, expect=0):
+    """run the reference, store stdout at out_path, return exit status (expect: the status it must have; -6 = SIGABRT)"""
     with open(out_path, "wb") as fo:
         p = subprocess.run([REF] + args, stdout=fo, stderr=subprocess.DEVNULL, stdin=stdin)
+    assert p.returncode == expect, (args, p.returncode)
     return p.returncode
 
 
@@ -124,19 +125,26 @@ def make_mix_fasta(rng) -> bytes:
     return b"".join(out)
 
 
-def make_bedgraphs(rng):
+BG_CTGS = [("ptg000001l", 120), ("ptg000002l", 2500), ("ptg000003l", 2551), ("ptg000004l", 12_000),
+           ("ptg000005l", 40_000), ("ptg000006l", 2450), ("ptg000007l", 10_000)]
+# a second pair for `-i` larger than `-w` (src/boringbits_main.c:338-369: sparse windows; the last one must reach the contig's end or
+# the reference aborts): every length is <= 64 or in (1000 k, 1000 k + 64], so `-w 64 -i 1000` gets through; 2033 = 1982 + 51 is the
+# contig of exactly w + 51 for `-w 1982 -i 7` (w % inc = 1: the head sums)
+SPARSE_CTGS = [("utg000001l", 15_001), ("utg000002l", 3064), ("utg000003l", 40), ("utg000004l", 64), ("utg000005l", 1001),
+               ("utg000006l", 2033), ("utg000007l", 7050)]
+
+
+def make_bedgraphs(rng, ctgs=BG_CTGS, step=4000, first=1500):
     """two lock-step per-base bedgraphs: lines `name\\tpos\\tpos+1\\tdepth`"""
-    ctgs = [("ptg000001l", 120), ("ptg000002l", 2500), ("ptg000003l", 2551), ("ptg000004l", 12_000),
-            ("ptg000005l", 40_000), ("ptg000006l", 2450), ("ptg000007l", 10_000)]
     tot_lines, mq_lines = [], []
     for name, n in ctgs:
         base = rng.poisson(30, size=(n + 999) // 1000).repeat(1000)[:n]
         depth = base + rng.integers(-2, 3, size=n)
         depth = np.clip(depth, 0, None)
         mq = depth.copy()
-        for pos in range(1500, n, 4000):
+        for pos in range(first, n, step):
             L = int(rng.integers(200, 1500))
-            k = (pos // 4000) % 5
+            k = (pos // step) % 5
             if k == 0:
                 depth[pos:pos + L] //= 5
                 mq[pos:pos + L] = depth[pos:pos + L]
@@ -248,6 +256,31 @@ def main():
     run(["noboringbits", t, "-q", q, "-w", "300", "-i", "7", "-L", "0.33", "-H", "1.45", "-Q", "0.9", "-m", "5000", "-e", "500"], "bg.fun_w300i7.exp")
     run(["boringbits", t, "-q", q, "-w", "300", "-i", "7", "-L", "0.33", "-H", "1.45", "-Q", "0.9", "-m", "5000", "-e", "500"], "bg.boring_w300i7.exp")
     run(["noboringbits", t, "-q", q, "-w", "1000", "-i", "1000", "-m", "2000", "-e", "10000"], "bg.fun_w1000i1000.exp")
+    # the options the reference accepts and ignores (src/boringbits_main.c:590-632): same bytes as the defaults
+    run(["noboringbits", t, "-q", q, "-t", "4", "-K", "10", "-B", "1M", "-o", os.path.join(tmp, "x"), "--debug-break", "1", "--profile-cpu", "yes", "--accel=yes"],
+        os.path.join(tmp, "ignored.out"))
+    assert open(os.path.join(tmp, "ignored.out"), "rb").read() == open("bg.fun_default.exp", "rb").read()
+    # -i larger than -w (:338-369): disjoint windows [j*inc, min(j*inc + w, len)); every contig's last window must be non-empty and end at
+    # the contig's end, else assert(st<end) (:353) raises SIGABRT before anything is printed (stdout is never flushed)
+    run(["noboringbits", t, "-q", q, "-w", "300", "-i", "301", "-m", "5000", "-e", "500"], "bg.fun_w300i301.exp")
+    run(["boringbits", t, "-q", q, "-w", "300", "-i", "301", "-m", "5000", "-e", "500", "-L", "0.33", "-H", "1.45"], "bg.boring_w300i301.exp")
+    run(["noboringbits", t, "-q", q, "-w", "300", "-i", "350"], "bg.abort_w300i350.exp", expect=-6)      # 2450 = 7 x 350: window 7 is empty
+    run(["boringbits", t, "-q", q, "-w", "64", "-i", "1000", "-m", "100"], "bg.abort_w64i1000.exp", expect=-6)   # the first contig (120) already; -m does not save it
+    rng2 = np.random.default_rng(20260808)      # (its own stream: nothing above moves when this part changes)
+    tot2, mq2 = make_bedgraphs(rng2, SPARSE_CTGS, step=1700, first=300)
+    for name, data in (("sparse-total.bg", tot2), ("sparse-mq20.bg", mq2)):
+        with gzip.GzipFile(name + ".gz", "wb", mtime=0) as f:
+            f.write(data)
+        with open(os.path.join(tmp, name), "wb") as f:
+            f.write(data)
+    t2, q2 = os.path.join(tmp, "sparse-total.bg"), os.path.join(tmp, "sparse-mq20.bg")
+    run(["noboringbits", t2, "-q", q2, "-w", "64", "-i", "1000", "-m", "1000", "-e", "200"], "sparse.fun_w64i1000.exp")
+    run(["boringbits", t2, "-q", q2, "-w", "64", "-i", "1000", "-m", "1000", "-e", "200", "-L", "0.2", "-H", "3"], "sparse.boring_w64i1000.exp")
+    run(["noboringbits", t2, "-q", q2, "-w", "64", "-i", "1000", "-m", "100000"], "sparse.fun_w64i1000_short.exp")   # every contig below -m: get_regs ran all the same
+    run(["noboringbits", t2, "-q", q2, "-w", "1982", "-i", "7", "-e", "5000", "-m", "1000"], "sparse.fun_w1982i7e5000.exp")   # -e beyond every contig, w % inc = 1
+    run(["boringbits", t2, "-q", q2, "-w", "1982", "-i", "7", "-e", "5", "-m", "1000", "-L", "0.2", "-H", "3"], "sparse.boring_w1982i7.exp")
+    run(["noboringbits", t2, "-q", q2], "sparse.fun_default.exp")
+    run(["noboringbits", t2, "-q", q2, "-w", "64", "-i", "999"], "sparse.abort_w64i999.exp", expect=-6)
 
     # ---------------- bigenough ----------------
     dst = os.path.join(HERE, "bigenough")

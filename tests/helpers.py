@@ -256,7 +256,19 @@ FASTA_SIDE = [
     (["telowin", "mix.telofind.exp", "99.9", "0.1"], "mix.t01.telowin.exp"),
 ]
 
-# "T" / "Q" stand for the uncompressed cov-total.bg / cov-mq20.bg
+def panel_argv(plain, args):
+    """"T" / "Q" stand for the uncompressed cov-total.bg / cov-mq20.bg, "T2" / "Q2" for sparse-total.bg / sparse-mq20.bg"""
+    names = {"T": "cov-total.bg", "Q": "cov-mq20.bg", "T2": "sparse-total.bg", "Q2": "sparse-mq20.bg"}
+    return [plain[names[x]] if x in names else x for x in args]
+
+
+# command lines on which the reference dies of an assert of get_regs() (src/boringbits_main.c:353): SIGABRT, nothing on stdout
+PANEL_ABORT = [
+    (["noboringbits", "T", "-q", "Q", "-w", "300", "-i", "350"], "bg.abort_w300i350.exp"),
+    (["boringbits", "T", "-q", "Q", "-w", "64", "-i", "1000", "-m", "100"], "bg.abort_w64i1000.exp"),
+    (["noboringbits", "T2", "-q", "Q2", "-w", "64", "-i", "999"], "sparse.abort_w64i999.exp"),
+]
+
 PANEL = [
     (["boringbits", "T", "-q", "Q", "-m", "10000", "-e", "1000", "-L", "0.6", "-Q", "0.6", "-H", "1.6"], "bg.boring_t1.exp"),
     (["noboringbits", "-H", "2.5", "-L", "0.5", "-Q", "0.5", "T", "-q", "Q", "-m", "10000", "-e", "1000"], "bg.fun_t2.exp"),
@@ -265,4 +277,16 @@ PANEL = [
     (["noboringbits", "T", "-q", "Q", "-w", "300", "-i", "7", "-L", "0.33", "-H", "1.45", "-Q", "0.9", "-m", "5000", "-e", "500"], "bg.fun_w300i7.exp"),
     (["boringbits", "T", "-q", "Q", "-w", "300", "-i", "7", "-L", "0.33", "-H", "1.45", "-Q", "0.9", "-m", "5000", "-e", "500"], "bg.boring_w300i7.exp"),
     (["noboringbits", "T", "-q", "Q", "-w", "1000", "-i", "1000", "-m", "2000", "-e", "10000"], "bg.fun_w1000i1000.exp"),
+    # the options the reference accepts and ignores (src/boringbits_main.c:590-632)
+    (["noboringbits", "T", "-q", "Q", "-t", "4", "-K", "10", "-B", "1M", "-o", "/dev/null", "--debug-break", "1", "--profile-cpu", "yes"], "bg.fun_default.exp"),
+    # -i larger than -w: sparse windows (:338-369)
+    (["noboringbits", "T", "-q", "Q", "-w", "300", "-i", "301", "-m", "5000", "-e", "500"], "bg.fun_w300i301.exp"),
+    (["boringbits", "T", "-q", "Q", "-w", "300", "-i", "301", "-m", "5000", "-e", "500", "-L", "0.33", "-H", "1.45"], "bg.boring_w300i301.exp"),
+    (["noboringbits", "T2", "-q", "Q2", "-w", "64", "-i", "1000", "-m", "1000", "-e", "200"], "sparse.fun_w64i1000.exp"),
+    (["boringbits", "T2", "-q", "Q2", "-w", "64", "-i", "1000", "-m", "1000", "-e", "200", "-L", "0.2", "-H", "3"], "sparse.boring_w64i1000.exp"),
+    (["noboringbits", "T2", "-q", "Q2", "-w", "64", "-i", "1000", "-m", "100000"], "sparse.fun_w64i1000_short.exp"),
+    # -e beyond every contig, w % inc = 1 (the head sums), a contig of exactly w + 51
+    (["noboringbits", "T2", "-q", "Q2", "-w", "1982", "-i", "7", "-e", "5000", "-m", "1000"], "sparse.fun_w1982i7e5000.exp"),
+    (["boringbits", "T2", "-q", "Q2", "-w", "1982", "-i", "7", "-e", "5", "-m", "1000", "-L", "0.2", "-H", "3"], "sparse.boring_w1982i7.exp"),
+    (["noboringbits", "T2", "-q", "Q2"], "sparse.fun_default.exp"),
 ]

@@ -54,6 +54,8 @@ def lib():
         L.orc_sdust.restype = C.POINTER(C.c_uint64)
         L.orc_n_reg.argtypes = [C.c_int32] * 3
         L.orc_n_reg.restype = C.c_int32
+        L.orc_regs_assert.argtypes = [C.c_int32] * 3
+        L.orc_regs_assert.restype = C.c_int
         L.orc_get_regs.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         L.orc_get_regs.restype = None
         L.orc_mean_depth.argtypes = [C.c_double, C.c_double]
@@ -136,6 +138,11 @@ def sdust(seq, T=20, W=64):
 
 def n_reg(length, w, inc):
     return lib().orc_n_reg(length, w, inc)
+
+
+def regs_assert(length, w, inc):
+    """0, or the line of the assert of get_regs() (src/boringbits_main.c:353,368,369) that ends the reference"""
+    return lib().orc_regs_assert(length, w, inc)
 
 
 def get_regs(depth, mq, w, inc):

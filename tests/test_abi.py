@@ -46,6 +46,10 @@ def test_no_device_is_a_status_not_a_fallback(lib):
 def test_pure_host_helpers(lib):
     assert lib.cornetto_n_reg(2551, 2500, 50) == 3
     assert lib.cornetto_n_reg(120, 2500, 50) == 1
+    # the asserts of get_regs() (src/boringbits_main.c:353,368): never with inc <= w; with inc > w the last window must reach the end
+    assert lib.cornetto_regs_assert(2551, 2500, 50) == 0 and lib.cornetto_regs_assert(120, 2500, 50) == 0
+    assert lib.cornetto_regs_assert(15001, 64, 1000) == 0 and lib.cornetto_regs_assert(15661, 64, 1000) == 353
+    assert lib.cornetto_regs_assert(2450, 300, 350) == 353 and lib.cornetto_regs_assert(2451, 300, 350) == 0
     assert lib.cornetto_cov_threshold(0.6, 22) == 13
     assert lib.cornetto_cov_threshold(1.6, 22) == 35
     assert abs(lib.cornetto_telowin_threshold(0.4, 99.9) - 0.397606) < 1e-6

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import cornetto_amd
-from helpers import FASTA_SIDE, PANEL, golden
+from helpers import FASTA_SIDE, PANEL, PANEL_ABORT, golden, panel_argv
 from test_oracle_golden import TELOBREAKS_CASES
 
 ASAN_PATH = cornetto_amd.CLI_PATH + "_asan"
@@ -42,7 +42,7 @@ HOST = {"CORNETTO_ACCEL": "no", "HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES
 def plain(golden_dir, tmp_path_factory):
     d = tmp_path_factory.mktemp("plain_host")
     out = {}
-    for fn in ("cov-total.bg.gz", "cov-mq20.bg.gz"):
+    for fn in ("cov-total.bg.gz", "cov-mq20.bg.gz", "sparse-total.bg.gz", "sparse-mq20.bg.gz"):
         dst = d / fn[:-3]
         dst.write_bytes(gzip.open(os.path.join(golden_dir, fn)).read())
         out[fn[:-3]] = str(dst)
@@ -70,7 +70,7 @@ def test_sdust_stdin_on_the_host(cli, golden_dir):
 def test_panel_on_the_host(cli, golden_dir, plain, args, exp, how):
     """the option sets of the reference's own test/test.sh:25,29, defaults and odd window sizes; --accel=no is the reference's
     own spelling of the choice (getopt_long: `--accel=no` and `--accel no` alike), CORNETTO_ACCEL=no the environment's"""
-    a = [plain["cov-total.bg"] if x == "T" else plain["cov-mq20.bg"] if x == "Q" else x for x in args]
+    a = panel_argv(plain, args)
     env = {"HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": ""}
     if how == "env":
         env = HOST
@@ -80,6 +80,17 @@ def test_panel_on_the_host(cli, golden_dir, plain, args, exp, how):
     assert rc == 0, err.decode()
     assert out == golden(golden_dir, exp)
     assert err.count(b"Average depth:") == 1
+
+
+@pytest.mark.parametrize("args,exp", PANEL_ABORT)
+def test_panel_dies_where_the_reference_asserts_on_the_host(cli, golden_dir, plain, args, exp):
+    """get_regs() runs over EVERY contig (it knows no -m) before anything is printed: assert(st<end), src/boringbits_main.c:353 -> SIGABRT,
+    empty stdout.  (The sanitizer build reports the abort as well; its status is the signal's either way.)"""
+    a = panel_argv(plain, args)
+    rc, out, err = run(cli, a[:1] + ["--accel=no"] + a[1:], {"HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": ""})
+    assert rc == -6, (rc, err.decode())
+    assert out == golden(golden_dir, exp) == b""
+    assert b"src/boringbits_main.c:353: get_regs: Assertion `st<end' failed." in err
 
 
 @pytest.mark.parametrize("lens_f,sd_f,tel_f,exp", TELOBREAKS_CASES)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import cornetto_amd
-from helpers import FASTA_SIDE, PANEL, golden
+from helpers import FASTA_SIDE, PANEL, PANEL_ABORT, golden, panel_argv
 
 pytestmark = pytest.mark.gpu
 
@@ -31,7 +31,7 @@ def plain(golden_dir, tmp_path_factory):
     """uncompressed copies of the gz fixtures (bedgraphs are read with fopen by the reference)"""
     d = tmp_path_factory.mktemp("plain")
     out = {}
-    for fn in ("cov-total.bg.gz", "cov-mq20.bg.gz", "mix.fa.gz"):
+    for fn in ("cov-total.bg.gz", "cov-mq20.bg.gz", "sparse-total.bg.gz", "sparse-mq20.bg.gz", "mix.fa.gz"):
         dst = d / fn[:-3]
         dst.write_bytes(gzip.open(os.path.join(golden_dir, fn)).read())
         out[fn[:-3]] = str(dst)
@@ -67,10 +67,43 @@ def test_sdust_stdin(cli, golden_dir):
 @pytest.mark.parametrize("args,exp", PANEL)
 def test_panel(cli, golden_dir, plain, args, exp):
     """the two option sets of the reference's own test/test.sh:25,29 plus defaults and odd window sizes"""
-    a = [plain["cov-total.bg"] if x == "T" else plain["cov-mq20.bg"] if x == "Q" else x for x in args]
+    a = panel_argv(plain, args)
     rc, out, err = run(cli, a)
     assert rc == 0, err.decode()
     assert out == golden(golden_dir, exp)
+
+
+@pytest.mark.parametrize("env", [{}, {"CORNETTO_DEVICES": "0,0,0"}, {"CORNETTO_DEVICES": "0,0", "CORNETTO_BG_SHARD_MIN": "1"}, {"CORNETTO_BG_PIECE": "4096"}])
+@pytest.mark.parametrize("args,exp", PANEL_ABORT)
+def test_panel_dies_where_the_reference_asserts(cli, golden_dir, plain, args, exp, env):
+    """-i larger than -w with a contig whose last window would be empty: get_regs() runs over every contig before the reference prints
+    anything and its assert(st<end) (src/boringbits_main.c:353) raises SIGABRT — same status, nothing on stdout, on one device, with the
+    contigs dealt to several, and with the text itself cut into shares"""
+    rc, out, err = run(cli, panel_argv(plain, args), env)
+    assert rc == -6, (rc, err.decode())
+    assert out == golden(golden_dir, exp) == b""
+    assert b"src/boringbits_main.c:353: get_regs: Assertion `st<end' failed." in err
+
+
+def test_panel_format_error_wins_over_the_assert(cli, plain, tmp_path):
+    """the reference parses both files completely (exit 1 on a malformed line) before get_regs() can assert"""
+    tot = open(plain["cov-total.bg"], "rb").read().splitlines(True)
+    mq = open(plain["cov-mq20.bg"], "rb").read().splitlines(True)
+    a, b = tmp_path / "t.bg", tmp_path / "q.bg"
+    a.write_bytes(b"".join(tot[:-1]) + b"ptg000007l\t9999\t10001\t3\n")
+    b.write_bytes(b"".join(mq[:-1]) + b"ptg000007l\t9999\t10001\t3\n")
+    for env in ({}, {"CORNETTO_DEVICES": "0,0", "CORNETTO_BG_SHARD_MIN": "1"}):
+        rc, out, err = run(cli, ["noboringbits", str(a), "-q", str(b), "-w", "300", "-i", "350"], env)
+        assert rc == 1 and out == b"", (rc, err.decode())
+
+
+def test_panel_accel_yes_and_the_ignored_options(cli, golden_dir, plain):
+    """--accel=yes is the reference's spelling of the default here; -t -K -B -o --debug-break --profile-cpu are accepted and ignored
+    (src/boringbits_main.c:590-632)"""
+    a = panel_argv(plain, ["noboringbits", "T", "-q", "Q", "-t", "4", "-K", "10", "-B", "1M", "-o", "/dev/null", "--debug-break", "1", "--profile-cpu", "yes", "--accel=yes"])
+    rc, out, err = run(cli, a)
+    assert rc == 0, err.decode()
+    assert out == golden(golden_dir, "bg.fun_default.exp")
 
 
 @pytest.mark.parametrize("devices", ["0,0", "0,0,0,0,0", "0,0,0,0,0,0,0,0,0,0,0,0"])
@@ -79,7 +112,7 @@ def test_panel_window_stage_over_several_devices(cli, golden_dir, plain, args, e
     """CORNETTO_DEVICES: the contigs are dealt to the devices after the ingest (cornetto_cov_shard), every device sums and
     classifies its share, the host adds the three totals up for the common thresholds — same bytes as one device (here the
     same GPU several times; more devices than contigs leaves some without work)"""
-    a = [plain["cov-total.bg"] if x == "T" else plain["cov-mq20.bg"] if x == "Q" else x for x in args]
+    a = panel_argv(plain, args)
     rc, out, err = run(cli, a, {"CORNETTO_DEVICES": devices})
     assert rc == 0, err.decode()
     assert out == golden(golden_dir, exp)
@@ -175,7 +208,7 @@ def test_panel_sharded_ingest_over_several_devices(cli, golden_dir, plain, args,
     """CORNETTO_DEVICES with two regular files: the text itself is cut into shares of whole contigs (the same line in both files), every
     device parses, sums and classifies its share; the host adds the three totals up — same bytes as one device.  (CORNETTO_BG_SHARD_MIN=1:
     the fixtures are far below the 64 MB per device at which the CLI cuts by itself.)"""
-    a = [plain["cov-total.bg"] if x == "T" else plain["cov-mq20.bg"] if x == "Q" else x for x in args]
+    a = panel_argv(plain, args)
     rc, out, err = run(cli, a, {"CORNETTO_DEVICES": devices, "CORNETTO_BG_SHARD_MIN": "1"})
     assert rc == 0, err.decode()
     assert out == golden(golden_dir, exp)
@@ -288,7 +321,7 @@ def test_panel_window_stage_over_distinct_devices(cli, golden_dir, plain, args, 
     n = _device_count()
     if n < 2:
         pytest.skip("one GPU visible")
-    a = [plain["cov-total.bg"] if x == "T" else plain["cov-mq20.bg"] if x == "Q" else x for x in args]
+    a = panel_argv(plain, args)
     for devices in ("0,1", "1,0", ",".join(str(i) for i in range(min(n, 8)))):
         rc, out, err = run(cli, a, {"CORNETTO_DEVICES": devices})
         assert rc == 0, err.decode()

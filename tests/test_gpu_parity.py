@@ -420,6 +420,27 @@ def test_sdust_sift_off_equals_on(acc, monkeypatch):
     assert len(on) > 200 and np.array_equal(on, off)
 
 
+def test_sdust_fused_tail_with_an_estimate_that_does_not_hold(acc, monkeypatch):
+    """the one-launch tail of a repeated call (gather + st_fused + copy, sized by the last call's counts) when the counts of THIS call
+    are larger than the estimate: no tile of st_fused may touch anything (rows beyond the estimate were never gathered, their heads
+    would land behind the output block) and the call takes the long way — same intervals, on a fresh and on the grown workspace"""
+    rng = np.random.default_rng(515)
+    seqs = [_sift_stress_seq(rng, 600_000, 1), _sift_stress_seq(rng, 90_000, 0)]
+    asm = acc.asm_upload(seqs)
+    monkeypatch.setenv("CORNETTO_SDUST_SIFT", "1")
+    first = acc.sdust(asm, 20, 64)
+    again = acc.sdust(asm, 20, 64)                       # the fused tail, estimate from the first call
+    assert len(first) > 1500 and np.array_equal(first, again)
+    for force in ("1", "1000", "1025", str(len(first) // 2)):
+        monkeypatch.setenv("CORNETTO_SDUST_EST_FORCE", force)
+        short = acc.sdust(asm, 20, 64)                   # estimate too small: st_fused returns at once, the long way answers
+        monkeypatch.delenv("CORNETTO_SDUST_EST_FORCE")
+        assert np.array_equal(first, short), force
+        assert np.array_equal(first, acc.sdust(asm, 20, 64))     # and the estimate is rebuilt (the long way leaves its counts)
+        assert np.array_equal(first, acc.sdust(asm, 20, 64))
+    asm.close()
+
+
 def test_sdust_boost_from_another_thread_does_not_change_results(acc, monkeypatch):
     """cornetto_accel_set_share + cornetto_accel_boost: the resident sift waves take part of the chip; another host thread says "the rest is
     free now" while the call runs and the remaining waves are launched as a second kernel on the same chunk counters — same intervals,
@@ -655,12 +676,58 @@ def gpu_panel_text(acc, ctgs, boring, w=2500, inc=50, L=0.4, H=2.5, Q=0.4, m=100
     return b"".join(out)
 
 
-from test_oracle_golden import PANEL_CASES  # noqa: E402
+from test_oracle_golden import ABORT_CASES, PANEL_CASES, SPARSE_CASES  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def sparse_ctgs(golden_dir):
+    return read_bedgraph_pair(os.path.join(golden_dir, "sparse-total.bg.gz"), os.path.join(golden_dir, "sparse-mq20.bg.gz"))
 
 
 @pytest.mark.parametrize("boring,kw,exp", PANEL_CASES)
 def test_panel_golden(acc, golden_dir, bg_ctgs, boring, kw, exp):
     assert gpu_panel_text(acc, bg_ctgs, boring, **kw) == golden(golden_dir, exp)
+
+
+@pytest.mark.parametrize("boring,kw,exp", SPARSE_CASES)
+def test_panel_golden_sparse_windows(acc, golden_dir, sparse_ctgs, boring, kw, exp):
+    """-i larger than -w (src/boringbits_main.c:338-369: disjoint windows, each the head of its own block on the device), -e beyond every
+    contig, w % inc = 1 with a contig of exactly w + 51: reference stdout"""
+    assert gpu_panel_text(acc, sparse_ctgs, boring, **kw) == golden(golden_dir, exp)
+
+
+@pytest.mark.parametrize("pair,boring,kw", ABORT_CASES)
+def test_cov_prepare_reports_the_asserts_of_get_regs(acc, bg_ctgs, sparse_ctgs, pair, boring, kw):
+    """where the reference dies of assert(st<end) (:353) the C ABI says so (CORNETTO_E_ASSERT = -7) and names the line; the CLI turns
+    that into the reference's SIGABRT (tests/test_gpu_cli.py)"""
+    import cornetto_amd
+    ctgs = bg_ctgs if pair == "cov" else sparse_ctgs
+    cov = acc.cov_upload([c[1] for c in ctgs], [c[2] for c in ctgs])
+    with pytest.raises(cornetto_amd.AccelError) as ei:
+        acc.cov_prepare(cov, kw["w"], kw["inc"])
+    assert ei.value.status == -7 and "boringbits_main.c:353" in str(ei.value)
+    sd, _sq, _n = acc.cov_prepare(cov, 2500, 50)      # the object is still good
+    assert sd == sum(int(c[1].astype(np.int64).sum()) for c in ctgs)
+    cov.close()
+
+
+@pytest.mark.parametrize("w,inc", [(64, 1000), (300, 301), (1, 2), (50, 127), (50, 128), (50, 129), (2500, 4000), (7, 50)])
+def test_cov_regs_sparse_windows_vs_oracle(acc, w, inc):
+    """inc > w on lengths the reference gets through (every length <= w, or in (k inc, k inc + w]): both block-sum kernels (LDS staging up
+    to inc = 128, direct loads beyond), heads clipped by the contig's end"""
+    rng = np.random.default_rng(w * 977 + inc)
+    lens = sorted({1, w, max(1, w - 1), inc + 1, inc + w, 2 * inc + 1, 5 * inc + max(1, w // 2), 300 * inc + 1, 300 * inc + w, 1000 * inc + 1 + w // 3})
+    assert all(ob.regs_assert(n, w, inc) == 0 for n in lens)
+    depths = [rng.integers(0, 65536, size=n).astype(np.uint16) for n in lens]
+    mqs = [rng.integers(0, 65536, size=n).astype(np.uint16) for n in lens]
+    cov = acc.cov_upload(depths, mqs)
+    sd, sq, n = acc.cov_prepare(cov, w, inc)
+    assert (sd, sq, n) == (sum(int(d.astype(np.int64).sum()) for d in depths), sum(int(q.astype(np.int64).sum()) for q in mqs), sum(lens))
+    for ci in range(len(lens)):
+        got = acc.cov_regs(cov, ci)
+        exp = ob.get_regs(depths[ci], mqs[ci], w, inc)
+        assert np.array_equal(got, exp.astype(got.dtype)), (w, inc, lens[ci])
+    cov.close()
 
 
 @pytest.mark.parametrize("w,inc", [(2500, 50), (300, 7), (1000, 1000), (2500, 49), (64, 1), (5000, 130), (777, 200), (50, 50)])

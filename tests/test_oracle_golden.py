@@ -99,6 +99,8 @@ def panel_text(ctgs, boring, w=2500, inc=50, L=0.4, H=2.5, Q=0.4, m=1000000, e=1
     _ = ob.mean_depth(totq, n)
     lo, hi = ob.threshold(L, mean), ob.threshold(H, mean)
     out = []
+    if any(ob.regs_assert(d.size, w, inc) for _, d, _ in ctgs):      # get_regs() over every contig comes first (:331-369): SIGABRT, no output
+        return None
     for name, d, q in ctgs:
         regs = ob.get_regs(d, q, w, inc)
         length = d.size
@@ -127,6 +129,23 @@ PANEL_CASES = [
     (False, dict(w=300, inc=7, L=0.33, H=1.45, Q=0.9, m=5000, e=500), "bg.fun_w300i7.exp"),
     (True, dict(w=300, inc=7, L=0.33, H=1.45, Q=0.9, m=5000, e=500), "bg.boring_w300i7.exp"),
     (False, dict(w=1000, inc=1000, m=2000, e=10000), "bg.fun_w1000i1000.exp"),
+    (False, dict(w=300, inc=301, m=5000, e=500), "bg.fun_w300i301.exp"),
+    (True, dict(w=300, inc=301, m=5000, e=500, L=0.33, H=1.45), "bg.boring_w300i301.exp"),
+]
+# the second pair of bedgraphs (sparse-*.bg.gz): -i larger than -w, -e beyond every contig, w % inc = 1
+SPARSE_CASES = [
+    (False, dict(w=64, inc=1000, m=1000, e=200), "sparse.fun_w64i1000.exp"),
+    (True, dict(w=64, inc=1000, m=1000, e=200, L=0.2, H=3), "sparse.boring_w64i1000.exp"),
+    (False, dict(w=64, inc=1000, m=100000), "sparse.fun_w64i1000_short.exp"),
+    (False, dict(w=1982, inc=7, e=5000, m=1000), "sparse.fun_w1982i7e5000.exp"),
+    (True, dict(w=1982, inc=7, e=5, m=1000, L=0.2, H=3), "sparse.boring_w1982i7.exp"),
+    (False, dict(), "sparse.fun_default.exp"),
+]
+# (pair, sub-command, options) on which the reference raises SIGABRT with nothing printed (make_golden.py asserts the status)
+ABORT_CASES = [
+    ("cov", False, dict(w=300, inc=350)),
+    ("cov", True, dict(w=64, inc=1000, m=100)),
+    ("sparse", False, dict(w=64, inc=999)),
 ]
 
 
@@ -135,9 +154,42 @@ def bg_ctgs(golden_dir):
     return read_bedgraph_pair(os.path.join(golden_dir, "cov-total.bg.gz"), os.path.join(golden_dir, "cov-mq20.bg.gz"))
 
 
+@pytest.fixture(scope="module")
+def sparse_ctgs(golden_dir):
+    return read_bedgraph_pair(os.path.join(golden_dir, "sparse-total.bg.gz"), os.path.join(golden_dir, "sparse-mq20.bg.gz"))
+
+
 @pytest.mark.parametrize("boring,kw,exp", PANEL_CASES)
 def test_panel_golden(golden_dir, bg_ctgs, boring, kw, exp):
     assert panel_text(bg_ctgs, boring, **kw) == golden(golden_dir, exp)
+
+
+@pytest.mark.parametrize("boring,kw,exp", SPARSE_CASES)
+def test_panel_golden_sparse_windows(golden_dir, sparse_ctgs, boring, kw, exp):
+    assert panel_text(sparse_ctgs, boring, **kw) == golden(golden_dir, exp)
+
+
+@pytest.mark.parametrize("pair,boring,kw", ABORT_CASES)
+def test_panel_where_the_reference_aborts(bg_ctgs, sparse_ctgs, pair, boring, kw):
+    assert panel_text(bg_ctgs if pair == "cov" else sparse_ctgs, boring, **kw) is None
+
+
+def test_regs_assert_closed_form_against_the_loop():
+    """the product decides the asserts of get_regs() from the last window alone (cornetto_regs_assert); the oracle runs the reference's loop
+    (src/boringbits_main.c:346-353,368-369).  Same answer on a grid that has every case: w < inc, w = inc, w > inc, len below / at / above w,
+    lengths at and around multiples of inc."""
+    import cornetto_amd
+    L = cornetto_amd.lib()
+    bad = 0
+    for w in (1, 2, 7, 50, 64, 300, 2500):
+        for inc in (1, 2, 7, 49, 50, 51, 64, 65, 299, 300, 301, 350, 1000, 2499, 2501):
+            for length in list(range(1, 140)) + [299, 300, 301, 349, 350, 351, 700, 999, 1000, 1001, 1064, 1065, 2450, 2500, 2551, 5000, 15001, 15661]:
+                a, b = L.cornetto_regs_assert(length, w, inc), ob.regs_assert(length, w, inc)
+                assert (a != 0) == (b != 0) and (a == b or (a, b) == (353, 369)), (w, inc, length, a, b)
+                bad += a != 0
+                if inc <= w:
+                    assert a == 0
+    assert bad > 1000
 
 
 def test_reference_exp_structure():

@@ -1,7 +1,8 @@
 /* main.c — `cornetto <command>` dispatcher; mirrors src/main.c:95-152 of the reference for the
  * panel-creation sub-commands (same names, same exit codes, same 3-line stderr footer).  Sub-commands of
- * the reference that are outside this path (fixasm, minidot, asmstats, nx, report, telocontigs,
- * telobreaks) are named in the usage text as not built here and exit with status 1. */
+ * the reference that are outside this path (fixasm, minidot, asmstats, nx, report, telocontigs)
+ * are named in the usage text as not built here and exit with status 1; telobreaks
+ * is built and dispatched below. */
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>

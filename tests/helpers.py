@@ -256,6 +256,19 @@ FASTA_SIDE = [
     (["telowin", "mix.telofind.exp", "99.9", "0.1"], "mix.t01.telowin.exp"),
 ]
 
+def build_asan_cli():
+    """`make asan=1` under a file lock: pytest-xdist workers of two test modules would otherwise link the same binary at the same time
+    (and one of them would run a half-written file)"""
+    import fcntl
+    import subprocess
+    import cornetto_amd
+    d = os.path.dirname(cornetto_amd.CLI_PATH)
+    with open(os.path.join(d, ".asan.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-C", d, "-s", "asan=1"])
+    return cornetto_amd.CLI_PATH + "_asan"
+
+
 def panel_argv(plain, args):
     """"T" / "Q" stand for the uncompressed cov-total.bg / cov-mq20.bg, "T2" / "Q2" for sparse-total.bg / sparse-mq20.bg"""
     names = {"T": "cov-total.bg", "Q": "cov-mq20.bg", "T2": "sparse-total.bg", "Q2": "sparse-mq20.bg"}

@@ -22,8 +22,8 @@ def cli(request):
     if request.param == "product":
         assert os.path.exists(cornetto_amd.CLI_PATH), "build the CLI first (make -C cornetto_amd)"
         return cornetto_amd.CLI_PATH
-    subprocess.check_call(["make", "-C", os.path.dirname(cornetto_amd.CLI_PATH), "-s", "asan=1"])
-    return ASAN_PATH
+    from helpers import build_asan_cli
+    return build_asan_cli()
 
 
 def run(cli, args, env=None, stdin=None):

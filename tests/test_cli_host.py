@@ -23,8 +23,8 @@ def cli(request):
         cornetto_amd.build()
     if request.param == "product":
         return cornetto_amd.CLI_PATH
-    subprocess.check_call(["make", "-C", os.path.dirname(cornetto_amd.CLI_PATH), "-s", "asan=1"])
-    return ASAN_PATH
+    from helpers import build_asan_cli
+    return build_asan_cli()
 
 
 def run(cli, args, cwd=None, stdin=None):

@@ -385,7 +385,10 @@ class _RefLib:
 
 
 def _sample_contigs(lens, budget_bases):
-    """the leading WHOLE contigs within the budget (at least one; a first contig beyond the budget is cut)"""
+    """the leading WHOLE contigs within the budget (at least one; a first contig beyond the budget is cut) — in the bench assembly the
+    two largest — plus three small ones that cost nothing and bring the other predicates into the in-run parity: the smallest contig of
+    at least 1 Mb (the -m boundary of print_fun_bits, windows against the edges), one of about 10 Mb, and the smallest contig of all
+    (below -m: no window is selected, boringbits_main.c:428)"""
     out, done = [], 0
     for i, n in enumerate(lens):
         if out and done + n > budget_bases:
@@ -393,7 +396,64 @@ def _sample_contigs(lens, budget_bases):
         n = int(min(n, budget_bases)) if not out else int(n)
         out.append((i, n))
         done += n
+    have = {i for i, _ in out}
+    if out and out[0][1] == lens[out[0][0]]:
+        big = [(n, i) for i, n in enumerate(lens) if n >= 1_000_000 and i not in have]
+        mid = [(abs(n - 10_000_000), i) for i, n in enumerate(lens) if i not in have and 1_000_000 <= n <= 40_000_000]
+        small = [(n, i) for i, n in enumerate(lens) if i not in have]
+        extra = []
+        if big:
+            extra.append(min(big)[1])
+        if mid:
+            extra.append(min(mid)[1])
+        if small:
+            extra.append(min(small)[1])
+        for i in dict.fromkeys(extra):
+            out.append((i, int(lens[i])))
     return out
+
+
+def cpu_all_cores(R, per_contig, lens_all):
+    """SURVEY 8d's second CPU line: the reference takes -t and ignores it (src/boringbits_main.c:590-595), so "all host cores" can only
+    mean one process per contig.  Measured: the sample's contigs at the same time, one thread each (ctypes drops the GIL; the reference's
+    functions share nothing), against the one-after-the-other time of the same contigs -> how well the host scales per contig.  The
+    whole-assembly figure is that per-core rate over min(cores, contigs) cores, BOUNDED by the largest contig, which one core has to
+    walk alone: bases / max(t_largest, sum_t / cores)."""
+    import threading
+    C = R.C
+    jobs = [j for j in per_contig if j["len"] >= 1_000_000][:max(2, min(8, os.cpu_count() or 2))]
+    if len(jobs) < 2:
+        return None
+
+    def work(j):
+        cnt = C.c_int()
+        r = R.so.sdust(None, j["seq"].ctypes.data, j["len"], 20, 64, C.byref(cnt))
+        R.libc.free(r)
+        ctg = R.CtgDepth(b"c", j["len"], j["len"], j["d"].ctypes.data, j["q"].ctypes.data)
+        asm = R.AsmDepth(1, 1, C.pointer(ctg), 30, 30)
+        R.so.free_asm_reg(R.so.get_regs(C.byref(asm), 2500, 50))
+    th = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    serial = sum(j["t_sdust_regs"] for j in jobs)
+    bases = sum(j["len"] for j in jobs)
+    cores = os.cpu_count() or 1
+    rate1 = sum(j["len"] for j in per_contig) / sum(j["t_all"] for j in per_contig)          # bases per second and core, all four stages
+    slow = wall / max(j["t_sdust_regs"] for j in jobs)                                        # >1: the contigs slow each other down (memory bandwidth)
+    total = float(sum(lens_all))
+    t_largest = max(lens_all) / rate1 * max(1.0, slow)
+    t_spread = total / rate1 / min(cores, len(lens_all)) * max(1.0, slow)
+    return {"value": round(total / max(t_largest, t_spread) / 1e9, 4), "unit": "Gbases/s", "cores": min(cores, len(lens_all)), "modelled": True,
+            "measured": {"threads": len(jobs), "bases": bases, "wall_s": round(wall, 2), "one_after_the_other_s": round(serial, 2),
+                         "stages": "sdust + get_regs (find / process_scaffold print to the one stdout: not run side by side)",
+                         "slowdown_of_the_slowest_contig_beside_the_others": round(slow, 3)},
+            "bound": "one process per contig (the reference has no threads: -t is accepted and ignored, src/boringbits_main.c:590-595): the largest contig "
+                     "(%d bases) takes %.1f s on one core, the other %d contigs fit beside it on %d cores -> %.3f Gbases/s for the assembly however many cores the host has" % (
+                         max(lens_all), t_largest, len(lens_all) - 1, cores, total / max(t_largest, t_spread) / 1e9)}
 
 
 def cpu_reference_leg(bases, depth, mq, offs, lens, own, budget_bases):
@@ -409,6 +469,7 @@ def cpu_reference_leg(bases, depth, mq, offs, lens, own, budget_bases):
     thr = ob.telowin_threshold(0.4, 99.9)
     t = {"telofind": 0.0, "telowin": 0.0, "sdust": 0.0, "get_regs": 0.0}
     results = []
+    per_contig = []
     sample = _sample_contigs([lens[i] for i in own], budget_bases)
     done = 0
     for li, n in sample:
@@ -439,6 +500,7 @@ def cpu_reference_leg(bases, depth, mq, offs, lens, own, budget_bases):
             res["wins_text"] = txt
             res["wins_thr"] = 0.4
             cnt = C.c_int()
+            t_before = dict(t)
             t0 = time.perf_counter()
             r = R.so.sdust(None, seq.ctypes.data, n, 20, 64, C.byref(cnt))
             t["sdust"] += time.perf_counter() - t0
@@ -455,6 +517,8 @@ def cpu_reference_leg(bases, depth, mq, offs, lens, own, budget_bases):
             cr = regs.contents.ctg_reg[0]
             res["regs"] = np.ctypeslib.as_array(C.cast(cr.reg, C.POINTER(C.c_int32)), shape=(cr.n_reg, 4)).copy()
             R.so.free_asm_reg(regs)
+            per_contig.append({"len": n, "seq": seq, "d": d, "q": q, "t_sdust_regs": (t["sdust"] - t_before["sdust"]) + (t["get_regs"] - t_before["get_regs"]),
+                               "t_all": 0.0})
         else:
             t0 = time.perf_counter()
             hits = ob.telofind(seq[:n], b"TTAGGG")
@@ -475,6 +539,8 @@ def cpu_reference_leg(bases, depth, mq, offs, lens, own, budget_bases):
             res["regs"] = np.stack([regs[k].astype(np.int32) for k in ("st", "end", "depth", "mq_depth")], axis=1)
         results.append(res)
         done += n
+        if per_contig and per_contig[-1]["t_all"] == 0.0:
+            per_contig[-1]["t_all"] = sum(t.values()) - sum(pc["t_all"] for pc in per_contig[:-1])
     total = sum(t.values())
     model = "unknown"
     try:
@@ -493,6 +559,13 @@ def cpu_reference_leg(bases, depth, mq, offs, lens, own, budget_bases):
                   "of it, one thread; %.1f s of CPU" % (len(sample), done, what, total),
         "stage_gbases_s": {k: round(done / v / 1e9, 4) for k, v in t.items()},
     }
+    if use_ref and os.environ.get("CORNETTO_BENCH_ALL_CORES", "1") != "0":
+        try:
+            ac = cpu_all_cores(R, per_contig, [lens[i] for i in own])
+            if ac:
+                base["all_cores"] = ac
+        except Exception as e:                      # (a reported extra: never the reason a bench line is lost)
+            base["all_cores"] = {"error": repr(e)}
     return base, results
 
 
@@ -634,6 +707,7 @@ class Rank:
         self.handshake = self.overlap and os.environ.get("CORNETTO_BENCH_HANDSHAKE", "1") != "0"
         self.lag_us = float(os.environ.get("CORNETTO_BENCH_SDUST_LAG_US", "0"))
         self.lazy = self.overlap and os.environ.get("CORNETTO_BENCH_LAZY", "1") != "0"
+        self.fused = os.environ.get("CORNETTO_BENCH_FUSED", "1") != "0"
         self.acc.set_lazy(self.lazy)
         self.thr = self.acc.telowin_threshold(0.4, 99.9)
         self.ktime, self.wall = {}, {}
@@ -745,41 +819,54 @@ class Rank:
                 t_lead = time.perf_counter() + self.lead_us * 1e-6
                 while time.perf_counter() < t_lead:
                     pass
-        cov_first = os.environ.get("CORNETTO_BENCH_COV_FIRST", "1") != "0"
-        if not cov_first:
+        need_exchange = world > 1 and (self.scaling == "strong" or self.args.allreduce_always)
+        if self.fused:
+            # the other thread's whole sequence as ONE call (cornetto_panel_step): totals -> [all-reduce of the three sums] -> thresholds ->
+            # selection + telomere scan queued in one go, sized by the last step's counts and checked afterwards: two synchronisations, no
+            # Python between the stages (round 5; CORNETTO_BENCH_FUSED=0 brings the three calls back)
             t0 = time.perf_counter()
-            hits, wins = acc.telo_scan(self.asm, b"TTAGGG", self.thr)
+            xchg = (lambda s_: allreduce_sums(s_, device=self.cdev)) if need_exchange else None
+            sums, (self.lo, self.hi), recs_pk, ctg_first, hits, wins = acc.panel_step(self.asm, self.cov, b"TTAGGG", self.thr, 2500, 50, 0.4, 2.5, 0.4, 100000, 1000000,
+                                                                                     False, xchg)
             if record:
                 self._note(acc)
-                self._lap("telo_scan", t0)
-        t0 = time.perf_counter()
-        sums = acc.cov_prepare(self.cov, 2500, 50)
-        if record:
-            self._note(acc)
-        # the one real exchange: the assembly-wide mean depth behind the thresholds (boringbits_main.c:293-294 -> :518-519).
-        # Weak scaling keeps every assembly's own mean (N independent assemblies); strong scaling needs the all-reduce.
-        if world > 1 and (self.scaling == "strong" or self.args.allreduce_always):
-            sd, sq, n = allreduce_sums(sums, device=self.cdev)
+                self._lap("panel_step", t0)
         else:
-            sd, sq, n = sums
-        mean = int(np.floor(sd / n + 0.5)) if n else 0
-        self.lo, self.hi = acc.cov_threshold(0.4, mean), acc.cov_threshold(2.5, mean)
-        if record:
-            self._lap("cov_prepare", t0)
-        t0 = time.perf_counter()
-        # the selected windows in packed form (8 B per window + the first record of every contig: include/cornetto_accel.h)
-        recs_pk, ctg_first = acc.cov_select_packed(self.cov, self.lo, self.hi, 0.4, 100000, 1000000, False)
-        if record:
-            self._note(acc)
-            self._lap("cov_select", t0)
-        if cov_first:
-            # the coverage stage goes first: its large result copy (8 B per selected window: 60 MB of the 3.16 Gbp assembly) travels beside
-            # the telomere kernels instead of being waited for at the end of the step
+            cov_first = os.environ.get("CORNETTO_BENCH_COV_FIRST", "1") != "0"
+            if not cov_first:
+                t0 = time.perf_counter()
+                hits, wins = acc.telo_scan(self.asm, b"TTAGGG", self.thr)
+                if record:
+                    self._note(acc)
+                    self._lap("telo_scan", t0)
             t0 = time.perf_counter()
-            hits, wins = acc.telo_scan(self.asm, b"TTAGGG", self.thr)
+            sums = acc.cov_prepare(self.cov, 2500, 50)
             if record:
                 self._note(acc)
-                self._lap("telo_scan", t0)
+            # the one real exchange: the assembly-wide mean depth behind the thresholds (boringbits_main.c:293-294 -> :518-519).
+            # Weak scaling keeps every assembly's own mean (N independent assemblies); strong scaling needs the all-reduce.
+            if need_exchange:
+                sd, sq, n = allreduce_sums(sums, device=self.cdev)
+            else:
+                sd, sq, n = sums
+            mean = int(np.floor(sd / n + 0.5)) if n else 0
+            self.lo, self.hi = acc.cov_threshold(0.4, mean), acc.cov_threshold(2.5, mean)
+            if record:
+                self._lap("cov_prepare", t0)
+            t0 = time.perf_counter()
+            # the selected windows in packed form (8 B per window + the first record of every contig: include/cornetto_accel.h)
+            recs_pk, ctg_first = acc.cov_select_packed(self.cov, self.lo, self.hi, 0.4, 100000, 1000000, False)
+            if record:
+                self._note(acc)
+                self._lap("cov_select", t0)
+            if cov_first:
+                # the coverage stage goes first: its large result copy (8 B per selected window: 60 MB of the 3.16 Gbp assembly) travels beside
+                # the telomere kernels instead of being waited for at the end of the step
+                t0 = time.perf_counter()
+                hits, wins = acc.telo_scan(self.asm, b"TTAGGG", self.thr)
+                if record:
+                    self._note(acc)
+                    self._lap("telo_scan", t0)
         if self.overlap and os.environ.get("CORNETTO_BENCH_BOOST", "1") != "0":
             self.acc2.boost(True)                     # this thread's kernels are through: the waves sdust had left to it join in (cornetto_accel_boost)
         if self.lazy:

@@ -34,6 +34,15 @@ class BgErr(C.Structure):
     _fields_ = [("kind", C.c_int32), ("record", C.c_int64), ("a", C.c_int32), ("b", C.c_int32)]
 
 
+class StepOpt(C.Structure):
+    """cornetto_step_opt_t (include/cornetto_accel.h)"""
+    _fields_ = [("motif", C.c_char_p), ("thr_adj", C.c_double), ("window_size", C.c_int32), ("window_inc", C.c_int32), ("low_cov", C.c_float),
+                ("high_cov", C.c_float), ("low_mq", C.c_float), ("edge_len", C.c_int32), ("min_ctg_len", C.c_int32), ("boring", C.c_int32)]
+
+
+SUMS_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_uint64), C.c_void_p)
+
+
 class BedgraphFormatError(ValueError):
     """a check of the reference's get_depths() failed (kind / record / numbers as in cornetto_bgerr_t)"""
 
@@ -115,6 +124,8 @@ def lib():
         "cornetto_cov_threshold": (i32, [C.c_float, i32]),
         "cornetto_cov_select": (C.c_int, [vp, vp, i32, i32, C.c_float, i32, i32, C.c_int, pp, C.POINTER(i64)]),
         "cornetto_cov_select_packed": (C.c_int, [vp, vp, i32, i32, C.c_float, i32, i32, C.c_int, pp, C.POINTER(i64), pp]),
+        "cornetto_panel_step": (C.c_int, [vp, vp, vp, C.POINTER(StepOpt), vp, vp, C.POINTER(C.c_uint64), C.POINTER(i32), pp, C.POINTER(i64), pp, pp, C.POINTER(i64),
+                                          pp, C.POINTER(i64)]),
         "cornetto_cov_n": (i32, [vp]),
         "cornetto_cov_lens": (C.POINTER(i32), [vp]),
         "cornetto_pinned_alloc": (vp, [C.c_size_t]),
@@ -423,6 +434,36 @@ class Accel:
         self._chk(self.L.cornetto_cov_select_packed(self.h, cov.ptr, lo, hi, low_mq, edge_len, min_ctg_len, int(boring),
                                                     C.byref(p), C.byref(n), C.byref(cf)))
         return _take(p, n.value, REGPK_DT), _take(cf, len(cov.lens) + 1, np.dtype("<i8"))
+
+    def panel_step(self, asm, cov, motif, thr_adj, w=2500, inc=50, low_cov=0.4, high_cov=2.5, low_mq=0.4, edge_len=100000, min_ctg_len=1000000, boring=False,
+                   exchange=None):
+        """cornetto_panel_step(): cov_prepare -> thresholds -> cov_select_packed -> telo_scan in one call with two synchronisations.
+        exchange(sums) -> sums (three ints): the all-reduce over the ranks, or None.
+        -> (sums, (lo, hi), packed records, ctg_first, hits, windows)"""
+        opt = StepOpt(motif, thr_adj, w, inc, low_cov, high_cov, low_mq, edge_len, min_ctg_len, int(bool(boring)))
+        box = {}
+
+        def _x(ptr, _ctx):
+            try:
+                r = exchange((int(ptr[0]), int(ptr[1]), int(ptr[2])))
+                ptr[0], ptr[1], ptr[2] = int(r[0]), int(r[1]), int(r[2])
+                return 0
+            except BaseException as e:      # (an exception must not travel through the C frames)
+                box["err"] = e
+                return 1
+        cb = SUMS_FN(_x) if exchange is not None else None
+        cb_p = C.cast(cb, C.c_void_p) if cb is not None else None
+        sums = (C.c_uint64 * 3)()
+        thr = (C.c_int32 * 2)()
+        p, n, cf, ph, nh, pw, nw = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+        rc = self.L.cornetto_panel_step(self.h, asm.ptr, cov.ptr, C.byref(opt), cb_p, None, sums, thr, C.byref(p), C.byref(n), C.byref(cf), C.byref(ph), C.byref(nh),
+                                        C.byref(pw), C.byref(nw))
+        if "err" in box:
+            raise box["err"]
+        self._chk(rc)
+        cov.w, cov.inc = w, inc
+        return ((int(sums[0]), int(sums[1]), int(sums[2])), (int(thr[0]), int(thr[1])), _take(p, n.value, REGPK_DT), _take(cf, len(cov.lens) + 1, np.dtype("<i8")),
+                _take(ph, nh.value, HIT_DT), _take(pw, nw.value, WIN_DT))
 
     @staticmethod
     def unpack_regs(recs, ctg_first, lens, w):

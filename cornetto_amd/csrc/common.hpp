@@ -115,7 +115,7 @@ enum {   // device workspace slots
 };
 static_assert(WS_COUNT <= 64, "cornetto_accel::dev has 64 slots");
 enum {   // pinned host slots
-    PIN_A, PIN_B, PIN_C, PIN_D, PIN_E, PIN_F, PIN_SMALL, PIN_TW, PIN_CW
+    PIN_A, PIN_B, PIN_C, PIN_D, PIN_E, PIN_F, PIN_SMALL, PIN_TW, PIN_CW, PIN_STEP
 };
 
 static inline int cn_fail(cornetto_accel_t *h, int status, const char *fmt, ...)
@@ -276,6 +276,10 @@ struct cornetto_asm {
     int2 *d_tf_tiles = nullptr;
     int32_t *d_tf_ct0 = nullptr;         //   tf_ctg_tile0 on the device
     int64_t tf_n_tiles = -1;
+    // telofind + telowin: the list totals and the windows of the last fused scan, and for which motif / threshold (cornetto_panel_step sizes
+    // the next scan's lists and copies by them and checks afterwards)
+    std::string tf_est_key;
+    int64_t tf_est_cnt[4] = {-1, -1, -1, -1}, tf_est_wins = -1;
     int64_t tw_n_words = -1, tw_n_tiles = 0;   // telowin on the marks of a fused scan: words of the bitmap (-1: layout not built yet), window tiles
     int64_t *d_tw_boff = nullptr;
     int2 *d_tw_tiles = nullptr;
@@ -326,6 +330,9 @@ struct cornetto_cov {
     int32_t *d_cw_first = nullptr;       //   first of them of every contig (their number: the contig has none)
     int cw_mode = -1;
     int32_t cw_min_len = 0, cw_only = -2;
+    // what the last packed selection gave, and for which parameters: the next one with the same parameters sizes its result copy by it
+    // and checks afterwards (cornetto_panel_step: no round trip for the count); -1: none yet
+    int64_t cw_est_key = -1, cw_est_cnt = -1;
 };
 
 static inline int64_t cn_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }

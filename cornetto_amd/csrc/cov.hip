@@ -23,6 +23,7 @@
 #include "common.hpp"
 #include "scan.hpp"
 #include "ivlmerge.hpp"
+#include "internal.hpp"
 
 namespace {
 
@@ -476,6 +477,17 @@ int32_t cornetto_cov_threshold(float factor, int32_t mean)
 int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int32_t inc, uint64_t sums[3])
 {
     if (!h || !c || !sums) return cn_fail(h, CORNETTO_E_ARG, "cov_prepare: bad argument");
+    CN_HIP(h, hipSetDevice(h->device));
+    cn_timing_begin(h);
+    const int rc = cn_cov_prepare_impl(h, c, w, inc, sums);
+    if (rc == CORNETTO_OK) cn_timing_end(h);
+    return rc;
+}
+
+}  // extern "C"
+
+int cn_cov_prepare_impl(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int32_t inc, uint64_t sums[3])
+{
     if (inc < 1) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "cov_prepare: needs window_inc >= 1 (got -i %d: the reference divides by it)", inc);
     // get_regs() runs over every contig before anything is printed, and its asserts (:353, :368) end the process: the first contig, in input
     // order, whose last window is empty or stops short of the contig's end (possible only with w < inc or w < 1) decides
@@ -485,8 +497,6 @@ int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int3
             return cn_fail(h, CORNETTO_E_ASSERT, "src/boringbits_main.c:%d: get_regs: Assertion `%s' failed. (contig %d of length %d, -w %d -i %d)", line,
                            line == 353 ? "st<end" : "end == length", i, c->len[i], w, inc);
     }
-    CN_HIP(h, hipSetDevice(h->device));
-    cn_timing_begin(h);
     const int32_t q = w / inc, r = w % inc;
     sums[0] = sums[1] = 0;
     sums[2] = (uint64_t)c->total;
@@ -512,7 +522,7 @@ int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int3
         if (c->d_cb_tiles) { (void)hipFree(c->d_cb_tiles); c->d_cb_tiles = nullptr; }
         if (c->d_n_reg) { (void)hipFree(c->d_n_reg); c->d_n_reg = nullptr; }
         const size_t nt = tiles.size();
-        if (nt == 0) { cn_timing_end(h); return CORNETTO_OK; }
+        if (nt == 0) return CORNETTO_OK;
         // prefixes [n_blk] uint2, heads [n_blk] uint2, then two arrays of tile offsets [nt] u32 each
         if (hipMalloc((void **)&c->d_blk, (size_t)c->n_blk * sizeof(uint4) + 2 * nt * sizeof(uint32_t)) != hipSuccess ||
             hipMalloc((void **)&c->d_blk_off, (size_t)(c->n + 1) * 8) != hipSuccess ||
@@ -525,7 +535,7 @@ int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int3
         CN_HIP(h, hipStreamSynchronize(h->stream));   // `tiles` is a local
     }
     const size_t nt = (size_t)c->n_cb_tiles;
-    if (nt == 0) { cn_timing_end(h); return CORNETTO_OK; }
+    if (nt == 0) return CORNETTO_OK;
     uint2 *d_t32 = (uint2 *)cn_ws(h, WS_CB_T32, nt * sizeof(uint2) + ((nt + 4095) / 4096 + 1) * 4 * 2);
     ulonglong2 *d_t64 = (ulonglong2 *)cn_ws(h, WS_CB_T64, nt * sizeof(ulonglong2));
     unsigned long long *d_grand = (unsigned long long *)cn_ws(h, WS_CB_GRAND, 16);
@@ -563,20 +573,39 @@ int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int3
     CN_LAUNCH(h, "cov_total64", cov_total64<<<dim3(nb64), dim3(256), 0, h->stream>>>(d_t64, (int64_t)nt, d_grand));
     CN_HIP(h, hipMemcpyAsync(p_grand, d_grand, 16, hipMemcpyDeviceToHost, h->stream));
     CN_HIP(h, hipStreamSynchronize(h->stream));
-    cn_timing_end(h);
     sums[0] = p_grand[0];
     sums[1] = p_grand[1];
     c->sums[0] = sums[0]; c->sums[1] = sums[1]; c->sums[2] = (uint64_t)c->total;
     return CORNETTO_OK;
 }
 
+extern "C" {
+
 // mode 0: all windows of contig only_ctg into regs_host; mode 1/2: selection into a malloc'd array
 // keep_on_device: *recs is the ordered DEVICE array (workspace WS_CW_SEL, valid until the next call), nothing is copied back
+static int64_t cov_est_key(const cornetto_cov_t *c, int mode, int32_t lo, int32_t hi, float low_mq, int32_t edge, int32_t min_len)
+{
+    uint32_t qb;
+    memcpy(&qb, &low_mq, 4);
+    uint64_t k = 1469598103934665603ull;
+    for (uint64_t v : {(uint64_t)(uint32_t)mode, (uint64_t)(uint32_t)lo, (uint64_t)(uint32_t)hi, (uint64_t)qb, (uint64_t)(uint32_t)edge, (uint64_t)(uint32_t)min_len,
+                       (uint64_t)(uint32_t)c->w, (uint64_t)(uint32_t)c->inc})
+        k = (k ^ v) * 1099511628211ull;
+    return (int64_t)(k >> 1);
+}
+
+// spec (packed form only): queue everything, the result copy sized by the last count for these parameters, and return WITHOUT synchronising
 static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_ctg, int mode, int32_t lo, int32_t hi,
                            float low_mq, int32_t edge, int32_t min_len, cornetto_reg_t *regs_host, cornetto_regrec_t **recs,
-                           int64_t *n_recs, bool keep_on_device = false, cornetto_regpk_t **pk_out = nullptr, int64_t **ctg_first = nullptr)
+                           int64_t *n_recs, bool keep_on_device = false, cornetto_regpk_t **pk_out = nullptr, int64_t **ctg_first = nullptr,
+                           CnCovSpec *spec = nullptr)
 {
-    const bool packed = pk_out != nullptr;
+    const bool packed = pk_out != nullptr || spec != nullptr;
+    const int64_t est_key = cov_est_key(c, mode, lo, hi, low_mq, edge, min_len);
+    if (spec) {
+        spec->queued = false;
+        if (c->cw_est_key != est_key || c->cw_est_cnt < 0) return CORNETTO_OK;   // nothing to size the copy by: the caller takes the exact call
+    }
     const size_t rec_bytes = packed ? sizeof(cornetto_regpk_t) : sizeof(cornetto_regrec_t);
     if (!c->d_blk) return cn_fail(h, CORNETTO_E_ARG, "cov: cornetto_cov_prepare() has not been called");
     const int32_t w = c->w, inc = c->inc, q = w / inc, r = w % inc;
@@ -614,14 +643,14 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
         c->cw_only = only_ctg;
     }
     const size_t nt = c->cw_tiles.size();
-    if (nt == 0) return CORNETTO_OK;
+    if (nt == 0) return CORNETTO_OK;                 // (spec: not queued — the exact call makes the empty result)
     const size_t nt_blk = (size_t)c->n_cb_tiles;
     const uint2 *d_pre = reinterpret_cast<const uint2 *>(c->d_blk), *d_head = d_pre + c->n_blk;
     const uint32_t *d_toff_d = reinterpret_cast<const uint32_t *>(d_head + c->n_blk), *d_toff_q = d_toff_d + nt_blk;
     unsigned long long *d_cnt = (unsigned long long *)cn_ws(h, WS_CW_CNT, 16);
     // per tile: {base,count} (8 B) + ordered offset (4 B) + scan partials
     uint2 *d_tres = (uint2 *)cn_ws(h, WS_CW_TRES, nt * 12 + ((nt + 4095) / 4096 + 1) * 4);
-    unsigned long long *p_cnt = (unsigned long long *)cn_pin(h, PIN_SMALL, 64);
+    unsigned long long *p_cnt = spec ? spec->p_cnt : (unsigned long long *)cn_pin(h, PIN_SMALL, 64);
     if (!d_cnt || !d_tres || !p_cnt) return cn_fail(h, CORNETTO_E_NOMEM, "cov: workspace allocation failed");
     uint32_t *d_ooff = reinterpret_cast<uint32_t *>(d_tres + nt), *d_part = d_ooff + nt;
     CwArgs A{};
@@ -686,6 +715,20 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
                 return cn_fail(h, CORNETTO_E_HIP, "cov_select: first records of the contigs failed");
         }
         CN_HIP(h, hipMemcpyAsync(p_cnt, d_cnt, 8, hipMemcpyDeviceToHost, h->stream));
+        if (spec) {
+            // the copy goes out now, for the count of last time plus head room (at most the block); whoever synchronises the stream checks
+            size_t n_copy = std::min<size_t>(cap, (size_t)c->cw_est_cnt + (size_t)c->cw_est_cnt / 16 + 1024);
+            if (const char *f = getenv("CORNETTO_STEP_EST_FORCE")) n_copy = std::min<size_t>(cap, (size_t)std::max(1, atoi(f)));   // (tests: an estimate that does not hold)
+            cornetto_regpk_t *o = (cornetto_regpk_t *)cn_result_alloc(n_copy * rec_bytes);
+            if (!o) return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: host allocation failed");
+            if (cn_result_d2h(h, o, d_dst, n_copy * rec_bytes) != hipSuccess) {
+                cn_result_quiesce(h);
+                cornetto_free(o);
+                return cn_fail(h, CORNETTO_E_HIP, "cov_select: copy back failed");
+            }
+            spec->queued = true; spec->o = o; spec->n_copy = n_copy; spec->cap = cap; spec->p_cf = p_cf; spec->key = est_key;
+            return CORNETTO_OK;
+        }
         CN_HIP(h, hipStreamSynchronize(h->stream));
         cnt = p_cnt[0];
         if (cnt <= cap) break;
@@ -712,8 +755,13 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
         if (!cf) { if (!keep_on_device) cornetto_free(o); return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: host allocation failed"); }
         *ctg_first = cf;
     }
-    if (packed) *pk_out = reinterpret_cast<cornetto_regpk_t *>(o);
-    else *recs = o;
+    if (packed) {
+        *pk_out = reinterpret_cast<cornetto_regpk_t *>(o);
+        c->cw_est_key = est_key;
+        c->cw_est_cnt = (int64_t)cnt;
+    } else {
+        *recs = o;
+    }
     *n_recs = (int64_t)cnt;
     return CORNETTO_OK;
 }
@@ -749,14 +797,53 @@ int cornetto_cov_select_packed(cornetto_accel_t *h, const cornetto_cov_t *c, int
                                int32_t min_ctg_len, int boring, cornetto_regpk_t **recs, int64_t *n_recs, int64_t **ctg_first)
 {
     if (!h || !c || !recs || !n_recs || !ctg_first) return cn_fail(h, CORNETTO_E_ARG, "cov_select_packed: bad argument");
+    CN_HIP(h, hipSetDevice(h->device));
+    cn_timing_begin(h);
+    const int rc = cn_cov_select_packed_impl(h, const_cast<cornetto_cov_t *>(c), lo, hi, low_mq, edge_len, min_ctg_len, boring, recs, n_recs, ctg_first);
+    cn_timing_end(h);
+    return rc;
+}
+
+}  // extern "C"
+
+int cn_cov_spec_queue(cornetto_accel_t *h, cornetto_cov_t *c, int32_t lo, int32_t hi, float low_mq, int32_t edge_len, int32_t min_ctg_len, int boring,
+                      unsigned long long *p_cnt, CnCovSpec *S)
+{
+    S->p_cnt = p_cnt;
+    return cov_run_windows(h, c, -1, boring ? 2 : 1, lo, hi, low_mq, edge_len, min_ctg_len, nullptr, nullptr, nullptr, false, nullptr, nullptr, S);
+}
+
+int cn_cov_spec_finish(cornetto_accel_t *h, cornetto_cov_t *c, CnCovSpec *S, cornetto_regpk_t **recs, int64_t *n_recs, int64_t **ctg_first)
+{
+    if (!S->queued) return 1;
+    S->queued = false;
+    const unsigned long long cnt = S->p_cnt[0];
+    int64_t *cf = cnt <= S->n_copy ? (int64_t *)malloc(((size_t)c->n + 1) * sizeof(int64_t)) : nullptr;
+    if (!cf) {                                        // the count outgrew the copy (or no memory): nothing of this attempt is returned
+        cn_result_quiesce(h);
+        cornetto_free(S->o);
+        S->o = nullptr;
+        c->cw_est_key = -1;
+        return cnt <= S->n_copy ? cn_fail(h, CORNETTO_E_NOMEM, "cov_select: host allocation failed") : 1;
+    }
+    for (int32_t i = 0; i < c->n; ++i) cf[i] = (int64_t)S->p_cf[i];
+    cf[c->n] = (int64_t)cnt;
+    *recs = S->o;
+    *n_recs = (int64_t)cnt;
+    *ctg_first = cf;
+    S->o = nullptr;
+    c->cw_est_key = S->key;
+    c->cw_est_cnt = (int64_t)cnt;
+    return CORNETTO_OK;
+}
+
+int cn_cov_select_packed_impl(cornetto_accel_t *h, cornetto_cov_t *c, int32_t lo, int32_t hi, float low_mq, int32_t edge_len, int32_t min_ctg_len, int boring,
+                              cornetto_regpk_t **recs, int64_t *n_recs, int64_t **ctg_first)
+{
     *recs = nullptr;
     *n_recs = 0;
     *ctg_first = nullptr;
-    CN_HIP(h, hipSetDevice(h->device));
-    cn_timing_begin(h);
-    int rc = cov_run_windows(h, const_cast<cornetto_cov_t *>(c), -1, boring ? 2 : 1, lo, hi, low_mq, edge_len, min_ctg_len, nullptr, nullptr, n_recs, false,
-                             recs, ctg_first);
-    cn_timing_end(h);
+    int rc = cov_run_windows(h, c, -1, boring ? 2 : 1, lo, hi, low_mq, edge_len, min_ctg_len, nullptr, nullptr, n_recs, false, recs, ctg_first);
     if (rc == CORNETTO_OK && !*recs) {   // nothing to scan (no contig qualifies): empty, freeable results
         *recs = (cornetto_regpk_t *)malloc(sizeof(cornetto_regpk_t));
         if (!*ctg_first) *ctg_first = (int64_t *)calloc((size_t)c->n + 1, sizeof(int64_t));
@@ -764,6 +851,8 @@ int cornetto_cov_select_packed(cornetto_accel_t *h, const cornetto_cov_t *c, int
     }
     return rc;
 }
+
+extern "C" {
 
 namespace {
 __global__ void cov_rec_spans(const cornetto_regrec_t *r, int64_t n, cornetto_ivl_t *out)

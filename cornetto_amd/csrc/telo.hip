@@ -26,6 +26,7 @@
 
 #include "common.hpp"
 #include "scan.hpp"
+#include "internal.hpp"
 
 namespace {
 
@@ -265,16 +266,18 @@ __global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
 // fixed rows -> dense lists in tile (= contig, position) order; wave q of a workgroup copies list q of one tile
 __global__ __launch_bounds__(256) void tf_gather(const int32_t *r0, const int32_t *r1, const int32_t *r2, const int32_t *r3,
                                                  const uint4 *tile_cnt, const uint32_t *o0, const uint32_t *o1, const uint32_t *o2,
-                                                 const uint32_t *o3, int32_t *d0, int32_t *d1, int32_t *d2, int32_t *d3)
+                                                 const uint32_t *o3, int32_t *d0, int32_t *d1, int32_t *d2, int32_t *d3, uint4 caps)
 {
     const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t tile = blockIdx.x;
     const uint4 c4 = tile_cnt[tile];
     const uint32_t cnt = q == 0 ? c4.x : q == 1 ? c4.y : q == 2 ? c4.z : c4.w;
+    const uint32_t cap = q == 0 ? caps.x : q == 1 ? caps.y : q == 2 ? caps.z : caps.w;    // entries list q has room for (lists sized by an estimate: telo spec)
     const int32_t *src = (q == 0 ? r0 : q == 1 ? r1 : q == 2 ? r2 : r3) + tile * TF_ROW;
     const uint32_t *off = q == 0 ? o0 : q == 1 ? o1 : q == 2 ? o2 : o3;
-    int32_t *dst = (q == 0 ? d0 : q == 1 ? d1 : q == 2 ? d2 : d3) + off[tile];
-    if ((uint32_t)lane < cnt && lane < TF_ROW) dst[lane] = src[lane];
+    const uint32_t at = off[tile];
+    int32_t *dst = (q == 0 ? d0 : q == 1 ? d1 : q == 2 ? d2 : d3) + at;
+    if ((uint32_t)lane < cnt && lane < TF_ROW && (unsigned long long)at + (uint32_t)lane < cap) dst[lane] = src[lane];
 }
 
 // list offsets at contig boundaries: ctg_off[q][c] = number of entries of list q before contig c (c = n: total)
@@ -311,6 +314,31 @@ __global__ void tf_pair(const int32_t *hf, const int32_t *tf, const int32_t *hr,
     }
     const int c = lo;
     const uint32_t pos = strand ? cf[c + 1] + cr[c] + (i - cr[c]) : cf[c] + cr[c] + (i - cf[c]);
+    const int32_t st = strand ? hr[i] : hf[i], en = (strand ? tr[i] : tf[i]) + k;
+    out[pos] = cornetto_hit_t{c, strand, st, en};
+}
+
+// the same with the list totals read on the device (lists and output sized by an estimate: nothing is touched when a total outgrew its list)
+__global__ void tf_pair_dev(const int32_t *hf, const int32_t *tf, const int32_t *hr, const int32_t *tr, const uint32_t *ctg_off, int32_t n_ctg,
+                            const unsigned long long *totals, uint4 caps, int32_t k, cornetto_hit_t *out)
+{
+    const unsigned long long t0 = totals[0], t1 = totals[1], t2 = totals[2], t3 = totals[3];
+    if (t0 > caps.x || t1 > caps.y || t2 > caps.z || t3 > caps.w || t0 != t1 || t2 != t3) return;
+    const uint32_t n_f = (uint32_t)t0, n_r = (uint32_t)t2;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_f + n_r) return;
+    const int strand = g >= n_f;
+    const uint32_t i = strand ? g - n_f : g;
+    const uint32_t *cf = ctg_off, *cr = ctg_off + 2 * (size_t)(n_ctg + 1);
+    const uint32_t *mine = strand ? cr : cf;
+    int lo = 0, hi = n_ctg;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (mine[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    const int c = lo;
+    const uint32_t pos = strand ? cf[c + 1] + cr[c] + (i - cr[c]) : cf[c] + cr[c] + (i - cf[c]);
+    if (pos >= n_f + n_r) return;                 // (unequal heads and tails inside a contig: the error flag of tf_ctgoff says so)
     const int32_t st = strand ? hr[i] : hf[i], en = (strand ? tr[i] : tf[i]) + k;
     out[pos] = cornetto_hit_t{c, strand, st, en};
 }
@@ -606,6 +634,7 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
     CN_HIP(h, hipSetDevice(h->device));
     if (hits) { *hits = nullptr; *n_hits = 0; }
     if (bitmap_valid) *bitmap_valid = false;
+    a->tf_est_cnt[0] = a->tf_est_cnt[1] = a->tf_est_cnt[2] = a->tf_est_cnt[3] = -1;
 
     const std::string rc = revcomp(motif);
     const bool bordered = long_motif || has_border(motif) || has_border(rc);
@@ -735,7 +764,8 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
                 hipEvent_t ea = cn_event(h), eb = cn_event(h);
                 (void)hipEventRecord(ea, h->stream);
                 tf_gather<<<dim3((unsigned)nt), dim3(256), 0, h->stream>>>(d_rows[0], d_rows[1], d_rows[2], d_rows[3], d_tc, d_offq[0], d_offq[1],
-                                                                           d_offq[2], d_offq[3], d_list[0], d_list[1], d_list[2], d_list[3]);
+                                                                           d_offq[2], d_offq[3], d_list[0], d_list[1], d_list[2], d_list[3],
+                                                                           make_uint4(~0u, ~0u, ~0u, ~0u));
                 (void)hipEventRecord(eb, h->stream);
                 h->recs.push_back(cornetto_accel::Rec{"tf_gather", ea, eb});
                 CN_HIP(h, hipGetLastError());
@@ -778,6 +808,7 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
                     return cn_fail(h, CORNETTO_E_HIP, "telofind: pairing run heads with tails failed%s", ok ? " (a contig has unequal heads and tails)" : "");
                 }
                 n_out = (int64_t)tot;
+                for (int q = 0; q < 4; ++q) a->tf_est_cnt[q] = (int64_t)cnt[q];
             } else {
                 // sequential greedy rule on the device over the dense match lists
                 std::vector<uint4> tc(nt);
@@ -867,6 +898,27 @@ int cornetto_telo_scan(cornetto_accel_t *h, const cornetto_asm_t *a, const char 
 {
     if (!h || !a || !wins || !n_wins || (hits && !n_hits)) return cn_fail(h, CORNETTO_E_ARG, "telo_scan: bad argument");
     cn_timing_begin(h);
+    const int rc = cn_telo_scan_impl(h, a, motif, thr_adj, hits, n_hits, wins, n_wins);
+    cn_timing_end(h);
+    return rc;
+}
+
+}  // extern "C"
+
+namespace {
+std::string tf_est_key_of(const char *motif, double thr_adj)
+{
+    char b[40];
+    unsigned long long bits;
+    memcpy(&bits, &thr_adj, 8);
+    snprintf(b, sizeof(b), "|%016llx", bits);
+    return std::string(motif ? motif : "") + b;
+}
+}  // namespace
+
+int cn_telo_scan_impl(cornetto_accel_t *h, const cornetto_asm_t *a, const char *motif, double thr_adj, cornetto_hit_t **hits, int64_t *n_hits, cornetto_win_t **wins,
+                      int64_t *n_wins)
+{
     unsigned long long *d_bitmap = nullptr;
     bool valid = false;
     cornetto_hit_t *hh = nullptr;
@@ -883,7 +935,16 @@ int cornetto_telo_scan(cornetto_accel_t *h, const cornetto_asm_t *a, const char 
             rc = telowin_from_hits(h, hh, nh, a->len.data(), a->n, thr_adj, wins, n_wins);
         }
     }
-    cn_timing_end(h);
+    {   // what the next scan of this assembly with this motif and threshold may size itself by (cn_telo_spec_queue); the list totals were
+        // noted by telofind_impl
+        cornetto_asm_t *am = const_cast<cornetto_asm_t *>(a);
+        if (rc == CORNETTO_OK && valid && hits && am->tf_est_cnt[0] >= 0) {
+            am->tf_est_key = tf_est_key_of(motif, thr_adj);
+            am->tf_est_wins = *n_wins;
+        } else {
+            am->tf_est_key.clear();
+        }
+    }
     if (rc != CORNETTO_OK || !hits) {
         // (a lazy handle may still be copying into hh on its copy stream; hh is library memory — the pinned pool for large results)
         cn_result_quiesce(h);
@@ -895,4 +956,140 @@ int cornetto_telo_scan(cornetto_accel_t *h, const cornetto_asm_t *a, const char 
     return rc;
 }
 
-}  // extern "C"
+// ---- the fused scan queued without its synchronisations (internal.hpp) ----------------------------------------------------------------
+int cn_telo_spec_queue(cornetto_accel_t *h, cornetto_asm_t *a, const char *motif_c, double thr_adj, unsigned long long *p_cnt, CnTeloSpec *S)
+{
+    S->queued = false;
+    S->p_cnt = p_cnt;
+    if (!motif_c || a->tf_est_key.empty() || a->tf_est_key != tf_est_key_of(motif_c, thr_adj) || a->tf_est_cnt[0] < 0 || a->tf_est_wins < 0) return CORNETTO_OK;
+    const std::string motif(motif_c);
+    const int k = (int)motif.size();
+    if (k < 1 || k > MAX_MOTIF || a->tf_n_tiles <= 0 || a->tw_n_words < 0 || a->tw_n_tiles <= 0) return CORNETTO_OK;
+    const std::string rc = revcomp(motif), both = motif + rc;
+    if (has_border(motif) || has_border(rc)) return CORNETTO_OK;
+    const size_t nt = (size_t)a->tf_n_tiles;
+    const size_t np = 4 * ((nt + 4095) / 4096) + 4;
+    uint2 *d_lut = (uint2 *)cn_ws(h, WS_TF_LUT, 256 * sizeof(uint2) + 2 * (size_t)k + 16);
+    if (!d_lut || h->tf_lut_key != both || h->tf_lut_ptr != d_lut) return CORNETTO_OK;      // (the tables of this motif are not on the device: the exact call uploads them)
+    const int H = k <= 8 ? 7 : (k <= 16 ? 15 : 31);
+    unsigned long long *d_cnt = (unsigned long long *)cn_ws(h, WS_TF_CNT, 64);
+    uint4 *d_tc = (uint4 *)cn_ws(h, WS_TF_TC, nt * sizeof(uint4));
+    uint32_t *d_off = (uint32_t *)cn_ws(h, WS_TF_TB, (4 * nt + np) * sizeof(uint32_t));
+    const size_t words = (size_t)a->tw_n_words;
+    unsigned long long *d_bitmap = (unsigned long long *)cn_ws(h, WS_TF_BITMAP, words * 8);
+    if (!d_cnt || !d_tc || !d_off || !d_bitmap) return cn_fail(h, CORNETTO_E_NOMEM, "telo_scan: workspace allocation failed");
+    uint32_t *d_offq[4] = {d_off, d_off + nt, d_off + 2 * nt, d_off + 3 * nt}, *d_part = d_off + 4 * nt;
+    uint32_t *d_ovf = reinterpret_cast<uint32_t *>(d_cnt + 4), *d_err = d_ovf + 1;
+    int32_t *d_rows[4];
+    for (int q = 0; q < 4; ++q) {
+        d_rows[q] = (int32_t *)cn_ws(h, WS_TF_L0 + q, nt * TF_ROW * sizeof(int32_t));
+        if (!d_rows[q]) return cn_fail(h, CORNETTO_E_NOMEM, "telo_scan: workspace allocation failed");
+    }
+    // lists, pairing and copies by the counts of last time plus head room
+    size_t seg[4], tot_cap = 0;
+    const char *force = getenv("CORNETTO_STEP_EST_FORCE");                          // (tests: estimates that do not hold)
+    for (int q = 0; q < 4; ++q) {
+        seg[q] = (size_t)a->tf_est_cnt[q] + (size_t)a->tf_est_cnt[q] / 16 + 1024;
+        if (force) seg[q] = (size_t)std::max(1, atoi(force));
+        if (seg[q] > 0x7fffffffull) return CORNETTO_OK;
+        S->seg_cap[q] = seg[q];
+    }
+    tot_cap = seg[0] + seg[2];
+    int32_t *d_dense = (int32_t *)cn_ws(h, WS_TF_RUNS, (seg[0] + seg[1] + seg[2] + seg[3] + 4) * sizeof(int32_t));
+    uint32_t *d_coff = (uint32_t *)cn_ws(h, WS_TF_ROFF, 4 * ((size_t)a->n + 1) * 4);
+    cornetto_hit_t *d_hits = (cornetto_hit_t *)cn_ws(h, WS_TF_HITS, tot_cap * sizeof(cornetto_hit_t));
+    unsigned long long *d_twcnt = (unsigned long long *)cn_ws(h, WS_TW_CNT, 16);
+    const size_t win_ws_cap = std::max<size_t>(1u << 16, h->dev[WS_TW_OUT].bytes / sizeof(int4));
+    int4 *d_wout = (int4 *)cn_ws(h, WS_TW_OUT, win_ws_cap * sizeof(int4));
+    const size_t win_cap = force ? std::min<size_t>(win_ws_cap, (size_t)std::max(1, atoi(force) / 64))
+                                 : std::min<size_t>(win_ws_cap, (size_t)a->tf_est_wins + (size_t)a->tf_est_wins / 8 + 1024);
+    int4 *p_wins = (int4 *)cn_pin(h, PIN_TW, win_cap * sizeof(int4));
+    if (!d_dense || !d_coff || !d_hits || !d_twcnt || !d_wout || !p_wins) return cn_fail(h, CORNETTO_E_NOMEM, "telo_scan: workspace allocation failed");
+    int32_t *d_list[4] = {d_dense, d_dense + seg[0], d_dense + seg[0] + seg[1], d_dense + seg[0] + seg[1] + seg[2]};
+    cornetto_hit_t *out = (cornetto_hit_t *)cn_result_alloc(tot_cap * sizeof(cornetto_hit_t));
+    if (!out) return cn_fail(h, CORNETTO_E_NOMEM, "telo_scan: host allocation failed");
+    struct Guard {                                   // (an error below gives the buffer back)
+        cornetto_accel_t *h;
+        cornetto_hit_t **o;
+        ~Guard() { if (*o) { cn_result_quiesce(h); cornetto_free(*o); } }
+    } guard{h, &out};
+
+    CN_HIP(h, hipMemsetAsync(d_cnt, 0, 64, h->stream));
+    static const int refill = [] { const char *v = getenv("CORNETTO_TF_BITMAP_REFILL"); return v ? atoi(v) : 0; }();
+    if (refill || !(h->tf_bm_uid == a->uid && h->tf_bm_ptr == d_bitmap && h->tf_bm_words == words)) {
+        h->tf_bm_uid = 0;
+        CN_HIP(h, hipMemsetAsync(d_bitmap, 0, words * 8, h->stream));
+        h->tf_bm_uid = a->uid; h->tf_bm_ptr = d_bitmap; h->tf_bm_words = words;
+    }
+    TfArgs A{};
+    A.bases = a->d_bases; A.ctg_off = a->d_off; A.ctg_len = a->d_len; A.tiles = a->d_tf_tiles; A.lut = d_lut; A.k = k; A.mot = reinterpret_cast<uint8_t *>(d_lut + 256);
+    A.bordered = 0; A.bitmap = d_bitmap; A.bm_off = a->d_tw_boff; A.tile_cnt = d_tc; A.ovf = d_ovf;
+    A.mode = 2;
+    A.list0 = d_rows[0]; A.list1 = d_rows[1]; A.list2 = d_rows[2]; A.list3 = d_rows[3];
+    if (H == 7) CN_LAUNCH(h, "tf_scan", tf_scan<7><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
+    else if (H == 15) CN_LAUNCH(h, "tf_scan", tf_scan<15><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
+    else CN_LAUNCH(h, "tf_scan", tf_scan<31><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
+    // the windows only need the marks: queued right behind the scan
+    CN_HIP(h, hipMemsetAsync(d_twcnt, 0, 8, h->stream));
+    TwArgs W{d_bitmap, a->d_tw_boff, a->d_len, a->d_tw_tiles, thr_adj, d_wout, d_twcnt, (uint32_t)std::min<size_t>(win_ws_cap, 0x7fffffff)};
+    CN_LAUNCH(h, "tw_scan", tw_scan<<<dim3((unsigned)a->tw_n_tiles), dim3(256), 0, h->stream>>>(W));
+    CN_TRY(cnscan::exclusive_u32_multi(h, "tf_order", reinterpret_cast<const uint32_t *>(d_tc), (int64_t)nt, 4, 4, d_offq, d_part, d_cnt));
+    const uint4 caps = make_uint4((uint32_t)seg[0], (uint32_t)seg[1], (uint32_t)seg[2], (uint32_t)seg[3]);
+    CN_LAUNCH(h, "tf_gather", tf_gather<<<dim3((unsigned)nt), dim3(256), 0, h->stream>>>(d_rows[0], d_rows[1], d_rows[2], d_rows[3], d_tc, d_offq[0], d_offq[1], d_offq[2],
+                                                                                        d_offq[3], d_list[0], d_list[1], d_list[2], d_list[3], caps));
+    {
+        hipEvent_t ea = cn_event(h), eb = cn_event(h);
+        (void)hipEventRecord(ea, h->stream);
+        tf_ctgoff<<<dim3((unsigned)((a->n + 256) / 256)), dim3(256), 0, h->stream>>>(a->d_tf_ct0, a->n, (int64_t)nt, d_offq[0], d_offq[1], d_offq[2], d_offq[3], d_cnt, d_coff,
+                                                                                   d_err);
+        tf_pair_dev<<<dim3((unsigned)((tot_cap + 255) / 256)), dim3(256), 0, h->stream>>>(d_list[0], d_list[1], d_list[2], d_list[3], d_coff, a->n, d_cnt, caps, k, d_hits);
+        (void)hipEventRecord(eb, h->stream);
+        h->recs.push_back(cornetto_accel::Rec{"tf_pair", ea, eb});
+        CN_HIP(h, hipGetLastError());
+    }
+    CN_HIP(h, hipMemcpyAsync(p_cnt, d_cnt, 64, hipMemcpyDeviceToHost, h->stream));
+    CN_HIP(h, hipMemcpyAsync(p_cnt + 8, d_twcnt, 8, hipMemcpyDeviceToHost, h->stream));
+    CN_HIP(h, hipMemcpyAsync(p_wins, d_wout, win_cap * sizeof(int4), hipMemcpyDeviceToHost, h->stream));
+    CN_HIP(h, cn_result_d2h(h, out, d_hits, tot_cap * sizeof(cornetto_hit_t)));
+    S->hits = out;
+    out = nullptr;
+    S->hit_cap = tot_cap;
+    S->p_wins = p_wins;
+    S->win_cap = win_cap;
+    S->queued = true;
+    return CORNETTO_OK;
+}
+
+int cn_telo_spec_finish(cornetto_accel_t *h, cornetto_asm_t *a, const char *motif, double thr_adj, CnTeloSpec *S, cornetto_hit_t **hits, int64_t *n_hits,
+                        cornetto_win_t **wins, int64_t *n_wins)
+{
+    if (!S->queued) return 1;
+    S->queued = false;
+    const unsigned long long *c = S->p_cnt;
+    const uint32_t ovf = (uint32_t)(c[4] & 0xFFFFFFFFull), err = (uint32_t)(c[4] >> 32);
+    const unsigned long long n_win = c[8];
+    bool ok = ovf <= TF_ROW && err == 0 && c[0] == c[1] && c[2] == c[3] && n_win <= S->win_cap;
+    for (int q = 0; q < 4; ++q) ok = ok && c[q] <= S->seg_cap[q];
+    cornetto_win_t *w = ok ? (cornetto_win_t *)malloc((n_win ? (size_t)n_win : 1) * sizeof(cornetto_win_t)) : nullptr;
+    if (!w) {                                         // an estimate did not hold (or anything the exact call has its own answer for): nothing of this attempt is returned
+        cn_result_quiesce(h);
+        cornetto_free(S->hits);
+        S->hits = nullptr;
+        a->tf_est_key.clear();
+        return 1;
+    }
+    std::vector<int4> host(S->p_wins, S->p_wins + n_win);
+    std::sort(host.begin(), host.end(), [](const int4 &x, const int4 &y) { return x.x != y.x ? x.x < y.x : x.y < y.y; });
+    for (size_t i = 0; i < host.size(); ++i) {
+        w[i].ctg = host[i].x; w[i].start = host[i].y; w[i].end = host[i].z; w[i].car = host[i].w;
+    }
+    *wins = w;
+    *n_wins = (int64_t)n_win;
+    *hits = S->hits;
+    *n_hits = (int64_t)(c[0] + c[2]);
+    S->hits = nullptr;
+    for (int q = 0; q < 4; ++q) a->tf_est_cnt[q] = (int64_t)c[q];
+    a->tf_est_wins = (int64_t)n_win;
+    (void)motif; (void)thr_adj;
+    return CORNETTO_OK;
+}

@@ -293,6 +293,28 @@ int cornetto_cov_select_packed(cornetto_accel_t *h, const cornetto_cov_t *c, int
                                int32_t edge_len, int32_t min_ctg_len, int boring, cornetto_regpk_t **recs, int64_t *n_recs,
                                int64_t **ctg_first);
 
+/* One pass of the panel path over a resident assembly and its resident coverage in one call: cornetto_cov_prepare() ->
+ * cornetto_cov_threshold() x 2 (mean = (int)round(sums[0] / sums[2]), src/boringbits_main.c:293, :518-519) ->
+ * cornetto_cov_select_packed() -> cornetto_telo_scan(), the same kernels and the same results.  What it saves is host round trips:
+ * everything behind the totals is queued in one go, sized by the counts the previous step over the same objects gave and checked
+ * afterwards (two synchronisations instead of five; a count that outgrew its estimate repeats that part through the exact entry
+ * point).  `exchange`, if not NULL, is called once with the three sums of THIS process's contigs and replaces them by the sums
+ * over all processes (one rank per GPU: a 3 x int64 all-reduce — the one exchange the path has, :283-294 -> :518-519); it returns 0
+ * or an error.  sums[] and thr[] (low, high) are returned; result arrays as from the single entry points (cornetto_free / free).
+ * With lazy copies (cornetto_accel_set_lazy) the contents of recs / hits are complete after cornetto_accel_wait(). */
+typedef struct {
+    const char *motif;              /* telofind motif (src/find_telomere.c:101-105) */
+    double thr_adj;                 /* cornetto_telowin_threshold() */
+    int32_t window_size, window_inc;
+    float low_cov, high_cov, low_mq;   /* -L -H -Q */
+    int32_t edge_len, min_ctg_len;     /* -e -m */
+    int32_t boring;                    /* 0: noboringbits' selection, 1: the deprecated boringbits' */
+} cornetto_step_opt_t;
+typedef int (*cornetto_sums_fn)(uint64_t sums[3], void *ctx);
+int cornetto_panel_step(cornetto_accel_t *h, const cornetto_asm_t *a, const cornetto_cov_t *c, const cornetto_step_opt_t *opt, cornetto_sums_fn exchange, void *ctx,
+                        uint64_t sums[3], int32_t thr[2], cornetto_regpk_t **recs, int64_t *n_recs, int64_t **ctg_first, cornetto_hit_t **hits, int64_t *n_hits,
+                        cornetto_win_t **wins, int64_t *n_wins);
+
 /* ---------------------------------------------------------------------------------------------------
  * bedgraph ingest on the device (the text parse of get_depths(), src/boringbits_main.c:204-287)
  * ------------------------------------------------------------------------------------------------- */

@@ -1,0 +1,7 @@
+Q="--steps 30 --warmup 3 --no-cpu --no-e2e --no-reads --no-profiles --check-steps 0 --emulate-ranks="
+for c in 0 1088 1280; do for i in 1 2; do
+echo -n "chunk $c: "; CORNETTO_SDUST_CHUNK=$c python bench.py $Q 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('ms/step', d['ms_per_step'], 'share', d.get('sdust_share_percent'), d.get('stage_wall_ms'), {k: v['ms'] for k, v in d['kernels'].items() if v.get('ms', 0) > 0.25})"
+done; done

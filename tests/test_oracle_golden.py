@@ -303,8 +303,9 @@ def _bench_cpu_leg(kind, monkeypatch):
     return bench, base, results, lens
 
 
-def _as_gpu_records(results):
-    """the CPU leg's own results laid out like the four GPU record arrays (for the parity checker's self-test)"""
+def _as_gpu_records(results, min_len=60000):
+    """the CPU leg's own results laid out like the four GPU record arrays (for the parity checker's self-test); a contig below
+    min_len has no selected windows (src/boringbits_main.c:428)"""
     HIT = np.dtype([("ctg", "<i4"), ("strand", "<i4"), ("start", "<i4"), ("end", "<i4")])
     WIN = np.dtype([("ctg", "<i4"), ("start", "<i4"), ("end", "<i4"), ("car", "<i4")])
     IVL = np.dtype([("ctg", "<i4"), ("start", "<i4"), ("finish", "<i4")])
@@ -322,7 +323,7 @@ def _as_gpu_records(results):
                 marks[a:b] = 1
             wins.append((li, st, en, int(marks[st:en].sum())))
         ivls += [(li, int(x) >> 32, int(x) & 0xFFFFFFFF) for x in r["sdust"]]
-        for st, en, dp, mq in r["regs"]:
+        for st, en, dp, mq in (r["regs"] if r["len"] >= min_len else []):
             flagged = dp < lo or dp > hi or (dp != 0 and mq / dp < np.float64(np.float32(q))) or (dp == 0 and False)
             if flagged:
                 recs.append((li, st, en, dp, mq))
@@ -340,12 +341,13 @@ def test_bench_cpu_leg_and_parity_checker(capfd, monkeypatch, kind):
     assert base["kind"] == kind and base["cores"] == 1 and base["value"] > 0 and base["host_cores"] >= 1 and base["host_cpu"]
     assert set(base["stage_gbases_s"]) == {"telofind", "telowin", "sdust", "get_regs"}
     assert capfd.readouterr().out == ""
-    assert [r["local"] for r in results] == [0, 1] and all(r["whole"] for r in results)      # whole leading contigs within the budget
+    # the whole leading contigs within the budget, and the smallest contig of all (below -m in the checker's call: the predicate that selects nothing)
+    assert [r["local"] for r in results] == [0, 1, 2] and all(r["whole"] for r in results)
     assert len(results[1]["hits"]) >= 2 and len(results[1]["sdust"]) >= 1 and results[1]["wins_text"].count(b"\n") >= 1
     gpu, (lo, hi, q) = _as_gpu_records(results)
     par = bench.check_parity(results, gpu, lo, hi, q, 60000, lens)
     assert par["ok"], par
-    assert par["checked_bases"] == 300000 and par["contigs"] == 2 and par["sdust_intervals"] == sum(len(r["sdust"]) for r in results)
+    assert par["checked_bases"] == 350000 and par["contigs"] == 3 and par["sdust_intervals"] == sum(len(r["sdust"]) for r in results)
     assert par["cov_windows_selected"] == len(gpu[3]) > 0
     # a single changed record of any stage is found
     for k in range(4):

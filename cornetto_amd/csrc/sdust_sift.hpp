@@ -67,11 +67,14 @@ constexpr int SIFT_PAD = 16;     // positions in front of the word / count buffe
 #define SIFT_K 16                // L2: partial sums over this many counts, the exact walk over the suffixes of up to this many words
 #endif
 constexpr int SIFT_LS = SIFT_K - 1;   // L2 walks the suffixes with l <= SIFT_LS
-// fixed part of the LDS of a wave: tables 4 x 64 x u32 | lists 2 x 128 x u16 | counters 8 x 64 x u32; then bits (cap / 8) and the
-// word / count buffer, two bytes per position (word, count)
-constexpr int SIFT_FIXED = 1024 + 512 + 2048;
+// fixed part of the LDS of a wave: tables 4 x 64 x u32 | lists 2 x 128 x u16; then bits (cap / 8) and the word / count buffer, two
+// bytes per position (word, count), and 16 bytes that the aligned dword reads of L2 may touch behind the last position.
+// (Round 5: the 2 KB of per-lane nibble counters of the L2 walk are gone — the walk counts equal words among the 16 packed in four
+// registers — and the columns of the dp tiles live in the two equal-word tables the resolve stage does not use: 7360 -> 5328 bytes
+// for a 1536-base chunk = five 1280-byte granules instead of six, 25 waves per CU instead of 21.)
+constexpr int SIFT_FIXED = 1024 + 512;
 // (bits: the sifted positions, then the coverage of the region, cap / 8 bytes each)
-__host__ __device__ constexpr uint32_t sift_lds_bytes(uint32_t cap) { return (SIFT_FIXED + cap / 4 + 2 * (SIFT_PAD + cap) + 15) / 16 * 16; }
+__host__ __device__ constexpr uint32_t sift_lds_bytes(uint32_t cap) { return (SIFT_FIXED + cap / 4 + 2 * (SIFT_PAD + cap) + 16 + 15) / 16 * 16; }
 
 
 // four bytes -> four codes: bits 0-1 the base (A0 C1 G2 T3), bit 2 set for anything that is not A/C/G/T/a/c/g/t
@@ -154,12 +157,13 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
     uint32_t *const tab = reinterpret_cast<uint32_t *>(L);
     uint16_t *const tl = reinterpret_cast<uint16_t *>(L + 1024);
     uint16_t *const tl2 = tl + 128;
-    uint32_t *const cnt = reinterpret_cast<uint32_t *>(L + 1536);
     uint32_t *const sb = reinterpret_cast<uint32_t *>(L + SIFT_FIXED);
     const uint32_t cap = A.reg_cap;
     uint32_t *const cb = sb + (cap >> 5);             // coverage of the region, one bit per base: what the chunk's rows are made of
-    // the dp tiles reuse the L2 counters (idle by then): the column of the position in front of a tile, per length
-    uint4 *const col = reinterpret_cast<uint4 *>(cnt);   // [length l]: c and B of the position in front of the tile, ceil(2^32 / l), floor(T l / 10)
+    // the dp tiles keep the column of the position in front of a tile, per length, in the two tables of parity 1 (the resolve stage reads
+    // windows through the pair of parity 0 only): [length l] = c and B of that position; the constants of a length (ceil(2^32 / l),
+    // floor(T l / 10)) come from lane l's registers
+    uint2 *const col = reinterpret_cast<uint2 *>(tab + 64);
     uint8_t *const wc = L + SIFT_FIXED + cap / 4 + 2 * SIFT_PAD;
     const int T = A.T, W = A.W, CAPW = W - 2;
 
@@ -438,75 +442,90 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
 
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     int ntl = 0, ntl2 = 0;                            // (uniform) entries in the two lists
-    // L2: the 16-term sums (every candidate of more than 16 words needs them positive), the exact walk over the shorter suffixes
+    // L2: the 16-term sums (every candidate of more than 16 words needs them positive), the exact walk over the shorter suffixes.
+    // Round 5: no counters.  The 16 (word, count) pairs that end at the lane's position are 32 consecutive bytes of the buffer: nine aligned
+    // dword reads, realigned by the lane's 0 or 2 bytes and split into four registers of words and four of counts (oldest position in byte
+    // 0 of register 0).  The suffix of a + 1 words has rr(a) = rr(a - 1) + [words among the a newer ones equal to the a-th last] equal-word
+    // pairs: the a-th last word, replicated, is compared with the registers that hold newer words — (x ^ rep) | 0x80 per byte, minus 1,
+    // leaves bit 7 clear exactly where the bytes were equal — and the population count of those bits goes straight into rr: 36 register
+    // compares of four vector instructions for the fifteen steps, no LDS operation, no per-lane state.  (Before: sixteen returning LDS
+    // atomics on 2 KB of 4-bit counters per wave, sixteen 16-bit reads and eight stores to clear them.)  A lane whose sixteen positions
+    // hold one without a word — the first two of a contig, another byte in the halo — is kept as it is (any superset of the inserting
+    // positions is exact), and so is every lane when the window has fewer than sixteen words.
     auto run_l2 = [&](int nb) {
         const bool on = lane < nb;
         const int o = on ? (int)tl2[lane] : 0;
-        const uint8_t *const p = wc + 2 * o;
-        // the reference-shaped form: every term with its own tests (windows of less than SIFT_K + 1 words; batches in which a walk meets a
-        // position without a word — the first words of a contig, another byte in the halo)
-        auto exact = [&]() {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) cnt[j * 64 + lane] = 0;
-            int d = 0, dmin = 0x7fffffff;
-#pragma unroll
-            for (int j = 0; j < SIFT_K; ++j) {
-                d += 10 * (int)p[1 - 2 * j] - T;
-                dmin = d < dmin ? d : dmin;
-            }
-            SD_LDS_ORDER();
-            int rr = 0;
-            bool alive = on, sc = false;
-            for (int a = 0; a <= LS; ++a) {
-                const uint32_t wv = p[-2 * a];
-                alive = alive && wv < 64u;
-                const uint32_t sh = (wv & 7u) << 2;
-                const uint32_t old = __hip_atomic_fetch_add(&cnt[((wv >> 3) & 7u) * 64 + lane], alive ? 1u << sh : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                rr += alive ? (int)((old >> sh) & 15u) : 0;
-                sc = sc | (alive & (a >= 1) & (__mul24(rr, 10) > T * a));        // (no short circuit: one compare instead of an exec-mask branch per step; rr <= 120)
-            }
-            return on && (sc || (dmin > 0 && long_ok));
-        };
-        bool keep;
+        bool keep = on;
         if (LS == SIFT_LS) {
-            // Every window but the shortest: the sums and the walk look at the same SIFT_K positions, word and count come in one 16-bit
-            // read, and the tests are compares against floor(k T / 10) (10 S > k T  <=>  S > floor(k T / 10)), made by the scalar unit
-            // for this batch.  Positions without a word are not tested per term: their bits are collected, and a batch that met one runs again
-            // in the exact form (a dozen VALU per term here, nineteen there).
-#pragma unroll
-            for (int j = 0; j < 8; ++j) cnt[j * 64 + lane] = 0;
-            const uint16_t *const p16 = reinterpret_cast<const uint16_t *>(p);
-            const uint32_t cl_a = (uint32_t)(uintptr_t)(lds_u32 *)(tab + lane);       // (the counters lie 1536 bytes behind the tables: the offset rides in the instruction)
-            uint32_t S = 0, rr = 0, seen = 0;
-            bool pos = true, sc = false;
-            uint32_t tt = (uint32_t)T, th0 = 0;
+            const uint32_t at = (uint32_t)(uintptr_t)(lds_u32 *)wc + 2u * (uint32_t)o - 2u * (uint32_t)(SIFT_K - 1);   // LDS address of the oldest pair
+            const lds_u32 *const pa = (const lds_u32 *)(uintptr_t)(at & ~3u);
+            const uint32_t sh = at & 3u;                 // 0 or 2
+            // The constants of the three-operand instructions (v_perm, v_bitop3: no literals on gfx950) are made HERE, in scalar registers: as
+            // plain constants the compiler moves them into vector registers in front of the chunk loop — ten registers that the tile loop does
+            // not have at six waves per SIMD (45 spilled registers, and the library refuses a build with scratch).
+            uint32_t k80, ksel1, ksel2, ksel3, kw, kc;
+            asm volatile("s_mov_b32 %0, 0x80808080\n\ts_mov_b32 %1, 0x01010101\n\ts_mov_b32 %2, 0x02020202\n\ts_mov_b32 %3, 0x03030303\n\t"
+                         "s_mov_b32 %4, 0x06040200\n\ts_mov_b32 %5, 0x07050301"
+                         : "=s"(k80), "=s"(ksel1), "=s"(ksel2), "=s"(ksel3), "=s"(kw), "=s"(kc));
+            uint32_t tt = (uint32_t)T;
             asm volatile("" : "+s"(tt));               // (the thresholds are made here, per batch: kept across the chunk loop they cost spilled scalar registers)
-            SD_LDS_ORDER();
-            uint32_t xn = p16[0];
-#pragma unroll 4
-            for (int a = 0; a < SIFT_K; ++a) {         // (four terms in flight: all sixteen returns at once do not fit the registers)
-                const uint32_t x = xn;
-                xn = p16[-(a + 1)];                    // (the next term's read travels with this term's counter update; the last one reads the pad)
-                asm("" : "+v"(xn));
-                seen |= x;
-                asm("v_add_u32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "+v"(S) : "v"(x));   // S += x >> 8
-                const uint32_t th1 = (tt * (uint32_t)(a + 1)) / 10u;      // floor((a + 1) T / 10): this term's bound for the sums, the next term's for the walk
-                pos = pos & (S > th1);
-                uint32_t row;                                              // the counter word of this lane for the word's upper three bits
-                asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(row) : "v"(__builtin_amdgcn_ubfe(x, 3, 3)), "v"(cl_a));
-                const uint32_t old = __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)row + 384, 1u << ((x << 2) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                rr += __builtin_amdgcn_ubfe(old, x << 2, 4);
-                if (a >= 1) sc = sc | (rr > th0);
-                th0 = th1;
+            // (the counts and their sums first, the words from a second read of the same dwords afterwards: four registers less at the peak)
+            uint32_t Q[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t d0 = pa[2 * q], d1 = pa[2 * q + 1], d2 = pa[2 * q + 2];
+                Q[q] = __builtin_amdgcn_perm(__builtin_amdgcn_alignbyte(d2, d1, sh), __builtin_amdgcn_alignbyte(d1, d0, sh), kc);
             }
-            if (sd_any(on && (seen & 0xC0u) != 0u)) {
-                SD_LDS_ORDER();
-                keep = exact();
-            } else {
-                keep = on && (sc || (pos && long_ok));
+            // the sums: 10 S_k > k T  <=>  S_k > floor(k T / 10), k = 1 .. 16, newest count first
+            uint32_t S = 0, nbad = 0;
+#pragma unroll
+            for (int a = 0; a < SIFT_K; ++a) {
+                const int idx = SIFT_K - 1 - a;
+                switch (idx & 3) {
+                case 0: asm("v_add_u32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "+v"(S) : "v"(Q[idx >> 2])); break;
+                case 1: asm("v_add_u32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "+v"(S) : "v"(Q[idx >> 2])); break;
+                case 2: asm("v_add_u32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "+v"(S) : "v"(Q[idx >> 2])); break;
+                default: asm("v_add_u32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "+v"(S) : "v"(Q[idx >> 2])); break;
+                }
+                // (an integer, not a lane mask, and tied to S: sixteen deferred compares would keep sixteen partial sums alive)
+                const uint32_t th = (tt * (uint32_t)(a + 1)) / 10u;
+                uint32_t bad = S <= th ? 1u : 0u;
+                asm volatile("" : "+v"(bad), "+v"(S));
+                nbad |= bad;
             }
-        } else {
-            keep = exact();
+            const bool pos = nbad == 0u;
+            uint32_t at2 = at & ~3u;
+            asm volatile("" : "+v"(at2), "+v"(nbad));  // (the second read starts when the sums are through)
+            const lds_u32 *const pb = (const lds_u32 *)(uintptr_t)at2;
+            uint32_t P[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t d0 = pb[2 * q], d1 = pb[2 * q + 1], d2 = pb[2 * q + 2];
+                P[q] = __builtin_amdgcn_perm(__builtin_amdgcn_alignbyte(d2, d1, sh), __builtin_amdgcn_alignbyte(d1, d0, sh), kw);
+            }
+            const uint32_t seen = (P[0] | P[1] | P[2] | P[3]) & 0xC0C0C0C0u;
+            // the walk: suffixes of 2 .. 16 words.  ne = the compared pairs that were NOT equal (bit 7 stays set there): rr = pairs - ne
+            uint32_t ne = 0, nhit = 0;
+#pragma unroll
+            for (int a = 1; a < SIFT_K; ++a) {
+                const int idx = SIFT_K - 1 - a, qi = idx >> 2, bj = idx & 3;
+                const uint32_t rep = __builtin_amdgcn_perm(P[qi], P[qi], bj == 0 ? 0u : bj == 1 ? ksel1 : bj == 2 ? ksel2 : ksel3);
+#pragma unroll
+                for (int q = qi; q < 4; ++q) {
+                    if (q == qi && bj == 3) continue;                                    // (no newer word in its own register)
+                    const uint32_t m = q == qi ? 0x80808080u << (8 * (bj + 1)) : 0x80808080u;   // the newer bytes of its own register / all of a newer one
+                    const uint32_t u = ((P[q] ^ rep) | k80) + 0xFEFEFEFFu;              // (- 0x01010101: no byte borrows, every byte is at least 0x80)
+                    ne += (uint32_t)__builtin_popcount(u & m);
+                }
+                // rr(a) = a (a + 1) / 2 - ne > floor(a T / 10)  <=>  ne < a (a + 1) / 2 - floor(a T / 10)   (never, when that is not positive)
+                const int lim = a * (a + 1) / 2 - (int)((tt * (uint32_t)a) / 10u);
+                uint32_t hit = (int)ne < lim ? 1u : 0u;
+                // (one step at a time — every step's inputs pass through here: scheduled freely, the compares of all fifteen steps start at once, twenty temporaries)
+                asm volatile("" : "+v"(hit), "+v"(ne), "+v"(P[0]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]));
+                nhit |= hit;
+            }
+            const bool sc = nhit != 0u;
+            keep = on && (seen != 0u || sc || (pos && long_ok));
         }
         if (STATS) st_l2 += (unsigned long long)__popcll(sd_ballot(keep));
         if (keep) (void)__hip_atomic_fetch_or(&sb[o >> 5], 1u << (o & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -648,6 +667,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
     const int s_lo = ch.start > 0 ? ch.start - W : -0x40000000, s_hi = islast ? 0x7fffffff : ch.end - W;
     const int Tl = T * lane;                          // stepping stages: lane = l
     const uint32_t m_recip = sd_recip_tab[lane];
+    const int Tl10 = Tl / 10;                         // dp tiles: floor(T l / 10), read from lane l
     auto mark64 = [&](int o, int nbits) {             // bits [o, o + nbits) of the region, 1 <= nbits <= 64
         const uint32_t d = (uint32_t)o >> 5, b = (uint32_t)o & 31u;
         const unsigned long long mk = nbits >= 64 ? ~0ull : (1ull << nbits) - 1ull;
@@ -750,35 +770,37 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
         int c = 0, rr = 0;
         uint32_t B = 1u, lbest = 0u;
         const bool last = lane == 63;
-        // one length: `cin` = the column entry of length l - 1 (lane 0's neighbour), `cl` = that of length l (its constants; lane 63 leaves c and B there)
-        auto step = [&](const int l, const uint4 cin, const uint4 cl) __attribute__((always_inline)) {
+        // one length: `cin` = the column entry of length l - 1 (lane 0's neighbour); lane 63 leaves its c and B in entry l
+        auto step = [&](const int l, const uint2 cin) __attribute__((always_inline)) {
             const uint32_t wv = pw[-2 * l];
+            const uint32_t rcp_l = (uint32_t)rdlane((int)m_recip, l);      // ceil(2^32 / l), floor(T l / 10): lane l holds them
+            const int thr_l = rdlane(Tl10, l);
             c = __builtin_amdgcn_update_dpp((int)cin.x, c, 0x138, 0xF, 0xF, false) + (wv == w_own ? 1 : 0);
             rr += c;
-            const uint32_t kq = __umulhi((uint32_t)rr << 13, cl.z);
-            const uint32_t key = rr > (int)cl.w ? kq : 0u;
+            const uint32_t kq = __umulhi((uint32_t)rr << 13, rcp_l);
+            const uint32_t key = rr > thr_l ? kq : 0u;
             const uint32_t Bn = (uint32_t)__builtin_amdgcn_update_dpp((int)cin.y, (int)B, 0x138, 0xF, 0xF, false);
             const uint32_t mx = B > Bn ? B : Bn;
             lbest = key >= mx ? (uint32_t)l : lbest;
             asm volatile("" : "+v"(lbest));           // (decided here: unrolled, the scheduler would keep key and mx of every length alive to the end)
             B = mx > key ? mx : key;
             SD_LDS_ORDER();
-            if (last) *reinterpret_cast<uint2 *>(&col[l]) = make_uint2((uint32_t)c, B);
+            if (last) col[l] = make_uint2((uint32_t)c, B);
         };
-        // (every column entry is read one step ahead of its use: lane 63 overwrites its c and B)
-        uint4 ca = col[0], cb_ = col[1];
+        // (every column entry is read one step ahead of its use: lane 63 overwrites it)
+        uint2 ca = col[0], cb_ = col[1];
         {   // l = 1: the key is r itself (2^32 / 1 has no 32-bit reciprocal)
-            const uint4 cn = col[2];
+            const uint2 cn = col[2];
             const uint32_t wv = pw[-2];
             c = __builtin_amdgcn_update_dpp((int)ca.x, c, 0x138, 0xF, 0xF, false) + (wv == w_own ? 1 : 0);
             rr += c;
-            const uint32_t key = rr > (int)cb_.w ? (uint32_t)rr << 13 : 0u;
+            const uint32_t key = rr > rdlane(Tl10, 1) ? (uint32_t)rr << 13 : 0u;
             const uint32_t Bn = (uint32_t)__builtin_amdgcn_update_dpp((int)ca.y, (int)B, 0x138, 0xF, 0xF, false);
             const uint32_t mx = B > Bn ? B : Bn;
             lbest = key >= mx ? 1u : lbest;
             B = mx > key ? mx : key;
             SD_LDS_ORDER();
-            if (last) *reinterpret_cast<uint2 *>(&col[1]) = make_uint2((uint32_t)c, B);
+            if (last) col[1] = make_uint2((uint32_t)c, B);
             ca = cb_;
             cb_ = cn;
         }
@@ -786,12 +808,15 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
         // l - 1, cb_ = entry l on entering
         int l = 2;
         for (; l + 1 < CAPW; l += 2) {
-            step(l, ca, cb_);
-            ca = col[l + 1];
-            step(l + 1, cb_, ca);
-            cb_ = col[l + 2 < 64 ? l + 2 : 63];
+            const uint2 c1 = col[l + 1];               // (entry l + 1 before lane 63 overwrites it in step l + 1; entry l is in cb_)
+            step(l, ca);
+            ca = cb_;
+            const uint2 c2 = col[l + 2 < 64 ? l + 2 : 63];
+            step(l + 1, ca);
+            ca = c1;
+            cb_ = c2;
         }
-        if (l < CAPW) step(l, ca, cb_);
+        if (l < CAPW) step(l, ca);
         if (lbest) mark(rb + o0 - 2 - (int)lbest, (int)lbest + 3);
         SD_LDS_ORDER();
         slot = lane >= 1 && lane < CAPW ? (int)col[lane].y : 0;
@@ -815,10 +840,10 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
                 asm volatile("v_sub_u32 %0, %1, %2" : "=v"(cc) : "v"(r), "v"(rprev));
                 const uint32_t bb = sd_scan_max_dpp((uint32_t)slot);
                 // (with the constants of length `lane`: lane 63 rewrites c and B only)
-                col[lane] = make_uint4((uint32_t)cc, bb > 1u ? bb : 1u, m_recip, (uint32_t)(Tl / 10));
+                col[lane] = make_uint2((uint32_t)cc, bb > 1u ? bb : 1u);
                 SD_LDS_ORDER();
             }
-            if (lane == 0) *reinterpret_cast<uint2 *>(&col[0]) = make_uint2(0u, 1u);
+            if (lane == 0) col[0] = make_uint2(0u, 1u);
             SD_LDS_ORDER();
             dp_tile(t);
             if (STATS) ++st_dp;

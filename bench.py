@@ -37,8 +37,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_FILE = os.path.join("profiles", "r04_%s_pmc_traffic_%s.json")   # % (workload profile, kernel symbol)
-SQ_FILE = os.path.join("profiles", "r04_%s_sq_%s.json")
+PMC_ROUNDS = ("r05", "r04")                                         # the newest committed counter passes first
+PMC_FILE = os.path.join("profiles", "%s_%s_pmc_traffic_%s.json")    # % (round, workload profile, kernel symbol)
+SQ_FILE = os.path.join("profiles", "%s_%s_sq_%s.json")
 
 
 def contig_lengths(total_target):
@@ -939,13 +940,15 @@ class Rank:
         self.wall.clear()
         self.fence()
         t0 = time.perf_counter()
-        counts = []
+        counts, marks = [], [t0]
         for _ in range(steps):
             self.step(True)
             counts.append(tuple(self.counts))
+            marks.append(time.perf_counter())         # (a step has delivered its results to the host when it returns)
         self.fence()
         elapsed = time.perf_counter() - t0
         self.elapsed_local = elapsed
+        self.step_ms = [(b - a) * 1e3 for a, b in zip(marks, marks[1:])]
         if self.world > 1:
             el = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self.cdev)
             self.dist.all_reduce(el, op=self.dist.ReduceOp.MAX)
@@ -1610,6 +1613,7 @@ def main():
 
     elapsed = R.timed(args.steps, args.warmup)
     elapsed_local = R.elapsed_local
+    steps_ms0 = list(getattr(R, "step_ms", []))        # (of the headline measurement: later legs time steps of their own)
     serial = R.serial_kernel_times()
     n_bases = R.my_bases
 
@@ -1661,18 +1665,24 @@ def main():
         ach = alg[dom] / (kavg[dom] * 1e-3) / 1e9 if kavg.get(dom, 0) > 0 else 0.0
         # HBM/fabric bytes per launch of the dominant kernel and its instruction mix: NOT measured in this run — taken from the
         # committed rocprofv3 PMC passes of this workload (profiles/README.md), scaled to the bases of this run
-        traffic, traffic_source, issue = None, None, None
-        for cand in (PMC_FILE % (args.profile, symbol), os.path.join("profiles", "r03_pmc_traffic_%s.json" % symbol), os.path.join("profiles", "r02_pmc_traffic.json")):
+        traffic, traffic_source, traffic_ms, issue = None, None, None, None
+        cands = [PMC_FILE % (rd, args.profile, symbol) for rd in PMC_ROUNDS] + [os.path.join("profiles", "r03_pmc_traffic_%s.json" % symbol), os.path.join("profiles", "r02_pmc_traffic.json")]
+        for cand in cands:
             try:
                 pmcs = json.load(open(os.path.join(ROOT, cand)))
                 pmc = pmcs.get(symbol) or pmcs["sdust_w64"]
                 traffic, traffic_source = round(pmc["hbm_bytes"] / pmc["bases"] * n_bases, 0), cand
+                traffic_ms = pmc.get("production_ms") or pmcs.get("production_ms")
                 break
             except Exception:
                 continue
         try:
-            sq_name = SQ_FILE % (args.profile, symbol)
-            if not os.path.exists(os.path.join(ROOT, sq_name)):
+            sq_name = None
+            for rd in PMC_ROUNDS:
+                if os.path.exists(os.path.join(ROOT, SQ_FILE % (rd, args.profile, symbol))):
+                    sq_name = SQ_FILE % (rd, args.profile, symbol)
+                    break
+            if sq_name is None:
                 sq_name = os.path.join("profiles", "r03_sq_%s.json" % symbol)
             sq = json.load(open(os.path.join(ROOT, sq_name)))
             pl = sq["per_launch"]
@@ -1681,8 +1691,45 @@ def main():
                      "counting_build_ms": sq.get("counting_build_ms", sq.get("kernel_ms")), "production_ms": sq.get("production_ms"),
                      "note": "a wave-64 vector instruction holds its SIMD's ALU for 4 cycles: valu_busy = 4 x SQ_INSTS_VALU / (SIMDs x cycles of the kernel); "
                              "not measured in this run: the committed rocprofv3 --pmc passes of the same workload"}
+            # the counters describe the kernel as it was when they were collected: compare that build's time alone on the chip with this run's
+            # (ms_uncontended of the dominant kernel) and say so when they are more than 10 % apart — a stale file must not survive a kernel change
+            now_ms = kern.get(dom, {}).get("ms_uncontended")
+            if now_ms and issue.get("production_ms"):
+                issue["this_run_ms_alone"] = now_ms
+                issue["stale"] = bool(abs(issue["production_ms"] - now_ms) > 0.10 * now_ms)
         except Exception:
             pass
+        # ---- roofline: the dominant kernel as the contract asks (algorithmic bytes / its launch duration against the HBM peak), what really
+        # bounds it, the other streaming kernels alone and inside the step, and the whole step (6 B/base: 1 B of sequence read by sdust,
+        # 1 B read again by the telomere scan, 4 B of coverage)
+        now_alone = kern.get(dom, {}).get("ms_uncontended")
+        stale_t = bool(traffic_ms and now_alone and abs(traffic_ms - now_alone) > 0.10 * now_alone)
+        kfr = {}
+        for kname in ("cov_blocks", "tf_scan", dom):
+            kk = kern.get(kname, {})
+            ent = {"bytes_per_base": alg[kname] / n_bases}
+            if kk.get("ms_uncontended"):
+                g = alg[kname] / (kk["ms_uncontended"] * 1e-3) / 1e9
+                ent["alone"] = {"ms": kk["ms_uncontended"], "GBps": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4)}
+            if kk.get("ms"):
+                g = alg[kname] / (kk["ms"] * 1e-3) / 1e9
+                ent["in_step"] = {"ms": kk["ms"], "GBps": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4)}
+            kfr[kname] = ent
+        step_gbps = 6.0 * n_bases / (ms_per_step * 1e-3) / 1e9
+        roof = {"bound": "hbm", "limited_by": "instruction issue and the LDS pipeline of the dominant kernel, not HBM (profiles/README.md)",
+                "kernel": dom, "kernel_symbol": symbol, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                "traffic_ratio": round(traffic / alg[dom], 3) if traffic else None, "traffic_source_production_ms": traffic_ms, "traffic_stale": stale_t,
+                "issue": issue,
+                "step": {"bytes_per_base": 6, "achieved_GBps": round(step_gbps, 1), "frac": round(step_gbps / HBM_PEAK_GBS, 4),
+                         "what": "all three scans of a step: 6 algorithmic bytes per base (SURVEY 8d) x bases / ms_per_step against the HBM peak"},
+                "kernels": kfr,
+                "note": "sdust is integer work per base, bound by instruction issue and LDS cycles, not by HBM (profiles/r05_<profile>_sq_<kernel>.json); achieved / peak / frac are "
+                        "against the HBM roofline as the contract asks (1 B/base algorithmic). traffic and issue are not measured in this run: "
+                        "the committed rocprofv3 PMC figures scaled by bases, flagged stale when that build's kernel time differs from this run's by more than 10 %"}
+        sm_ = sorted(steps_ms0) if steps_ms0 else []
+        spread = {"min": round(sm_[0], 3), "median": round(sm_[len(sm_) // 2], 3), "max": round(sm_[-1], 3), "steps": len(sm_),
+                  "what": "host time from one step's return to the next's on rank 0 inside the timed region (ms_per_step is the region / steps)"} if sm_ else None
         nst = 2 if R.overlap else 1
         wl = "%s over %s synthetic HG002-like hifiasm assembly%s (%d contigs, %.3f Gbp%s, planted telomeres/STRs/N runs%s; per-base u16 depth+mq)" % (
             "telowin+sdust+noboringbits", "one" if args.scaling == "strong" or world == 1 else "%d" % world,
@@ -1691,18 +1738,15 @@ def main():
         line = {
             "metric": "Gbases/s scanned (telowin+sdust+boringbits)", "value": round(value, 4), "unit": "Gbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8/u16 integer",
+            "ms_per_step_spread": spread,
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "single", "vs_baseline": None, "dtype": "u8/u16 integer",
             "data": "synthetic",
             "config": {"workload": wl, "profile": args.profile, "bases_per_gpu": n_bases, "bases_job": R.job_bases, "contigs": len(R.lens),
                        "contigs_rank0": len(R.own), "motif": "TTAGGG", "sdust": "-w 64 -t 20", "windows": "-w 2500 -i 50",
                        "parallelism": "contig-sharded (%s), %d process(es), 1 GPU each; per GPU %s" % (
                            "LPT over the contigs of one assembly" if args.scaling == "strong" else "one assembly per rank", world,
                            "2 HIP streams (sdust || telofind+coverage), sdust on %d %% of the wave slots" % getattr(R, "share", 100) if nst == 2 else "stages serial on one stream")},
-            "roofline": {"bound": "valu-issue", "kernel": dom, "kernel_symbol": symbol, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source, "issue": issue,
-                         "note": "sdust is integer work per base, bound by instruction issue, not by HBM (profiles/r04_<profile>_sq_<kernel>.json); achieved / peak / frac are "
-                                 "against the HBM roofline as the contract asks (1 B/base algorithmic). traffic and issue are not measured in this run: "
-                                 "the committed rocprofv3 PMC figures scaled by bases"},
+            "roofline": roof,
             "kernels": kern,
             "stage_wall_ms": {k: round(float(np.mean(v)), 3) for k, v in R.wall.items()},
             "results_per_rank": dict(zip(("telomere_runs", "telomere_windows", "sdust_intervals", "selected_cov_windows"), R.counts)),

@@ -146,7 +146,7 @@ __device__ __forceinline__ int sd_wave_find_start(const SdChunk ch, const uint8_
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6))) void sd_sift(SiftArgs A, SdArgs O)
+__global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(7))) void sd_sift(SiftArgs A, SdArgs O)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sift_lds[];
     const int lane = threadIdx.x & 63;
@@ -247,6 +247,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
     if (A.abl & 128) general = false;                 // (instruction counting only: no staging at all; with bit 4)
     if (!general && !(A.abl & 128)) {
         uint32_t acc = 0u;
+        int lane_s = lane * 16;
         for (int b16 = lane * 16, it = 0; b16 < rlen; b16 += 1024, ++it) {
             uint4 q;
             uint32_t pw;
@@ -254,8 +255,12 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
                 q = D.q[it];
                 pw = D.pw[it];
             } else {
-                q = *reinterpret_cast<const uint4 *>(seq + rb + b16);
-                pw = *reinterpret_cast<const uint32_t *>(seq + rb + b16 - 4);
+                // (regions beyond 2 KB — chunk sizes chosen by hand —: the address from a value the compiler cannot compute in front of the chunk
+                // loop, where it would hold a vector register all through the tile loop for a path that the default chunk never takes)
+                asm volatile("" : "+v"(lane_s));
+                const uint8_t *const g = seq + rb + lane_s + it * 1024;
+                q = *reinterpret_cast<const uint4 *>(g);
+                pw = *reinterpret_cast<const uint32_t *>(g - 4);
             }
             const uint32_t ipw = pw & 0x07070707u;
             uint32_t pcn = __builtin_amdgcn_perm(0x02000003u, 0x01000000u, ipw);
@@ -665,8 +670,12 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(6
     // are marked in the coverage bits of the region when they are inserted (the result is the union of the inserted intervals: header);
     // the runs of the coverage are the chunk's rows.  No entry has to be followed until it leaves the window.
     const int s_lo = ch.start > 0 ? ch.start - W : -0x40000000, s_hi = islast ? 0x7fffffff : ch.end - W;
-    const int Tl = T * lane;                          // stepping stages: lane = l
-    const uint32_t m_recip = sd_recip_tab[lane];
+    // (made from a lane number the compiler cannot see through: as functions of `lane` alone the three would be computed once in front of the
+    // chunk loop and occupy three vector registers all through the tile loop, which has none to spare)
+    int lane_r = lane;
+    asm volatile("" : "+v"(lane_r));
+    const int Tl = T * lane_r;                        // stepping stages: lane = l
+    const uint32_t m_recip = sd_recip_tab[lane_r];
     const int Tl10 = Tl / 10;                         // dp tiles: floor(T l / 10), read from lane l
     auto mark64 = [&](int o, int nbits) {             // bits [o, o + nbits) of the region, 1 <= nbits <= 64
         const uint32_t d = (uint32_t)o >> 5, b = (uint32_t)o & 31u;

@@ -53,7 +53,7 @@ def test_two_ranks_strong_scaling_equals_one_rank():
     shared = [] if _n_gpus() >= 2 else ["--allow-shared-device"]
     one = _run(1, ["--scaling", "strong"])
     two = _run(2, ["--scaling", "strong"] + shared)
-    assert one["scaling"] == "strong" and two["scaling"] == "strong" and two["n_gpus"] == 2
+    assert one["scaling"] == "single" and two["scaling"] == "strong" and two["n_gpus"] == 2      # (one GPU has no scaling mode to name)
     assert one["determinism"]["identical"] and two["determinism"]["identical"]
     assert len(one["gathered_digests"]) == 1
     assert two["gathered_digests"] == one["gathered_digests"]

@@ -15,7 +15,7 @@ __all__ = ["lib", "Accel", "AccelError", "HIT_DT", "WIN_DT", "IVL_DT", "TELROW_D
            "LIB_PATH", "CLI_PATH"]
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcornetto_hip.so")
+LIB_PATH = os.environ.get("CORNETTO_LIB") or os.path.join(HERE, "libcornetto_hip.so")    # (CORNETTO_LIB: another build of the same library — A/B runs of kernel variants on one box)
 CLI_PATH = os.path.join(HERE, "cornetto")
 
 HIT_DT = np.dtype([("ctg", "<i4"), ("strand", "<i4"), ("start", "<i4"), ("end", "<i4")])

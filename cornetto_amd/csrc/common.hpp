@@ -49,6 +49,7 @@ struct cornetto_accel {
     int sd_slots = 0;   // sdust: waves the device holds at once (occupancy query, cached)
     int sd_cus = 0;
     int sift_per_cu = 0; // sdust sift: workgroups per CU by the occupancy query (cached)
+    int sift_per_cu_default = -1;   //   ... of which build of the kernel (1: buffer size a literal, 0: run-time size)
     // cornetto_accel_set_lazy(): the large result copies of a call go out on a stream of their own and the call returns when its kernels are
     // through; cornetto_accel_wait() before the results are read
     int lazy = 0;

@@ -1637,14 +1637,14 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
         // there is nothing to test.  What was tightened meanwhile: the P-slot hand-off between lanes waits for the wave's
         // outstanding stores in front of EVERY slot load.  The guard covers both instantiations that can be launched;
         // CORNETTO_SDUST_ALLOW_SCRATCH=1 lifts it.
-        for (int inst = 0; inst < 3; ++inst) {           // (sd_sift: the production build; its counting build may keep a register in scratch)
+        for (int inst = 0; inst < 4; ++inst) {           // (sd_sift: the production builds; its counting build may keep a register in scratch)
             hipFuncAttributes fa;
-            const void *fn = inst == 2 ? reinterpret_cast<const void *>(&sd_sift<false>)
+            const void *fn = inst == 3 ? reinterpret_cast<const void *>(&sd_sift<false, SIFT_CAP_DEFAULT>) : inst == 2 ? reinterpret_cast<const void *>(&sd_sift<false>)
                              : inst ? reinterpret_cast<const void *>(&sdust_w64<true>) : reinterpret_cast<const void *>(&sdust_w64<false>);
             if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return cn_fail(h, CORNETTO_E_HIP, "sdust: hipFuncGetAttributes failed");
             if (fa.localSizeBytes != 0 && !env_int("CORNETTO_SDUST_ALLOW_SCRATCH", 0))
                 return cn_fail(h, CORNETTO_E_HIP, "sdust: kernel%s built with %zu bytes of scratch per lane (register spills): refusing to run it",
-                               inst == 1 ? " (statistics build)" : inst == 2 ? " sd_sift" : "", (size_t)fa.localSizeBytes);
+                               inst == 1 ? " (statistics build)" : inst >= 2 ? " sd_sift" : "", (size_t)fa.localSizeBytes);
         }
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sdust_w64<false>, 64 * SD_WPB, 0) != hipSuccess || per_cu < 1) per_cu = 16;
@@ -1868,10 +1868,14 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                 // when another stream computes beside this one (cornetto_accel_set_share): a launch of one workgroup per chunk keeps
                 // the other stream's kernels waiting until it is through (13.1 instead of 9 ms per bench step).  The waves take their
                 // chunks from one counter (static strides were measured 10-50 % slower: chunks differ a lot in cost; 64 counters: one was a 14 ns serial point).
-                if (h->sift_per_cu == 0) {
+                const bool cap_default = reg_cap == SIFT_CAP_DEFAULT && !env_int("CORNETTO_SIFT_GENERIC", 0) && !env_int("CORNETTO_SIFT_ABL", 0);     // (the build with the buffer size as a literal)
+                if (h->sift_per_cu == 0 || h->sift_per_cu_default != (cap_default ? 1 : 0)) {
                     int per_cu = 0;
-                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sd_sift<false>, 64 * SIFT_WPB, lds_wave * SIFT_WPB) != hipSuccess || per_cu < 1) per_cu = 8;
+                    const hipError_t oe = cap_default ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sd_sift<false, SIFT_CAP_DEFAULT>, 64 * SIFT_WPB, lds_wave * SIFT_WPB)
+                                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sd_sift<false>, 64 * SIFT_WPB, lds_wave * SIFT_WPB);
+                    if (oe != hipSuccess || per_cu < 1) per_cu = 8;
                     h->sift_per_cu = per_cu;
+                    h->sift_per_cu_default = cap_default ? 1 : 0;
                 }
                 const int per_cu_all = std::max(1, std::min<int>(h->sift_per_cu, (int)(163840 / ((lds_wave * SIFT_WPB + 1279) / 1280 * 1280))));
                 const bool free_now = __atomic_load_n(&h->boost, __ATOMIC_ACQUIRE) != 0;        // (cornetto_accel_boost)
@@ -1898,6 +1902,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                     CN_HIP(h, hipEventRecord(h->ev1, h->stream));               // the state of this call is set up
                 }
                 if (want_stats) CN_LAUNCH(h, "sdust_kernel", sd_sift<true><<<dim3(nbk), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream>>>(S, R));
+                else if (cap_default) CN_LAUNCH(h, "sdust_kernel", sd_sift<false, SIFT_CAP_DEFAULT><<<dim3(nbk), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream>>>(S, R));
                 else CN_LAUNCH(h, "sdust_kernel", sd_sift<false><<<dim3(nbk), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream>>>(S, R));
                 __atomic_fetch_add(&h->launch_seq, 1ull, __ATOMIC_RELEASE);      // (cornetto_accel_launch_count)
                 if (may_help) {
@@ -1906,7 +1911,8 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                     while (hipEventQuery(h->ev3) == hipErrorNotReady) {
                         if (!helped && __atomic_load_n(&h->boost, __ATOMIC_ACQUIRE) != 0) {
                             CN_HIP(h, hipStreamWaitEvent(h->stream2, h->ev1, 0));
-                            sd_sift<false><<<dim3(extra), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream2>>>(S, R);
+                            if (cap_default) sd_sift<false, SIFT_CAP_DEFAULT><<<dim3(extra), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream2>>>(S, R);
+                            else sd_sift<false><<<dim3(extra), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream2>>>(S, R);
                             dense_pending = true;                                // (every exit from here on joins the second stream: DenseJoin)
                             CN_HIP(h, hipGetLastError());
                             CN_HIP(h, hipEventRecord(h->ev2, h->stream2));

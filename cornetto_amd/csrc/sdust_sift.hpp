@@ -145,20 +145,31 @@ __device__ __forceinline__ int sd_wave_find_start(const SdChunk ch, const uint8_
     return -2;
 }
 
-template <bool STATS>
-__global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(7))) void sd_sift(SiftArgs A, SdArgs O)
+// CAP: the positions the word / count buffer holds when they are known at compile time (1664 = the default chunk of 1536 bases with the two
+// tiles in front), else 0 = A.reg_cap.  With it every LDS address of a wave is the lane's part plus a literal: the build for a run-time size
+// keeps dozens of derived addresses in scalar registers it does not have (84 spilled to vector-register lanes, a v_readlane per use:
+// 5-8 of the 46 vector instructions per 64 bases, round 5).
+constexpr uint32_t SIFT_CAP_DEFAULT = 1536 + 128;
+template <bool STATS, uint32_t CAP = 0>
+__global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(CAP ? 7 : 6))) void sd_sift(SiftArgs A, SdArgs O)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sift_lds[];
     const int lane = threadIdx.x & 63;
     const int wave = SIFT_WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // (uniform: the chunk table is read with scalar loads)
-    uint8_t *const L = sift_lds + (size_t)wave * A.lds_per_wave;
+    uint8_t *const L = sift_lds + (size_t)wave * (CAP ? sift_lds_bytes(CAP) : A.lds_per_wave);
     // equal-word tables: [tile parity][half of the wave][word] -> the lanes of that half that hold the word.  32-bit entries, 64 per
     // table: the entry of word w lies in LDS bank w of every table.
     uint32_t *const tab = reinterpret_cast<uint32_t *>(L);
     uint16_t *const tl = reinterpret_cast<uint16_t *>(L + 1024);
     uint16_t *const tl2 = tl + 128;
     uint32_t *const sb = reinterpret_cast<uint32_t *>(L + SIFT_FIXED);
-    const uint32_t cap = A.reg_cap;
+    const uint32_t cap = CAP ? CAP : A.reg_cap;
+    // development aid (CORNETTO_SIFT_ABL: stages switched off for instruction counting, results are wrong): only in the build without a
+    // compile-time buffer size — in the production build its seven tests were seven lane masks held in scalar registers
+    const int abl = CAP ? 0 : A.abl;
+    // rounds of 1024 bases the staging of a region takes: with the default size the two rounds whose bases the chunk loop has fetched ahead
+    // (no third round, no address for it held through the kernel)
+    constexpr int STAGE_ROUNDS = CAP ? (int)((CAP + 1023) / 1024) : 4;
     uint32_t *const cb = sb + (cap >> 5);             // coverage of the region, one bit per base: what the chunk's rows are made of
     // the dp tiles keep the column of the position in front of a tile, per length, in the two tables of parity 1 (the resolve stage reads
     // windows through the pair of parity 0 only): [length l] = c and B of that position; the constants of a length (ceil(2^32 / l),
@@ -243,15 +254,15 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(7
     // Nearly every chunk holds letters only and lies inside its contig: the codes without the "not a base" flags, the words without the "no
     // word" bit, one accumulated difference to the letters that must be there — 12 instead of 25 vector instructions per dword.  Anything
     // else (another byte anywhere, the contig's first or last chunk) is staged again the general way below.
-    bool general = rb <= 0 || rb + ((rlen + 15) & ~15) > len || (A.abl & 32);
-    if (A.abl & 128) general = false;                 // (instruction counting only: no staging at all; with bit 4)
-    if (!general && !(A.abl & 128)) {
+    bool general = rb <= 0 || rb + ((rlen + 15) & ~15) > len || (abl & 32);
+    if (abl & 128) general = false;                 // (instruction counting only: no staging at all; with bit 4)
+    if (!general && !(abl & 128)) {
         uint32_t acc = 0u;
         int lane_s = lane * 16;
-        for (int b16 = lane * 16, it = 0; b16 < rlen; b16 += 1024, ++it) {
+        for (int b16 = lane * 16, it = 0; it < STAGE_ROUNDS && b16 < rlen; b16 += 1024, ++it) {
             uint4 q;
             uint32_t pw;
-            if (it < 2) {
+            if (STAGE_ROUNDS <= 2 || it < 2) {
                 q = D.q[it];
                 pw = D.pw[it];
             } else {
@@ -285,11 +296,11 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(7
         general = sd_any(acc != 0u);
     }
     if (general)
-    for (int b16 = lane * 16, it = 0; b16 < rlen; b16 += 1024, ++it) {
+    for (int b16 = lane * 16, it = 0; it < STAGE_ROUNDS && b16 < rlen; b16 += 1024, ++it) {
         const int p0 = rb + b16;
         uint4 q;
         uint32_t pw;
-        if (it < 2) {
+        if (STAGE_ROUNDS <= 2 || it < 2) {
             q = D.q[it];
             pw = D.pw[it];
         } else {                                      // (regions beyond 2 KB: chunk sizes chosen by hand)
@@ -451,9 +462,9 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(7
     // Round 5: no counters.  The 16 (word, count) pairs that end at the lane's position are 32 consecutive bytes of the buffer: nine aligned
     // dword reads, realigned by the lane's 0 or 2 bytes and split into four registers of words and four of counts (oldest position in byte
     // 0 of register 0).  The suffix of a + 1 words has rr(a) = rr(a - 1) + [words among the a newer ones equal to the a-th last] equal-word
-    // pairs: the a-th last word, replicated, is compared with the registers that hold newer words — (x ^ rep) | 0x80 per byte, minus 1,
-    // leaves bit 7 clear exactly where the bytes were equal — and the population count of those bits goes straight into rr: 36 register
-    // compares of four vector instructions for the fifteen steps, no LDS operation, no per-lane state.  (Before: sixteen returning LDS
+    // pairs: the a-th last word, replicated, is compared with the registers that hold newer words — (x ^ rep) + 0x3f per byte sets bit 6
+    // exactly where the six-bit words differed — and the population count of those bits counts the unequal pairs: 36 register compares of
+    // three vector instructions (v_xad, v_and, v_bcnt) for the fifteen steps, no LDS operation, no per-lane state.  (Before: sixteen returning LDS
     // atomics on 2 KB of 4-bit counters per wave, sixteen 16-bit reads and eight stores to clear them.)  A lane whose sixteen positions
     // hold one without a word — the first two of a contig, another byte in the halo — is kept as it is (any superset of the inserting
     // positions is exact), and so is every lane when the window has fewer than sixteen words.
@@ -469,7 +480,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(7
             // plain constants the compiler moves them into vector registers in front of the chunk loop — ten registers that the tile loop does
             // not have at six waves per SIMD (45 spilled registers, and the library refuses a build with scratch).
             uint32_t k80, ksel1, ksel2, ksel3, kw, kc;
-            asm volatile("s_mov_b32 %0, 0x80808080\n\ts_mov_b32 %1, 0x01010101\n\ts_mov_b32 %2, 0x02020202\n\ts_mov_b32 %3, 0x03030303\n\t"
+            asm volatile("s_mov_b32 %0, 0x3f3f3f3f\n\ts_mov_b32 %1, 0x01010101\n\ts_mov_b32 %2, 0x02020202\n\ts_mov_b32 %3, 0x03030303\n\t"
                          "s_mov_b32 %4, 0x06040200\n\ts_mov_b32 %5, 0x07050301"
                          : "=s"(k80), "=s"(ksel1), "=s"(ksel2), "=s"(ksel3), "=s"(kw), "=s"(kc));
             uint32_t tt = (uint32_t)T;
@@ -482,7 +493,10 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(7
                 Q[q] = __builtin_amdgcn_perm(__builtin_amdgcn_alignbyte(d2, d1, sh), __builtin_amdgcn_alignbyte(d1, d0, sh), kc);
             }
             // the sums: 10 S_k > k T  <=>  S_k > floor(k T / 10), k = 1 .. 16, newest count first
-            uint32_t S = 0, nbad = 0;
+            // (every test is a compare into a lane mask that the scalar unit accumulates; the masks are tied to the vector values they were made
+            // from, one step at a time — deferred, sixteen compares keep sixteen partial sums alive)
+            uint32_t S = 0;
+            unsigned long long pos_m = ~0ull;
 #pragma unroll
             for (int a = 0; a < SIFT_K; ++a) {
                 const int idx = SIFT_K - 1 - a;
@@ -492,15 +506,13 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(7
                 case 2: asm("v_add_u32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "+v"(S) : "v"(Q[idx >> 2])); break;
                 default: asm("v_add_u32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "+v"(S) : "v"(Q[idx >> 2])); break;
                 }
-                // (an integer, not a lane mask, and tied to S: sixteen deferred compares would keep sixteen partial sums alive)
                 const uint32_t th = (tt * (uint32_t)(a + 1)) / 10u;
-                uint32_t bad = S <= th ? 1u : 0u;
-                asm volatile("" : "+v"(bad), "+v"(S));
-                nbad |= bad;
+                unsigned long long ok = __builtin_amdgcn_ballot_w64(S > th);
+                asm volatile("" : "+s"(ok), "+v"(S));
+                pos_m &= ok;
             }
-            const bool pos = nbad == 0u;
             uint32_t at2 = at & ~3u;
-            asm volatile("" : "+v"(at2), "+v"(nbad));  // (the second read starts when the sums are through)
+            asm volatile("" : "+v"(at2), "+s"(pos_m));  // (the second read starts when the sums are through)
             const lds_u32 *const pb = (const lds_u32 *)(uintptr_t)at2;
             uint32_t P[4];
 #pragma unroll
@@ -509,8 +521,9 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(7
                 P[q] = __builtin_amdgcn_perm(__builtin_amdgcn_alignbyte(d2, d1, sh), __builtin_amdgcn_alignbyte(d1, d0, sh), kw);
             }
             const uint32_t seen = (P[0] | P[1] | P[2] | P[3]) & 0xC0C0C0C0u;
-            // the walk: suffixes of 2 .. 16 words.  ne = the compared pairs that were NOT equal (bit 7 stays set there): rr = pairs - ne
-            uint32_t ne = 0, nhit = 0;
+            // the walk: suffixes of 2 .. 16 words.  ne = the compared pairs that were NOT equal: rr = pairs - ne
+            uint32_t ne = 0;
+            unsigned long long sc_m = 0ull;
 #pragma unroll
             for (int a = 1; a < SIFT_K; ++a) {
                 const int idx = SIFT_K - 1 - a, qi = idx >> 2, bj = idx & 3;
@@ -518,18 +531,18 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(7
 #pragma unroll
                 for (int q = qi; q < 4; ++q) {
                     if (q == qi && bj == 3) continue;                                    // (no newer word in its own register)
-                    const uint32_t m = q == qi ? 0x80808080u << (8 * (bj + 1)) : 0x80808080u;   // the newer bytes of its own register / all of a newer one
-                    const uint32_t u = ((P[q] ^ rep) | k80) + 0xFEFEFEFFu;              // (- 0x01010101: no byte borrows, every byte is at least 0x80)
+                    const uint32_t m = q == qi ? 0x40404040u << (8 * (bj + 1)) : 0x40404040u;   // the newer bytes of its own register / all of a newer one
+                    const uint32_t u = (P[q] ^ rep) + k80;                              // (words are six bits: byte + 0x3f reaches bit 6 unless the two were equal, and never the next byte — one v_xad_u32)
                     ne += (uint32_t)__builtin_popcount(u & m);
                 }
                 // rr(a) = a (a + 1) / 2 - ne > floor(a T / 10)  <=>  ne < a (a + 1) / 2 - floor(a T / 10)   (never, when that is not positive)
                 const int lim = a * (a + 1) / 2 - (int)((tt * (uint32_t)a) / 10u);
-                uint32_t hit = (int)ne < lim ? 1u : 0u;
+                unsigned long long hit = __builtin_amdgcn_ballot_w64((int)ne < lim);
                 // (one step at a time — every step's inputs pass through here: scheduled freely, the compares of all fifteen steps start at once, twenty temporaries)
-                asm volatile("" : "+v"(hit), "+v"(ne), "+v"(P[0]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]));
-                nhit |= hit;
+                asm volatile("" : "+s"(hit), "+v"(ne), "+v"(P[0]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]));
+                sc_m |= hit;
             }
-            const bool sc = nhit != 0u;
+            const bool sc = (sc_m >> lane) & 1ull, pos = (pos_m >> lane) & 1ull;
             keep = on && (seen != 0u || sc || (pos && long_ok));
         }
         if (STATS) st_l2 += (unsigned long long)__popcll(sd_ballot(keep));
@@ -631,7 +644,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(7
                 ntl += __popcll(m);
                 SD_LDS_ORDER();
                 if (ntl >= 64) {
-                    if (!(A.abl & 2)) run_l1(64);
+                    if (!(abl & 2)) run_l1(64);
                     const uint16_t mv = tl[64 + lane];
                     SD_LDS_ORDER();
                     tl[lane] = mv;
@@ -641,7 +654,7 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(7
             }
         }
     };
-    if (!(A.abl & 4)) {
+    if (!(abl & 4)) {
         using P0 = std::integral_constant<int, 0>;
         using P1 = std::integral_constant<int, 1>;
         int q = 0;
@@ -659,9 +672,9 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(7
         }
     }
     SD_LDS_ORDER();
-    if (ntl > 0 && !(A.abl & 2)) run_l1(ntl);
+    if (ntl > 0 && !(abl & 2)) run_l1(ntl);
     if (ntl2 > 0) run_l2(ntl2);
-    if (A.abl & 1) { finish(); return; }
+    if (abl & 1) { finish(); return; }
     SD_LDS_ORDER();
 
     // ---- resolve: the set bits in order ---------------------------------------------------------------------------------
@@ -780,10 +793,16 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(7
         uint32_t B = 1u, lbest = 0u;
         const bool last = lane == 63;
         // one length: `cin` = the column entry of length l - 1 (lane 0's neighbour); lane 63 leaves its c and B in entry l
-        auto step = [&](const int l, const uint2 cin) __attribute__((always_inline)) {
+        auto step = [&](const int l, const uint2 cin, const uint32_t rcp_s) __attribute__((always_inline)) {
             const uint32_t wv = pw[-2 * l];
-            const uint32_t rcp_l = (uint32_t)rdlane((int)m_recip, l);      // ceil(2^32 / l), floor(T l / 10): lane l holds them
+#ifndef SIFT_DP_SCALAR                                  // ceil(2^32 / l), floor(T l / 10): lane l holds them — two v_readlane per length
+            const uint32_t rcp_l = (uint32_t)rdlane((int)m_recip, l);
             const int thr_l = rdlane(Tl10, l);
+            (void)rcp_s;
+#else                                                   // (A/B, round 5: a scalar load one turn ahead + the scalar unit's division: 1 % slower — 12.68-13.05 against 12.58-12.94 ms on the humanlike profile, alternating on one box)
+            const uint32_t rcp_l = rcp_s;
+            const int thr_l = (int)(((uint32_t)T * (uint32_t)l) / 10u);
+#endif
             c = __builtin_amdgcn_update_dpp((int)cin.x, c, 0x138, 0xF, 0xF, false) + (wv == w_own ? 1 : 0);
             rr += c;
             const uint32_t kq = __umulhi((uint32_t)rr << 13, rcp_l);
@@ -816,16 +835,28 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(7
         // two lengths per turn: an entry is loaded into the register whose entry has just had its last use (no copies); ca = entry
         // l - 1, cb_ = entry l on entering
         int l = 2;
+#ifdef SIFT_DP_SCALAR
+        uint32_t ra = sd_recip_tab[2], rb_ = sd_recip_tab[3];
+#else
+        uint32_t ra = 0, rb_ = 0;
+#endif
         for (; l + 1 < CAPW; l += 2) {
             const uint2 c1 = col[l + 1];               // (entry l + 1 before lane 63 overwrites it in step l + 1; entry l is in cb_)
-            step(l, ca);
+#ifdef SIFT_DP_SCALAR
+            const uint32_t rn0 = sd_recip_tab[(l + 2) & 63], rn1 = sd_recip_tab[(l + 3) & 63];
+#else
+            const uint32_t rn0 = 0, rn1 = 0;
+#endif
+            step(l, ca, ra);
             ca = cb_;
             const uint2 c2 = col[l + 2 < 64 ? l + 2 : 63];
-            step(l + 1, ca);
+            step(l + 1, ca, rb_);
             ca = c1;
             cb_ = c2;
+            ra = rn0;
+            rb_ = rn1;
         }
-        if (l < CAPW) step(l, ca);
+        if (l < CAPW) step(l, ca, ra);
         if (lbest) mark(rb + o0 - 2 - (int)lbest, (int)lbest + 3);
         SD_LDS_ORDER();
         slot = lane >= 1 && lane < CAPW ? (int)col[lane].y : 0;

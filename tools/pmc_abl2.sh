@@ -6,7 +6,7 @@ mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 export CORNETTO_SDUST_SIFT=1
 for abl in ${@:-0 1 3 7}; do
-  export CORNETTO_SIFT_ABL=$abl
+  if [ "$abl" = "0" ]; then unset CORNETTO_SIFT_ABL; elif [ "$abl" = "g" ]; then unset CORNETTO_SIFT_ABL; export CORNETTO_SIFT_GENERIC=1; else export CORNETTO_SIFT_ABL=$abl; fi   # (0: the production build; g: the build for run-time buffer sizes; other values run that build with stages off)
   for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"; do
   rm -rf $R/gpurun_out/pmcabl_x
   timeout 300 rocprofv3 --pmc $set -d $R/gpurun_out/pmcabl_x --output-format csv -- python3 $R/tools/perf_probe.py sdust --mbases 3160 --features 1 --reps 2 --profile $P > $R/gpurun_out/pmcabl_x.log 2>&1

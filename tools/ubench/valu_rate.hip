@@ -18,7 +18,7 @@
 template <int KIND>
 __global__ __launch_bounds__(64) void k(unsigned long long *t0, unsigned long long *t1, unsigned *sink, int sarg)
 {
-    __shared__ unsigned lds[64 * 17];
+    __shared__ __attribute__((aligned(16))) unsigned lds[64 * 17];
     unsigned v[8];
     for (int i = 0; i < 8; ++i) v[i] = threadIdx.x * 2654435761u + i * 40503u + sarg;
     lds[threadIdx.x] = 0;
@@ -115,6 +115,65 @@ __global__ __launch_bounds__(64) void k(unsigned long long *t0, unsigned long lo
 #define X(i) asm volatile("v_writelane_b32 %0, %1, 7" : "+v"(v[i]) : "s"(s1));
             R16(X)
 #undef X
+        } else if (KIND == 21) {  // 32 x 32 -> high 32 (the ratio key of the dp tiles, round 4)
+#define X(i) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(v[i]) : "v"(v[(i + 1) & 7]));
+            R16(X)
+#undef X
+        } else if (KIND == 22) {  // 24 x 24 -> low 32
+#define X(i) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(v[i]) : "v"(v[(i + 1) & 7]));
+            R16(X)
+#undef X
+        } else if (KIND == 23) {  // 24 x 24 -> high 16
+#define X(i) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(v[i]) : "v"(v[(i + 1) & 7]));
+            R16(X)
+#undef X
+        } else if (KIND == 24) {  // 32 x 32 -> low 32
+#define X(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(v[i]) : "v"(v[(i + 1) & 7]));
+            R16(X)
+#undef X
+        } else if (KIND == 25) {  // v_bcnt accumulate
+#define X(i) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(v[i]) : "v"(v[(i + 1) & 7]));
+            R16(X)
+#undef X
+        } else if (KIND == 26) {  // v_alignbit
+#define X(i) asm volatile("v_alignbit_b32 %0, %0, %1, 13" : "+v"(v[i]) : "v"(v[(i + 1) & 7]));
+            R16(X)
+#undef X
+        } else if (KIND == 27) {  // LDS gather at random dword addresses of a 64-entry table (the equal-word tables of sd_sift), 4 in flight
+#define X(i) { unsigned addr = ((v[i] >> 9) & 63) * 4, r; asm volatile("ds_read_b32 %0, %1" : "=v"(r) : "v"(addr) : "memory"); v[i] += r + 0x9e3779b9u; }
+            R8(X)
+#undef X
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (KIND == 28) {  // the same gather with lane-indexed (conflict-free) addresses
+#define X(i) { unsigned addr = (threadIdx.x & 63) * 4, r; asm volatile("ds_read_b32 %0, %1" : "=v"(r) : "v"(addr) : "memory"); v[i] += r + 0x9e3779b9u; }
+            R8(X)
+#undef X
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (KIND == 29) {  // ds_or_b32 (no return) at random entries of a 64-entry table
+#define X(i) { unsigned addr = ((v[i] >> 9) & 63) * 4; asm volatile("ds_or_b32 %0, %1" :: "v"(addr), "v"(1u << (threadIdx.x & 31)) : "memory"); v[i] = v[i] * 1664525u + 1013904223u; }
+            R8(X)
+#undef X
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (KIND == 30) {  // ds_bpermute_b32 from random lanes
+#define X(i) { unsigned addr = ((v[i] >> 9) & 63) * 4, r; asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(r) : "v"(addr), "v"(v[(i + 1) & 7]) : "memory"); v[i] += r + 0x9e3779b9u; }
+            R8(X)
+#undef X
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (KIND == 31) {  // ds_bpermute_b32 from the neighbouring lane (no two lanes read the same source)
+#define X(i) { unsigned addr = ((threadIdx.x + 1) & 63) * 4, r; asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(r) : "v"(addr), "v"(v[(i + 1) & 7]) : "memory"); v[i] += r + 0x9e3779b9u; }
+            R8(X)
+#undef X
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (KIND == 32) {  // ds_read_b64 gather at random 8-byte entries of a 64-entry table
+#define X(i) { unsigned addr = ((v[i] >> 9) & 63) * 8; unsigned long long r; asm volatile("ds_read_b64 %0, %1" : "=v"(r) : "v"(addr) : "memory"); v[i] += (unsigned)r + (unsigned)(r >> 32) + 0x9e3779b9u; }
+            R8(X)
+#undef X
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (KIND == 33) {  // ds_read_b128 gather at random 16-byte entries of a 64-entry table
+#define X(i) { unsigned addr = ((v[i] >> 9) & 63) * 16; uint4 r; asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory"); v[i] += r.x + r.y + r.z + r.w + 0x9e3779b9u; }
+            R8(X)
+#undef X
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
     const unsigned long long b = __builtin_amdgcn_s_memtime();
@@ -137,6 +196,10 @@ int main(int argc, char **argv)
         {"s_add+s_and (SALU)", 16, k<13>}, {"ds_add_rtn_u32 + wait + use", 8, k<14>}, {"v_add + s_add interleaved (pairs)", 16, k<15>},
         {"ballot idiom (v_cmp,s_and,s_cmp,s_cselect)", 8, k<16>}, {"v_and_or_b32", 16, k<17>}, {"ds_read_u8+wait+ds_write_b8", 8, k<18>},
         {"v_mbcnt lo+hi (pairs)", 8, k<19>}, {"v_writelane_b32", 16, k<20>},
+        {"v_mul_hi_u32", 16, k<21>}, {"v_mul_u32_u24", 16, k<22>}, {"v_mul_hi_u32_u24", 16, k<23>}, {"v_mul_lo_u32", 16, k<24>}, {"v_bcnt_u32_b32", 16, k<25>},
+        {"v_alignbit_b32", 16, k<26>}, {"ds_read_b32 random of 64 entries (8 in flight)", 8, k<27>}, {"ds_read_b32 lane-indexed (8 in flight)", 8, k<28>},
+        {"ds_or_b32 random of 64 entries (8 in flight)", 8, k<29>}, {"ds_bpermute_b32 random lanes (8 in flight)", 8, k<30>},
+        {"ds_bpermute_b32 neighbour lane (8 in flight)", 8, k<31>}, {"ds_read_b64 random of 64 entries", 8, k<32>}, {"ds_read_b128 random of 64 entries", 8, k<33>},
     };
     unsigned long long *t0, *t1; unsigned *sink;
     const int maxb = cus * 32;

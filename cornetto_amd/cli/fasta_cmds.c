@@ -339,8 +339,9 @@ typedef struct {
     int fd, n_threads, started;
     const char *cur;      /* piece k */
     int64_t cur_n, cur_off; /* its bytes and the file offset of its first byte */
-    char *dst;            /* buffer of piece k + 1 (allocated by the thread on first use) */
-    int64_t cap;
+    char *dst;            /* buffer of piece k + 1 (allocated by the thread on first use, and again when it is smaller than cap) */
+    int64_t dst_cap;      /* its size */
+    int64_t cap;          /* bytes to read ahead */
     int64_t pred;         /* out: predicted consumed bytes of piece k (-1: no prediction: nothing was read) */
     int64_t got;          /* out: bytes of piece k + 1 (-1: read error) */
     int eof;              /* out: the file ends inside piece k + 1 */
@@ -368,8 +369,16 @@ static void *fa_ahead_thread(void *p)
         a->pred = -1;
         return NULL;
     }
-    if (!a->dst) a->dst = (char *)cornetto_pinned_alloc((size_t)a->cap);
+    if (a->dst && a->dst_cap < a->cap) {          /* (the small first piece of the file, handed back as the second buffer) */
+        cornetto_pinned_free(a->dst);
+        a->dst = NULL;
+    }
     if (!a->dst) {
+        a->dst = (char *)cornetto_pinned_alloc((size_t)a->cap);
+        a->dst_cap = a->cap;
+    }
+    if (!a->dst) {
+        a->dst_cap = 0;
         a->pred = -1;
         return NULL;
     }
@@ -414,7 +423,19 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
             if (strcmp(path, "-") && gzdirect(fp) && stat(path, &st) == 0 && S_ISREG(st.st_mode)) raw_fd = open(path, O_RDONLY);
         }
         cli_accel_open_begin();
-        buf = (char *)cornetto_pinned_alloc((size_t)piece);
+        /* read-ahead (uncompressed FASTA file; CORNETTO_CLI_AHEAD=0 switches it off) */
+        const char *ahead_env = getenv("CORNETTO_CLI_AHEAD");
+        const int use_ahead = fasta && raw_fd >= 0 && !(ahead_env && !atoi(ahead_env));
+        /* With read-ahead the FIRST piece is small (64 MiB; CORNETTO_CLI_FIRST_MB): pinning and reading it takes a quarter of the time of a
+         * full piece, and that time stands in front of the first scan — beside the device's start-up, on this thread; the full-size buffers
+         * are made by the read-ahead thread while the device works (round 5). */
+        int64_t cap_buf = piece, cap_other = 0;
+        if (use_ahead && !getenv("CORNETTO_FASTQ_PIECE")) {
+            const char *fm = getenv("CORNETTO_CLI_FIRST_MB");
+            const int64_t first_bytes = (int64_t)(fm && atoi(fm) > 0 ? atoi(fm) : 64) << 20;
+            if (first_bytes < cap_buf) cap_buf = first_bytes;
+        }
+        buf = (char *)cornetto_pinned_alloc((size_t)cap_buf);
         if (!buf) {
             h = cli_accel_open_end(); /* no usable device: its message and exit(EXIT_FAILURE) */
             CLI_ERROR("could not allocate a %lld-byte pinned read buffer", (long long)piece);
@@ -422,9 +443,6 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
         }
         buf[0] = first;
         TRACE("pinned piece allocated");
-        /* read-ahead (uncompressed FASTA file; CORNETTO_CLI_AHEAD=0 switches it off) */
-        const char *ahead_env = getenv("CORNETTO_CLI_AHEAD");
-        const int use_ahead = fasta && raw_fd >= 0 && !(ahead_env && !atoi(ahead_env));
         fa_ahead_t ah;
         memset(&ah, 0, sizeof(ah));
         char *other = NULL;          /* the second buffer, once the thread has made it */
@@ -440,8 +458,8 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
                 have -= start;
                 start = 0;
             }
-            if (raw_fd >= 0 && have < piece && !eof) {
-                const int64_t want = piece - have;
+            if (raw_fd >= 0 && have < cap_buf && !eof) {
+                const int64_t want = cap_buf - have;
                 const int64_t r = cli_pread_parallel(raw_fd, buf + have, want, raw_off, READ_THREADS);
                 if (r < 0) {
                     CLI_ERROR("reading %s failed", path);
@@ -451,8 +469,8 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
                 raw_off += r;
                 if (r < want) eof = 1;
             }
-            while (raw_fd < 0 && have < piece && !eof) {
-                const int64_t want = piece - have > (1 << 30) ? (1 << 30) : piece - have;
+            while (raw_fd < 0 && have < cap_buf && !eof) {
+                const int64_t want = cap_buf - have > (1 << 30) ? (1 << 30) : cap_buf - have;
                 const int r = gzread(fp, buf + have, (unsigned)want);
                 if (r < 0) {
                     CLI_ERROR("reading %s failed", path);
@@ -471,6 +489,7 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
                 ah.cur_n = have;
                 ah.cur_off = buf_off;
                 ah.dst = other;
+                ah.dst_cap = cap_other;
                 ah.cap = piece;
                 ah.started = pthread_create(&ah.th, NULL, fa_ahead_thread, &ah) == 0;
             }
@@ -511,11 +530,15 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
                 pthread_join(ah.th, NULL);
                 ah.started = 0;
                 other = ah.dst;
+                cap_other = ah.dst_cap;
                 if (plain && !eof && ah.pred == used && ah.got > 0) {
                     /* the piece that was read ahead begins where this one stopped: swap the buffers */
                     char *t = buf;
                     buf = other;
                     other = t;
+                    const int64_t tc = cap_buf;
+                    cap_buf = cap_other;
+                    cap_other = tc;
                     buf_off += used;
                     raw_off = buf_off + ah.got;
                     have = ah.got;
@@ -531,17 +554,20 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
             }
             if (!plain || eof) break;              /* not plain from buf + start on / the input is finished */
             buf_off += start;                      /* (the bytes in front of `start` are dropped by the memmove above) */
-            if (used == 0 && have == piece) { /* one record larger than the piece: a larger one, as long as the index allows */
-                if (piece >= piece_max) break;
-                const int64_t bigger = piece * 2 > piece_max ? piece_max : piece * 2;
+            if (used == 0 && have == cap_buf) { /* one record larger than the buffer: a larger one, as long as the index allows */
+                if (cap_buf >= piece_max) break;
+                int64_t bigger = cap_buf < piece ? piece : cap_buf * 2;        /* (the small first buffer: to a full piece first) */
+                if (bigger > piece_max) bigger = piece_max;
                 char *nb = (char *)cornetto_pinned_alloc((size_t)bigger);
                 if (!nb) break;
                 memcpy(nb, buf, (size_t)have);
                 cornetto_pinned_free(buf);
                 buf = nb;
-                piece = bigger;
+                cap_buf = bigger;
+                if (bigger > piece) piece = bigger;
                 if (other) cornetto_pinned_free(other);   /* (the read-ahead buffer is made again at the new size) */
                 other = NULL;
+                cap_other = 0;
             }
         }
         if (!h) h = cli_accel_open_end();

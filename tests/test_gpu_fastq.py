@@ -438,6 +438,39 @@ def test_cli_fasta_then_fastq_in_one_file_and_stdin(tmp_path):
     assert rc == 0 and out == want
 
 
+@pytest.mark.parametrize("big_at", [None, 0, 7, 19])
+def test_cli_small_first_piece_then_full_pieces_read_ahead(tmp_path, big_at):
+    """round 5: with read-ahead the first pinned piece of an uncompressed FASTA file is small (CORNETTO_CLI_FIRST_MB, here 1 MiB of a
+    ~7 MB file) and the full-size buffers are made by the read-ahead thread; the small buffer comes back as the second buffer and is
+    made again at the full size; a record larger than the first piece (at the start, in the middle, at the end) grows it.  Same bytes as
+    without read-ahead and as the reference's sdust over the same records."""
+    rng = np.random.default_rng(99 if big_at is None else big_at)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    recs = []
+    for i in range(20):
+        L = 1_600_000 if big_at == i else int(rng.integers(150_000, 400_000))
+        sq = acgt[rng.integers(0, 4, L)].copy()
+        for _ in range(L // 20_000):
+            a = int(rng.integers(0, L - 300))
+            sq[a:a + 240] = np.frombuffer(b"TTAGGG" * 40, dtype=np.uint8)
+        body = sq.tobytes()
+        w = 80 if i % 3 else 0
+        recs.append(b">ctg%d some text\n" % i + (b"".join(body[k:k + w] + b"\n" for k in range(0, L, w)) if w else body + b"\n"))
+    text = b"".join(recs)
+    f = str(tmp_path / "big.fa")
+    open(f, "wb").write(text)
+    want = sdust_text(text)
+    assert len(want) > 2000
+    rc0, out0, err0 = run_cli(["sdust", f], env={"CORNETTO_CLI_AHEAD": "0"})
+    assert rc0 == 0 and out0 == want
+    for first in ("1", "2", "64"):
+        rc, out, err = run_cli(["sdust", f], env={"CORNETTO_CLI_FIRST_MB": first})
+        assert rc == 0 and out == want, (first, err[-300:])
+    rc, out, err = run_cli(["telofind", f], env={"CORNETTO_CLI_FIRST_MB": "1"})
+    rc1, out1, _ = run_cli(["telofind", f], env={"CORNETTO_CLI_AHEAD": "0"})
+    assert rc == 0 and rc1 == 0 and out == out1 and len(out) > 1000
+
+
 def test_cli_pieces_grow_until_the_largest_record_fits(golden_dir):
     env = {"CORNETTO_FASTQ_PIECE": "128", "CORNETTO_FASTQ_GROW": "1"}
     for args, exp in ((["sdust", "mix.fa.gz"], "mix.sdust.exp"), (["telofind", "probe.fa"], "probe.telofind.exp"), (["sdust", "reads.fq"], "reads.sdust.exp")):

@@ -708,7 +708,10 @@ class Rank:
         self.handshake = self.overlap and os.environ.get("CORNETTO_BENCH_HANDSHAKE", "1") != "0"
         self.lag_us = float(os.environ.get("CORNETTO_BENCH_SDUST_LAG_US", "0"))
         self.lazy = self.overlap and os.environ.get("CORNETTO_BENCH_LAZY", "1") != "0"
-        self.fused = os.environ.get("CORNETTO_BENCH_FUSED", "1") != "0"
+        # cornetto_panel_step (the other thread's three calls as one, two synchronisations instead of five): measured and NOT the default — with its
+        # kernels queued back to back the resident sdust waves find no idle issue slots (3.16 Gbp, share 72: 7.55 against 6.98-7.01 ms per step with the
+        # three calls; a 1/8 share: 1.15-1.18 against 1.18-1.19, within the noise: the sdust thread bounds the step either way).  CORNETTO_BENCH_FUSED=1.
+        self.fused = os.environ.get("CORNETTO_BENCH_FUSED", "0") != "0"
         self.acc.set_lazy(self.lazy)
         self.thr = self.acc.telowin_threshold(0.4, 99.9)
         self.ktime, self.wall = {}, {}
@@ -914,7 +917,7 @@ class Rank:
         for _ in range(2):                             # (the result pools of a new workload grow in its first steps: not the share's doing)
             self.step(False)
         best, seen = None, {}
-        for sh in (85, 80, 76, 72, 92, 100, 85):       # (the first one twice: the first candidate measured is the one that pays for what is still warming up)
+        for sh in (85, 80, 76, 72, 68, 92, 100, 85):   # (the first one twice: the first candidate measured is the one that pays for what is still warming up)
             self.acc2.set_share(sh)
             self.step(False)
             self.torch.cuda.synchronize()

@@ -223,12 +223,15 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(C
         for (int it = 0; it < 2; ++it) {
             const int b16 = lane * 16 + it * 1024;
             d.q[it] = make_uint4(0, 0, 0, 0);
-            d.pw[it] = 0;
-            if (b16 < rlen) {
-                d.q[it] = *reinterpret_cast<const uint4 *>(m.seq + rb + b16);
-                if (rb + b16 > 0) d.pw[it] = *reinterpret_cast<const uint32_t *>(m.seq + rb + b16 - 4);
-            }
+            if (b16 < rlen) d.q[it] = *reinterpret_cast<const uint4 *>(m.seq + rb + b16);
         }
+        // The four bases in front of a lane's sixteen are the neighbouring lane's last dword (round 5: one DPP move instead of a second global
+        // load per 16 bytes — a third of the kernel's vector-memory instructions); lane 0 takes lane 63's of the round before, and in the first
+        // round the dword in front of the region, one scalar load (the region starts at a multiple of 64 inside the contig, or at its base 0).
+        uint32_t first = 0;
+        if (rb > 0) first = *reinterpret_cast<const uint32_t *>(m.seq + rb - 4);      // (uniform address)
+        d.pw[0] = (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)d.q[0].w, 0x138, 0xF, 0xF, false);
+        d.pw[1] = (uint32_t)__builtin_amdgcn_update_dpp(rdlane((int)d.q[0].w, 63), (int)d.q[1].w, 0x138, 0xF, 0xF, false);
         return d;
     };
 

@@ -1,7 +1,7 @@
 # development aid: bench step time against the share of the CU wave slots given to sdust
-for sh in ${@:-70 80 85 90 100}; do for i in 1 2; do
-python bench.py --steps 40 --no-profiles --no-e2e --no-cpu --sdust-share $sh 2>/dev/null | python -c "
+for sh in ${@:-60 64 68 72 76}; do for i in 1 2; do
+python bench.py --steps 30 --warmup 3 --no-profiles --no-e2e --no-cpu --no-reads --check-steps 0 --emulate-ranks= --sdust-share $sh 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('share', $sh, 'ms/step', d['ms_per_step'], d.get('stage_wall_ms'), {k: v['ms'] for k, v in d['kernels'].items() if v['ms'] > 0.25})"
+print('share', $sh, 'ms/step', d['ms_per_step'], d['ms_per_step_spread']['median'], d.get('stage_wall_ms'), {k: v['ms'] for k, v in d['kernels'].items() if v.get('ms', 0) > 0.25})"
 done; done

@@ -1901,6 +1901,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                     if (!h->ev3) CN_HIP(h, hipEventCreateWithFlags(&h->ev3, hipEventDisableTiming));
                     CN_HIP(h, hipEventRecord(h->ev1, h->stream));               // the state of this call is set up
                 }
+                stamp("set up");
                 if (want_stats) CN_LAUNCH(h, "sdust_kernel", sd_sift<true><<<dim3(nbk), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream>>>(S, R));
                 else if (cap_default) CN_LAUNCH(h, "sdust_kernel", sd_sift<false, SIFT_CAP_DEFAULT><<<dim3(nbk), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream>>>(S, R));
                 else CN_LAUNCH(h, "sdust_kernel", sd_sift<false><<<dim3(nbk), dim3(64 * SIFT_WPB), lds_wave * SIFT_WPB, h->stream>>>(S, R));
@@ -1921,6 +1922,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                         sched_yield();
                     }
                     if (helped) CN_HIP(h, hipStreamWaitEvent(h->stream, h->ev2, 0));
+                    stamp(helped ? "kernel done (helped)" : "kernel done (polled)");
                 }
                 if (sift_walk_pending) {
                     CN_TRY(cnscan::exclusive_u32(h, "sdust_order", d_wflag, (int64_t)nc, 1, d_wrank, d_wpart, nullptr));
@@ -2076,6 +2078,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                     CN_HIP(h, hipMemsetAsync(d_tot + 9, 0xFF, 8, h->stream));          // (the merge writes the count only when every row had its tile)
                     int rcf = cnivl::merge_fused(h, "sdust_stitch", d_dst, d_tot, (int64_t)n_cap, 0, d_st, d_tot + 9);
                     if (rcf != CORNETTO_OK) { cornetto_free(of); return rcf; }
+                    stamp("tail queued");
                     if (hipMemcpyAsync(of, d_st, m_cap * sizeof(cornetto_ivl_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
                         hipMemcpyAsync(p_tot, d_tot, 128, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
                         cornetto_free(of);
@@ -2085,6 +2088,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                     const bool wtab_f = (p_tot[1] >> 32) != 0;
                     const unsigned long long rows_f = p_tot[0], out_f = rows_f ? p_tot[9] : 0ull;
                     if (!wtab_f && ovf_f <= cap && rows_f <= n_cap && out_f != ~0ull && out_f <= m_cap && out_f <= rows_f && (rows_f == 0 || out_f > 0)) {
+                        stamp("results on the host (one go)");
                         if (sift_walk_pending) a->sd_walk_key = key;
                         a->sd_est_rows = (int64_t)rows_f;
                         a->sd_est_out = (int64_t)out_f;

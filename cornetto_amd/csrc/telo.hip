@@ -263,21 +263,28 @@ __global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
     }
 }
 
-// fixed rows -> dense lists in tile (= contig, position) order; wave q of a workgroup copies list q of one tile
+// fixed rows -> dense lists in tile (= contig, position) order.  One WAVE per tile (round 5; before: a 256-thread workgroup per tile, one wave per
+// list with half its lanes idle — 776 000 waves for the 194 000 tiles of a 3.16 Gbp assembly, 0.5 ms beside the resident sdust waves for 12 MB of
+// traffic): a lane moves two of the tile's 4 x TF_ROW entries
 __global__ __launch_bounds__(256) void tf_gather(const int32_t *r0, const int32_t *r1, const int32_t *r2, const int32_t *r3,
                                                  const uint4 *tile_cnt, const uint32_t *o0, const uint32_t *o1, const uint32_t *o2,
-                                                 const uint32_t *o3, int32_t *d0, int32_t *d1, int32_t *d2, int32_t *d3, uint4 caps)
+                                                 const uint32_t *o3, int32_t *d0, int32_t *d1, int32_t *d2, int32_t *d3, uint4 caps, int64_t n_tiles)
 {
-    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t tile = blockIdx.x;
+    static_assert(TF_ROW == 32, "two entries per lane: 4 lists x 32 entries per tile");
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
     const uint4 c4 = tile_cnt[tile];
-    const uint32_t cnt = q == 0 ? c4.x : q == 1 ? c4.y : q == 2 ? c4.z : c4.w;
-    const uint32_t cap = q == 0 ? caps.x : q == 1 ? caps.y : q == 2 ? caps.z : caps.w;    // entries list q has room for (lists sized by an estimate: telo spec)
-    const int32_t *src = (q == 0 ? r0 : q == 1 ? r1 : q == 2 ? r2 : r3) + tile * TF_ROW;
-    const uint32_t *off = q == 0 ? o0 : q == 1 ? o1 : q == 2 ? o2 : o3;
-    const uint32_t at = off[tile];
-    int32_t *dst = (q == 0 ? d0 : q == 1 ? d1 : q == 2 ? d2 : d3) + at;
-    if ((uint32_t)lane < cnt && lane < TF_ROW && (unsigned long long)at + (uint32_t)lane < cap) dst[lane] = src[lane];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int q = (lane >> 5) + 2 * k, idx = lane & 31;            // lanes 0-31: lists 0 / 2, lanes 32-63: lists 1 / 3
+        const uint32_t cnt = q == 0 ? c4.x : q == 1 ? c4.y : q == 2 ? c4.z : c4.w;
+        const uint32_t cap = q == 0 ? caps.x : q == 1 ? caps.y : q == 2 ? caps.z : caps.w;    // entries list q has room for (lists sized by an estimate: telo spec)
+        const int32_t *src = (q == 0 ? r0 : q == 1 ? r1 : q == 2 ? r2 : r3) + tile * TF_ROW;
+        const uint32_t at = (q == 0 ? o0 : q == 1 ? o1 : q == 2 ? o2 : o3)[tile];
+        int32_t *dst = (q == 0 ? d0 : q == 1 ? d1 : q == 2 ? d2 : d3) + at;
+        if ((uint32_t)idx < cnt && (unsigned long long)at + (uint32_t)idx < cap) dst[idx] = src[idx];
+    }
 }
 
 // list offsets at contig boundaries: ctg_off[q][c] = number of entries of list q before contig c (c = n: total)
@@ -763,9 +770,9 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
             if (rows_mode && ovf <= TF_ROW) {
                 hipEvent_t ea = cn_event(h), eb = cn_event(h);
                 (void)hipEventRecord(ea, h->stream);
-                tf_gather<<<dim3((unsigned)nt), dim3(256), 0, h->stream>>>(d_rows[0], d_rows[1], d_rows[2], d_rows[3], d_tc, d_offq[0], d_offq[1],
-                                                                           d_offq[2], d_offq[3], d_list[0], d_list[1], d_list[2], d_list[3],
-                                                                           make_uint4(~0u, ~0u, ~0u, ~0u));
+                tf_gather<<<dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, h->stream>>>(d_rows[0], d_rows[1], d_rows[2], d_rows[3], d_tc, d_offq[0], d_offq[1],
+                                                                                       d_offq[2], d_offq[3], d_list[0], d_list[1], d_list[2], d_list[3],
+                                                                                       make_uint4(~0u, ~0u, ~0u, ~0u), (int64_t)nt);
                 (void)hipEventRecord(eb, h->stream);
                 h->recs.push_back(cornetto_accel::Rec{"tf_gather", ea, eb});
                 CN_HIP(h, hipGetLastError());
@@ -1035,8 +1042,9 @@ int cn_telo_spec_queue(cornetto_accel_t *h, cornetto_asm_t *a, const char *motif
     CN_LAUNCH(h, "tw_scan", tw_scan<<<dim3((unsigned)a->tw_n_tiles), dim3(256), 0, h->stream>>>(W));
     CN_TRY(cnscan::exclusive_u32_multi(h, "tf_order", reinterpret_cast<const uint32_t *>(d_tc), (int64_t)nt, 4, 4, d_offq, d_part, d_cnt));
     const uint4 caps = make_uint4((uint32_t)seg[0], (uint32_t)seg[1], (uint32_t)seg[2], (uint32_t)seg[3]);
-    CN_LAUNCH(h, "tf_gather", tf_gather<<<dim3((unsigned)nt), dim3(256), 0, h->stream>>>(d_rows[0], d_rows[1], d_rows[2], d_rows[3], d_tc, d_offq[0], d_offq[1], d_offq[2],
-                                                                                        d_offq[3], d_list[0], d_list[1], d_list[2], d_list[3], caps));
+    CN_LAUNCH(h, "tf_gather", tf_gather<<<dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, h->stream>>>(d_rows[0], d_rows[1], d_rows[2], d_rows[3], d_tc, d_offq[0], d_offq[1],
+                                                                                                    d_offq[2], d_offq[3], d_list[0], d_list[1], d_list[2], d_list[3], caps,
+                                                                                                    (int64_t)nt));
     {
         hipEvent_t ea = cn_event(h), eb = cn_event(h);
         (void)hipEventRecord(ea, h->stream);

@@ -250,7 +250,7 @@ def test_satellite_dense_1gbp_through_the_sift_stages(monkeypatch):
 def test_humanlike_1gbp_against_the_oracle():
     """bench.py --profile humanlike at 1 Gbp — isochores with 35-55 % GC, CpG at a fifth of its expectation, 10 % Alu-like and 15 %
     L1-like diverged copies, microsatellites, 3 % satellite arrays: the composition the sieve of sd_sift is sensitive to.  Canonical
-    result, two calls equal, several times the masked fraction of uniform sequence outside the arrays, and the four smallest of
+    result, two calls equal, several times the masked fraction of uniform sequence outside the arrays, and the eight smallest of
     the contigs of 12 Mb or more record for record against the oracle (sdust and telofind / telowin)"""
     import bench
     lens = bench.contig_lengths(1_000_000_000)
@@ -268,7 +268,7 @@ def test_humanlike_1gbp_against_the_oracle():
         small = [i for i in range(len(lens)) if 1_000_000 <= lens[i] < 12_000_000]          # no arrays there
         m_small = sum(int((fi - st)[c == i].sum()) for i in small) / float(sum(lens[i] for i in small))
         assert m_small > 0.008, m_small                       # (uniform sequence: 0.0016)
-        big = sorted([i for i in range(len(lens)) if lens[i] >= 12_000_000], key=lambda i: lens[i])[:4]
+        big = sorted([i for i in range(len(lens)) if lens[i] >= 12_000_000], key=lambda i: lens[i])[:8]
         thr = acc.telowin_threshold(0.4, 99.9)
         hits, wins = acc.telo_scan(asm, b"TTAGGG", thr)
         _compare_contigs(w, big, hits, wins, ivls, thr, stages=("telo", "sdust"))

@@ -14,7 +14,8 @@ import sys
 OURS = ("sd_sift", "sd_sample_count", "sdust_w64", "sdust_dense", "sdust_kernel", "sdust_gather", "tf_scan", "tf_gather", "tf_pair", "tf_ctgoff", "tf_greedy", "tw_scan", "tw_fill",
         "cov_blocks", "cov_windows", "cov_order", "cov_total64", "scan_local", "scan_partials", "scan_add",
         "tk_count", "tk_scatter", "bg_records", "bg_layout", "sd_wordcount",
-        "fq_nl_count", "fq_nl_scatter", "fq_records", "fq_pack", "fa_lines", "fa_heads", "fa_records", "fa_linedst", "fa_copy", "sd_prep", "sd_order", "st_local", "st_emit")
+        "fq_nl_count", "fq_nl_scatter", "fq_records", "fq_pack", "fa_lines", "fa_heads", "fa_records", "fa_linedst", "fa_copy", "sd_prep", "sd_order", "st_local", "st_emit",
+        "scan_lookback", "st_fused", "cov_ctg_first", "sd_make_order")
 
 
 def short(name):

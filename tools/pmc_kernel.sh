@@ -62,10 +62,11 @@ f, w = per.get("FETCH_SIZE"), per.get("WRITE_SIZE")
 if f is not None and w is not None:
     # FETCH_SIZE / WRITE_SIZE count kilobytes; on gfx950 a coalesced stream is counted at half its bytes (profiles/r02_pmc_traffic.json:
     # tools/ubench/fetch_calib measured 2.000), the per-lane 32-byte requests of sdust_w64 at 1 / 1.68
-    scale = 2.0 if kern == "sd_sift" else 1.68
+    # (sd_sift: calibrated in the kernel's own access pattern, tools/pmc_fetch_calib_sift.sh -> profiles/r05_fetch_calib_sift.txt: 1.0833 known B/base read as 0.6236)
+    scale = 1.737 if kern == "sd_sift" else 1.68
     tr = {kern: {"bases": bases, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "fetch_scale_used": scale, "fetch_bytes": f * 1024 * scale, "write_bytes": w * 1024,
                  "hbm_bytes": f * 1024 * scale + w * 1024, "bytes_per_base": round((f * 1024 * scale + w * 1024) / bases, 4)},
-          "workload": out["workload"], "calibration_note": "profiles/r02_pmc_traffic.json holds the calibration runs (tools/ubench/fetch_calib)"}
+          "workload": out["workload"], "production_ms": production_ms, "calibration_note": "profiles/r02_pmc_traffic.json holds the calibration runs (tools/ubench/fetch_calib)"}
     json.dump(tr, open("gpurun_out/%s_pmc_traffic_%s.json" % (tag, kern), "w"), indent=1)
     print(json.dumps(tr[kern]))
 print(json.dumps({k: out[k] for k in ("kernel_ms", "per_64_bases", "valu_busy_of_kernel_time", "clock_GHz_from_counters") if k in out}, indent=1))

@@ -171,10 +171,11 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(C
     // (no third round, no address for it held through the kernel)
     constexpr int STAGE_ROUNDS = CAP ? (int)((CAP + 1023) / 1024) : 4;
     uint32_t *const cb = sb + (cap >> 5);             // coverage of the region, one bit per base: what the chunk's rows are made of
-    // the dp tiles keep the column of the position in front of a tile, per length, in the two tables of parity 1 (the resolve stage reads
-    // windows through the pair of parity 0 only): [length l] = c and B of that position; the constants of a length (ceil(2^32 / l),
-    // floor(T l / 10)) come from lane l's registers
-    uint2 *const col = reinterpret_cast<uint2 *>(tab + 64);
+    // the dp tiles keep the column of the position in front of a tile, per length, in the kilobyte of the equal-word tables: [length l] = c and
+    // B of that position, ceil(2^32 / l), floor(T l / 10) — one 16-byte read per length gets all four.  The window reads of the stepping stage
+    // (jump) use the first and the last quarter of the same kilobyte as their table pair and need them zero: they clear them when a dp tile
+    // has been there (col_dirty).
+    uint4 *const col = reinterpret_cast<uint4 *>(tab);
     uint8_t *const wc = L + SIFT_FIXED + cap / 4 + 2 * SIFT_PAD;
     const int T = A.T, W = A.W, CAPW = W - 2;
 
@@ -692,7 +693,6 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(C
     asm volatile("" : "+v"(lane_r));
     const int Tl = T * lane_r;                        // stepping stages: lane = l
     const uint32_t m_recip = sd_recip_tab[lane_r];
-    const int Tl10 = Tl / 10;                         // dp tiles: floor(T l / 10), read from lane l
     auto mark64 = [&](int o, int nbits) {             // bits [o, o + nbits) of the region, 1 <= nbits <= 64
         const uint32_t d = (uint32_t)o >> 5, b = (uint32_t)o & 31u;
         const unsigned long long mk = nbits >= 64 ? ~0ull : (1ull << nbits) - 1ull;
@@ -750,7 +750,14 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(C
     int dp_at = -1;                                   // the columns in LDS are those of this position
     int wt = 0, wt_tile = -1;                         // words of tile wt_tile of the region, lane <-> position
     // the state at position i, read from the staged words (a gap behind cur: the slots age by it); no pass
+    bool col_dirty = false;                           // (uniform) the dp columns lie where jump's table pair must be zero
     auto jump = [&](int i) {
+        if (col_dirty) {
+            tab[lane] = 0;
+            tab[192 + lane] = 0;
+            col_dirty = false;
+            SD_LDS_ORDER();
+        }
         const int o = i - rb;
         const int amax = i - 2 < CAPW - 1 ? i - 2 : CAPW - 1;
         if (STATS) ++st_jumps;
@@ -795,17 +802,13 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(C
         int c = 0, rr = 0;
         uint32_t B = 1u, lbest = 0u;
         const bool last = lane == 63;
-        // one length: `cin` = the column entry of length l - 1 (lane 0's neighbour); lane 63 leaves its c and B in entry l
-        auto step = [&](const int l, const uint2 cin, const uint32_t rcp_s) __attribute__((always_inline)) {
+        // one length: `cin` = the column entry of length l - 1 (lane 0's neighbour), `cl` = that of length l (its constants; lane 63 leaves c and B there).
+        // (Round 5 tried the constants from lane l's registers — two v_readlane per length: 134 instead of 122 vector instructions per 64 bases on
+        // the humanlike profile — and from scalar loads one turn ahead: 1 % slower still, A/B on one box.)
+        auto step = [&](const int l, const uint4 cin, const uint4 cl) __attribute__((always_inline)) {
             const uint32_t wv = pw[-2 * l];
-#ifndef SIFT_DP_SCALAR                                  // ceil(2^32 / l), floor(T l / 10): lane l holds them — two v_readlane per length
-            const uint32_t rcp_l = (uint32_t)rdlane((int)m_recip, l);
-            const int thr_l = rdlane(Tl10, l);
-            (void)rcp_s;
-#else                                                   // (A/B, round 5: a scalar load one turn ahead + the scalar unit's division: 1 % slower — 12.68-13.05 against 12.58-12.94 ms on the humanlike profile, alternating on one box)
-            const uint32_t rcp_l = rcp_s;
-            const int thr_l = (int)(((uint32_t)T * (uint32_t)l) / 10u);
-#endif
+            const uint32_t rcp_l = cl.z;
+            const int thr_l = (int)cl.w;
             c = __builtin_amdgcn_update_dpp((int)cin.x, c, 0x138, 0xF, 0xF, false) + (wv == w_own ? 1 : 0);
             rr += c;
             const uint32_t kq = __umulhi((uint32_t)rr << 13, rcp_l);
@@ -816,50 +819,35 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(C
             asm volatile("" : "+v"(lbest));           // (decided here: unrolled, the scheduler would keep key and mx of every length alive to the end)
             B = mx > key ? mx : key;
             SD_LDS_ORDER();
-            if (last) col[l] = make_uint2((uint32_t)c, B);
+            if (last) *reinterpret_cast<uint2 *>(&col[l]) = make_uint2((uint32_t)c, B);
         };
-        // (every column entry is read one step ahead of its use: lane 63 overwrites it)
-        uint2 ca = col[0], cb_ = col[1];
+        // (every column entry is read one step ahead of its use: lane 63 overwrites its c and B)
+        uint4 ca = col[0], cb_ = col[1];
         {   // l = 1: the key is r itself (2^32 / 1 has no 32-bit reciprocal)
-            const uint2 cn = col[2];
+            const uint4 cn = col[2];
             const uint32_t wv = pw[-2];
             c = __builtin_amdgcn_update_dpp((int)ca.x, c, 0x138, 0xF, 0xF, false) + (wv == w_own ? 1 : 0);
             rr += c;
-            const uint32_t key = rr > rdlane(Tl10, 1) ? (uint32_t)rr << 13 : 0u;
+            const uint32_t key = rr > (int)cb_.w ? (uint32_t)rr << 13 : 0u;
             const uint32_t Bn = (uint32_t)__builtin_amdgcn_update_dpp((int)ca.y, (int)B, 0x138, 0xF, 0xF, false);
             const uint32_t mx = B > Bn ? B : Bn;
             lbest = key >= mx ? 1u : lbest;
             B = mx > key ? mx : key;
             SD_LDS_ORDER();
-            if (last) col[1] = make_uint2((uint32_t)c, B);
+            if (last) *reinterpret_cast<uint2 *>(&col[1]) = make_uint2((uint32_t)c, B);
             ca = cb_;
             cb_ = cn;
         }
         // two lengths per turn: an entry is loaded into the register whose entry has just had its last use (no copies); ca = entry
         // l - 1, cb_ = entry l on entering
         int l = 2;
-#ifdef SIFT_DP_SCALAR
-        uint32_t ra = sd_recip_tab[2], rb_ = sd_recip_tab[3];
-#else
-        uint32_t ra = 0, rb_ = 0;
-#endif
         for (; l + 1 < CAPW; l += 2) {
-            const uint2 c1 = col[l + 1];               // (entry l + 1 before lane 63 overwrites it in step l + 1; entry l is in cb_)
-#ifdef SIFT_DP_SCALAR
-            const uint32_t rn0 = sd_recip_tab[(l + 2) & 63], rn1 = sd_recip_tab[(l + 3) & 63];
-#else
-            const uint32_t rn0 = 0, rn1 = 0;
-#endif
-            step(l, ca, ra);
-            ca = cb_;
-            const uint2 c2 = col[l + 2 < 64 ? l + 2 : 63];
-            step(l + 1, ca, rb_);
-            ca = c1;
-            cb_ = c2;
-            ra = rn0;
-            rb_ = rn1;
+            step(l, ca, cb_);
+            ca = col[l + 1];
+            step(l + 1, cb_, ca);
+            cb_ = col[l + 2 < 64 ? l + 2 : 63];
         }
-        if (l < CAPW) step(l, ca, ra);
+        if (l < CAPW) step(l, ca, cb_);
         if (lbest) mark(rb + o0 - 2 - (int)lbest, (int)lbest + 3);
         SD_LDS_ORDER();
         slot = lane >= 1 && lane < CAPW ? (int)col[lane].y : 0;
@@ -883,10 +871,11 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(C
                 asm volatile("v_sub_u32 %0, %1, %2" : "=v"(cc) : "v"(r), "v"(rprev));
                 const uint32_t bb = sd_scan_max_dpp((uint32_t)slot);
                 // (with the constants of length `lane`: lane 63 rewrites c and B only)
-                col[lane] = make_uint2((uint32_t)cc, bb > 1u ? bb : 1u);
+                col[lane] = make_uint4((uint32_t)cc, bb > 1u ? bb : 1u, m_recip, (uint32_t)(Tl / 10));
+                col_dirty = true;
                 SD_LDS_ORDER();
             }
-            if (lane == 0) col[0] = make_uint2(0u, 1u);
+            if (lane == 0) *reinterpret_cast<uint2 *>(&col[0]) = make_uint2(0u, 1u);
             SD_LDS_ORDER();
             dp_tile(t);
             if (STATS) ++st_dp;

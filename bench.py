@@ -1549,23 +1549,49 @@ def spawn_ranks(args):
     if ndev < 1:
         sys.stderr.write("bench.py needs a GPU (there is no CPU fallback of the product path)\n")
         return 1
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
-    for raw in p.stdout:
-        txt = raw.decode(errors="replace")
-        if txt.startswith("{"):
-            sys.stdout.write(txt)
-            sys.stdout.flush()
-        else:                                            # anything else the ranks print is not the line
-            sys.stderr.write(txt)
-    return p.wait()
+    rc = 1
+    for attempt in range(3):                             # (a port found free can be taken before the launcher binds it: try another one)
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        got_line = False
+        import threading
+        err_tail = []
+
+        def _pump():
+            for raw in p.stderr:
+                txt = raw.decode(errors="replace")
+                err_tail.append(txt)
+                del err_tail[:-200]
+                sys.stderr.write(txt)
+        th = threading.Thread(target=_pump, daemon=True)
+        th.start()
+        for raw in p.stdout:
+            txt = raw.decode(errors="replace")
+            is_line = False
+            if txt.startswith("{"):
+                try:
+                    is_line = "metric" in json.loads(txt)    # (rank 0's ONE result line, nothing else that happens to look like JSON)
+                except ValueError:
+                    is_line = False
+            if is_line:
+                got_line = True
+                sys.stdout.write(txt)
+                sys.stdout.flush()
+            else:                                        # anything else the ranks print is not the line
+                sys.stderr.write(txt)
+        rc = p.wait()
+        th.join(timeout=5)
+        if rc != 0 and not got_line and any("EADDRINUSE" in t or "Address already in use" in t or "address already in use" in t for t in err_tail):
+            continue
+        break
+    return rc
 
 
 def main():

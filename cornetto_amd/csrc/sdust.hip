@@ -1888,8 +1888,11 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                 // the counts and the walk list of THIS call are reset: it waits for an event recorded behind those memsets, in front of the main launch.
                 const unsigned extra = (unsigned)std::min<size_t>(all_blocks > nbk ? all_blocks - nbk : 0, (size_t)(per_cu_all - per_cu) * std::max(h->sd_cus, 1));
                 // (from 85 % on the waves left out are too few to matter — measured: 7.57 ms per step with and without them at 92 % — and without
-                // the poll below the rest of the call is queued behind the kernel while it runs)
-                const bool may_help = extra > 0 && !want_stats && h->share < env_int("CORNETTO_SDUST_HELP_BELOW", 85);
+                // the poll below the rest of the call is queued behind the kernel while it runs.  Round 5: at the shares the probe picks for a
+                // balanced step, 72-80 %, the other thread ends a few hundred microseconds before this kernel and the helper buys less than the
+                // call's tail loses by being queued only after the poll: 6.66 against 6.8-7.0 ms per step at 76 %, tools/ab_help.sh — so the
+                // helper is for shares below 70 % only)
+                const bool may_help = extra > 0 && !want_stats && h->share < env_int("CORNETTO_SDUST_HELP_BELOW", 70);
                 if (may_help) {
                     if (!h->stream2) {
                         int pr_least = 0, pr_greatest = 0;

@@ -926,6 +926,9 @@ std::string tf_est_key_of(const char *motif, double thr_adj)
 int cn_telo_scan_impl(cornetto_accel_t *h, const cornetto_asm_t *a, const char *motif, double thr_adj, cornetto_hit_t **hits, int64_t *n_hits, cornetto_win_t **wins,
                       int64_t *n_wins)
 {
+    // (Round 5 measured the one-go form of cn_telo_spec_queue here as well — one synchronisation instead of three for a repeated scan: the scan
+    // itself no shorter inside the bench step, 2.53 against 2.54 ms, and its 26 MB of telomere runs copied at the very end instead of beside the
+    // window kernel and the last two waits: 7.24-7.30 against 6.82-6.89 ms per step.  Not kept; cornetto_panel_step uses that form.)
     unsigned long long *d_bitmap = nullptr;
     bool valid = false;
     cornetto_hit_t *hh = nullptr;

@@ -85,6 +85,44 @@ def test_panel_dies_where_the_reference_asserts(cli, golden_dir, plain, args, ex
     assert b"src/boringbits_main.c:353: get_regs: Assertion `st<end' failed." in err
 
 
+def test_panel_random_windows_against_the_reference_binary(cli, tmp_path):
+    """(no)boringbits on random per-base bedgraph pairs with random -w / -i (smaller, equal, larger than each other), -m, -e and thresholds, contig
+    lengths at and around multiples of -i: stdout AND exit status of the device path against the unmodified reference's (oracle/_ref/cornetto,
+    which travels with the snapshot) — including the command lines on which the reference dies of its assert (SIGABRT, empty stdout)"""
+    import random
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "cornetto")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/cornetto not built")
+    rnd = random.Random(2025)
+    aborts = ok = 0
+    for it in range(48):
+        w = rnd.choice([1, 2, 7, 50, 64, 100, 300, 777, 2500])
+        inc = rnd.choice([1, 2, 7, 49, 50, 51, 64, 65, 100, 299, 301, 350, 1000, 2600])
+        lens = []
+        for c in range(rnd.randint(1, 4)):
+            r = rnd.random()
+            L = rnd.randint(1, 200) if r < 0.3 else rnd.choice([inc, inc + 1, inc * 3, inc * 3 + 1, inc * 2 + w, w, w + 1, w + 51, inc * 5 + rnd.randint(0, w)]) if r < 0.6 else rnd.randint(200, 6000)
+            lens.append(max(1, L))
+        t, q = [], []
+        for ci, L in enumerate(lens):
+            for p in range(L):
+                d = rnd.randint(0, 60)
+                t.append("c%d\t%d\t%d\t%d\n" % (ci, p, p + 1, d))
+                q.append("c%d\t%d\t%d\t%d\n" % (ci, p, p + 1, rnd.randint(0, d)))
+        a, b = tmp_path / "t.bg", tmp_path / "q.bg"
+        a.write_text("".join(t))
+        b.write_text("".join(q))
+        args = [rnd.choice(["noboringbits", "boringbits"]), str(a), "-q", str(b), "-w", str(w), "-i", str(inc), "-m", str(rnd.choice([1, 100, 1000, 100000])),
+                "-e", str(rnd.choice([0, 5, 100, 5000])), "-L", rnd.choice(["0.4", "0.2", "0.9"]), "-H", rnd.choice(["2.5", "1.2", "3"]), "-Q", rnd.choice(["0.4", "0.9", "0.1"])]
+        pr = subprocess.run([ref] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        env = {"CORNETTO_DEVICES": "0,0", "CORNETTO_BG_SHARD_MIN": "1"} if it % 4 == 3 else {"CORNETTO_DEVICES": "0,0,0"} if it % 4 == 2 else {}
+        rc, out, err = run(cli, args, env)
+        assert (rc, out) == (pr.returncode, pr.stdout), (args, lens, env, rc, pr.returncode, err.decode()[-300:])
+        aborts += pr.returncode == -6
+        ok += pr.returncode == 0
+    assert aborts >= 8 and ok >= 20
+
+
 def test_panel_format_error_wins_over_the_assert(cli, plain, tmp_path):
     """the reference parses both files completely (exit 1 on a malformed line) before get_regs() can assert"""
     tot = open(plain["cov-total.bg"], "rb").read().splitlines(True)

@@ -102,6 +102,54 @@ def test_every_contig_equals_the_oracle_at_1gbp(world):
     _compare_contigs(world, list(range(len(lens))), hits, wins, ivls, thr)
 
 
+@pytest.mark.timeout(1800)
+def test_the_bench_assembly_itself_every_contig_at_3gbp():
+    """the exact workload `python bench.py` times — 3 160 108 082 bases in 100 contigs, seed 0xC0FFEE, with its coverage — EVERY contig against the
+    oracle: telomere runs and windows, sdust intervals, every coverage window (63 M).  bench.py itself checks 5 contigs (453 Mbases) of it against the
+    reference's own functions in the timed run; this is the other 86 %."""
+    import bench
+    lens = bench.contig_lengths(0)
+    assert sum(lens) == 3_160_108_082 and len(lens) == 100
+    w = _make(lens, 0xC0FFEE)
+    try:
+        acc, asm, cov = w["acc"], w["asm"], w["cov"]
+        thr = acc.telowin_threshold(0.4, 99.9)
+        hits, wins = acc.telo_scan(asm, b"TTAGGG", thr)
+        ivls = acc.sdust(asm, 20, 64)
+        again = acc.sdust(asm, 20, 64)                      # (the second call: long chunks first, the one-go tail)
+        assert np.array_equal(ivls, again)
+        acc.cov_prepare(cov, 2500, 50)
+        assert len(hits) > 1_000_000 and len(ivls) > 500_000
+        _compare_contigs(w, list(range(len(lens))), hits, wins, ivls, thr)
+    finally:
+        _close(w)
+
+
+@pytest.mark.timeout(3000)
+@pytest.mark.parametrize("profile", ["humanlike", "satellite"])
+def test_the_repeat_rich_bench_assemblies_every_contig_at_3gbp(profile):
+    """bench.py's other two workload profiles at their full 3.16 Gbp: sdust intervals and telomere runs / windows against the oracle (the stages the
+    composition matters to: dp tiles, L2 skip, stepping, long chunks first).  CORNETTO_TEST_FULL=1: EVERY contig (2.4 minutes of 16 host cores for the
+    two profiles: the oracle walks find_perfect at every base of the arrays; run green at the end of round 5); by default the 80 smallest contigs — the
+    20 largest are what the 1 Gbp tests of the same profiles check the like of."""
+    import bench
+    lens = bench.contig_lengths(0)
+    w = _make(lens, 0xC0FFEE, profile, coverage=False)
+    try:
+        acc, asm = w["acc"], w["asm"]
+        thr = acc.telowin_threshold(0.4, 99.9)
+        hits, wins = acc.telo_scan(asm, b"TTAGGG", thr)
+        ivls = acc.sdust(asm, 20, 64)
+        assert np.array_equal(ivls, acc.sdust(asm, 20, 64))
+        assert len(ivls) > 900_000
+        which = list(range(len(lens)))
+        if os.environ.get("CORNETTO_TEST_FULL", "0") in ("", "0"):
+            which = sorted(which, key=lambda i: lens[i])[:80]
+        _compare_contigs(w, which, hits, wins, ivls, thr, stages=("telo", "sdust"))
+    finally:
+        _close(w)
+
+
 def test_sdust_decomposition_invariance_and_canonical_form(world, monkeypatch):
     acc, asm = world["acc"], world["asm"]
     a = acc.sdust(asm, 20, 64).copy()

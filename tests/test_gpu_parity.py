@@ -778,6 +778,41 @@ def test_cov_select_more_windows_than_the_first_block_holds(w, inc):
     a.close()
 
 
+@pytest.mark.parametrize("w,inc", [(40_000, 1000), (70_000, 50), (33_000, 33_001)])
+def test_cov_select_windows_whose_int_sums_wrap(w, inc):
+    """windows beyond 32768 positions of depth up to 65535: the reference's `int` sums wrap (gcc -O2: two's complement; the oracle restates that) and
+    a mean can be negative — it does not fit the packed 16-bit form, so the raw records stay full-size on the device, the packed interface refuses,
+    and the unpacked selection equals the oracle's windows under the reference's predicate (src/boringbits_main.c:439,467,473-474)"""
+    import cornetto_amd
+    rng = np.random.default_rng(w + inc)
+    lens = [3 * w + 17, w + 1, 2 * inc + (w if inc > w else 5), 1200]
+    lens = [n for n in lens if ob.regs_assert(n, w, inc) == 0]
+    depths = [rng.integers(60_000, 65_536, size=n).astype(np.uint16) for n in lens]
+    mqs = [np.minimum(d, rng.integers(30_000, 65_536, size=d.size)).astype(np.uint16) for d in depths]
+    a = cornetto_amd.Accel(0)
+    cov = a.cov_upload(depths, mqs)
+    a.cov_prepare(cov, w, inc)
+    lo, hi, Q, edge, min_len = 100, 64_000, 0.6, 10, 1000
+    assert any(int(r["depth"]) < 60_000 for r in ob.get_regs(depths[0], mqs[0], w, inc)) or w < 36_000      # (the wrapped sums: means far from the 60 000-65 535 of the data)
+    for boring in (False, True):
+        exp = []
+        for ci, (d, q) in enumerate(zip(depths, mqs)):
+            n = d.size
+            if (n > min_len) if boring else (n >= min_len):
+                for r in ob.get_regs(d, q, w, inc):
+                    st, end, dep, mq = int(r["st"]), int(r["end"]), int(r["depth"]), int(r["mq_depth"])
+                    fun = bool(ob.is_fun(dep, mq, lo, hi, Q))
+                    if (st > edge and end < n - edge and not fun) if boring else fun:
+                        exp.append((ci, st, end, dep, mq))
+        recs = a.cov_select(cov, lo, hi, Q, edge, min_len, boring)
+        assert [tuple(int(x) for x in r) for r in recs] == exp, boring
+    with pytest.raises(cornetto_amd.AccelError) as ei:
+        a.cov_select_packed(cov, lo, hi, Q, edge, min_len, False)
+    assert ei.value.status == -5
+    cov.close()
+    a.close()
+
+
 def test_sdust_repeatable_with_many_small_chunks(acc, golden_dir, monkeypatch):
     """the chunk queue hands the chunks to different lanes / waves at different times on every run: 24 runs over
     ~100 k tiny chunks must all give the golden answer (a build of the kernel that spilled registers did not)"""

@@ -19,9 +19,10 @@
 //            inside its window — five LDS operations per 64 bases instead of two counter updates per base.
 //            Positions with ct > T / 10 (7 % of random sequence) are compacted, 64 at a time, into
 //              L1: the partial sums above over the last min(lmin, 16) and 16 words (lmin = shortest candidate) -> 1.4 %
-//              L2: an exact walk over the suffixes of up to 16 words (4-bit counters in LDS), or the 16-term sum for the longer
-//                  ones -> 0.07 % of the positions of random sequence: one bit per base.  Any superset of the positions at
-//                  which something is inserted would do.
+//              L2: an exact walk over the suffixes of up to 16 words (round 5: the 16 words packed in four registers, equal words
+//                  counted by byte compares — no counters, no LDS atomics), or the 16-term sum for the longer ones -> 0.07 % of the
+//                  positions of random sequence: one bit per base.  Any superset of the positions at which something is inserted
+//                  would do.
 //   resolve  the wave steps through the set bits with lane <-> age of the window's words (newest = lane 0), everything in
 //            registers: word, suffix score r, P slot (ratio key | l << 24).  Consecutive positions are one incremental step
 //            (equal-word ballot, mbcnt, three DPP shifts: ~11 vector instructions, ~30 with candidates); after a gap the window

@@ -447,14 +447,22 @@ __global__ __launch_bounds__(256) void tw_scan(TwArgs A)
     __builtin_amdgcn_s_setprio(3);   // short streaming kernel: issue ahead of a long compute-bound kernel of another stream
 
     __shared__ int bc[256 + 4];
+    __shared__ unsigned long long sw[816];            // the workgroup's 260 blocks of marks: 52 000 bits from any bit of a word
     const int2 tile = A.tiles[blockIdx.x];
     const int ctg = tile.x;
     const int len = A.ctg_len[ctg];
     const long long boff = A.bit_off[ctg];
+    // the words once, side by side (round 5; before: every thread its own 4-5 words one after the other — a chain of dependent round trips
+    // to memory per workgroup, 0.166 ms for 0.4 GB; 0.138 now), the counts from LDS
+    const long long bit0 = boff + (long long)tile.y * 200, bit1 = boff + len < bit0 + 260 * 200 ? boff + len : bit0 + 260 * 200;
+    const long long w0 = bit0 >> 6;
+    const int nw = bit1 > bit0 ? (int)(((bit1 + 63) >> 6) - w0) : 0;
+    for (int k = threadIdx.x; k < nw; k += 256) sw[k] = A.bitmap[w0 + k];
+    __syncthreads();
     for (int k = threadIdx.x; k < 260; k += 256) {
         const long long lo = ((long long)tile.y + k) * 200;
         const long long hi = lo + 200 < len ? lo + 200 : len;
-        bc[k] = lo < hi ? popc_range(A.bitmap, boff + lo, boff + hi) : 0;
+        bc[k] = lo < hi ? popc_range(sw, boff + lo - (w0 << 6), boff + hi - (w0 << 6)) : 0;
     }
     __syncthreads();
     const long long j = (long long)tile.y + threadIdx.x;

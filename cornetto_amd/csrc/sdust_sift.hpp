@@ -983,7 +983,25 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(C
     for (;;) {
         const long long kk = (long long)__builtin_amdgcn_readfirstlane((int)nxt) * SIFT_NCTR + c;
         if (kk >= A.n_chunks) {
-            if (++dry >= SIFT_NCTR) break;            // every counter seen dry
+            // This counter is dry: a look at ALL of them at once, lane <-> counter (round 5; before: one request after the other at the next
+            // counter until SIFT_NCTR of them had come back dry — at the end of the kernel every wave's 64 dependent atomic round trips, 7168 waves
+            // on each address: 0.1 ms of a launch whatever its size, a seventh of the kernel of a 1/8 share).  Counters only grow, so one read at
+            // or above its limit is final; one read below it is asked as before.
+            static_assert(SIFT_NCTR == 64, "one lane per counter");
+            if (dry < 2 * SIFT_NCTR) {
+                const uint32_t seen = __hip_atomic_load(&A.counter[lane * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const long long left = (long long)A.n_chunks - lane;                    // counter `lane` hands out lane, lane + 64, ...: (left + 63) / 64 of them
+                const unsigned long long open = sd_ballot(left > 0 && (long long)seen < (left + SIFT_NCTR - 1) / SIFT_NCTR);
+                if (!open) break;
+                ++dry;                                                                  // (a wave loses the race for a counter's last chunk once per counter at most)
+                const int from = c + 1 == SIFT_NCTR ? 0 : c + 1;
+                const unsigned long long rot = from ? (open >> from) | (open << (SIFT_NCTR - from)) : open;
+                c = (from + __builtin_ctzll(rot)) & (SIFT_NCTR - 1);
+                nxt = ask(c);
+                continue;
+            }
+            // (not seen: reads that keep showing an open counter.  The exhaustive way: SIFT_NCTR dry answers in a row, one counter after the other)
+            if (++dry >= 3 * SIFT_NCTR) break;
             c = c + 1 == SIFT_NCTR ? 0 : c + 1;
             nxt = ask(c);
             continue;

@@ -706,6 +706,8 @@ class Rank:
         # the two large result arrays of this thread (telomere runs, selected windows) travel beside its next kernels
         self.lead_us = float(os.environ.get("CORNETTO_BENCH_LEAD_US", "0"))
         self.handshake = self.overlap and os.environ.get("CORNETTO_BENCH_HANDSHAKE", "1") != "0"
+        self.sd_async = self.overlap and os.environ.get("CORNETTO_BENCH_SDUST_ASYNC", "1") == "1"
+        self.sd_begun = False
         self.lag_us = float(os.environ.get("CORNETTO_BENCH_SDUST_LAG_US", "0"))
         self.lazy = self.overlap and os.environ.get("CORNETTO_BENCH_LAZY", "1") != "0"
         # cornetto_panel_step (the other thread's three calls as one, two synchronisations instead of five): measured and NOT the default — with its
@@ -792,7 +794,10 @@ class Rank:
                     t_lag = t0 + self.lag_us * 1e-6
                     while time.perf_counter() < t_lag:
                         pass
-                box["ivls"] = self.acc2.sdust(self.asm2, 20, 64)
+                if self.sd_begun:                     # (the step's own thread queued the call: cornetto_sdust_asm_begin)
+                    box["ivls"] = self.acc2.sdust_end(self.asm2, 20, 64)
+                else:
+                    box["ivls"] = self.acc2.sdust(self.asm2, 20, 64)
                 if record:
                     self._note(self.acc2)
                     self._lap("sdust", t0)
@@ -802,7 +807,9 @@ class Rank:
 
     def step(self, record, keep=False):
         """The FASTA-side scans (telofind+telowin, sdust) and the coverage stage are independent until the results are
-        put together, so a step runs them on two host threads with one handle (= one HIP stream + workspaces) each: the
+        put together, so a step runs them on two handles (= one HIP stream + workspaces each) — from the second step on from ONE host thread:
+        cornetto_sdust_asm_begin() queues the whole sdust call, this thread runs the coverage and telomere stages, cornetto_sdust_asm_end() takes the
+        intervals (the first step over an assembly, and CORNETTO_BENCH_SDUST_ASYNC=0: sdust on a second host thread, as in rounds 2-4) —: the
         coverage kernels and every device-to-host copy overlap the long sdust kernel.  (ctypes drops the GIL.)"""
         from cornetto_amd.dist import allreduce_sums, gather_records
         acc, world = self.acc, self.world
@@ -810,8 +817,21 @@ class Rank:
             self.acc2.boost(False)                    # this thread's kernels want their share of the chip again
             seq = self.acc2.launch_count() if self.handshake else 0
             t0 = time.perf_counter()
-            self.jobs.put(record)
-            if self.handshake:
+            self.sd_begun = False
+            direct = False
+            if self.sd_async:
+                # the sdust call queued from THIS thread (cornetto_sdust_asm_begin: the whole call in one go where the last step left its counts)
+                # and finished by it at the end of the step (cornetto_sdust_asm_end): no hand-over to a thread that has to wake up in front of the
+                # kernel launch, none back behind the last result.  Nothing queued (the first step over an assembly): the other thread runs the call
+                seq0 = self.acc2.launch_count()
+                self.acc2.sdust_begin(self.asm2, 20, 64)
+                self.sd_begun = True
+                direct = self.acc2.launch_count() != seq0
+                if direct and record:
+                    self._lap("sdust_begin", t0)
+            if not direct:
+                self.jobs.put(record)
+            if self.handshake and not direct:
                 # where the resident sdust waves land decides how much room this thread's kernels find on every CU: let them get there first
                 # (8.2 ms per step when they do, 9.2 when they arrive 30 us behind tf_scan: cornetto_accel_launch_count)
                 t_end = time.perf_counter() + 1e-3
@@ -881,12 +901,19 @@ class Rank:
         recs = recs_pk
         if keep or self.args.gather:                  # rows with their contig and end, as cornetto_cov_select() returns them
             recs = acc.unpack_regs(recs_pk, ctg_first, self.lens_own, 2500)
-        if not self.overlap:
-            self.jobs.put(record)
-        box = self.done.get()
-        if "err" in box:
-            raise box["err"]
-        ivls = box["ivls"]
+        if self.overlap and direct:
+            t0 = time.perf_counter()
+            ivls = self.acc2.sdust_end(self.asm2, 20, 64)
+            if record:
+                self._note(self.acc2)
+                self._lap("sdust_end", t0)            # (what is left to wait for when this thread's own stages are through)
+        else:
+            if not self.overlap:
+                self.jobs.put(record)
+            box = self.done.get()
+            if "err" in box:
+                raise box["err"]
+            ivls = box["ivls"]
         gathered = None
         if self.args.gather:                          # optional: all BED/TSV records to rank 0 (RCCL / gloo), global contig order
             t0 = time.perf_counter()

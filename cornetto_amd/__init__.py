@@ -109,6 +109,8 @@ def lib():
         "cornetto_telowin": (C.c_int, [vp, vp, i64, vp, i32, C.c_double, pp, C.POINTER(i64)]),
         "cornetto_telo_scan": (C.c_int, [vp, vp, cp, C.c_double, pp, C.POINTER(i64), pp, C.POINTER(i64)]),
         "cornetto_sdust_asm": (C.c_int, [vp, vp, i32, i32, pp, C.POINTER(i64)]),
+        "cornetto_sdust_asm_begin": (C.c_int, [vp, vp, i32, i32]),
+        "cornetto_sdust_asm_end": (C.c_int, [vp, vp, i32, i32, pp, C.POINTER(i64)]),
         "cornetto_sdust": (C.POINTER(C.c_uint64), [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
         "cornetto_sdust_buf_init": (vp, [vp]),
         "cornetto_sdust_buf_destroy": (None, [vp]),
@@ -326,6 +328,15 @@ class Accel:
     def sdust(self, asm, T=20, W=64):
         p, n = C.c_void_p(), C.c_int64()
         self._chk(self.L.cornetto_sdust_asm(self.h, asm.ptr, T, W, C.byref(p), C.byref(n)))
+        return _take(p, n.value, IVL_DT)
+
+    def sdust_begin(self, asm, T=20, W=64):
+        """cornetto_sdust_asm_begin(): queue the call without waiting where the last call's counts allow it (else nothing); sdust_end() delivers"""
+        self._chk(self.L.cornetto_sdust_asm_begin(self.h, asm.ptr, T, W))
+
+    def sdust_end(self, asm, T=20, W=64):
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self.L.cornetto_sdust_asm_end(self.h, asm.ptr, T, W, C.byref(p), C.byref(n)))
         return _take(p, n.value, IVL_DT)
 
     def sdust_stats(self, asm, T=20, W=64):

@@ -61,6 +61,17 @@ struct cornetto_accel {
     hipEvent_t ev3 = nullptr;
     int share = 100;    // percent of every CU the resident sdust kernel may take (cornetto_accel_set_share)
     int sd_stats = 0;   // sdust: run the statistics build of the kernel (cornetto_accel_sdust_stats)
+    // cornetto_sdust_asm_begin() -> _end(): 0 nothing pending, 1 the whole call is queued on the stream (one go: sized by the last call's counts,
+    // checked by _end), 2 _begin had to run the call to its end (the result waits here)
+    struct SdPend {
+        int state = 0;
+        const void *a = nullptr;
+        int32_t T = 0, W = 0;
+        void *of = nullptr;                   // the result array the queued copy fills
+        size_t m_cap = 0, n_cap = 0, cap = 0;
+        int64_t key = 0, n_done = 0;
+        bool walk_pending = false;
+    } sd_pend;
     unsigned long long sd_last[256] = {0};   // its counters from the most recent such run
     // scan.hpp: the single-pass scans keep their tile states in WS_SCAN; a state counts only with the epoch of its call (no clearing
     // between calls), the tiles of a call take their numbers from a ticket counter that is never reset

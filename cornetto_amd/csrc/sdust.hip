@@ -1602,8 +1602,39 @@ int env_int(const char *name, int dflt)
 
 extern "C" {
 
-int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, int32_t W, cornetto_ivl_t **ivls,
-                       int64_t *n_ivls)
+}  // extern "C"
+
+namespace {
+// what is left of a call whose work cornetto_sdust_asm_begin() queued in one go: wait, look at the counts, hand the result over.
+// 1: the estimates did not hold (the caller runs the call the long way); 0: done; < 0: error
+int sd_one_go_finish(cornetto_accel_t *h, cornetto_asm_t *a, cornetto_ivl_t *of, unsigned long long *p_tot, size_t cap, size_t n_cap, size_t m_cap, int64_t key,
+                     bool walk_pending, cornetto_ivl_t **ivls, int64_t *n_ivls)
+{
+    if (hipStreamSynchronize(h->stream) != hipSuccess) {
+        cornetto_free(of);
+        return cn_fail(h, CORNETTO_E_HIP, "sdust: stitch / copy back failed");
+    }
+    const uint32_t ovf_f = (uint32_t)(p_tot[1] & 0xFFFFFFFFull);
+    const bool wtab_f = (p_tot[1] >> 32) != 0;
+    const unsigned long long rows_f = p_tot[0], out_f = rows_f ? p_tot[9] : 0ull;
+    if (!wtab_f && ovf_f <= cap && rows_f <= n_cap && out_f != ~0ull && out_f <= m_cap && out_f <= rows_f && (rows_f == 0 || out_f > 0)) {
+        if (walk_pending) a->sd_walk_key = key;
+        a->sd_est_rows = (int64_t)rows_f;
+        a->sd_est_out = (int64_t)out_f;
+        cn_timing_end(h);
+        *ivls = of;
+        *n_ivls = (int64_t)out_f;
+        return 0;
+    }
+    cornetto_free(of);                                         // (the estimate did not hold: the long way)
+    a->sd_est_key = -1;
+    return 1;
+}
+
+// phase 0: the whole call.  phase 1 (cornetto_sdust_asm_begin): queue it in one go if the last call for this table left its counts behind and
+// return without waiting (h->sd_pend.state = 1); nothing queued if not (state 0); or, where the one-go form could not be set up after the main
+// kernel was launched, the whole call (state 2, the result kept in h->sd_pend)
+int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, int32_t W, cornetto_ivl_t **ivls, int64_t *n_ivls, const int phase)
 {
     // CORNETTO_SDUST_TRACE=1: host-side time stamps of the call's phases on stderr (development aid)
     static const bool trace = env_int("CORNETTO_SDUST_TRACE", 0) != 0;
@@ -1818,6 +1849,8 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
         if (h->dev[WS_SD_OUT].bytes / (nc * sizeof(uint2)) > cap) cap = h->dev[WS_SD_OUT].bytes / (nc * sizeof(uint2));
         unsigned long long tot = 0;
         uint2 *d_out = nullptr;
+        if (phase == 1 && !(w64_path && sift_on && !want_stats && a->sd_est_key == key * 131 + T * 1031 + W && a->sd_est_rows >= 0 && env_int("CORNETTO_SDUST_FUSED", 1)))
+            return CORNETTO_OK;                        // (nothing to size the rest of the call by: cornetto_sdust_asm_end runs it)
         for (int attempt = 0; attempt < 4; ++attempt) {
             d_out = (uint2 *)cn_ws(h, WS_SD_OUT, nc * cap * sizeof(uint2));
             if (!d_out) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation of %zu bytes failed", nc * cap * sizeof(uint2));
@@ -1892,7 +1925,7 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                 // balanced step, 72-80 %, the other thread ends a few hundred microseconds before this kernel and the helper buys less than the
                 // call's tail loses by being queued only after the poll: 6.66 against 6.8-7.0 ms per step at 76 %, tools/ab_help.sh — so the
                 // helper is for shares below 70 % only)
-                const bool may_help = extra > 0 && !want_stats && h->share < env_int("CORNETTO_SDUST_HELP_BELOW", 70);
+                const bool may_help = phase == 0 && extra > 0 && !want_stats && h->share < env_int("CORNETTO_SDUST_HELP_BELOW", 70);      // (its poll waits for the kernel: not in _begin)
                 if (may_help) {
                     if (!h->stream2) {
                         int pr_least = 0, pr_greatest = 0;
@@ -2073,7 +2106,9 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                 if (env_int("CORNETTO_SDUST_EST_FORCE", 0) > 0) n_cap = (size_t)env_int("CORNETTO_SDUST_EST_FORCE", 0);   // (tests: an estimate that does not hold)
                 const size_t m_cap = (size_t)(a->sd_est_out + a->sd_est_out / 16 + 1024);
                 uint8_t *ws = (uint8_t *)cn_ws(h, WS_SD_DST, 2 * n_cap * sizeof(cornetto_ivl_t) + cnivl::ws_bytes(n_cap));
-                cornetto_ivl_t *of = (cornetto_ivl_t *)cn_result_alloc(m_cap * sizeof(cornetto_ivl_t));
+                // (a pinned array whatever its size — the pool's smallest block is 1 MB —: a copy into plain memory is not asynchronous, and
+                // cornetto_sdust_asm_begin() returns behind it)
+                cornetto_ivl_t *of = (cornetto_ivl_t *)cn_result_alloc(std::max<size_t>(m_cap * sizeof(cornetto_ivl_t), (size_t)1 << 20));
                 if (ws && of && n_cap < 0x7fffffffull) {
                     cornetto_ivl_t *d_dst = (cornetto_ivl_t *)(ws + cnivl::ws_bytes(n_cap)), *d_st = d_dst + n_cap;
                     const unsigned nbg = (unsigned)((nc + 255) / 256);
@@ -2083,25 +2118,21 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
                     if (rcf != CORNETTO_OK) { cornetto_free(of); return rcf; }
                     stamp("tail queued");
                     if (hipMemcpyAsync(of, d_st, m_cap * sizeof(cornetto_ivl_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-                        hipMemcpyAsync(p_tot, d_tot, 128, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
+                        hipMemcpyAsync(p_tot, d_tot, 128, hipMemcpyDeviceToHost, h->stream) != hipSuccess) {
+                        (void)hipStreamSynchronize(h->stream);
                         cornetto_free(of);
                         return cn_fail(h, CORNETTO_E_HIP, "sdust: stitch / copy back failed");
                     }
-                    const uint32_t ovf_f = (uint32_t)(p_tot[1] & 0xFFFFFFFFull);
-                    const bool wtab_f = (p_tot[1] >> 32) != 0;
-                    const unsigned long long rows_f = p_tot[0], out_f = rows_f ? p_tot[9] : 0ull;
-                    if (!wtab_f && ovf_f <= cap && rows_f <= n_cap && out_f != ~0ull && out_f <= m_cap && out_f <= rows_f && (rows_f == 0 || out_f > 0)) {
-                        stamp("results on the host (one go)");
-                        if (sift_walk_pending) a->sd_walk_key = key;
-                        a->sd_est_rows = (int64_t)rows_f;
-                        a->sd_est_out = (int64_t)out_f;
-                        cn_timing_end(h);
-                        *ivls = of;
-                        *n_ivls = (int64_t)out_f;
+                    if (phase == 1) {                                          // cornetto_sdust_asm_end() waits and checks
+                        h->sd_pend.state = 1; h->sd_pend.a = a; h->sd_pend.T = T; h->sd_pend.W = W; h->sd_pend.of = of;
+                        h->sd_pend.m_cap = m_cap; h->sd_pend.n_cap = n_cap; h->sd_pend.cap = cap; h->sd_pend.key = key; h->sd_pend.walk_pending = sift_walk_pending;
                         return CORNETTO_OK;
                     }
-                    cornetto_free(of);                                         // (the estimate did not hold: the long way, from the counts that are on the host now)
-                    a->sd_est_key = -1;
+                    const int fin = sd_one_go_finish(h, a, of, p_tot, cap, n_cap, m_cap, key, sift_walk_pending, ivls, n_ivls);
+                    if (fin <= 0) {
+                        if (fin == 0) stamp("results on the host (one go)");
+                        return fin;
+                    }
                 } else if (of) {
                     cornetto_free(of);
                 }
@@ -2195,9 +2226,62 @@ int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t 
         o = (cornetto_ivl_t *)malloc(sizeof(cornetto_ivl_t));
         if (!o) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: host allocation failed");
     }
+    if (phase == 1) {                                  // (the call ran to its end inside _begin: _end hands the result over)
+        h->sd_pend.state = 2; h->sd_pend.a = a; h->sd_pend.T = T; h->sd_pend.W = W; h->sd_pend.of = o; h->sd_pend.n_done = n_out;
+        return CORNETTO_OK;
+    }
     *ivls = o;
     *n_ivls = n_out;
     return CORNETTO_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, int32_t W, cornetto_ivl_t **ivls, int64_t *n_ivls)
+{
+    if (h && h->sd_pend.state != 0) {                  // a _begin nobody finished: its result is dropped
+        cornetto_ivl_t *dv = nullptr;
+        int64_t dn = 0;
+        if (cornetto_sdust_asm_end(h, reinterpret_cast<const cornetto_asm_t *>(h->sd_pend.a), h->sd_pend.T, h->sd_pend.W, &dv, &dn) == CORNETTO_OK) cornetto_free(dv);
+    }
+    return sdust_asm_impl(h, a_in, T, W, ivls, n_ivls, 0);
+}
+
+int cornetto_sdust_asm_begin(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, int32_t W)
+{
+    if (!h || !a_in) return cn_fail(h, CORNETTO_E_ARG, "sdust: bad argument");
+    if (h->sd_pend.state != 0) return cn_fail(h, CORNETTO_E_ARG, "sdust: cornetto_sdust_asm_begin() twice without cornetto_sdust_asm_end()");
+    cornetto_ivl_t *dv = nullptr;
+    int64_t dn = 0;
+    return sdust_asm_impl(h, a_in, T, W, &dv, &dn, 1);
+}
+
+int cornetto_sdust_asm_end(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, int32_t W, cornetto_ivl_t **ivls, int64_t *n_ivls)
+{
+    if (!h || !a_in || !ivls || !n_ivls) return cn_fail(h, CORNETTO_E_ARG, "sdust: bad argument");
+    *ivls = nullptr;
+    *n_ivls = 0;
+    const cornetto_accel::SdPend P = h->sd_pend;
+    h->sd_pend = cornetto_accel::SdPend{};
+    if (P.state != 0 && (P.a != a_in || P.T != T || P.W != W)) {      // not the call that was begun: that one is finished and dropped first
+        if (P.state == 2) cornetto_free(P.of);
+        else { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); cornetto_free(P.of); }
+        return sdust_asm_impl(h, a_in, T, W, ivls, n_ivls, 0);
+    }
+    if (P.state == 2) {
+        *ivls = (cornetto_ivl_t *)P.of;
+        *n_ivls = P.n_done;
+        return CORNETTO_OK;
+    }
+    if (P.state == 1) {
+        CN_HIP(h, hipSetDevice(h->device));
+        unsigned long long *p_tot = (unsigned long long *)cn_pin(h, PIN_SMALL, 2048);
+        if (!p_tot) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
+        const int fin = sd_one_go_finish(h, const_cast<cornetto_asm_t *>(a_in), (cornetto_ivl_t *)P.of, p_tot, P.cap, P.n_cap, P.m_cap, P.key, P.walk_pending, ivls, n_ivls);
+        if (fin <= 0) return fin;
+    }
+    return sdust_asm_impl(h, a_in, T, W, ivls, n_ivls, 0);
 }
 
 int cornetto_accel_sdust_stats(cornetto_accel_t *h, int enable, uint64_t *out, int cap)

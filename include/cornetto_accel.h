@@ -205,6 +205,16 @@ int cornetto_telo_scan(cornetto_accel_t *h, const cornetto_asm_t *a, const char 
 int cornetto_sdust_asm(cornetto_accel_t *h, const cornetto_asm_t *a, int32_t T, int32_t W,
                        cornetto_ivl_t **ivls, int64_t *n_ivls);
 
+/* The same call in two parts, for a host that has other work for the device meanwhile (a second stream through a second handle) and no thread
+ * to spare: _begin queues the call on the handle's stream and returns without waiting WHEN the rest of the call can be sized by the counts the
+ * last call over the same assembly, T and W left behind (the scan, the kernel, the stitch and the result copy in one go; the counts are checked
+ * by _end, and a call whose counts outgrew them is run again the long way: never a truncated answer); otherwise — the first call for an
+ * assembly, the statistics build — it queues nothing (cornetto_accel_launch_count() tells) and _end runs the whole call.  Between the two the
+ * handle must not be used for anything else; the same (a, T, W) go to both.  Results, order and errors are those of cornetto_sdust_asm(). */
+int cornetto_sdust_asm_begin(cornetto_accel_t *h, const cornetto_asm_t *a, int32_t T, int32_t W);
+int cornetto_sdust_asm_end(cornetto_accel_t *h, const cornetto_asm_t *a, int32_t T, int32_t W,
+                           cornetto_ivl_t **ivls, int64_t *n_ivls);
+
 /* Drop-in for `uint64_t *sdust(void *km, const uint8_t *seq, int l_seq, int T, int W, int *n)`
  * (src/sdust/sdust.h:19): same arguments, same ownership (caller free()s), l_seq < 0 means strlen.
  * km must be NULL.  Uses a process-wide handle on device $CORNETTO_DEVICE (default 0); returns NULL and

@@ -31,10 +31,13 @@ int main()
     CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sc, hipStreamNonBlocking));
     CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     CK(hipMemset(d_big, 1, big)); CK(hipMemset(d_mid, 1, 64u << 20)); CK(hipDeviceSynchronize());
-    const char *names[] = {"memset 64 B", "tiny kernel", "memset + tiny kernel", "16M-thread kernel", "memset + 16M-thread kernel"};
+    const char *names[] = {"memset 64 B", "tiny kernel", "memset + tiny kernel", "16M-thread kernel", "memset + 16M-thread kernel", "tiny kernel + 64 B to the host", "memset + kernel + 64 B to the host", "the same between two timed events"};
+    hipEvent_t te0, te1; CK(hipEventCreate(&te0)); CK(hipEventCreate(&te1));
+    unsigned *p_small;
+    CK(hipHostMalloc(&p_small, 4096, hipHostMallocDefault));
     for (int with_res = 0; with_res < 2; ++with_res)
     for (int with_copy = 0; with_copy < 2; ++with_copy)
-        for (int what = 0; what < 5; ++what) {
+        for (int what = 0; what < 8; ++what) {
             double best = 1e30, sum = 0;
             for (int rep = 0; rep < 12; ++rep) {
                 CK(hipDeviceSynchronize());
@@ -48,6 +51,13 @@ int main()
                 if (what == 0 || what == 2 || what == 4) CK(hipMemsetAsync(d_small, 0, 64, sb));
                 if (what == 1 || what == 2) tiny<<<1, 64, 0, sb>>>(d_small);
                 if (what == 3 || what == 4) mid<<<dim3((16u << 20) / 256), dim3(256), 0, sb>>>(d_mid, 16u << 20);
+                if (what == 6 || what == 7) CK(hipMemsetAsync(d_small, 0, 64, sb));
+                if (what == 7) CK(hipEventRecord(te0, sb));
+                if (what == 5 || what == 6 || what == 7) {
+                    tiny<<<1, 64, 0, sb>>>(d_small);
+                    if (what == 7) CK(hipEventRecord(te1, sb));
+                    CK(hipMemcpyAsync(p_small, d_small, 64, hipMemcpyDeviceToHost, sb));
+                }
                 CK(hipStreamSynchronize(sb));
                 const double t = now() - t0;
                 if (rep >= 2) { sum += t; if (t < best) best = t; }

@@ -15,6 +15,11 @@
 
 #include "../../include/cornetto_accel.h"
 
+// wave priority of the short streaming kernels that run beside the resident sdust waves (cov_blocks, cov_windows, tf_scan, tw_scan)
+#ifndef CN_STREAM_PRIO
+#define CN_STREAM_PRIO 3
+#endif
+
 inline std::atomic<uint64_t> cn_uid_counter{1};    // resident objects are told apart by number, not by address (addresses come back)
 
 struct cornetto_accel {

@@ -82,7 +82,7 @@ typedef unsigned int cb_u4 __attribute__((ext_vector_type(4)));
 template <bool STAGE, int INC, int NT = 1>
 __global__ __launch_bounds__(CB_THREADS) void cov_blocks(CbArgs A)
 {
-    __builtin_amdgcn_s_setprio(3);   // short streaming kernel: issue ahead of a long compute-bound kernel of another stream
+    __builtin_amdgcn_s_setprio(CN_STREAM_PRIO);   // short streaming kernel: issue ahead of a long compute-bound kernel of another stream
 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t wsum[2][CB_THREADS / 64];
@@ -317,7 +317,7 @@ __device__ __forceinline__ uint2 cw_prefix(const CwArgs &A, int64_t x)   // incl
 
 __global__ __launch_bounds__(256) void cov_windows(CwArgs A)
 {
-    __builtin_amdgcn_s_setprio(3);   // short streaming kernel: issue ahead of a long compute-bound kernel of another stream
+    __builtin_amdgcn_s_setprio(CN_STREAM_PRIO);   // short streaming kernel: issue ahead of a long compute-bound kernel of another stream
 
     __shared__ uint32_t wcnt[4];
     const int t = threadIdx.x;

@@ -91,7 +91,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v)
 template <int H>  // halo bytes behind the 64 positions of a thread; motif length k <= H + 1
 __global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
 {
-    __builtin_amdgcn_s_setprio(3);   // short streaming kernel: issue ahead of a long compute-bound kernel of another stream
+    __builtin_amdgcn_s_setprio(CN_STREAM_PRIO);   // short streaming kernel: issue ahead of a long compute-bound kernel of another stream
 
     __shared__ uint2 lut[256];
     __shared__ unsigned long long shF[TF_THREADS], shR[TF_THREADS];
@@ -444,7 +444,7 @@ __device__ __forceinline__ int popc_range(const unsigned long long *bm, long lon
 // counted the 16-17 words of every window per thread: 0.11 G wave-instructions per 3.16 Gbp step, a quarter of that now.
 __global__ __launch_bounds__(256) void tw_scan(TwArgs A)
 {
-    __builtin_amdgcn_s_setprio(3);   // short streaming kernel: issue ahead of a long compute-bound kernel of another stream
+    __builtin_amdgcn_s_setprio(CN_STREAM_PRIO);   // short streaming kernel: issue ahead of a long compute-bound kernel of another stream
 
     __shared__ int bc[256 + 4];
     __shared__ unsigned long long sw[816];            // the workgroup's 260 blocks of marks: 52 000 bits from any bit of a word

@@ -80,6 +80,8 @@ void cornetto_accel_close(cornetto_accel_t *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->sd_pend.state != 0 && h->sd_pend.of) cornetto_free(h->sd_pend.of);      // (a cornetto_sdust_asm_begin() nobody finished: its copy is through now)
+    h->sd_pend.state = 0;
     for (auto &r : h->recs) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);

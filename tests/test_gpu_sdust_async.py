@@ -102,3 +102,12 @@ def test_end_for_another_call_and_a_begin_left_alone(acc):
     finally:
         a1.close()
         a2.close()
+
+
+def test_close_with_a_call_begun():
+    a = cornetto_amd.Accel(0)
+    asm, _ = _asm(a, 16)
+    a.sdust(asm, 20, 64)
+    a.sdust_begin(asm, 20, 64)                  # queued, never finished
+    asm.close()
+    a.close()                                   # waits for the stream, gives the result array back

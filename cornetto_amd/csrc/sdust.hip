@@ -1742,9 +1742,9 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
         }
     }
     bool sift_on = w64_path && (sift_env > 0 || (sift_env < 0 && a->sd_auto == 1));
-    // (its own default: 1536 bases = 26 tiles with the two in front; 7.2 KB of LDS per wave = six 1280-byte granules, 21 waves per
+    // (its own default, SIFT_CHUNK_DEFAULT in sdust_sift.hpp: 1792 bases since round 5.  Rounds 3-4: 1536 bases = 26 tiles with the two in front; 7.2 KB of LDS per wave = six 1280-byte granules, 21 waves per
     // CU; 1792 needs a seventh granule: measured 6.85 against 7.2 ms on the 3.16 Gbp assembly)
-    if (sift_on && env_int("CORNETTO_SDUST_CHUNK", 0) <= 0) chunk = 1536;
+    if (sift_on && env_int("CORNETTO_SDUST_CHUNK", 0) <= 0) chunk = SIFT_CHUNK_DEFAULT;
     if (sift_on && (chunk % 64 != 0 || chunk < 256 || chunk > 3968)) sift_on = false;     // (64 tiles with the two in front)
     // Optionally the last part of the work is cut into shorter chunks, handed out last and in one pass: when the queue runs
     // dry every wave still has to finish the chunks its lanes hold, and a wave-step costs the same with 3 busy lanes as with

@@ -146,11 +146,19 @@ __device__ __forceinline__ int sd_wave_find_start(const SdChunk ch, const uint8_
     return -2;
 }
 
-// CAP: the positions the word / count buffer holds when they are known at compile time (1664 = the default chunk of 1536 bases with the two
+// CAP: the positions the word / count buffer holds when they are known at compile time (SIFT_CAP_DEFAULT = the default chunk of SIFT_CHUNK_DEFAULT bases with the two
 // tiles in front), else 0 = A.reg_cap.  With it every LDS address of a wave is the lane's part plus a literal: the build for a run-time size
 // keeps dozens of derived addresses in scalar registers it does not have (84 spilled to vector-register lanes, a v_readlane per use:
 // 5-8 of the 46 vector instructions per 64 bases, round 5).
-constexpr uint32_t SIFT_CAP_DEFAULT = 1536 + 128;
+// The default chunk: 1792 bases = 28 tiles, with the two in front 1920 positions — 5904 bytes of LDS per wave, the five 1280-byte granules that 1536 bases
+// took as well (25 waves per CU), two staging rounds of 1024 bases.  Round 5, once the L2 counters were gone: per-chunk work (the flush of L1 / L2 with a third
+// of a batch, staging, set-up: 19 of the 43 vector instructions per 64 bases) is spread over a sixth more bases — alone 4.53-4.69 against 4.62-4.84 ms
+// (uniform), 11.9-12.2 against 12.2-12.5 (humanlike); in the step 6.47-6.59 against 6.66-6.71, 10.5 against 10.7, 14.2 against 14.5-15.0.  1920 bases (2048
+// positions: still five granules) keeps a register in scratch; 2048 needs a sixth granule and a third staging round.
+#ifndef SIFT_CHUNK_DEFAULT
+#define SIFT_CHUNK_DEFAULT 1792
+#endif
+constexpr uint32_t SIFT_CAP_DEFAULT = SIFT_CHUNK_DEFAULT + 128;
 template <bool STATS, uint32_t CAP = 0>
 __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(CAP ? 7 : 6))) void sd_sift(SiftArgs A, SdArgs O)
 {

@@ -844,7 +844,7 @@ def test_sdust_queue_and_order_do_not_change_results(acc, golden_dir, monkeypatc
         assert gpu_sdust_text(acc, recs, 20, 64) == exp, (tail, div, dense)
 
 
-@pytest.mark.parametrize("chunk", ["64", "500", "1536"])
+@pytest.mark.parametrize("chunk", ["64", "500", "1536", "1792"])
 def test_sdust_long_word_free_stretches_vs_oracle(acc, monkeypatch, chunk):
     """more than 1024 bases without W-2 word emissions before a chunk: the lane's local backward scan gives
     up, the host builds the word-count table and reruns (sdust.hip, SD_SCAN_CAP) — still exact, including the

@@ -52,6 +52,7 @@ struct TfArgs {
     const uint32_t *off0, *off1, *off2, *off3;   // mode 1: exclusive scan of the per-tile counts
     uint4 *tile_cnt;
     uint32_t *ovf;       // mode 2: max per-tile count when it exceeds TF_ROW
+    int64_t n_tiles;
 };
 
 __device__ __forceinline__ unsigned long long shfl_up64(unsigned long long v, int d)
@@ -88,6 +89,15 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v)
     return (uint32_t)x;
 }
 
+// TF_NT consecutive tiles per workgroup (round 5).  One tile per workgroup loaded its 80 bytes per thread, waited for them, then computed: beside
+// the resident sdust waves only two such waves fit on a SIMD (their registers), and with all of a wave's loads ahead of all of its work the
+// scan was bound by the round trips — 1.6 ms in the bench step against 0.71 alone.  Now the 16 bytes a thread has just used up are re-loaded
+// with the NEXT tile's 16 bytes at the same place (the same registers): the loads of tile i + 1 travel while tile i is computed — 1.28 ms in
+// the step (0.84 alone: the loop costs there).  Measured twice: with sdust on a second host thread and chunks of 1536 bases what this stream
+// gained the other lost (step 6.86-6.95 against 6.78-6.80 ms); with the step on one host thread and chunks of 1792 bases the telomere scan was
+// what the step waited for at the share the coverage kernel wants, and the step is 6.32-6.34 (share 76) against 6.49-6.57 (share 72) ms.
+constexpr int TF_NT = 4;
+
 template <int H>  // halo bytes behind the 64 positions of a thread; motif length k <= H + 1
 __global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
 {
@@ -99,12 +109,50 @@ __global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
 
     const int t = threadIdx.x;
     lut[t] = A.lut[t];
-    const int2 tile = A.tiles[blockIdx.x];
-    const int ctg = tile.x;
-    const int len = A.ctg_len[ctg];
-    const int64_t off = A.ctg_off[ctg];
-    const int s0 = tile.y + (t - 1) * TF_SEG;
+    constexpr int HH = H < 0 ? 0 : H;
+    constexpr int NW = (TF_SEG + HH + 3) / 4;      // dwords touched
+    constexpr int NV = H < 0 ? 1 : (NW + 3) / 4;   // 16-byte loads
+    uint32_t w[NV * 4];
+    const int64_t ti0 = (int64_t)blockIdx.x * TF_NT;
+    // what the tiles of this workgroup are, through LDS: read inside the loop from memory these values would come by vector loads (the kernel
+    // stores, so nothing is invariant to the compiler), in order with the tiles' bytes on the one counter both are waited for with
+    __shared__ int m_ctg[TF_NT + 1], m_y[TF_NT + 1], m_len[TF_NT + 1];
+    __shared__ int64_t m_off[TF_NT + 1], m_bm[TF_NT + 1];
+    if (t <= TF_NT) {
+        const bool there = t < TF_NT && ti0 + t < A.n_tiles;
+        const int2 tl = there ? A.tiles[ti0 + t] : make_int2(-1, 0);
+        m_ctg[t] = tl.x;
+        m_y[t] = tl.y;
+        m_len[t] = there ? A.ctg_len[tl.x] : 0;          // (no tile: no thread has positions, everybody loads the array's first bytes)
+        m_off[t] = there ? A.ctg_off[tl.x] : 0;
+        m_bm[t] = there && A.bm_off ? A.bm_off[tl.x] : 0;
+    }
+    // a thread without positions in its tile (in front of the contig, behind its end) loads from the start of the array: any bytes will do
+    auto src_at = [&](int y, int len, int64_t off) {
+        const int s = y + (t - 1) * TF_SEG;
+        return reinterpret_cast<const uint4 *>(s >= 0 && s < len ? A.bases + off + s : A.bases);
+    };
+    if constexpr (H >= 0) {
+        const int2 tl = A.tiles[ti0];
+        const uint4 *src = src_at(tl.y, A.ctg_len[tl.x], A.ctg_off[tl.x]);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const uint4 v = src[i];
+            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        }
+    }
     __syncthreads();
+
+    for (int it = 0; it < TF_NT; ++it) {
+    const int64_t ti = ti0 + it;
+    const int ctg = __builtin_amdgcn_readfirstlane(m_ctg[it]);
+    if (ctg < 0) break;
+    const int len = __builtin_amdgcn_readfirstlane(m_len[it]);
+    const int64_t off = (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m_off[it] >> 32)) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)m_off[it]));
+    const int s0 = __builtin_amdgcn_readfirstlane(m_y[it]) + (t - 1) * TF_SEG;
+    const uint4 *nsrc = nullptr;                    // the next tile's bytes (behind the last tile: the array's first bytes, loaded and dropped)
+    if constexpr (H >= 0) nsrc = src_at(m_y[it + 1], m_len[it + 1], m_off[it + 1]);
 
     unsigned long long Mf = 0, Mr = 0;
     if constexpr (H < 0) {
@@ -126,20 +174,24 @@ __global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
                 Mr |= (unsigned long long)mr << b;
             }
         }
-    } else
-    if (s0 >= 0 && s0 < len) {
-        constexpr int HH = H < 0 ? 0 : H;
-        constexpr int NW = (TF_SEG + HH + 3) / 4;      // dwords touched
-        constexpr int NV = (NW + 3) / 4;              // 16-byte loads
-        uint32_t w[NV * 4];
-        const uint4 *src = reinterpret_cast<const uint4 *>(A.bases + off + s0);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            uint4 v = src[i];
-            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
-        }
+    } else {
+        // (every thread computes — one without positions on whatever it loaded; its masks are cleared below)
         constexpr uint32_t INJ = 1u << (31 - HH);
         uint32_t Sf = 0, Sr = 0, Af = 0, Bf = 0, Ar = 0, Br = 0;
+        // the 16 bytes behind byte e are through: the next tile's come into their place
+        auto refill = [&](int e, int last, uint32_t &S0, uint32_t &S1) __attribute__((always_inline)) {
+            if ((e & 15) == 15 || e == last) {
+                const int i = e >> 4;
+                // (the load is tied behind the last use of the registers it fills: left to itself the compiler issues all of them at the top of
+                // the tile into twenty registers of their own, and a SIMD that holds the sdust waves has room for one such wave instead of two;
+                // the automaton's state as well: what the table gave for these 16 bytes is used up here, not kept for a chain of steps at the tile's end)
+                unsigned long long pa = reinterpret_cast<unsigned long long>(nsrc);
+                asm volatile("" : "+v"(pa), "+v"(w[4 * i]), "+v"(w[4 * i + 1]), "+v"(w[4 * i + 2]), "+v"(w[4 * i + 3]), "+v"(S0), "+v"(S1));
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 v = reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(pa)[i];      // (a global load, not a flat one)
+                w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+            }
+        };
         if constexpr (H == 7) {
             // Motifs of up to 8 bytes (every telomere unit): BOTH automata in one 32-bit state, each followed by an 8-bit delay
             // line — reverse strand: automaton bits 0-7 (match = bit 7), delay 8-15; forward: automaton 16-23, delay 24-31.  The
@@ -162,8 +214,9 @@ __global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
                         Br = (Br << 8) | rb;
                     }
                 }
+                refill(e, TF_SEG + 8 - 1, S, Af);
             }
-        } else
+        } else {
 #pragma unroll
         for (int e = 0; e < TF_SEG + HH; ++e) {
             const uint32_t c = (w[e >> 2] >> (8 * (e & 3))) & 0xFFu;
@@ -179,7 +232,11 @@ __global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
                     Br = __builtin_amdgcn_alignbit(Br, Sr, 31);
                 }
             }
+            if ((e & 7) == 7) asm volatile("" : "+v"(Sf), "+v"(Sr), "+v"(Af), "+v"(Ar), "+v"(Bf), "+v"(Br) : : "memory");      // (table reads are looked ahead eight bases, not a tile: registers)
+            refill(e, TF_SEG + HH - 1, Sf, Sr);
         }
+        }
+        if (s0 >= 0 && s0 < len) {
         Mf = (unsigned long long)__brev(Af) | ((unsigned long long)__brev(Bf) << 32);
         Mr = (unsigned long long)__brev(Ar) | ((unsigned long long)__brev(Br) << 32);
         const int nvalid = len - A.k + 1 - s0;        // start positions p with p + k <= len
@@ -187,6 +244,7 @@ __global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
             const unsigned long long m = nvalid <= 0 ? 0ull : ((1ull << nvalid) - 1ull);
             Mf &= m;
             Mr &= m;
+        }
         }
     }
     shF[t] = Mf;
@@ -207,7 +265,7 @@ __global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
             q2 = Mr & ~((Mr << k) | (pR >> (64 - k)));
             q3 = Mr & ~((Mr >> k) | (nR << (64 - k)));
             if (A.bitmap && s0 >= 0 && s0 < len)
-                A.bitmap[(A.bm_off[ctg] + s0) >> 6] = smear(Mf, pF, k) | smear(Mr, pR, k);
+                A.bitmap[(m_bm[it] + s0) >> 6] = smear(Mf, pF, k) | smear(Mr, pR, k);
         }
     }
     // packed 4 x 16-bit exclusive scan over the workgroup (a tile holds < 2^15 heads per list)
@@ -232,10 +290,10 @@ __global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
             cnt[q] = (uint32_t)((total >> (16 * q)) & 0xFFFFu);
             mx = cnt[q] > mx ? cnt[q] : mx;
         }
-        if (A.mode != 1) A.tile_cnt[blockIdx.x] = make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]);
+        if (A.mode != 1) A.tile_cnt[ti] = make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]);
         if (A.mode == 2 && mx > TF_ROW) atomicMax(A.ovf, mx);   // rare: second pass will write densely
     }
-    if (!inner || A.mode == 0) return;
+    if (!inner || A.mode == 0) continue;
     int32_t *lists[4] = {A.list0, A.list1, A.list2, A.list3};
     const uint32_t *offs[4] = {A.off0, A.off1, A.off2, A.off3};
     unsigned long long qs[4] = {q0, q1, q2, q3};
@@ -245,14 +303,14 @@ __global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
         if (!m) continue;
         uint32_t idx = (uint32_t)((excl >> (16 * q)) & 0xFFFFu);
         if (A.mode == 1) {
-            int32_t *dst = lists[q] + offs[q][blockIdx.x];
+            int32_t *dst = lists[q] + offs[q][ti];
             while (m) {
                 const int b = __ffsll((long long)m) - 1;
                 m &= m - 1;
                 dst[idx++] = s0 + b;
             }
         } else {
-            int32_t *dst = lists[q] + (size_t)blockIdx.x * TF_ROW;
+            int32_t *dst = lists[q] + (size_t)ti * TF_ROW;
             while (m) {
                 const int b = __ffsll((long long)m) - 1;
                 m &= m - 1;
@@ -260,6 +318,7 @@ __global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
                 ++idx;
             }
         }
+    }
     }
 }
 
@@ -737,15 +796,15 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
             if (bitmap_out) *bitmap_out = d_bitmap;
         }
         auto launch = [&](const TfArgs &A) -> int {
-            if (long_motif) CN_LAUNCH(h, "tf_scan", tf_scan<-1><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
-            else if (H == 7) CN_LAUNCH(h, "tf_scan", tf_scan<7><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
-            else if (H == 15) CN_LAUNCH(h, "tf_scan", tf_scan<15><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
-            else CN_LAUNCH(h, "tf_scan", tf_scan<31><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
+            if (long_motif) CN_LAUNCH(h, "tf_scan", tf_scan<-1><<<dim3((unsigned)((nt + TF_NT - 1) / TF_NT)), dim3(TF_THREADS), 0, h->stream>>>(A));
+            else if (H == 7) CN_LAUNCH(h, "tf_scan", tf_scan<7><<<dim3((unsigned)((nt + TF_NT - 1) / TF_NT)), dim3(TF_THREADS), 0, h->stream>>>(A));
+            else if (H == 15) CN_LAUNCH(h, "tf_scan", tf_scan<15><<<dim3((unsigned)((nt + TF_NT - 1) / TF_NT)), dim3(TF_THREADS), 0, h->stream>>>(A));
+            else CN_LAUNCH(h, "tf_scan", tf_scan<31><<<dim3((unsigned)((nt + TF_NT - 1) / TF_NT)), dim3(TF_THREADS), 0, h->stream>>>(A));
             return CORNETTO_OK;
         };
         TfArgs A{};
         A.bases = a->d_bases; A.ctg_off = a->d_off; A.ctg_len = a->d_len; A.tiles = a->d_tf_tiles; A.lut = d_lut; A.k = k; A.mot = d_mot;
-        A.bordered = bordered ? 1 : 0; A.bitmap = want_bitmap ? d_bitmap : nullptr; A.bm_off = a->d_tw_boff; A.tile_cnt = d_tc; A.ovf = d_ovf;
+        A.bordered = bordered ? 1 : 0; A.bitmap = want_bitmap ? d_bitmap : nullptr; A.bm_off = a->d_tw_boff; A.tile_cnt = d_tc; A.ovf = d_ovf; A.n_tiles = (int64_t)nt;
         // pass 1: single pass into fixed rows (unbordered motif, hits wanted), or counts only
         const bool rows_mode = hits && !bordered;
         int32_t *d_rows[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1041,12 +1100,12 @@ int cn_telo_spec_queue(cornetto_accel_t *h, cornetto_asm_t *a, const char *motif
     }
     TfArgs A{};
     A.bases = a->d_bases; A.ctg_off = a->d_off; A.ctg_len = a->d_len; A.tiles = a->d_tf_tiles; A.lut = d_lut; A.k = k; A.mot = reinterpret_cast<uint8_t *>(d_lut + 256);
-    A.bordered = 0; A.bitmap = d_bitmap; A.bm_off = a->d_tw_boff; A.tile_cnt = d_tc; A.ovf = d_ovf;
+    A.bordered = 0; A.bitmap = d_bitmap; A.bm_off = a->d_tw_boff; A.tile_cnt = d_tc; A.ovf = d_ovf; A.n_tiles = (int64_t)nt;
     A.mode = 2;
     A.list0 = d_rows[0]; A.list1 = d_rows[1]; A.list2 = d_rows[2]; A.list3 = d_rows[3];
-    if (H == 7) CN_LAUNCH(h, "tf_scan", tf_scan<7><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
-    else if (H == 15) CN_LAUNCH(h, "tf_scan", tf_scan<15><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
-    else CN_LAUNCH(h, "tf_scan", tf_scan<31><<<dim3((unsigned)nt), dim3(TF_THREADS), 0, h->stream>>>(A));
+    if (H == 7) CN_LAUNCH(h, "tf_scan", tf_scan<7><<<dim3((unsigned)((nt + TF_NT - 1) / TF_NT)), dim3(TF_THREADS), 0, h->stream>>>(A));
+    else if (H == 15) CN_LAUNCH(h, "tf_scan", tf_scan<15><<<dim3((unsigned)((nt + TF_NT - 1) / TF_NT)), dim3(TF_THREADS), 0, h->stream>>>(A));
+    else CN_LAUNCH(h, "tf_scan", tf_scan<31><<<dim3((unsigned)((nt + TF_NT - 1) / TF_NT)), dim3(TF_THREADS), 0, h->stream>>>(A));
     // the windows only need the marks: queued right behind the scan
     CN_HIP(h, hipMemsetAsync(d_twcnt, 0, 8, h->stream));
     TwArgs W{d_bitmap, a->d_tw_boff, a->d_len, a->d_tw_tiles, thr_adj, d_wout, d_twcnt, (uint32_t)std::min<size_t>(win_ws_cap, 0x7fffffff)};

@@ -28,7 +28,10 @@
 namespace {
 
 constexpr int CB_THREADS = 256;
-constexpr int CB_PARTS = 2;           // a tile goes through LDS in this many parts
+#ifndef CN_CB_PARTS
+#define CN_CB_PARTS 2
+#endif
+constexpr int CB_PARTS = CN_CB_PARTS;   // a tile goes through LDS in this many parts
 constexpr int CB_MAX_INC_LDS = 128;   // inc <= this: LDS staging path (256 / CB_PARTS x inc x 2 B <= 32 KiB)
 
 struct CbArgs {

@@ -1912,14 +1912,19 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
                 }
                 const int per_cu_all = std::max(1, std::min<int>(h->sift_per_cu, (int)(163840 / ((lds_wave * SIFT_WPB + 1279) / 1280 * 1280))));
                 const bool free_now = __atomic_load_n(&h->boost, __ATOMIC_ACQUIRE) != 0;        // (cornetto_accel_boost)
-                const int per_cu = free_now ? per_cu_all : std::max(1, per_cu_all * h->share / 100);
+                // (the share of ALL the chip's slots, not of a CU's rounded down: 25 slots per CU make whole waves per CU steps of 4 %.  Measured with it: the
+                // other stream's coverage kernel does not degrade gradually between 19 and 20 resident waves per CU — 3.10 ms at 76 %, 3.29 at 77 %
+                // (a quarter wave per CU more), 3.55 at 78-80 % — so the balance of a bench step stays at 76 %)
+                const size_t cus_n = (size_t)std::max(h->sd_cus, 1);
+                const size_t slots_all = (size_t)per_cu_all * cus_n;
+                const size_t slots = free_now ? slots_all : std::max<size_t>(cus_n, slots_all * (size_t)h->share / 100);
                 const size_t all_blocks = (nc + SIFT_WPB - 1) / SIFT_WPB;
-                const unsigned nbk = (unsigned)std::min<size_t>(all_blocks, (size_t)env_int("CORNETTO_SIFT_BLOCKS", per_cu * std::max(h->sd_cus, 1)));
+                const unsigned nbk = (unsigned)std::min<size_t>(all_blocks, (size_t)env_int("CORNETTO_SIFT_BLOCKS", (int)slots));
                 // The waves left to the other stream: when its owner says it is through (cornetto_accel_boost, from another host thread) while
                 // this kernel still runs, they are launched as a second kernel on a second stream — same arguments, same chunk counters: the two
                 // launches drain them together — and the stream of this call waits for both.  The helper must not start before the counters,
                 // the counts and the walk list of THIS call are reset: it waits for an event recorded behind those memsets, in front of the main launch.
-                const unsigned extra = (unsigned)std::min<size_t>(all_blocks > nbk ? all_blocks - nbk : 0, (size_t)(per_cu_all - per_cu) * std::max(h->sd_cus, 1));
+                const unsigned extra = (unsigned)std::min<size_t>(all_blocks > nbk ? all_blocks - nbk : 0, slots_all > slots ? slots_all - slots : 0);
                 // (from 85 % on the waves left out are too few to matter — measured: 7.57 ms per step with and without them at 92 % — and without
                 // the poll below the rest of the call is queued behind the kernel while it runs.  Round 5: at the shares the probe picks for a
                 // balanced step, 72-80 %, the other thread ends a few hundred microseconds before this kernel and the helper buys less than the

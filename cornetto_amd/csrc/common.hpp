@@ -339,6 +339,7 @@ struct cornetto_cov {
     uint64_t sums[3] = {0, 0, 0};
     // cached work decompositions
     int2 *d_cb_tiles = nullptr;          // block tiles for (w, inc)
+    int4 *d_cb_tmeta = nullptr;          // the same with what cov_blocks needs of the contig in ONE 32-byte record: {ctg, first block, length, -} {offset lo, hi, -, -}
     int64_t n_cb_tiles = 0;
     std::vector<int32_t> n_reg;          // windows per contig for (w, inc)
     int32_t *d_n_reg = nullptr;

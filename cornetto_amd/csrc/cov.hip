@@ -43,6 +43,7 @@ struct CbArgs {
     uint2 *pre;                // [tile*256 + b] = local inclusive prefix {depth, mq} of the block sums
     uint2 *head;               // [tile*256 + b] = {depth, mq} sums of the block's first r positions (r > 0 only: w not a multiple of inc)
     int64_t n_tiles;
+    const int4 *tmeta;         // (or NULL) per tile {ctg, first block, contig length, -} {contig offset lo, hi, -, -}: one scalar load instead of three, two of them dependent
     uint2 *tile_tot32;         // wrapping tile totals {depth, mq}
     ulonglong2 *tile_tot64;    // exact tile totals
 };
@@ -101,9 +102,15 @@ __global__ __launch_bounds__(CB_THREADS) void cov_blocks(CbArgs A)
         for (int ti = 0; ti < NT; ++ti) {
             const int64_t tix = (int64_t)blockIdx.x * NT + ti;
             if (tix >= A.n_tiles) continue;
-            const int2 tl = A.tiles[tix];
-            const int ln = A.ctg_len[tl.x];
-            const int64_t of = A.ctg_off[tl.x];
+            int2 tl;
+            int ln;
+            int64_t of;
+            if (A.tmeta) {
+                const int4 m0 = A.tmeta[2 * tix], m1 = A.tmeta[2 * tix + 1];
+                tl = make_int2(m0.x, m0.y); ln = m0.z; of = (int64_t)(((unsigned long long)(uint32_t)m1.y << 32) | (uint32_t)m1.x);
+            } else {
+                tl = A.tiles[tix]; ln = A.ctg_len[tl.x]; of = A.ctg_off[tl.x];
+            }
             const int64_t e0l = (int64_t)tl.y * inc;
             const int nvec = PBc * inc / 8;
 #pragma unroll
@@ -124,9 +131,15 @@ __global__ __launch_bounds__(CB_THREADS) void cov_blocks(CbArgs A)
     const int64_t tix = (int64_t)blockIdx.x * NT + ti;
     if (tix >= A.n_tiles) break;
     if (ti) __syncthreads();                            // (the tile before is through with the staging buffer and the wave sums)
-    const int2 tile = A.tiles[tix];
-    const int len = A.ctg_len[tile.x];
-    const int64_t off = A.ctg_off[tile.x];
+    int2 tile;
+    int len;
+    int64_t off;
+    if (A.tmeta) {
+        const int4 m0 = A.tmeta[2 * tix], m1 = A.tmeta[2 * tix + 1];
+        tile = make_int2(m0.x, m0.y); len = m0.z; off = (int64_t)(((unsigned long long)(uint32_t)m1.y << 32) | (uint32_t)m1.x);
+    } else {
+        tile = A.tiles[tix]; len = A.ctg_len[tile.x]; off = A.ctg_off[tile.x];
+    }
     const int64_t e0 = (int64_t)tile.y * inc;           // first element of the tile within the contig
     const int64_t p0 = e0 + (int64_t)t * inc;           // first element of my block
 
@@ -523,6 +536,7 @@ int cn_cov_prepare_impl(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int32
         if (c->d_blk) { (void)hipFree(c->d_blk); c->d_blk = nullptr; }
         if (c->d_blk_off) { (void)hipFree(c->d_blk_off); c->d_blk_off = nullptr; }
         if (c->d_cb_tiles) { (void)hipFree(c->d_cb_tiles); c->d_cb_tiles = nullptr; }
+        if (c->d_cb_tmeta) { (void)hipFree(c->d_cb_tmeta); c->d_cb_tmeta = nullptr; }
         if (c->d_n_reg) { (void)hipFree(c->d_n_reg); c->d_n_reg = nullptr; }
         const size_t nt = tiles.size();
         if (nt == 0) return CORNETTO_OK;
@@ -533,6 +547,15 @@ int cn_cov_prepare_impl(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int32
             hipMalloc((void **)&c->d_n_reg, (size_t)c->n * 4) != hipSuccess)
             return cn_fail(h, CORNETTO_E_NOMEM, "cov_prepare: device allocation failed");
         CN_HIP(h, hipMemcpyAsync(c->d_cb_tiles, tiles.data(), nt * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+        std::vector<int4> tmeta(2 * nt);
+        for (size_t k = 0; k < nt; ++k) {
+            const int32_t ci = tiles[k].x;
+            const unsigned long long o = (unsigned long long)c->off[ci];
+            tmeta[2 * k] = make_int4(ci, tiles[k].y, c->len[ci], 0);
+            tmeta[2 * k + 1] = make_int4((int)(uint32_t)o, (int)(uint32_t)(o >> 32), 0, 0);
+        }
+        if (hipMalloc((void **)&c->d_cb_tmeta, 2 * nt * sizeof(int4)) != hipSuccess) return cn_fail(h, CORNETTO_E_NOMEM, "cov_prepare: device allocation failed");
+        CN_HIP(h, hipMemcpyAsync(c->d_cb_tmeta, tmeta.data(), 2 * nt * sizeof(int4), hipMemcpyHostToDevice, h->stream));
         CN_HIP(h, hipMemcpyAsync(c->d_blk_off, c->blk_off.data(), (size_t)(c->n + 1) * 8, hipMemcpyHostToDevice, h->stream));
         CN_HIP(h, hipMemcpyAsync(c->d_n_reg, c->n_reg.data(), (size_t)c->n * 4, hipMemcpyHostToDevice, h->stream));
         CN_HIP(h, hipStreamSynchronize(h->stream));   // `tiles` is a local
@@ -548,7 +571,8 @@ int cn_cov_prepare_impl(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int32
     uint2 *d_pre = reinterpret_cast<uint2 *>(c->d_blk), *d_head = d_pre + c->n_blk;
     uint32_t *d_toff_d = reinterpret_cast<uint32_t *>(d_head + c->n_blk), *d_toff_q = d_toff_d + nt;
     CN_HIP(h, hipMemsetAsync(d_grand, 0, 16, h->stream));
-    CbArgs A{c->d_depth, c->d_mq, c->d_off, c->d_len, c->d_cb_tiles, inc, r, d_pre, d_head, (int64_t)nt, d_t32, d_t64};
+    static const int cb_tmeta = [] { const char *e = getenv("CORNETTO_COV_TMETA"); return e ? atoi(e) : 1; }();
+    CbArgs A{c->d_depth, c->d_mq, c->d_off, c->d_len, c->d_cb_tiles, inc, r, d_pre, d_head, (int64_t)nt, cb_tmeta ? c->d_cb_tmeta : nullptr, d_t32, d_t64};
     if (inc <= CB_MAX_INC_LDS) {
         const size_t lds = (size_t)CB_THREADS / CB_PARTS * inc * sizeof(uint16_t);
         static_assert(CB_THREADS / CB_PARTS * 50 / 8 <= 4 * CB_THREADS, "cov_blocks<true, INC>: at most 4 vectors per thread and part");

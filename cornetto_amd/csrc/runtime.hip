@@ -345,6 +345,7 @@ void cornetto_cov_free(cornetto_accel_t *h, cornetto_cov_t *c)
     if (c->d_blk) (void)hipFree(c->d_blk);
     if (c->d_blk_off) (void)hipFree(c->d_blk_off);
     if (c->d_cb_tiles) (void)hipFree(c->d_cb_tiles);
+    if (c->d_cb_tmeta) (void)hipFree(c->d_cb_tmeta);
     if (c->d_n_reg) (void)hipFree(c->d_n_reg);
     if (c->d_cw_tiles) (void)hipFree(c->d_cw_tiles);
     if (c->d_cw_first) (void)hipFree(c->d_cw_first);

@@ -42,283 +42,11 @@ PMC_FILE = os.path.join("profiles", "%s_%s_pmc_traffic_%s.json")    # % (round, 
 SQ_FILE = os.path.join("profiles", "%s_%s_sq_%s.json")
 
 
-def contig_lengths(total_target):
-    """hifiasm-like contig lengths: the reference's own HG002 assembly BED fixture (100 contigs, 3.16 Gb,
-    largest 242 Mb), data file of test/bigenough/hg002-cornetto-E_3 kept under tests/golden/."""
-    path = os.path.join(ROOT, "tests", "golden", "bigenough", "chroms.bed")
-    lens = [int(l.split()[2]) for l in open(path) if l.strip()]
-    if total_target and total_target < sum(lens):
-        scale = total_target / float(sum(lens))
-        lens = [max(1000, int(x * scale)) for x in lens]
-    return lens
-
-
-def _plant(torch, dev, bases, starts, lengths, units, unit_ids):
-    """write tandem repeats: feature j = units[unit_ids[j]] repeated over bases[starts[j] : starts[j] + lengths[j]]
-    (all features at once on the device; lengths <= 512)"""
-    if len(starts) == 0:
-        return
-    maxlen = int(max(lengths))
-    umax = max(len(u) for u in units)
-    utab = torch.zeros((len(units), umax), dtype=torch.uint8)
-    ulen = torch.zeros(len(units), dtype=torch.int64)
-    for i, u in enumerate(units):
-        utab[i, :len(u)] = torch.frombuffer(bytearray(u), dtype=torch.uint8)
-        ulen[i] = len(u)
-    utab, ulen = utab.to(dev), ulen.to(dev)
-    st = torch.from_numpy(np.asarray(starts, dtype=np.int64)).to(dev)
-    ln = torch.from_numpy(np.asarray(lengths, dtype=np.int64)).to(dev)
-    ui = torch.from_numpy(np.asarray(unit_ids, dtype=np.int64)).to(dev)
-    step = 1 << 16
-    ar = torch.arange(maxlen, device=dev)
-    for s in range(0, len(starts), step):
-        e = min(len(starts), s + step)
-        idx = st[s:e, None] + ar[None, :]
-        ok = ar[None, :] < ln[s:e, None]
-        val = utab[ui[s:e, None], ar[None, :] % ulen[ui[s:e], None]]
-        bases[idx[ok]] = val[ok]
-
-
-def _revcomp_np(a):
-    comp = np.zeros(256, dtype=np.uint8)
-    comp[list(b"ACGT")] = list(b"TGCA")
-    return comp[a[::-1]]
-
-
-def _humanlike_base(torch, dev, total, seed, g):
-    """the background of the humanlike profile: isochores of 100 kb - 1 Mb (log-uniform) whose GC content is drawn from 35-55 %,
-    bases independent inside an isochore, then CpG taken down to ~20 % of its expectation the way genomes lose it (80 % of the CpG
-    dinucleotides deaminated: CG -> TG or, for the other strand, CG -> CA) — which also gives the TpG / CpA excess of a real genome"""
-    rs = np.random.default_rng(seed ^ 0x150C40)
-    n_iso = int(total / 2.0e5) + 16
-    iso_len = (10 ** rs.uniform(5.0, 6.0, size=n_iso)).astype(np.int64)
-    while int(iso_len.sum()) < total:
-        iso_len = np.concatenate([iso_len, (10 ** rs.uniform(5.0, 6.0, size=n_iso)).astype(np.int64)])
-    bounds = torch.from_numpy(np.cumsum(iso_len)).to(dev)
-    gc = torch.from_numpy(rs.uniform(0.35, 0.55, size=len(iso_len)).astype(np.float32)).to(dev)
-    bases = torch.empty(total, dtype=torch.uint8, device=dev)
-    step = 1 << 27
-    at = torch.tensor(list(b"AT"), dtype=torch.uint8, device=dev)
-    cg = torch.tensor(list(b"CG"), dtype=torch.uint8, device=dev)
-    for s0 in range(0, total, step):
-        e0 = min(total, s0 + step)
-        pos = torch.arange(s0, e0, device=dev)
-        p_gc = gc[torch.bucketize(pos, bounds, right=True).clamp_(max=len(iso_len) - 1)]
-        del pos
-        is_gc = torch.rand(e0 - s0, device=dev, generator=g) < p_gc
-        del p_gc
-        bit = torch.randint(0, 2, (e0 - s0,), device=dev, generator=g)
-        bases[s0:e0] = torch.where(is_gc, cg[bit], at[bit])
-        del is_gc, bit
-    for s0 in range(0, total - 1, step):                # CpG depletion (a chunk's last base pairs with the next chunk's first)
-        e0 = min(total - 1, s0 + step)
-        cpg = (bases[s0:e0] == 67) & (bases[s0 + 1:e0 + 1] == 71)
-        r = torch.rand(e0 - s0, device=dev, generator=g)
-        c2t = cpg & (r < 0.4)
-        g2a = cpg & (r >= 0.4) & (r < 0.8)
-        del cpg, r
-        bases[s0:e0][c2t] = 84
-        bases[s0 + 1:e0 + 1][g2a] = 65
-        del c2t, g2a
-    return bases
-
-
-def _plant_copies(torch, dev, bases, starts, lens_, cons_off, cons, flip, div, g):
-    """diverged copies of (a part of) a consensus: copy j = cons[cons_off[j] : cons_off[j] + lens_[j]] (its reverse complement when
-    flip[j]), every base substituted with probability div[j], written at bases[starts[j] ...] (ragged, batched on the device)"""
-    if len(starts) == 0:
-        return
-    # copies that would overlap an earlier one (by start) are dropped: a scatter with colliding destinations has no defined winner,
-    # and the assembly must be the same bytes in every process
-    starts, lens_, cons_off = np.asarray(starts, np.int64), np.asarray(lens_, np.int64), np.asarray(cons_off, np.int64)
-    flip, div = np.asarray(flip, bool), np.asarray(div, np.float32)
-    order = np.argsort(starts, kind="stable")
-    starts, lens_, cons_off, flip, div = starts[order], lens_[order], cons_off[order], flip[order], div[order]
-    keep = np.ones(len(starts), bool)
-    end = -1
-    for j in range(len(starts)):
-        if starts[j] < end:
-            keep[j] = False
-        else:
-            end = starts[j] + lens_[j]
-    starts, lens_, cons_off, flip, div = starts[keep], lens_[keep], cons_off[keep], flip[keep], div[keep]
-    cons_f = torch.from_numpy(np.ascontiguousarray(cons)).to(dev)
-    cons_r = torch.from_numpy(np.ascontiguousarray(_revcomp_np(cons))).to(dev)
-    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    n_cons = len(cons)
-    csum = np.concatenate([[0], np.cumsum(lens_)])
-    budget, i = 1 << 25, 0                               # elements per batch
-    while i < len(starts):
-        j = int(np.searchsorted(csum, csum[i] + budget, "right")) - 1
-        j = max(j, i + 1)
-        ln = torch.from_numpy(lens_[i:j]).to(dev)
-        tot = int(csum[j] - csum[i])
-        rep = torch.repeat_interleave(torch.arange(j - i, device=dev), ln, output_size=tot)
-        within = torch.arange(tot, device=dev) - torch.from_numpy(csum[i:j] - csum[i]).to(dev)[rep]
-        dst = torch.from_numpy(starts[i:j]).to(dev)[rep] + within
-        co = torch.from_numpy(cons_off[i:j]).to(dev)[rep]
-        fl = torch.from_numpy(flip[i:j]).to(dev)[rep]
-        # a flipped copy reads the reverse complement of the same stretch of the consensus
-        src_f = co + within
-        src_r = (n_cons - co - ln[rep]) + within
-        val = torch.where(fl, cons_r[src_r.clamp_(0, n_cons - 1)], cons_f[src_f.clamp_(0, n_cons - 1)])
-        mut = torch.rand(tot, device=dev, generator=g) < torch.from_numpy(div[i:j]).to(dev)[rep]
-        val = torch.where(mut, lut[torch.randint(0, 4, (tot,), device=dev, generator=g)], val)
-        bases[dst] = val
-        del rep, within, dst, co, fl, src_f, src_r, val, mut
-        i = j
-
-
-def make_assembly(torch, dev, lens, seed, profile="uniform"):
-    """bases (uint8 ASCII, contigs at 64-byte aligned offsets) with planted features — SURVEY 8d, C2.
-    profile "satellite" additionally plants what a real human assembly is full of: HSat2/3-like (CATTC)n / (GGAAT)n
-    arrays of 0.1-5 Mb (half of them exact, half with 2 % substitutions) over >= 3 % of the bases, (AT)n / (AAAG)n
-    microsatellites every ~20 kb and poly-A / poly-T runs every ~10 kb.
-    profile "humanlike" has those on a background with the COMPOSITION of a human assembly instead of uniform bases (what the
-    position-parallel sieve of sd_sift is sensitive to): isochores with 35-55 % GC, CpG at ~20 % of its expectation, ~10 % of the
-    bases in 85-95 %-identity copies of a 300-bp Alu-like consensus with 10-40-base poly-A tails, ~15 % in 5'-truncated
-    80-95 %-identity copies of an AT-rich 6 kb L1-like consensus."""
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    offs, pos = [], 0
-    for n in lens:
-        offs.append(pos)
-        pos = (pos + n + 63) // 64 * 64
-    total = pos + 256
-    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    if profile == "humanlike":
-        bases = _humanlike_base(torch, dev, total, seed, g)
-    else:
-        codes = torch.randint(0, 4, (total,), dtype=torch.uint8, device=dev, generator=g)
-        bases = lut[codes.long()] if total < (1 << 28) else None
-        if bases is None:                                  # chunked lookup keeps the int64 index temporary small
-            bases = torch.empty_like(codes)
-            step = 1 << 28
-            for s in range(0, total, step):
-                bases[s:s + step] = lut[codes[s:s + step].long()]
-        del codes
-    rng = np.random.default_rng(seed)
-
-    def put(p, b):
-        bases[p:p + len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
-
-    if profile == "humanlike":
-        rh = np.random.default_rng(seed ^ 0xA1B2C3)
-        acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
-        # L1-like: 6 kb, 58 % AT, ends in a poly-A tail; copies are 5'-truncated (they keep the 3' end), 80-95 % identity
-        l1 = acgt[rh.choice(4, size=6000, p=[0.33, 0.21, 0.21, 0.25])].copy()
-        l1[-30:] = ord("A")
-        # Alu-like: two GC-rich arms around an A-rich linker, then the poly-A tail (drawn per copy: 10-40)
-        alu = acgt[rh.choice(4, size=340, p=[0.21, 0.30, 0.31, 0.18])].copy()
-        alu[120:135] = np.frombuffer(b"AAAAATACAAAAAAT"[:15], dtype=np.uint8)
-        alu[300:] = ord("A")
-        big = [(o, n) for o, n in zip(offs, lens) if n >= 20000]
-        wts = np.array([n for _, n in big], dtype=np.float64)
-        wts /= wts.sum()
-        nb = float(sum(n for _, n in big))
-
-        def scatter(count, max_len):
-            ci = rh.choice(len(big), size=count, p=wts)
-            o = np.array([big[i][0] for i in ci], dtype=np.int64)
-            n = np.array([big[i][1] for i in ci], dtype=np.int64)
-            return o + 2000 + (rh.random(count) * (n - max_len - 4000)).astype(np.int64)
-
-        n_l1 = int(0.17 * nb / 1050.0)                     # (about a tenth of them overlap an earlier one and are dropped)                     # mean fragment ~1.05 kb (log-uniform 100 .. 6000)
-        ln = np.minimum(6000, (10 ** rh.uniform(2.0, np.log10(6000.0), size=n_l1)).astype(np.int64))
-        _plant_copies(torch, dev, bases, scatter(n_l1, 6000), ln, 6000 - ln, l1, rh.random(n_l1) < 0.5, rh.uniform(0.05, 0.20, size=n_l1), g)
-        n_alu = int(0.11 * nb / 325.0)
-        ln = 300 + rh.integers(10, 41, size=n_alu)
-        _plant_copies(torch, dev, bases, scatter(n_alu, 340), ln, np.zeros(n_alu, np.int64), alu, rh.random(n_alu) < 0.5, rh.uniform(0.05, 0.15, size=n_alu), g)
-    if profile in ("satellite", "humanlike"):
-        rs = np.random.default_rng(seed ^ 0x5A7E111)
-        # microsatellites and homopolymer runs, everywhere
-        st, ln, ui = [], [], []
-        units = [b"AT", b"AAAG", b"A", b"T", b"CA", b"TTTC"]
-        for off, n in zip(offs, lens):
-            if n < 50000:
-                continue
-            p = np.arange(7000, n - 2000, 20000) + rs.integers(0, 4000, size=len(np.arange(7000, n - 2000, 20000)))
-            st += (off + p).tolist(); ln += rs.integers(20, 121, size=len(p)).tolist(); ui += rs.choice([0, 1, 4, 5], size=len(p)).tolist()
-            p = np.arange(3000, n - 2000, 10000) + rs.integers(0, 2000, size=len(np.arange(3000, n - 2000, 10000)))
-            st += (off + p).tolist(); ln += rs.integers(12, 41, size=len(p)).tolist(); ui += rs.choice([2, 3], size=len(p)).tolist()
-        _plant(torch, dev, bases, st, ln, units, ui)
-        # satellite arrays: log-uniform 0.1-5 Mb, in the larger contigs, until 3.2 % of the bases are covered
-        want = int(0.032 * sum(lens))
-        have, k = 0, 0
-        big = [i for i in range(len(lens)) if lens[i] >= 12_000_000] or [int(np.argmax(lens))]
-        slots = {}
-        while have < want:
-            ci = big[k % len(big)]
-            L = int(min(10 ** rs.uniform(5.0, 6.7), lens[ci] // 8))
-            nth = slots.get(ci, 0)
-            slots[ci] = nth + 1
-            p = int(lens[ci] * (0.15 + 0.1 * nth) % (lens[ci] - L - 100000)) + 50000
-            unit = (b"CATTC", b"GGAAT")[k % 2]
-            arr = torch.frombuffer(bytearray(unit), dtype=torch.uint8).to(dev).repeat(L // 5 + 1)[:L].clone()
-            if k % 4 >= 2:                             # diverged copy: 2 % substitutions
-                m = torch.rand(L, device=dev, generator=g) < 0.02
-                arr[m] = lut[torch.randint(0, 4, (int(m.sum()),), device=dev, generator=g)]
-            bases[offs[ci] + p: offs[ci] + p + L] = arr
-            have += L
-            k += 1
-    for off, n in zip(offs, lens):
-        if n < 50000:
-            continue
-        put(off, b"CCCTAA" * 2000)
-        put(off + n - 9000, b"TTAGGG" * 1500)
-        k = 0
-        for p in range(500000, n - 20000, 500000):
-            kind = k % 4
-            k += 1
-            if kind == 0:
-                put(off + p, b"TTAGGG" * int(rng.integers(3, 81)))
-            elif kind == 1:
-                put(off + p, bytes([b"ACGT"[int(rng.integers(0, 4))]]) * int(rng.integers(10, 301)))
-            elif kind == 2:
-                u = bytes(b"ACGT"[int(x)] for x in rng.integers(0, 4, size=2))
-                put(off + p, u * int(rng.integers(10, 201)))
-            else:
-                put(off + p, b"N" * int(rng.integers(1, 501)))
-        lo = off + n // 2
-        bases[lo:lo + 500] |= 0x20                     # one 500-bp lower-case stretch
-    return bases, np.array(offs, dtype=np.int64)
-
-
-def make_coverage(torch, dev, lens, offs, seed):
-    """per-base depth / mq-depth (u16 stored as int16 bit patterns) — SURVEY 8d, C3"""
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed + 1)
-    total = int(offs[-1] + (lens[-1] + 63) // 64 * 64 + 256)
-    nk = (total + 999) // 1000
-    base = torch.poisson(torch.full((nk,), 30.0, device=dev), generator=g).to(torch.int16)
-    depth = base.repeat_interleave(1000)[:total].contiguous()
-    del base
-    step = 1 << 28
-    for s in range(0, total, step):
-        e = min(total, s + step)
-        depth[s:e] += torch.randint(-2, 3, (e - s,), dtype=torch.int16, device=dev, generator=g)
-    depth.clamp_(min=0)
-    mq = depth.clone()
-    rng = np.random.default_rng(seed + 1)
-    for off, n in zip(offs, lens):
-        k = 0
-        for p in range(400000, n - 70000, 400000):
-            L = int(rng.integers(2000, 60001))
-            s = int(off) + p
-            if k % 2 == 0:
-                depth[s:s + L] //= 5
-            else:
-                depth[s:s + L] *= 3
-            mq[s:s + L] = depth[s:s + L]
-            k += 1
-        for p in range(500000, n - 70000, 500000):
-            L = int(rng.integers(2000, 60001))
-            s = int(off) + p + 100000
-            mq[s:s + L] //= 4
-    return depth, mq
+from cornetto_amd.synth import contig_lengths, make_assembly, make_coverage, make_bedgraph_text, make_fastq_piece, FQ_HEAD   # noqa: E402,F401  (tests and tools import the generators from cornetto_amd.synth)
 
 
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libcornetto_ref.so")
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "cornetto")
 HIT_KEYS = ("strand", "start", "end")
 
 
@@ -457,10 +185,10 @@ def cpu_all_cores(R, per_contig, lens_all):
                          max(lens_all), t_largest, len(lens_all) - 1, cores, total / max(t_largest, t_spread) / 1e9)}
 
 
-def cpu_reference_leg(bases, depth, mq, offs, lens, own, budget_bases):
+def cpu_reference_leg(bases, depth, mq, offs, lens, own, budget_bases, pick=None):
     """The CPU side of the run on one host core: the reference itself (oracle/_ref) where it was built, else the oracle
-    port, over the leading contigs `own[0..]` of the same workload.  Returns (cpu_baseline dict, per-contig results for
-    the parity check)."""
+    port, over the leading contigs `own[0..]` of the same workload (or over the local contigs `pick` names, whole).  Returns
+    (cpu_baseline dict, per-contig results for the parity check)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_bind as ob
     use_ref = os.path.exists(REF_SO) and os.environ.get("CORNETTO_BENCH_BASELINE", "reference") != "port"
@@ -471,7 +199,7 @@ def cpu_reference_leg(bases, depth, mq, offs, lens, own, budget_bases):
     t = {"telofind": 0.0, "telowin": 0.0, "sdust": 0.0, "get_regs": 0.0}
     results = []
     per_contig = []
-    sample = _sample_contigs([lens[i] for i in own], budget_bases)
+    sample = _sample_contigs([lens[i] for i in own], budget_bases) if pick is None else [(li, int(lens[own[li]])) for li in pick]
     done = 0
     for li, n in sample:
         gi = own[li]
@@ -560,7 +288,7 @@ def cpu_reference_leg(bases, depth, mq, offs, lens, own, budget_bases):
                   "of it, one thread; %.1f s of CPU" % (len(sample), done, what, total),
         "stage_gbases_s": {k: round(done / v / 1e9, 4) for k, v in t.items()},
     }
-    if use_ref and os.environ.get("CORNETTO_BENCH_ALL_CORES", "1") != "0":
+    if use_ref and pick is None and os.environ.get("CORNETTO_BENCH_ALL_CORES", "1") != "0":
         try:
             ac = cpu_all_cores(R, per_contig, [lens[i] for i in own])
             if ac:
@@ -732,10 +460,9 @@ class Rank:
         self.scaling = scaling or args.scaling
         self.lens = contig_lengths(int(args.gbases * 1e9) if args.gbases > 0 else 0)
         nctg = len(self.lens)
+        self.plan = None
         if self.scaling == "strong":
-            from cornetto_amd.dist import lpt_partition
             asm_index = args.assembly_index
-            own = lpt_partition(self.lens, self.world)[self.rank]            # ascending global contig indices
             self.job_bases = int(sum(self.lens))
             self.gl_of = lambda own_: np.array(own_, dtype=np.int64)
         else:
@@ -748,8 +475,38 @@ class Rank:
         self.depth, self.mq = make_coverage(torch, self.dev, self.lens, self.offs, seed)
         torch.cuda.synchronize()
         self.profile = profile
-        self.asm = self.asm2 = self.cov = None
+        self.asm = self.asm2 = self.cov = self.cov_halo = None
+        if self.scaling == "strong":
+            # whole contigs by LPT while they pack within --split-tol of the fair share (the HG002 assembly up to 8 ranks); beyond that the
+            # contigs are cut on clean positions and a rank scans pieces with halos (cornetto_amd.dist.SplitPlan).  Every rank asks
+            # the same question of the same resident bases: no message
+            from cornetto_amd.dist import SplitPlan, make_clean
+            seq_of = lambda ci, lo, hi: self.bases[int(self.offs[ci]) + lo:int(self.offs[ci]) + hi].cpu().numpy()      # noqa: E731
+            plan = SplitPlan(self.lens, self.world, clean=make_clean(seq_of, b"TTAGGG"), window=2500, inc=50, W=64, min_ctg_len=1000000,
+                             tol=args.split_tol)
+            if plan.any_split:
+                self.plan = plan
+                self.wrap_pieces(plan.pieces[self.rank])
+                return
+            own = [p[0] for p in plan.pieces[self.rank]]                     # (= lpt_partition(lens, world)[rank])
         self.wrap(own)
+
+    def wrap_pieces(self, pieces):
+        """strong scaling with contigs above the fair share: this rank's pieces (ctg, start, end, lo, hi) as sequences [lo, hi) of their own"""
+        self.unwrap()
+        self.pieces = list(pieces)
+        self.own = [p[0] for p in pieces]
+        self.gl_ctg = np.array(self.own, dtype=np.int64)
+        self.lens_own = [p[4] - p[3] for p in pieces]
+        self.my_bases = int(sum(p[2] - p[1] for p in pieces))                 # what the rank OWNS (it scans the halos on top: lens_own)
+        o = np.array([int(self.offs[p[0]]) + p[3] for p in pieces], dtype=np.int64)
+        self.asm = self.acc.asm_wrap(self.bases.data_ptr(), o, np.array(self.lens_own, dtype=np.int64))
+        self.asm2 = self.acc2.asm_wrap(self.bases.data_ptr(), o, np.array(self.lens_own, dtype=np.int64))
+        self.cov = self.acc.cov_wrap(self.depth.data_ptr(), self.mq.data_ptr(), o, np.array(self.lens_own, dtype=np.int32))
+        hr = self.plan.halo_ranges(self.rank)
+        if hr:                                                                # the halos alone: their sums leave the totals again
+            ho = np.array([int(self.offs[c]) + a for c, a, b in hr], dtype=np.int64)
+            self.cov_halo = self.acc.cov_wrap(self.depth.data_ptr(), self.mq.data_ptr(), ho, np.array([b - a for c, a, b in hr], dtype=np.int32))
 
     def wrap(self, own):
         """(re-)wrap a subset of the resident contigs: what this process scans in a step"""
@@ -764,7 +521,7 @@ class Rank:
         self.cov = self.acc.cov_wrap(self.depth.data_ptr(), self.mq.data_ptr(), o, np.array(self.lens_own, dtype=np.int32))
 
     def unwrap(self):
-        for x in ("asm", "asm2", "cov"):
+        for x in ("asm", "asm2", "cov", "cov_halo"):
             if getattr(self, x, None) is not None:
                 getattr(self, x).close()
                 setattr(self, x, None)
@@ -844,7 +601,7 @@ class Rank:
                 while time.perf_counter() < t_lead:
                     pass
         need_exchange = world > 1 and (self.scaling == "strong" or self.args.allreduce_always)
-        if self.fused:
+        if self.fused and self.plan is None:
             # the other thread's whole sequence as ONE call (cornetto_panel_step): totals -> [all-reduce of the three sums] -> thresholds ->
             # selection + telomere scan queued in one go, sized by the last step's counts and checked afterwards: two synchronisations, no
             # Python between the stages (round 5; CORNETTO_BENCH_FUSED=0 brings the three calls back)
@@ -867,6 +624,9 @@ class Rank:
             sums = acc.cov_prepare(self.cov, 2500, 50)
             if record:
                 self._note(acc)
+            if self.plan is not None and self.cov_halo is not None:      # pieces: every position counts once
+                hs = acc.cov_prepare(self.cov_halo, 2500, 50)
+                sums = tuple(int(a) - int(b) for a, b in zip(sums, hs))
             # the one real exchange: the assembly-wide mean depth behind the thresholds (boringbits_main.c:293-294 -> :518-519).
             # Weak scaling keeps every assembly's own mean (N independent assemblies); strong scaling needs the all-reduce.
             if need_exchange:
@@ -899,7 +659,7 @@ class Rank:
             if record:
                 self._lap("result_copies", t0)
         recs = recs_pk
-        if keep or self.args.gather:                  # rows with their contig and end, as cornetto_cov_select() returns them
+        if keep or self.args.gather or self.plan is not None:        # rows with their contig and end, as cornetto_cov_select() returns them
             recs = acc.unpack_regs(recs_pk, ctg_first, self.lens_own, 2500)
         if self.overlap and direct:
             t0 = time.perf_counter()
@@ -914,10 +674,21 @@ class Rank:
             if "err" in box:
                 raise box["err"]
             ivls = box["ivls"]
+        if self.plan is not None:
+            # pieces: records in contig coordinates, cut down to what each piece owns (part of the step: what a sharded run does before it prints)
+            t0 = time.perf_counter()
+            pl, rk = self.plan, self.rank
+            hits, wins, ivls, recs = pl.own_points(rk, hits, "start"), pl.own_points(rk, wins, "start"), pl.own_intervals(rk, ivls), pl.own_points(rk, recs, "st")
+            if record:
+                self._lap("own_records", t0)
         gathered = None
         if self.args.gather:                          # optional: all BED/TSV records to rank 0 (RCCL / gloo), global contig order
             t0 = time.perf_counter()
-            gathered = [gather_records(arr, self.gl_ctg, device=self.cdev, concat=keep) for arr in (hits, wins, ivls, recs)]
+            gathered = [gather_records(arr, self.gl_ctg, device=self.cdev, concat=keep or self.plan is not None) for arr in (hits, wins, ivls, recs)]
+            if self.plan is not None and gathered[0] is not None:
+                from cornetto_amd.dist import order_records, stitch_intervals
+                gathered = [order_records(gathered[0], ("strand", "start")), order_records(gathered[1], ("start",)), stitch_intervals(gathered[2]),
+                            order_records(gathered[3], ("st",))]
             if record:
                 self._lap("gather", t0)
         self.counts = [len(hits), len(wins), len(ivls), len(recs)]
@@ -1035,6 +806,24 @@ def kernel_table(R, serial, n_bases):
     return kavg, alg, kern
 
 
+def _hash_lines(chunks):
+    """(blake2b-128 of the concatenated bytes, number of newlines)"""
+    import hashlib
+    h, n = hashlib.blake2b(digest_size=16), 0
+    buf = []
+    for c in chunks:
+        buf.append(c)
+        if len(buf) >= 65536:
+            b = b"".join(buf)
+            h.update(b)
+            n += b.count(b"\n")
+            buf = []
+    b = b"".join(buf)
+    h.update(b)
+    n += b.count(b"\n")
+    return h.hexdigest(), n
+
+
 def e2e_cli(R, cornetto_amd):
     """the C CLI end to end on the rank's assembly written as a single-line FASTA into memory-backed /dev/shm (or /tmp):
     process start, HIP initialisation, file read, record framing on the device, scan, printing — the file- and PCIe-bound
@@ -1055,8 +844,18 @@ def e2e_cli(R, cornetto_amd):
                 f.write(b"\n")
         del hb
         out["fasta_bytes"] = os.path.getsize(path)
+        # what the CLI must print: the records of a step over the same resident assembly (the step's records are compared with the reference's own
+        # functions in this run: "parity"), put into text with the reference's printf formats (sdust.c:201 "%s\t%d\t%d\n"; find_telomere.c:51,56
+        # "%s\t%zu\t0\t%zu" + "\t%zu\t%zu\n", strand column 1 for the reverse search :66,71)
+        (hits, _wins, ivls, _recs), _ = R.step(False, keep=True)
+        names = [b"ptg%06dl" % i for i in R.own]
+        lens_own = R.lens_own
+        want = {"sdust": _hash_lines(b"%s\t%d\t%d\n" % (names[c], a, b) for c, a, b in zip(ivls["ctg"].tolist(), ivls["start"].tolist(), ivls["finish"].tolist())),
+                "telofind": _hash_lines(b"%s\t%d\t%d\t%d\t%d\t%d\n" % (names[c], lens_own[c], sd, a, b, b - a)
+                                        for c, sd, a, b in zip(hits["ctg"].tolist(), hits["strand"].tolist(), hits["start"].tolist(), hits["end"].tolist()))}
+        del hits, ivls, _wins, _recs
         for sub in ("sdust", "telofind"):
-            best, nbytes = None, 0
+            best, nbytes, got = None, 0, None
             for _ in range(2):
                 t0 = time.perf_counter()
                 p = subprocess.run([cornetto_amd.CLI_PATH, sub, path], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
@@ -1067,9 +866,45 @@ def e2e_cli(R, cornetto_amd):
                     best = None
                     break
                 nbytes = len(p.stdout)
+                got = _hash_lines([p.stdout])
                 best = dt if best is None else min(best, dt)
             if best is not None:
-                out[sub] = {"wall_s": round(best, 3), "gbases_s": round(R.my_bases / best / 1e9, 3), "stdout_bytes": nbytes}
+                out[sub] = {"wall_s": round(best, 3), "gbases_s": round(R.my_bases / best / 1e9, 3), "stdout_bytes": nbytes,
+                            "stdout_equals_step_records": bool(got == want[sub]), "stdout_lines": want[sub][1]}
+        # and the CLI beside the unmodified reference binary (oracle/_ref/cornetto, where it was built) on a FASTA both finish in seconds: the
+        # smallest contigs of the assembly up to 40 Mbases plus the smallest contig of at least 12 Mb (telomere arrays at both ends, every planted
+        # feature kind), byte for byte
+        if os.path.exists(REF_BIN):
+            sub_path = path + ".sub"
+            order = sorted(range(len(R.own)), key=lambda li: R.lens_own[li])
+            take, tot = [], 0
+            for li in order:
+                if tot + R.lens_own[li] > 40_000_000:
+                    break
+                take.append(li)
+                tot += R.lens_own[li]
+            mid = [li for li in order if R.lens_own[li] >= 12_000_000 and li not in take][:1]
+            take = sorted(take + mid)
+            hb = R.bases.cpu().numpy()
+            with open(sub_path, "wb") as f:
+                for li in take:
+                    i = R.own[li]
+                    f.write(b">ptg%06dl\n" % i)
+                    f.write(memoryview(hb[int(R.offs[i]):int(R.offs[i]) + int(R.lens[i])]))
+                    f.write(b"\n")
+            del hb
+            try:
+                same = {}
+                for sub in ("sdust", "telofind"):
+                    pr = subprocess.run([REF_BIN, sub, sub_path], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+                    pg = subprocess.run([cornetto_amd.CLI_PATH, sub, sub_path], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                        env=dict(os.environ, CORNETTO_DEVICE=str(R.local_dev)))
+                    same[sub] = bool(pr.returncode == 0 and pg.returncode == 0 and pr.stdout == pg.stdout and len(pr.stdout) > 0)
+                    same[sub + "_bytes"] = len(pr.stdout)
+                out["same_as_reference"] = dict(same, ok=bool(same["sdust"] and same["telofind"]), contigs=len(take), bases=int(sum(R.lens_own[li] for li in take)),
+                                                what="stdout of `cornetto sdust` / `telofind` of this build and of oracle/_ref/cornetto (the unmodified reference) on the same FASTA, byte for byte")
+            finally:
+                os.remove(sub_path)
         # where the time of `cornetto sdust` goes (CORNETTO_CLI_TRACE: milliseconds since process start at each point; the pinned piece
         # can only be allocated once the HIP runtime is up, so "pinned piece allocated" = runtime initialisation + code object + pinning)
         t0 = time.perf_counter()
@@ -1098,7 +933,31 @@ def e2e_cli(R, cornetto_amd):
     return out
 
 
-def profile_leg(R, steps):
+def profile_parity(R, budget_bases=40_000_000):
+    """parity of the step's records on the workload currently loaded against the reference's own functions (oracle/_ref; the oracle port where
+    that is absent) on the two smallest contigs that hold planted satellite arrays (make_assembly plants them in the contigs of at least 12 Mb),
+    all four stages, record for record: the repeat-rich profiles print numbers of their own in the line, so they carry a check of their own"""
+    big = sorted((R.lens_own[li], li) for li in range(len(R.lens_own)) if R.lens_own[li] >= 12_000_000)
+    if not big:
+        big = sorted(((R.lens_own[li], li) for li in range(len(R.lens_own))), reverse=True)[:2]
+    pick, tot = [], 0
+    for n, li in big:
+        if pick and (len(pick) >= 2 or tot + n > budget_bases):
+            break
+        pick.append(li)
+        tot += n
+    pick.sort()
+    t0 = time.perf_counter()
+    base, results = cpu_reference_leg(R.bases, R.depth, R.mq, R.offs, R.lens, R.own, 0, pick=pick)
+    last, _ = R.step(False, keep=True)
+    par = check_parity(results, last, R.lo, R.hi, 0.4, 1000000, R.lens_own)
+    par["against"] = "the reference's own functions (oracle/_ref)" if base["kind"] == "reference" else "the oracle port"
+    par["contigs_local"] = pick
+    par["cpu_s"] = round(time.perf_counter() - t0, 2)
+    return par
+
+
+def profile_leg(R, steps, parity=True):
     """ms/step and the sdust kernel on the workload currently loaded, plus the kernel's own statistics run"""
     el = R.timed(steps, 1)
     kavg = {k: float(np.mean(v)) for k, v in R.ktime.items()}
@@ -1113,42 +972,13 @@ def profile_leg(R, steps):
     st = R.acc2.sdust_stats(R.asm2, 20, 64) if hasattr(R.acc2, "sdust_stats") else None
     if st:
         out["sdust_stats"] = st
+    if parity:
+        out["parity"] = profile_parity(R)
     return out
 
 
 def _shm_dir():
     return "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
-
-
-def make_bedgraph_text(torch, dev, n, seed, mq, ctg_len=10_000_000):
-    """n lines `ptg%06dl\t%09d\t%09d\t%02d\n` (34 bytes; %d reads the zero-padded numbers the same) on the device: contigs of ctg_len
-    positions (the last one shorter), depth around 30 with a 20 kb dip every 400 kb (mq: a quarter of the depth in a 20 kb segment every 500 kb)"""
-    gpos = torch.arange(n, device=dev, dtype=torch.int64)
-    ctg = gpos // ctg_len + 1
-    pos = gpos - (ctg - 1) * ctg_len
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    depth = 28 + torch.randint(0, 5, (n,), device=dev, generator=g)
-    depth = torch.where((pos % 400000) < 20000, depth // 5, depth)
-    if mq:
-        depth = torch.where(((pos + 100000) % 500000) < 20000, depth // 4, depth)
-    out = torch.empty((n, 34), dtype=torch.uint8, device=dev)
-    out[:, :10] = torch.tensor(list(b"ptg000000l"), dtype=torch.uint8, device=dev)
-    out[:, 10] = 9
-    out[:, 20] = 9
-    out[:, 30] = 9
-    out[:, 33] = 10
-
-    def digits(v, col, nd):
-        for k in range(nd):
-            out[:, col + nd - 1 - k] = (v % 10 + 48).to(torch.uint8)
-            v = v // 10
-
-    digits(ctg, 3, 6)
-    digits(pos.clone(), 11, 9)
-    digits(pos + 1, 21, 9)
-    digits(depth.clone(), 31, 2)
-    return out.reshape(-1)
 
 
 def e2e_noboringbits(R, torch, cornetto_amd, mlines=100.0):
@@ -1189,6 +1019,31 @@ def e2e_noboringbits(R, torch, cornetto_amd, mlines=100.0):
                             env=dict(os.environ, CORNETTO_DEVICES="%d,%d" % (R.local_dev, R.local_dev)))
         out["sharded_ingest_same_gpu_twice"] = {"wall_s": round(time.perf_counter() - t0, 3), "same_stdout": p2.returncode == 0 and p2.stdout == so,
                                                 "sharded": b"sharded ingest" in p2.stderr}
+        # the same CLI beside the unmodified reference binary on the leading 10 M positions (= the first contig) of both files, stdout byte for
+        # byte and the exit status (the reference's fscanf loop reads 20 M lines in a few seconds; boringbits_main.c:204-287)
+        if os.path.exists(REF_BIN):
+            sl = [p_ + ".slice" for p_ in paths]
+            try:
+                nsl = min(n, 10_000_000)
+                for src_, dst_ in zip(paths, sl):
+                    with open(src_, "rb") as f, open(dst_, "wb") as g_:
+                        g_.write(f.read(34 * nsl))
+                t0 = time.perf_counter()
+                pr = subprocess.run([REF_BIN, "noboringbits", sl[0], "-q", sl[1]], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+                t_ref = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                pg = subprocess.run([cornetto_amd.CLI_PATH, "noboringbits", sl[0], "-q", sl[1]], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                    env=dict(os.environ, CORNETTO_DEVICE=str(R.local_dev)))
+                t_gpu = time.perf_counter() - t0
+                out["same_as_reference"] = {"ok": bool(pr.returncode == 0 and pg.returncode == 0 and pr.stdout == pg.stdout and len(pr.stdout) > 0),
+                                            "positions": nsl, "stdout_bytes": len(pr.stdout), "reference_wall_s": round(t_ref, 2), "wall_s": round(t_gpu, 2),
+                                            "what": "stdout of `cornetto noboringbits` of this build and of oracle/_ref/cornetto on the same two bedgraph files, byte for byte"}
+            finally:
+                for p_ in sl:
+                    try:
+                        os.remove(p_)
+                    except OSError:
+                        pass
         out.update({"positions": n, "contigs": (n + 9_999_999) // 10_000_000, "text_bytes": nbytes, "wall_s": round(best, 3), "text_GBps": round(nbytes / best / 1e9, 2),
                     "gbases_s": round(n / best / 1e9, 3), "stdout_bytes": len(so), "stdout_lines": so.count(b"\n"),
                     "command": "cornetto noboringbits cov-total.bg -q cov-mq20.bg (defaults: -w 2500 -i 50 -L 0.4 -H 2.5 -Q 0.4)"})
@@ -1201,57 +1056,6 @@ def e2e_noboringbits(R, torch, cornetto_amd, mlines=100.0):
             except OSError:
                 pass
     return out
-
-
-FQ_HEAD = b"@read%07d runid=5c1f3b2a9d ch=%03d\n"
-
-
-def make_fastq_piece(torch, dev, target_bases, seed):
-    """One piece of ONT-like FASTQ text built on the device: read lengths log-normal(mu 9.2, sigma 0.9)
-    clipped to [200, 200 000], uniform bases with a 200-base poly-A / poly-T stretch in every fourth read, qualities U[3, 40] + 33,
-    header `@read%07d runid=... ch=%03d`.  -> (uint8 tensor of the text, read lengths, byte offset of every record)"""
-    rng = np.random.default_rng(seed)
-    m = int(target_bases / 14000 * 1.3) + 16
-    L = np.clip(rng.lognormal(9.2, 0.9, size=m), 200, 200000).astype(np.int64)
-    n = int(np.searchsorted(np.cumsum(L), target_bases)) + 1
-    L = L[:n]
-    hl = len(FQ_HEAD % (0, 0))
-    size = hl + 2 * L + 4
-    off = np.concatenate([[0], np.cumsum(size)[:-1]]).astype(np.int64)
-    total = int(size.sum())
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    text = torch.empty(total, dtype=torch.uint8, device=dev)
-    step = 1 << 28
-    for s0 in range(0, total, step):
-        e0 = min(total, s0 + step)
-        text[s0:e0] = lut[torch.randint(0, 4, (e0 - s0,), device=dev, generator=g)]
-    # quality bytes: [hl + L + 3, hl + 2 L + 3) of every record
-    seg = np.empty(2 * n, dtype=np.int64)
-    seg[0::2] = hl + L + 3
-    seg[1::2] = L + 1
-    isq = torch.repeat_interleave(torch.tensor([0, 1], dtype=torch.uint8, device=dev).repeat(n), torch.from_numpy(seg).to(dev)).bool()
-    for s0 in range(0, total, step):
-        e0 = min(total, s0 + step)
-        q = torch.randint(36, 74, (e0 - s0,), dtype=torch.uint8, device=dev, generator=g)
-        text[s0:e0] = torch.where(isq[s0:e0], q, text[s0:e0])
-    del isq
-    offd = torch.from_numpy(off).to(dev)
-    Ld = torch.from_numpy(L).to(dev)
-    heads = np.frombuffer(b"".join(FQ_HEAD % (i, i % 512) for i in range(n)), dtype=np.uint8).reshape(n, hl)
-    text[(offd[:, None] + torch.arange(hl, device=dev)[None, :]).reshape(-1)] = torch.from_numpy(heads.copy()).to(dev).reshape(-1)
-    sep = offd + hl + Ld
-    text[sep] = 10
-    text[sep + 1] = 43
-    text[sep + 2] = 10
-    text[offd + torch.from_numpy(size).to(dev) - 1] = 10
-    pick = np.nonzero((np.arange(n) % 4 == 0) & (L > 400))[0]
-    if len(pick):
-        pa = (offd[torch.from_numpy(pick).to(dev)] + hl + 100)[:, None] + torch.arange(200, device=dev)[None, :]
-        letter = torch.where(torch.from_numpy((pick % 8 == 0)).to(dev), torch.tensor(84, dtype=torch.uint8, device=dev), torch.tensor(65, dtype=torch.uint8, device=dev))
-        text[pa.reshape(-1)] = letter[:, None].expand(-1, 200).reshape(-1)
-    return text, L, off
 
 
 def reads_shares(piece_lens, n_pieces, world):
@@ -1643,6 +1447,8 @@ def main():
     ap.add_argument("--no-second", action="store_true", help="--gpus > 1: skip the second measurement (the other scaling mode with --gather)")
     ap.add_argument("--emulate-ranks", type=str, default="2,4,8", help="N=1: model the strong-scaling curve for these rank counts on this one GPU ('' = skip)")
     ap.add_argument("--rank-share", type=str, default="", help="N,k (profiling aid, N=1 only): the main workload is the share rank k of an N-rank strong-scaling run would own")
+    ap.add_argument("--split-tol", type=float, default=0.05, help="strong scaling: contigs are cut into pieces with halos (cornetto_amd.dist.SplitPlan) when whole contigs "
+                    "cannot be packed within this fraction of the fair share (the HG002 assembly: 3.8 %% over it on 8 ranks, 22 %% on 16); negative: always")
     ap.add_argument("--allow-shared-device", action="store_true", help="--gpus > 1 with fewer GPUs than ranks (tests): ranks share devices, collectives over gloo")
     ap.add_argument("--sdust-share", type=int, default=-1, help="percent of the wave slots the resident sdust waves could hold on a CU that they take while the other stream runs beside them; -1 / 0 (default): probed during warm-up (72 / 85 / 92 / 100, four untimed steps each) for every resident workload — with the coverage stage in front of the telomere scan the two host threads of a step balance at 85-92 on the uniform profile (7.6-7.8 ms per step; 72: 8.1), repeat-rich profiles want 85-100.  The rest of the slots joins in when the other thread of the step is through (cornetto_accel_boost)")
     ap.add_argument("--timing", type=int, default=1, help="HIP events in the timed steps around: 1 the three main kernels only (roofline), 2 every launch, 0 none; the extra serial pass that fills the kernel table always uses 2")
@@ -1803,7 +1609,8 @@ def main():
             "higher_is_better": True, "scaling": args.scaling if world > 1 else "single", "vs_baseline": None, "dtype": "u8/u16 integer",
             "data": "synthetic",
             "config": {"workload": wl, "profile": args.profile, "bases_per_gpu": n_bases, "bases_job": R.job_bases, "contigs": len(R.lens),
-                       "contigs_rank0": len(R.own), "motif": "TTAGGG", "sdust": "-w 64 -t 20", "windows": "-w 2500 -i 50",
+                       "contigs_rank0": len(R.own), "cut_contigs": (sum(1 for c in R.plan.cuts.values() if c) if getattr(R, "plan", None) is not None else 0),
+                       "motif": "TTAGGG", "sdust": "-w 64 -t 20", "windows": "-w 2500 -i 50",
                        "parallelism": "contig-sharded (%s), %d process(es), 1 GPU each; per GPU %s" % (
                            "LPT over the contigs of one assembly" if args.scaling == "strong" else "one assembly per rank", world,
                            "2 HIP streams (sdust || telofind+coverage), sdust on %d %% of the wave slots" % getattr(R, "share", 100) if nst == 2 else "stages serial on one stream")},
@@ -1871,11 +1678,20 @@ def main():
                 continue
             R.unload()
             R.load(other)
-            profs[other] = profile_leg(R, min(args.steps, 5))
+            profs[other] = profile_leg(R, min(args.steps, 5), parity=not args.no_cpu)
+            if not profs[other].get("parity", {}).get("ok", True):
+                ok = False
         line["profiles"] = profs
     R.unload()
     if rank == 0 and world == 1 and not args.no_e2e:
         line["e2e"]["noboringbits"] = e2e_noboringbits(R, torch, cornetto_amd)
+        e2 = line["e2e"]
+        e2_ok = [e2.get("sdust", {}).get("stdout_equals_step_records", True), e2.get("telofind", {}).get("stdout_equals_step_records", True),
+                 e2.get("same_as_reference", {}).get("ok", True), e2["noboringbits"].get("same_as_reference", {}).get("ok", True),
+                 e2["noboringbits"].get("sharded_ingest_same_gpu_twice", {}).get("same_stdout", True)]
+        e2["parity_ok"] = bool(all(e2_ok))
+        if not e2["parity_ok"]:
+            ok = False
     if not args.no_reads:                               # every rank: N > 1 streams one FASTQ stream sharded by cumulative bases (config 5)
         rd = reads_leg(R, torch, dist, cornetto_amd, args.reads_gbases)
         if rank == 0:

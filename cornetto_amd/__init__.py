@@ -15,6 +15,7 @@ __all__ = ["lib", "Accel", "AccelError", "HIT_DT", "WIN_DT", "IVL_DT", "TELROW_D
            "LIB_PATH", "CLI_PATH"]
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+DEV_LIB_PATH = os.path.join(HERE, "libcornetto_hip_dev.so")   # the same sources with -DCN_DEV: the development switches (CORNETTO_SDUST_CHUNK, ...) exist in this build only
 LIB_PATH = os.environ.get("CORNETTO_LIB") or os.path.join(HERE, "libcornetto_hip.so")    # (CORNETTO_LIB: another build of the same library — A/B runs of kernel variants on one box)
 CLI_PATH = os.path.join(HERE, "cornetto")
 
@@ -63,18 +64,20 @@ def build(verbose=False):
     subprocess.check_call(["make", "-C", HERE] + ([] if verbose else ["-s"]))
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    """the loaded C ABI; raises if the HIP library has not been built"""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def lib(dev=False):
+    """the loaded C ABI; raises if the HIP library has not been built.  dev=True: the development build of the same sources
+    (libcornetto_hip_dev.so, -DCN_DEV), the only one that reads the development switches from the environment — a second, independent copy
+    of the library in the process (own handles, own result pool)"""
+    path = DEV_LIB_PATH if dev else LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise ImportError("%s is missing: run `make -C cornetto_amd` (or __graft_entry__.build()); "
-                          "there is no fallback implementation" % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+                          "there is no fallback implementation" % path)
+    L = C.CDLL(path)
     vp, i32, i64, cp = C.c_void_p, C.c_int32, C.c_int64, C.c_char_p
     pp = C.POINTER(vp)
     sig = {
@@ -146,33 +149,33 @@ def lib():
         fn.restype = res
         fn.argtypes = args
     L._declared = sorted(sig)
-    _lib = L
+    _libs[path] = L
     return L
 
 
 class _Owner:
     """keeps a library-owned result buffer alive for the numpy view over it; released with cornetto_free()"""
 
-    def __init__(self, ptr):
-        self.ptr = ptr
+    def __init__(self, L, ptr):
+        self.L, self.ptr = L, ptr
 
     def __del__(self):
         try:
             if self.ptr:
-                lib().cornetto_free(self.ptr)
+                self.L.cornetto_free(self.ptr)
                 self.ptr = None
         except Exception:
             pass
 
 
-def _take(ptr, n, dt):
-    """zero-copy numpy view of a library-owned result array (freed when the array is garbage collected)"""
+def _take(L, ptr, n, dt):
+    """zero-copy numpy view of a result array owned by library L (freed when the array is garbage collected)"""
     if not n:
-        lib().cornetto_free(ptr)
+        L.cornetto_free(ptr)
         return np.zeros(0, dtype=dt)
     addr = ptr.value if isinstance(ptr, C.c_void_p) else int(ptr)
     buf = (C.c_char * (n * dt.itemsize)).from_address(addr)
-    buf._owner = _Owner(addr)          # the ctypes array is the numpy base; the owner dies with it
+    buf._owner = _Owner(L, addr)          # the ctypes array is the numpy base; the owner dies with it
     return np.frombuffer(buf, dtype=dt)
 
 
@@ -195,8 +198,8 @@ class _Resident:
 class Accel:
     """one device + stream; mirrors the handle of include/cornetto_accel.h"""
 
-    def __init__(self, device=0, stream=None):
-        self.L = lib()
+    def __init__(self, device=0, stream=None, dev=False):
+        self.L = lib(dev)
         h = C.c_void_p()
         rc = self.L.cornetto_accel_open(C.byref(h), device, stream)
         if rc != 0:
@@ -279,7 +282,7 @@ class Accel:
         p, cnt, used, plain, reads = C.c_void_p(), C.c_int64(), C.c_int64(), C.c_int32(), C.c_void_p()
         self._chk(self.L.cornetto_fastq_split(self.h, addr, n, 1 if final else 0, min_len, C.byref(p), C.byref(cnt), C.byref(used),
                                               C.byref(plain), C.byref(reads) if want_reads else None))
-        recs = _take(p, cnt.value, FQREC_DT)
+        recs = _take(self.L, p, cnt.value, FQREC_DT)
         res = _Resident(self, reads, self.L.cornetto_asm_free, recs["len"][recs["keep"] == 1]) if want_reads else None
         return recs, used.value, bool(plain.value), res
 
@@ -295,7 +298,7 @@ class Accel:
         p, cnt, used, plain, seqs = C.c_void_p(), C.c_int64(), C.c_int64(), C.c_int32(), C.c_void_p()
         self._chk(self.L.cornetto_fasta_split(self.h, addr, n, 1 if final else 0, C.byref(p), C.byref(cnt), C.byref(used), C.byref(plain),
                                               C.byref(seqs) if want_seqs else None))
-        recs = _take(p, cnt.value, FAREC_DT)
+        recs = _take(self.L, p, cnt.value, FAREC_DT)
         res = _Resident(self, seqs, self.L.cornetto_asm_free, recs["len"]) if want_seqs else None
         return recs, used.value, bool(plain.value), res
 
@@ -303,7 +306,7 @@ class Accel:
     def telofind(self, asm, motif=b"TTAGGG"):
         p, n = C.c_void_p(), C.c_int64()
         self._chk(self.L.cornetto_telofind(self.h, asm.ptr, motif, C.byref(p), C.byref(n)))
-        return _take(p, n.value, HIT_DT)
+        return _take(self.L, p, n.value, HIT_DT)
 
     def telowin_threshold(self, thr, identity):
         return self.L.cornetto_telowin_threshold(thr, identity)
@@ -314,21 +317,21 @@ class Accel:
         p, n = C.c_void_p(), C.c_int64()
         self._chk(self.L.cornetto_telowin(self.h, hits.ctypes.data, hits.size, ctg_len.ctypes.data, ctg_len.size,
                                           thr_adj, C.byref(p), C.byref(n)))
-        return _take(p, n.value, WIN_DT)
+        return _take(self.L, p, n.value, WIN_DT)
 
     def telo_scan(self, asm, motif, thr_adj, want_hits=True):
         ph, nh, pw, nw = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
         self._chk(self.L.cornetto_telo_scan(self.h, asm.ptr, motif, thr_adj,
                                             C.byref(ph) if want_hits else None, C.byref(nh) if want_hits else None,
                                             C.byref(pw), C.byref(nw)))
-        hits = _take(ph, nh.value, HIT_DT) if want_hits else None
-        return hits, _take(pw, nw.value, WIN_DT)
+        hits = _take(self.L, ph, nh.value, HIT_DT) if want_hits else None
+        return hits, _take(self.L, pw, nw.value, WIN_DT)
 
     # ---- sdust -----------------------------------------------------------------------------------
     def sdust(self, asm, T=20, W=64):
         p, n = C.c_void_p(), C.c_int64()
         self._chk(self.L.cornetto_sdust_asm(self.h, asm.ptr, T, W, C.byref(p), C.byref(n)))
-        return _take(p, n.value, IVL_DT)
+        return _take(self.L, p, n.value, IVL_DT)
 
     def sdust_begin(self, asm, T=20, W=64):
         """cornetto_sdust_asm_begin(): queue the call without waiting where the last call's counts allow it (else nothing); sdust_end() delivers"""
@@ -337,7 +340,7 @@ class Accel:
     def sdust_end(self, asm, T=20, W=64):
         p, n = C.c_void_p(), C.c_int64()
         self._chk(self.L.cornetto_sdust_asm_end(self.h, asm.ptr, T, W, C.byref(p), C.byref(n)))
-        return _take(p, n.value, IVL_DT)
+        return _take(self.L, p, n.value, IVL_DT)
 
     def sdust_stats(self, asm, T=20, W=64):
         """one extra sdust pass with the counting build of the kernel -> its counters as a dict (see
@@ -371,13 +374,13 @@ class Accel:
         p, n = C.c_void_p(), C.c_int64()
         self._chk(self.L.cornetto_cov_select_merged(self.h, cov.ptr, lo, hi, low_mq, edge_len, min_ctg_len, 1 if boring else 0, merge_dist, min_len,
                                                     C.byref(p), C.byref(n)))
-        return _take(p, n.value, IVL_DT)
+        return _take(self.L, p, n.value, IVL_DT)
 
     def ivl_merge(self, ivls, dist):
         ivls = np.ascontiguousarray(ivls, dtype=IVL_DT)
         p, n = C.c_void_p(), C.c_int64()
         self._chk(self.L.cornetto_ivl_merge(self.h, ivls.ctypes.data, len(ivls), dist, C.byref(p), C.byref(n)))
-        return _take(p, n.value, IVL_DT)
+        return _take(self.L, p, n.value, IVL_DT)
 
     # ---- telobreaks ------------------------------------------------------------------------------
     def telobreaks(self, ctg_len, sd, tel):
@@ -389,7 +392,7 @@ class Accel:
         p, n = C.c_void_p(), C.c_int64()
         self._chk(self.L.cornetto_telobreaks(self.h, ctg_len.ctypes.data, len(ctg_len), sd.ctypes.data, len(sd), tel.ctypes.data, len(tel),
                                              C.byref(p), C.byref(n)))
-        return _take(p, n.value, IVL_DT)
+        return _take(self.L, p, n.value, IVL_DT)
 
     # ---- coverage --------------------------------------------------------------------------------
     def cov_upload(self, depths, mqs):
@@ -436,7 +439,7 @@ class Accel:
         p, n = C.c_void_p(), C.c_int64()
         self._chk(self.L.cornetto_cov_select(self.h, cov.ptr, lo, hi, low_mq, edge_len, min_ctg_len, int(boring),
                                              C.byref(p), C.byref(n)))
-        return _take(p, n.value, REGREC_DT)
+        return _take(self.L, p, n.value, REGREC_DT)
 
     def cov_select_packed(self, cov, lo, hi, low_mq, edge_len, min_ctg_len, boring):
         """-> (REGPK_DT records {st, depth, mq_depth}, int64 ctg_first[n + 1]): the windows of contig i are
@@ -444,7 +447,7 @@ class Accel:
         p, n, cf = C.c_void_p(), C.c_int64(), C.c_void_p()
         self._chk(self.L.cornetto_cov_select_packed(self.h, cov.ptr, lo, hi, low_mq, edge_len, min_ctg_len, int(boring),
                                                     C.byref(p), C.byref(n), C.byref(cf)))
-        return _take(p, n.value, REGPK_DT), _take(cf, len(cov.lens) + 1, np.dtype("<i8"))
+        return _take(self.L, p, n.value, REGPK_DT), _take(self.L, cf, len(cov.lens) + 1, np.dtype("<i8"))
 
     def panel_step(self, asm, cov, motif, thr_adj, w=2500, inc=50, low_cov=0.4, high_cov=2.5, low_mq=0.4, edge_len=100000, min_ctg_len=1000000, boring=False,
                    exchange=None):
@@ -473,8 +476,8 @@ class Accel:
             raise box["err"]
         self._chk(rc)
         cov.w, cov.inc = w, inc
-        return ((int(sums[0]), int(sums[1]), int(sums[2])), (int(thr[0]), int(thr[1])), _take(p, n.value, REGPK_DT), _take(cf, len(cov.lens) + 1, np.dtype("<i8")),
-                _take(ph, nh.value, HIT_DT), _take(pw, nw.value, WIN_DT))
+        return ((int(sums[0]), int(sums[1]), int(sums[2])), (int(thr[0]), int(thr[1])), _take(self.L, p, n.value, REGPK_DT), _take(self.L, cf, len(cov.lens) + 1, np.dtype("<i8")),
+                _take(self.L, ph, nh.value, HIT_DT), _take(self.L, pw, nw.value, WIN_DT))
 
     @staticmethod
     def unpack_regs(recs, ctg_first, lens, w):
@@ -563,4 +566,4 @@ def panel_boring(ctg_len, fun, lowq, recreate=False, **kw):
     rc = L.cornetto_panel_boring(ctg_len.ctypes.data, len(ctg_len), fun.ctypes.data, len(fun), lowq.ctypes.data, len(lowq), C.byref(opt), C.byref(p), C.byref(n))
     if rc != 0:
         raise ValueError("cornetto_panel_boring: status %d" % rc)
-    return _take(p, n.value, IVL_DT)
+    return _take(L, p, n.value, IVL_DT)

@@ -353,6 +353,21 @@ struct cornetto_cov {
     int64_t cw_est_key = -1, cw_est_cnt = -1;
 };
 
+// Development switches (chunk sizes, kernel-family selection, forced estimates, ablations): read from the environment ONLY in the development
+// build of the library (`make dev` -> libcornetto_hip_dev.so, -DCN_DEV; the tests of the decomposition invariance and of the fallback kernel
+// families load that one).  In the product build every switch is its default at compile time and the names do not exist in the binary
+// (tests/test_abi.py greps libcornetto_hip.so for them).
+#ifdef CN_DEV
+static inline int cn_dev_int(const char *name, int dflt)
+{
+    const char *s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+#define CN_DEV_INT(name, dflt) cn_dev_int(name, dflt)
+#else
+#define CN_DEV_INT(name, dflt) (dflt)
+#endif
+
 static inline int64_t cn_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 // Result arrays handed to the caller.  Small ones are malloc'd; large ones (>= 1 MiB) come from a process-wide

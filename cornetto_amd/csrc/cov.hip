@@ -517,7 +517,13 @@ int cn_cov_prepare_impl(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int32
     sums[0] = sums[1] = 0;
     sums[2] = (uint64_t)c->total;
     if (c->w != w || c->inc != inc || !c->d_blk) {
-        // (re)build the decomposition for these window sizes; cached for later calls
+        // (re)build the decomposition for these window sizes; cached for later calls.  A failure anywhere inside (an allocation, a copy) leaves
+        // the cache invalid — the next call with the same sizes rebuilds instead of indexing with offsets that were never uploaded.
+        struct Invalidate {
+            cornetto_cov_t *c;
+            bool keep = false;
+            ~Invalidate() { if (!keep) c->w = c->inc = -1; }
+        } built{c};
         c->w = w;
         c->inc = inc;
         c->cw_mode = -1;
@@ -539,7 +545,7 @@ int cn_cov_prepare_impl(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int32
         if (c->d_cb_tmeta) { (void)hipFree(c->d_cb_tmeta); c->d_cb_tmeta = nullptr; }
         if (c->d_n_reg) { (void)hipFree(c->d_n_reg); c->d_n_reg = nullptr; }
         const size_t nt = tiles.size();
-        if (nt == 0) return CORNETTO_OK;
+        if (nt == 0) { built.keep = true; return CORNETTO_OK; }
         // prefixes [n_blk] uint2, heads [n_blk] uint2, then two arrays of tile offsets [nt] u32 each
         if (hipMalloc((void **)&c->d_blk, (size_t)c->n_blk * sizeof(uint4) + 2 * nt * sizeof(uint32_t)) != hipSuccess ||
             hipMalloc((void **)&c->d_blk_off, (size_t)(c->n + 1) * 8) != hipSuccess ||
@@ -559,6 +565,7 @@ int cn_cov_prepare_impl(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int32
         CN_HIP(h, hipMemcpyAsync(c->d_blk_off, c->blk_off.data(), (size_t)(c->n + 1) * 8, hipMemcpyHostToDevice, h->stream));
         CN_HIP(h, hipMemcpyAsync(c->d_n_reg, c->n_reg.data(), (size_t)c->n * 4, hipMemcpyHostToDevice, h->stream));
         CN_HIP(h, hipStreamSynchronize(h->stream));   // `tiles` is a local
+        built.keep = true;
     }
     const size_t nt = (size_t)c->n_cb_tiles;
     if (nt == 0) return CORNETTO_OK;
@@ -571,13 +578,13 @@ int cn_cov_prepare_impl(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int32
     uint2 *d_pre = reinterpret_cast<uint2 *>(c->d_blk), *d_head = d_pre + c->n_blk;
     uint32_t *d_toff_d = reinterpret_cast<uint32_t *>(d_head + c->n_blk), *d_toff_q = d_toff_d + nt;
     CN_HIP(h, hipMemsetAsync(d_grand, 0, 16, h->stream));
-    static const int cb_tmeta = [] { const char *e = getenv("CORNETTO_COV_TMETA"); return e ? atoi(e) : 1; }();
+    static const int cb_tmeta = CN_DEV_INT("CORNETTO_COV_TMETA", 1);
     CbArgs A{c->d_depth, c->d_mq, c->d_off, c->d_len, c->d_cb_tiles, inc, r, d_pre, d_head, (int64_t)nt, cb_tmeta ? c->d_cb_tmeta : nullptr, d_t32, d_t64};
     if (inc <= CB_MAX_INC_LDS) {
         const size_t lds = (size_t)CB_THREADS / CB_PARTS * inc * sizeof(uint16_t);
         static_assert(CB_THREADS / CB_PARTS * 50 / 8 <= 4 * CB_THREADS, "cov_blocks<true, INC>: at most 4 vectors per thread and part");
         if (A.inc == 50) {                               // the default step (-i 50)
-            static const int cb_nt = [] { const char *e = getenv("CORNETTO_COV_TILES"); return e ? atoi(e) : 1; }();   // (2: two tiles per workgroup, all loads up front — 138 registers: does not fit beside the resident sdust waves, 8.4 instead of 3.9 ms in the step)
+            static const int cb_nt = CN_DEV_INT("CORNETTO_COV_TILES", 1);   // (2: two tiles per workgroup, all loads up front — 138 registers: does not fit beside the resident sdust waves, 8.4 instead of 3.9 ms in the step)
             if (cb_nt == 2) {
                 CN_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&cov_blocks<true, 50, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 CN_LAUNCH(h, "cov_blocks", cov_blocks<true, 50, 2><<<dim3((unsigned)((nt + 1) / 2)), dim3(CB_THREADS), lds, h->stream>>>(A));
@@ -745,7 +752,7 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
         if (spec) {
             // the copy goes out now, for the count of last time plus head room (at most the block); whoever synchronises the stream checks
             size_t n_copy = std::min<size_t>(cap, (size_t)c->cw_est_cnt + (size_t)c->cw_est_cnt / 16 + 1024);
-            if (const char *f = getenv("CORNETTO_STEP_EST_FORCE")) n_copy = std::min<size_t>(cap, (size_t)std::max(1, atoi(f)));   // (tests: an estimate that does not hold)
+            if (const int f = CN_DEV_INT("CORNETTO_STEP_EST_FORCE", 0)) n_copy = std::min<size_t>(cap, (size_t)std::max(1, f));   // (tests: an estimate that does not hold)
             cornetto_regpk_t *o = (cornetto_regpk_t *)cn_result_alloc(n_copy * rec_bytes);
             if (!o) return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: host allocation failed");
             if (cn_result_d2h(h, o, d_dst, n_copy * rec_bytes) != hipSuccess) {

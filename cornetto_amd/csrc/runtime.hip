@@ -246,6 +246,13 @@ void cornetto_asm_free(cornetto_accel_t *h, cornetto_asm_t *a)
 {
     if (!a) return;
     if (h) (void)hipSetDevice(h->device);
+    if (h && h->sd_pend.state != 0 && h->sd_pend.a == a) {
+        // a cornetto_sdust_asm_begin() over this assembly that nobody finished: its kernels and its result copy are let through, the result
+        // is dropped, and the handle forgets the assembly (the next sdust call would otherwise finish it through a dangling pointer)
+        if (h->sd_pend.state == 1) (void)hipStreamSynchronize(h->stream);
+        if (h->sd_pend.of) cornetto_free(h->sd_pend.of);
+        h->sd_pend = cornetto_accel::SdPend{};
+    }
     if (a->owned) (void)hipFree(a->owned);
     if (a->d_off) (void)hipFree(a->d_off);
     if (a->d_len) (void)hipFree(a->d_len);

@@ -254,10 +254,7 @@ __global__ __launch_bounds__(SC_THREADS) void scan_lookback(LbArgs A)
 
 static inline int scan_mode()
 {
-    static const int mode = [] {
-        const char *e = getenv("CORNETTO_SCAN");
-        return e ? atoi(e) : 1;
-    }();
+    static const int mode = CN_DEV_INT("CORNETTO_SCAN", 1);
     return mode;
 }
 

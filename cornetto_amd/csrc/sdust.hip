@@ -1592,12 +1592,6 @@ __global__ void sd_make_order(const uint32_t *walk, const uint32_t *iswalk, cons
     if (!iswalk[k]) order[nw + (uint32_t)k - rank[k]] = (uint32_t)k;
 }
 
-int env_int(const char *name, int dflt)
-{
-    const char *s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
-}
-
 }  // namespace
 
 extern "C" {
@@ -1637,7 +1631,7 @@ int sd_one_go_finish(cornetto_accel_t *h, cornetto_asm_t *a, cornetto_ivl_t *of,
 int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, int32_t W, cornetto_ivl_t **ivls, int64_t *n_ivls, const int phase)
 {
     // CORNETTO_SDUST_TRACE=1: host-side time stamps of the call's phases on stderr (development aid)
-    static const bool trace = env_int("CORNETTO_SDUST_TRACE", 0) != 0;
+    static const bool trace = CN_DEV_INT("CORNETTO_SDUST_TRACE", 0) != 0;
     struct timespec ts0;
     clock_gettime(CLOCK_MONOTONIC, &ts0);
     auto stamp = [&](const char *what) {
@@ -1658,7 +1652,7 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
     cn_timing_begin(h);
 
     // waves the chip holds at once (LDS-bound: 19 per CU), once per handle
-    const int variant0 = env_int("CORNETTO_SDUST_VARIANT", 0);
+    const int variant0 = CN_DEV_INT("CORNETTO_SDUST_VARIANT", 0);
     const bool w64_path = W - 2 <= 64 && T >= 5 && T <= 100000 && variant0 == 0;
     if (w64_path && h->sd_slots == 0) {
         // The kernel must not spill: round-1 builds of it that kept registers in scratch memory gave results that changed from
@@ -1673,7 +1667,7 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
             const void *fn = inst == 3 ? reinterpret_cast<const void *>(&sd_sift<false, SIFT_CAP_DEFAULT>) : inst == 2 ? reinterpret_cast<const void *>(&sd_sift<false>)
                              : inst ? reinterpret_cast<const void *>(&sdust_w64<true>) : reinterpret_cast<const void *>(&sdust_w64<false>);
             if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return cn_fail(h, CORNETTO_E_HIP, "sdust: hipFuncGetAttributes failed");
-            if (fa.localSizeBytes != 0 && !env_int("CORNETTO_SDUST_ALLOW_SCRATCH", 0))
+            if (fa.localSizeBytes != 0 && !CN_DEV_INT("CORNETTO_SDUST_ALLOW_SCRATCH", 0))
                 return cn_fail(h, CORNETTO_E_HIP, "sdust: kernel%s built with %zu bytes of scratch per lane (register spills): refusing to run it",
                                inst == 1 ? " (statistics build)" : inst >= 2 ? " sd_sift" : "", (size_t)fa.localSizeBytes);
         }
@@ -1691,12 +1685,12 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
         h->sd_slots = per_cu * cus;
         h->sd_cus = cus;
     }
-    const int64_t sd_waves = w64_path ? env_int("CORNETTO_SDUST_WAVES", std::max(1, h->sd_slots / h->sd_cus * h->share / 100) * h->sd_cus) : 0;
+    const int64_t sd_waves = w64_path ? CN_DEV_INT("CORNETTO_SDUST_WAVES", std::max(1, h->sd_slots / h->sd_cus * h->share / 100) * h->sd_cus) : 0;
 
     // chunk = bases per lane.  Small enough that a long low-complexity array is shared by many waves, large
     // enough that the ~3W-base speculative warm-up stays a few percent.  CORNETTO_SDUST_CHUNK overrides
     // (tests use tiny chunks to stress the speculative start).
-    int64_t chunk = env_int("CORNETTO_SDUST_CHUNK", 0);
+    int64_t chunk = CN_DEV_INT("CORNETTO_SDUST_CHUNK", 0);
     if (chunk <= 0) {
         // about 1536, adjusted so that the chunks come out as a whole number of rounds over the resident lanes: every
         // lane works through its chunks at the same pace, and 6.6 chunks per lane cost as much time as 7
@@ -1708,7 +1702,7 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
         }
     }
     chunk = std::max<int64_t>(16, chunk);
-    if (W > 257 && env_int("CORNETTO_SDUST_CHUNK", 0) <= 0) chunk = std::max<int64_t>(chunk, 32 * (int64_t)W);   // (warm-up: 3 W bases per chunk)
+    if (W > 257 && CN_DEV_INT("CORNETTO_SDUST_CHUNK", 0) <= 0) chunk = std::max<int64_t>(chunk, 32 * (int64_t)W);   // (warm-up: 3 W bases per chunk)
     // The sift / resolve stages (sdust_sift.hpp) take every chunk of plain letters; they want chunks of whole 64-base tiles,
     // at least 256 bases (the look-back of a chunk stays inside the chunk before it), at most 62 tiles.  CORNETTO_SDUST_SIFT=0 keeps the
     // per-lane recurrence of sdust_w64 for everything (also what an explicit chunk size outside that range does: the tests
@@ -1718,7 +1712,7 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
     // keeps the per-lane recurrence; -1 decides once per resident assembly from one 64-byte sample per 2048 bases (sift when at least 1 in
     // 256 lies inside a repeat array, for read-level sets and for assemblies below 2 Gbases) — how the choice was made while the
     // per-lane kernel was still ahead on uniform sequence.
-    const int sift_env = env_int("CORNETTO_SDUST_SIFT", 1);      // 1 (default) sift / resolve, 0 the per-lane recurrence, -1 decide by the sample
+    const int sift_env = CN_DEV_INT("CORNETTO_SDUST_SIFT", 1);      // 1 (default) sift / resolve, 0 the per-lane recurrence, -1 decide by the sample
     if (w64_path && sift_env < 0 && a->sd_auto < 0) {
         // (below ~2 Gbases the resident lanes of sdust_w64 have less than one chunk each and its time stops falling — one chunk is 4 ms
         // of sequential steps for a lane: 395 Mb take 4.7 ms against 1.0 ms in sd_sift, whose unit of work is a wave)
@@ -1744,7 +1738,7 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
     bool sift_on = w64_path && (sift_env > 0 || (sift_env < 0 && a->sd_auto == 1));
     // (its own default, SIFT_CHUNK_DEFAULT in sdust_sift.hpp: 1792 bases since round 5.  Rounds 3-4: 1536 bases = 26 tiles with the two in front; 7.2 KB of LDS per wave = six 1280-byte granules, 21 waves per
     // CU; 1792 needs a seventh granule: measured 6.85 against 7.2 ms on the 3.16 Gbp assembly)
-    if (sift_on && env_int("CORNETTO_SDUST_CHUNK", 0) <= 0) chunk = SIFT_CHUNK_DEFAULT;
+    if (sift_on && CN_DEV_INT("CORNETTO_SDUST_CHUNK", 0) <= 0) chunk = SIFT_CHUNK_DEFAULT;
     if (sift_on && (chunk % 64 != 0 || chunk < 256 || chunk > 3968)) sift_on = false;     // (64 tiles with the two in front)
     // Optionally the last part of the work is cut into shorter chunks, handed out last and in one pass: when the queue runs
     // dry every wave still has to finish the chunks its lanes hold, and a wave-step costs the same with 3 busy lanes as with
@@ -1752,8 +1746,8 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
     // 20 % / 4x 8.7-9.1, 20 % / 2x 8.5-9.0, 30 % / 4x 8.9-9.2 — the extra warm-ups cost what the shorter drain saves, so it is
     // OFF by default.  CORNETTO_SDUST_TAIL = percent of the bases, CORNETTO_SDUST_TAILDIV = how many times shorter (4).
     // Results do not depend on the decomposition.
-    const int tail_pct = sift_on ? 0 : std::min(90, std::max(0, env_int("CORNETTO_SDUST_TAIL", 0)));
-    const int tail_div = std::min(16, std::max(1, env_int("CORNETTO_SDUST_TAILDIV", 4)));
+    const int tail_pct = sift_on ? 0 : std::min(90, std::max(0, CN_DEV_INT("CORNETTO_SDUST_TAIL", 0)));
+    const int tail_div = std::min(16, std::max(1, CN_DEV_INT("CORNETTO_SDUST_TAILDIV", 4)));
     const int64_t small = std::max<int64_t>(64, (chunk / tail_div + 63) / 64 * 64);
     const int64_t tail_from = tail_pct > 0 && tail_div > 1 ? a->total - a->total * tail_pct / 100 : a->total + 1;   // in bases, assembly order
     const int64_t key = chunk + (int64_t)tail_pct * (1ll << 40) + (int64_t)tail_div * (1ll << 48) + (sift_on ? 1ll << 56 : 0);
@@ -1793,10 +1787,10 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
     // 28 / 31 ms, n = 4 27-32 / 34 ms, n = 8 35-40 / 38 ms: at 28 KB of LDS per dense wave only five fit on a CU, so more jobs
     // are more rounds (plus their warm-ups), not more waves per SIMD.  The split pays only once the dense state is smaller
     // (16-bit P slots, 12-bit ring entries: ~18 KB) — DESIGN.md section 8.
-    if (w64_path && !sift_on && !a->sd_refined && a->sd_n_chunks > 0 && env_int("CORNETTO_SDUST_ORDER", 1)) {
+    if (w64_path && !sift_on && !a->sd_refined && a->sd_n_chunks > 0 && CN_DEV_INT("CORNETTO_SDUST_ORDER", 1)) {
         a->sd_refined = true;
-        const int dense_mode = env_int("CORNETTO_SDUST_DENSE", 1);
-        const int split = std::min(16, std::max(1, env_int("CORNETTO_SDUST_DENSE_SPLIT", 1)));
+        const int dense_mode = CN_DEV_INT("CORNETTO_SDUST_DENSE", 1);
+        const int split = std::min(16, std::max(1, CN_DEV_INT("CORNETTO_SDUST_DENSE_SPLIT", 1)));
         const size_t n0 = (size_t)a->sd_n_chunks;
         if (dense_mode && split > 1) {
             uint8_t *d_f = (uint8_t *)cn_ws(h, WS_SD_PERM, n0 + 64);
@@ -1842,14 +1836,18 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
         unsigned long long *p_tot = (unsigned long long *)cn_pin(h, PIN_SMALL, 2048);
         if (!d_cnt || !d_tot || !p_tot) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
         uint32_t *d_off = d_cnt + nc, *d_part = d_off + nc;
-        const bool env_stats = env_int("CORNETTO_SDUST_STATS", 0) != 0;
+        const bool env_stats = CN_DEV_INT("CORNETTO_SDUST_STATS", 0) != 0;
         const bool want_stats = env_stats || h->sd_stats != 0;
         size_t cap = (size_t)std::max<int64_t>(16, chunk / 32);
-        cap = (size_t)env_int("CORNETTO_SDUST_CAP", (int)cap);
+        cap = (size_t)CN_DEV_INT("CORNETTO_SDUST_CAP", (int)cap);
         if (h->dev[WS_SD_OUT].bytes / (nc * sizeof(uint2)) > cap) cap = h->dev[WS_SD_OUT].bytes / (nc * sizeof(uint2));
         unsigned long long tot = 0;
         uint2 *d_out = nullptr;
-        if (phase == 1 && !(w64_path && sift_on && !want_stats && a->sd_est_key == key * 131 + T * 1031 + W && a->sd_est_rows >= 0 && env_int("CORNETTO_SDUST_FUSED", 1)))
+        // the rest of the call in one go (below) needs the counts the last call for this table left behind: ONE predicate for the early-out of
+        // cornetto_sdust_asm_begin() here and for the one-go form itself
+        const int64_t est_key = key * 131 + T * 1031 + W;
+        const bool one_go = w64_path && sift_on && !want_stats && a->sd_est_key == est_key && a->sd_est_rows >= 0 && CN_DEV_INT("CORNETTO_SDUST_FUSED", 1);
+        if (phase == 1 && !one_go)
             return CORNETTO_OK;                        // (nothing to size the rest of the call by: cornetto_sdust_asm_end runs it)
         for (int attempt = 0; attempt < 4; ++attempt) {
             d_out = (uint2 *)cn_ws(h, WS_SD_OUT, nc * cap * sizeof(uint2));
@@ -1861,7 +1859,7 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
             const bool use_w64 = w64_path;                              // CORNETTO_SDUST_VARIANT=1 forces the per-lane reference-shaped kernel
             SdArgs A{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, d_out, d_cnt, (uint32_t)cap,
                      want_stats ? d_tot + 2 : nullptr, reinterpret_cast<uint32_t *>(d_tot + 1), d_slots, nullptr,
-                     reinterpret_cast<uint32_t *>(d_tot + 8), nullptr, 0, env_int("CORNETTO_SDUST_RUNON", 1), (int32_t)chunk, a->d_wtab, a->d_wtab_base, reinterpret_cast<uint32_t *>(d_tot + 1) + 1};
+                     reinterpret_cast<uint32_t *>(d_tot + 8), nullptr, 0, CN_DEV_INT("CORNETTO_SDUST_RUNON", 1), (int32_t)chunk, a->d_wtab, a->d_wtab_base, reinterpret_cast<uint32_t *>(d_tot + 1) + 1};
             unsigned nb = (unsigned)((nc + 63) / 64);
             bool sift_walk_pending = false;
             bool dense_pending = false;
@@ -1892,8 +1890,8 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
                 uint32_t *d_wflag = a->d_sd_walk + 2 + nc, *d_wrank = d_wflag + nc, *d_worder = d_wrank + nc, *d_wpart = d_worder + nc;
                 SiftArgs S{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, lds_wave, reg_cap,
                            walk_known ? d_worder : nullptr, walk_known ? nullptr : a->d_sd_walk, walk_known ? nullptr : d_wflag,
-                           reinterpret_cast<uint32_t *>(d_tot + 256), T / 10 + 1, lmin, env_int("CORNETTO_SIFT_ABL", 0),
-                           std::min(65, std::max(1, env_int("CORNETTO_SIFT_DP", 24))), std::min(65, std::max(1, env_int("CORNETTO_SIFT_L2SKIP", 48)))};
+                           reinterpret_cast<uint32_t *>(d_tot + 256), T / 10 + 1, lmin, CN_DEV_INT("CORNETTO_SIFT_ABL", 0),
+                           std::min(65, std::max(1, CN_DEV_INT("CORNETTO_SIFT_DP", 24))), std::min(65, std::max(1, CN_DEV_INT("CORNETTO_SIFT_L2SKIP", 48)))};
                 sift_walk_pending = !walk_known;
                 SdArgs R = A;
                 R.stats = want_stats ? d_tot + 200 : nullptr;
@@ -1901,7 +1899,7 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
                 // when another stream computes beside this one (cornetto_accel_set_share): a launch of one workgroup per chunk keeps
                 // the other stream's kernels waiting until it is through (13.1 instead of 9 ms per bench step).  The waves take their
                 // chunks from one counter (static strides were measured 10-50 % slower: chunks differ a lot in cost; 64 counters: one was a 14 ns serial point).
-                const bool cap_default = reg_cap == SIFT_CAP_DEFAULT && !env_int("CORNETTO_SIFT_GENERIC", 0) && !env_int("CORNETTO_SIFT_ABL", 0);     // (the build with the buffer size as a literal)
+                const bool cap_default = reg_cap == SIFT_CAP_DEFAULT && !CN_DEV_INT("CORNETTO_SIFT_GENERIC", 0) && !CN_DEV_INT("CORNETTO_SIFT_ABL", 0);     // (the build with the buffer size as a literal)
                 if (h->sift_per_cu == 0 || h->sift_per_cu_default != (cap_default ? 1 : 0)) {
                     int per_cu = 0;
                     const hipError_t oe = cap_default ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sd_sift<false, SIFT_CAP_DEFAULT>, 64 * SIFT_WPB, lds_wave * SIFT_WPB)
@@ -1919,7 +1917,7 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
                 const size_t slots_all = (size_t)per_cu_all * cus_n;
                 const size_t slots = free_now ? slots_all : std::max<size_t>(cus_n, slots_all * (size_t)h->share / 100);
                 const size_t all_blocks = (nc + SIFT_WPB - 1) / SIFT_WPB;
-                const unsigned nbk = (unsigned)std::min<size_t>(all_blocks, (size_t)env_int("CORNETTO_SIFT_BLOCKS", (int)slots));
+                const unsigned nbk = (unsigned)std::min<size_t>(all_blocks, (size_t)CN_DEV_INT("CORNETTO_SIFT_BLOCKS", (int)slots));
                 // The waves left to the other stream: when its owner says it is through (cornetto_accel_boost, from another host thread) while
                 // this kernel still runs, they are launched as a second kernel on a second stream — same arguments, same chunk counters: the two
                 // launches drain them together — and the stream of this call waits for both.  The helper must not start before the counters,
@@ -1930,7 +1928,7 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
                 // balanced step, 72-80 %, the other thread ends a few hundred microseconds before this kernel and the helper buys less than the
                 // call's tail loses by being queued only after the poll: 6.66 against 6.8-7.0 ms per step at 76 %, tools/ab_help.sh — so the
                 // helper is for shares below 70 % only)
-                const bool may_help = phase == 0 && extra > 0 && !want_stats && h->share < env_int("CORNETTO_SDUST_HELP_BELOW", 70);      // (its poll waits for the kernel: not in _begin)
+                const bool may_help = phase == 0 && extra > 0 && !want_stats && h->share < CN_DEV_INT("CORNETTO_SDUST_HELP_BELOW", 70);      // (its poll waits for the kernel: not in _begin)
                 if (may_help) {
                     if (!h->stream2) {
                         int pr_least = 0, pr_greatest = 0;
@@ -1978,15 +1976,15 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
                 const unsigned nbs = (unsigned)((nc + 255) / 256);
                 A.claim = d_claim;
                 A.q_len = (int32_t)nc;
-                if (!env_int("CORNETTO_SDUST_ORDER", 1)) {
+                if (!CN_DEV_INT("CORNETTO_SDUST_ORDER", 1)) {
                     CN_HIP(h, hipMemsetAsync(d_claim, 0, nc * 4, h->stream));
                     CN_HIP(h, hipMemsetAsync(d_cnt, 0, nc * 4, h->stream));      // chunks a lane runs on into publish nothing of their own
                 } else {
                     // CORNETTO_SDUST_DENSE: 1 (default) the chunks inside repeat arrays go to sdust_dense when there are enough of
                     // them to pay for it, 2 always (tests), 0 never (they stay in the main kernel's queue, first, one per wave)
-                    const int dense_mode = env_int("CORNETTO_SDUST_DENSE", 1);
+                    const int dense_mode = CN_DEV_INT("CORNETTO_SDUST_DENSE", 1);
                     SdPasses ps;
-                    ps.P = (uint32_t)std::min(64, std::max(1, env_int("CORNETTO_SDUST_PASSES", 8)));
+                    ps.P = (uint32_t)std::min(64, std::max(1, CN_DEV_INT("CORNETTO_SDUST_PASSES", 8)));
                     // The plan of a call — which chunks are sampled as low-complexity, the order of the queue, the list for the
                     // dense kernel, the initial claim flags — depends on the resident assembly and the chunk table only: it is
                     // built by the first call and kept with the assembly (like the chunk table itself); later calls copy the
@@ -2105,10 +2103,9 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
             // ---- the rest of the call in one go when the last call for this table left its counts behind (round 4): gather, merge (one
             // launch that reads the number of rows from the device) and the result copy are sized by them, ONE synchronisation, and
             // the counts are checked afterwards — anything that does not fit takes the steps below as before
-            const int64_t est_key = key * 131 + T * 1031 + W;
-            if (sift_on && !want_stats && a->sd_est_key == est_key && a->sd_est_rows >= 0 && env_int("CORNETTO_SDUST_FUSED", 1)) {
+            if (one_go) {
                 size_t n_cap = (size_t)(a->sd_est_rows + a->sd_est_rows / 8 + 4096);
-                if (env_int("CORNETTO_SDUST_EST_FORCE", 0) > 0) n_cap = (size_t)env_int("CORNETTO_SDUST_EST_FORCE", 0);   // (tests: an estimate that does not hold)
+                if (CN_DEV_INT("CORNETTO_SDUST_EST_FORCE", 0) > 0) n_cap = (size_t)CN_DEV_INT("CORNETTO_SDUST_EST_FORCE", 0);   // (tests: an estimate that does not hold)
                 const size_t m_cap = (size_t)(a->sd_est_out + a->sd_est_out / 16 + 1024);
                 uint8_t *ws = (uint8_t *)cn_ws(h, WS_SD_DST, 2 * n_cap * sizeof(cornetto_ivl_t) + cnivl::ws_bytes(n_cap));
                 // (a pinned array whatever its size — the pool's smallest block is 1 MB —: a copy into plain memory is not asynchronous, and
@@ -2221,7 +2218,7 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
             stamp("results on the host");
         }
         if (sift_on) {                                 // what the next call for this table may count on
-            a->sd_est_key = key * 131 + T * 1031 + W;
+            a->sd_est_key = est_key;
             a->sd_est_rows = (int64_t)tot;
             a->sd_est_out = n_out;
         }

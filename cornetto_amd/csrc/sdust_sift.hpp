@@ -175,7 +175,11 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(C
     const uint32_t cap = CAP ? CAP : A.reg_cap;
     // development aid (CORNETTO_SIFT_ABL: stages switched off for instruction counting, results are wrong): only in the build without a
     // compile-time buffer size — in the production build its seven tests were seven lane masks held in scalar registers
+#ifdef CN_DEV
     const int abl = CAP ? 0 : A.abl;
+#else
+    constexpr int abl = 0;                            // (the ablations exist in the development build only: their results are wrong by design)
+#endif
     // rounds of 1024 bases the staging of a region takes: with the default size the two rounds whose bases the chunk loop has fetched ahead
     // (no third round, no address for it held through the kernel)
     constexpr int STAGE_ROUNDS = CAP ? (int)((CAP + 1023) / 1024) : 4;

@@ -42,7 +42,9 @@ int cornetto_panel_step(cornetto_accel_t *h, const cornetto_asm_t *asm_in, const
     CnCovSpec CS;
     CnTeloSpec TS;
     int rc = cn_cov_spec_queue(h, c, thr[0], thr[1], o->low_mq, o->edge_len, o->min_ctg_len, o->boring, p, &CS);
-    if (rc == CORNETTO_OK && CS.queued) rc = cn_telo_spec_queue(h, a, o->motif, o->thr_adj, p + 8, &TS);
+    // (queued whether or not the coverage side could be — no contig passes -m, or -w above the packed form's 32768: its exact entry point
+    // answers or refuses below, the telomere scan keeps its one synchronisation)
+    if (rc == CORNETTO_OK) rc = cn_telo_spec_queue(h, a, o->motif, o->thr_adj, p + 8, &TS);
     if (rc == CORNETTO_OK && (CS.queued || TS.queued)) {
         if (hipStreamSynchronize(h->stream) != hipSuccess) rc = cn_fail(h, CORNETTO_E_HIP, "panel_step: the queued scans failed");
     }

@@ -787,7 +787,7 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
             // the block from one call for THIS assembly's layout to the next: filled once per (assembly, block).  (Round 4, five bench runs each
             // way: 7.84-7.90 ms per 3.16 Gbp step without the 395 MB fill, 7.87-7.94 with it, one slow run of 8.2 in either; the 1/8 share of the
             // assembly 0.31 instead of 0.39 ms per call.  Round 3 had measured the opposite with the telomere scan first in the step.)
-            static const int refill = [] { const char *v = getenv("CORNETTO_TF_BITMAP_REFILL"); return v ? atoi(v) : 0; }();
+            static const int refill = CN_DEV_INT("CORNETTO_TF_BITMAP_REFILL", 0);
             if (refill || !(h->tf_bm_uid == a->uid && h->tf_bm_ptr == d_bitmap && h->tf_bm_words == words)) {
                 h->tf_bm_uid = 0;
                 CN_HIP(h, hipMemsetAsync(d_bitmap, 0, words * 8, h->stream));
@@ -1064,10 +1064,10 @@ int cn_telo_spec_queue(cornetto_accel_t *h, cornetto_asm_t *a, const char *motif
     }
     // lists, pairing and copies by the counts of last time plus head room
     size_t seg[4], tot_cap = 0;
-    const char *force = getenv("CORNETTO_STEP_EST_FORCE");                          // (tests: estimates that do not hold)
+    const int force = CN_DEV_INT("CORNETTO_STEP_EST_FORCE", 0);                          // (tests: estimates that do not hold)
     for (int q = 0; q < 4; ++q) {
         seg[q] = (size_t)a->tf_est_cnt[q] + (size_t)a->tf_est_cnt[q] / 16 + 1024;
-        if (force) seg[q] = (size_t)std::max(1, atoi(force));
+        if (force) seg[q] = (size_t)std::max(1, force);
         if (seg[q] > 0x7fffffffull) return CORNETTO_OK;
         S->seg_cap[q] = seg[q];
     }
@@ -1078,7 +1078,7 @@ int cn_telo_spec_queue(cornetto_accel_t *h, cornetto_asm_t *a, const char *motif
     unsigned long long *d_twcnt = (unsigned long long *)cn_ws(h, WS_TW_CNT, 16);
     const size_t win_ws_cap = std::max<size_t>(1u << 16, h->dev[WS_TW_OUT].bytes / sizeof(int4));
     int4 *d_wout = (int4 *)cn_ws(h, WS_TW_OUT, win_ws_cap * sizeof(int4));
-    const size_t win_cap = force ? std::min<size_t>(win_ws_cap, (size_t)std::max(1, atoi(force) / 64))
+    const size_t win_cap = force ? std::min<size_t>(win_ws_cap, (size_t)std::max(1, force / 64))
                                  : std::min<size_t>(win_ws_cap, (size_t)a->tf_est_wins + (size_t)a->tf_est_wins / 8 + 1024);
     int4 *p_wins = (int4 *)cn_pin(h, PIN_TW, win_cap * sizeof(int4));
     if (!d_dense || !d_coff || !d_hits || !d_twcnt || !d_wout || !p_wins) return cn_fail(h, CORNETTO_E_NOMEM, "telo_scan: workspace allocation failed");
@@ -1092,7 +1092,7 @@ int cn_telo_spec_queue(cornetto_accel_t *h, cornetto_asm_t *a, const char *motif
     } guard{h, &out};
 
     CN_HIP(h, hipMemsetAsync(d_cnt, 0, 64, h->stream));
-    static const int refill = [] { const char *v = getenv("CORNETTO_TF_BITMAP_REFILL"); return v ? atoi(v) : 0; }();
+    static const int refill = CN_DEV_INT("CORNETTO_TF_BITMAP_REFILL", 0);
     if (refill || !(h->tf_bm_uid == a->uid && h->tf_bm_ptr == d_bitmap && h->tf_bm_words == words)) {
         h->tf_bm_uid = 0;
         CN_HIP(h, hipMemsetAsync(d_bitmap, 0, words * 8, h->stream));

@@ -15,7 +15,10 @@
  *   - result arrays are allocated by the library (malloc, or pinned host memory from a pool for large
  *     results) and MUST be released with cornetto_free(), never free(); the one exception is
  *     cornetto_sdust(), which keeps the reference's contract (caller free()s);
- *   - calls are synchronous; one cornetto_accel_t may be used by one host thread at a time;
+ *   - calls are synchronous; one cornetto_accel_t may be used by one host thread at a time, and so may one
+ *     cornetto_asm_t / cornetto_cov_t: a resident object caches its decomposition tables and the result counts of
+ *     its last scan (what the next scan's buffers are sized by), so scans of the same object from two handles must
+ *     not run at the same moment (two handles over two objects that wrap the same device memory may);
  *   - coordinates are 0-based, half-open, per contig, 32-bit (kseq_read returns int: src/kseq.h:185).
  */
 #ifndef CORNETTO_ACCEL_H
@@ -311,7 +314,8 @@ int cornetto_cov_select_packed(cornetto_accel_t *h, const cornetto_cov_t *c, int
  * point).  `exchange`, if not NULL, is called once with the three sums of THIS process's contigs and replaces them by the sums
  * over all processes (one rank per GPU: a 3 x int64 all-reduce — the one exchange the path has, :283-294 -> :518-519); it returns 0
  * or an error.  sums[] and thr[] (low, high) are returned; result arrays as from the single entry points (cornetto_free / free).
- * With lazy copies (cornetto_accel_set_lazy) the contents of recs / hits are complete after cornetto_accel_wait(). */
+ * With lazy copies (cornetto_accel_set_lazy) the contents of recs / hits are complete after cornetto_accel_wait().
+ * window_size above 32768 is CORNETTO_E_UNSUPPORTED here as in cornetto_cov_select_packed() (the packed record's 16-bit means). */
 typedef struct {
     const char *motif;              /* telofind motif (src/find_telomere.c:101-105) */
     double thr_adj;                 /* cornetto_telowin_threshold() */

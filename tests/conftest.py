@@ -25,3 +25,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def dacc():
+    """a handle of the DEVELOPMENT build of the library (libcornetto_hip_dev.so: the same sources with -DCN_DEV), the only build that reads
+    the development switches (CORNETTO_SDUST_CHUNK, CORNETTO_SDUST_SIFT, CORNETTO_SIFT_DP, *_EST_FORCE ...) from the environment; the tests
+    that force decompositions, kernel families and failing estimates use it, everything else runs on the product build"""
+    import cornetto_amd
+    a = cornetto_amd.Accel(0, dev=True)
+    yield a
+    a.close()

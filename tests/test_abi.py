@@ -30,6 +30,28 @@ def test_exports_every_declared_symbol(lib):
     assert sorted(lib._declared) == names
 
 
+def test_the_product_build_has_no_development_switches():
+    """every environment name the library sources mention (csrc/: CN_DEV_INT("CORNETTO_...")) is in the development build and NOT in the product
+    build, whose only environment variable is CORNETTO_DEVICE: no knob in the shipped library can change what a scan returns (round 5's
+    CORNETTO_SIFT_ABL did); the development build exports the same entry points"""
+    import cornetto_amd
+    srcdir = os.path.join(ROOT, "cornetto_amd", "csrc")
+    names = set()
+    for f in os.listdir(srcdir):
+        if f.endswith((".hip", ".hpp")):
+            names |= set(re.findall(r'CN_DEV_INT\("(CORNETTO_[A-Z0-9_]+)"', open(os.path.join(srcdir, f)).read()))
+            assert not re.findall(r'getenv\("CORNETTO_(?!DEVICE")', open(os.path.join(srcdir, f)).read()), f
+    assert len(names) >= 25 and "CORNETTO_SIFT_ABL" in names and "CORNETTO_SDUST_EST_FORCE" in names
+    prod = open(cornetto_amd.LIB_PATH, "rb").read()
+    dev = open(cornetto_amd.DEV_LIB_PATH, "rb").read()
+    in_prod = set(m.decode() for m in re.findall(rb"CORNETTO_[A-Z0-9_]+", prod))
+    assert in_prod == {"CORNETTO_DEVICE"}, in_prod
+    for n in names:
+        assert n.encode() in dev, n
+    d = cornetto_amd.lib(dev=True)
+    assert sorted(d._declared) == declared_symbols()
+
+
 def test_no_device_is_a_status_not_a_fallback(lib):
     import ctypes as C
     import torch

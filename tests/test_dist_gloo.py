@@ -144,3 +144,173 @@ def test_plain_bench_with_several_gpus_starts_its_own_ranks_or_refuses():
         pytest.skip("two GPUs visible: the launch is tested by tests/test_gpu_bench_ranks.py")
     assert p.returncode == 3, p.stderr.decode(errors="replace")[-2000:]
     assert p.stdout == b"" and b"refusing" in p.stderr
+
+
+# ---- contigs larger than the fair share: pieces with halos (cornetto_amd.dist.SplitPlan) -----------------------------------------------
+
+HIT_DT = np.dtype([("ctg", "<i4"), ("strand", "<i4"), ("start", "<i4"), ("end", "<i4")])
+WIN_DT = np.dtype([("ctg", "<i4"), ("start", "<i4"), ("end", "<i4"), ("car", "<i4")])
+REG_DT = np.dtype([("ctg", "<i4"), ("st", "<i4"), ("end", "<i4"), ("depth", "<i4"), ("mq_depth", "<i4")])
+
+
+def split_case(scale=1):
+    """three contigs, the first 70 % of the bases; around the middle of the first (where a two-rank plan wants its cut): an N run on the ideal
+    position, a telomere array in front of it (no clean position on that side for 12 kb), an (AC)n array behind it — the first clean position lies
+    INSIDE that array, so sdust intervals cross the cut and must be put together again; N runs, poly-A and lower case elsewhere"""
+    rng = np.random.default_rng(2024)
+    lens = [4_200_000 * scale, 1_000_000 * scale, 800_000 * scale]
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs, depth, mq = [], [], []
+    for n in lens:
+        s = acgt[rng.integers(0, 4, size=n)].copy()
+        for p in range(20000, n - 20000, 150000):
+            kind = (p // 150000) % 4
+            if kind == 0:
+                s[p:p + 240] = ord("A")
+            elif kind == 1:
+                s[p:p + 300] = ord("N")
+                s[p + 310:p + 400] = np.frombuffer(b"AC" * 45, dtype=np.uint8)
+            elif kind == 2:
+                s[p:p + 600] = np.frombuffer(b"TTAGGG" * 100, dtype=np.uint8)
+            else:
+                s[p:p + 500] |= 0x20
+        s[:6000] = np.frombuffer(b"CCCTAA" * 1000, dtype=np.uint8)
+        s[n - 3000:] = np.frombuffer(b"TTAGGG" * 500, dtype=np.uint8)
+        seqs.append(s)
+        d = rng.poisson(30, size=(n + 999) // 1000).repeat(1000)[:n].astype(np.int64) + rng.integers(-2, 3, size=n)
+        d = np.clip(d, 0, 65535)
+        q = d.copy()
+        for p in range(40000, n - 70000, 90000):
+            if (p // 90000) % 2:
+                d[p:p + 7000] //= 5
+                q[p:p + 7000] = d[p:p + 7000]
+            else:
+                q[p + 20000:p + 31000] //= 4
+        depth.append(d.astype(np.uint16))
+        mq.append(q.astype(np.uint16))
+    ideal = int(round(sum(lens) / 2.0 / 1600)) * 1600            # where a two-rank plan wants its border: half of the bases, inside contig 0
+    s = seqs[0]
+    s[ideal - 50:ideal + 50] = ord("N")
+    s[ideal - 12000:ideal - 4002] = np.frombuffer(b"TTAGGG" * 1333, dtype=np.uint8)
+    s[ideal + 3000:ideal + 12000] = np.frombuffer(b"AC" * 4500, dtype=np.uint8)
+    return lens, seqs, depth, mq, ideal
+
+
+def oracle_scan(seq, d, q, thr):
+    """one sequence through the CPU oracle: (hits, wins, sdust intervals, all coverage windows) with ctg = 0"""
+    import oracle_bind as ob
+    oh = ob.telofind(seq, b"TTAGGG")
+    hits = np.array([(0, int(h["strand"]), int(h["start"]), int(h["end"])) for h in oh], dtype=HIT_DT)
+    wins = np.array([(0, int(w["start"]), int(w["end"]), int(w["car"])) for w in ob.telowin(oh, len(seq), thr)], dtype=WIN_DT)
+    ivls = np.array([(0, int(x) >> 32, int(x) & 0xFFFFFFFF) for x in ob.sdust(seq, 20, 64)], dtype=IVL_DT)
+    r = ob.get_regs(d, q, 2500, 50)
+    regs = np.zeros(len(r), dtype=REG_DT)
+    for k in ("st", "end", "depth", "mq_depth"):
+        regs[k] = r[k]
+    return hits, wins, ivls, regs
+
+
+def _cat(parts, dt):
+    parts = [p for p in parts if len(p)]
+    return np.concatenate(parts) if parts else np.zeros(0, dtype=dt)
+
+
+def scan_pieces(plan, rank, seqs, depth, mq, thr, scan=oracle_scan):
+    """what a rank does: its pieces as sequences of their own, the records moved to contig coordinates and cut down to what the piece owns;
+    the three sums without the halos"""
+    H, Wn, I, R = [], [], [], []
+    sums = np.zeros(3, dtype=np.int64)
+    for li, (ci, s, e, lo, hi) in enumerate(plan.pieces[rank]):
+        h, w, iv, rg = scan(seqs[ci][lo:hi], depth[ci][lo:hi], mq[ci][lo:hi], thr)
+        for a in (h, w, iv, rg):
+            a["ctg"] = li
+        H.append(h), Wn.append(w), I.append(iv), R.append(rg)
+        sums += (int(depth[ci][lo:hi].astype(np.int64).sum()), int(mq[ci][lo:hi].astype(np.int64).sum()), hi - lo)
+    for ci, a, b in plan.halo_ranges(rank):
+        sums -= (int(depth[ci][a:b].astype(np.int64).sum()), int(mq[ci][a:b].astype(np.int64).sum()), b - a)
+    return (plan.own_points(rank, _cat(H, HIT_DT), "start"), plan.own_points(rank, _cat(Wn, WIN_DT), "start"),
+            plan.own_intervals(rank, _cat(I, IVL_DT)), plan.own_points(rank, _cat(R, REG_DT), "st"), sums)
+
+
+def _whole(lens, seqs, depth, mq, thr):
+    out = [[], [], [], []]
+    for ci in range(len(lens)):
+        for k, a in enumerate(oracle_scan(seqs[ci], depth[ci], mq[ci], thr)):
+            a["ctg"] = ci
+            out[k].append(a)
+    return [_cat(out[0], HIT_DT), _cat(out[1], WIN_DT), _cat(out[2], IVL_DT), _cat(out[3], REG_DT)]
+
+
+def _split_worker(rank, world, port, q):
+    from cornetto_amd.dist import SplitPlan, make_clean, order_records, stitch_intervals
+    import oracle_bind as ob
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lens, seqs, depth, mq, ideal = split_case()
+    plan = SplitPlan(lens, world, clean=make_clean(lambda ci, lo, hi: seqs[ci][lo:hi]), min_piece=100000, min_ctg_len=100000)
+    thr = ob.telowin_threshold(0.4, 99.9)
+    hits, wins, ivls, regs, sums = scan_pieces(plan, rank, seqs, depth, mq, thr)
+    gl = plan.global_ctg(rank)
+    g = [gather_records(a, gl) for a in (hits, wins, ivls, regs)]
+    tot = allreduce_sums(sums)
+    if rank == 0:
+        res = [order_records(g[0], ("strand", "start")), order_records(g[1], ("start",)), stitch_intervals(g[2]), order_records(g[3], ("st",))]
+        q.put(([r.tolist() for r in res], tot, plan.cuts, [[tuple(int(x) for x in p) for p in pp] for pp in plan.pieces], ideal))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_a_contig_larger_than_the_fair_share_is_cut_and_two_ranks_equal_one():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, tot, cuts, pieces, ideal = q.get(timeout=500)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import oracle_bind as ob
+    lens, seqs, depth, mq, _ = split_case()
+    # the plan: contig 0 (70 % of the bases) in two pieces, the cut on the first clean position — inside the (AC)n array behind the N run
+    assert cuts[0] == [ideal + 4800] and cuts[1] == [] and cuts[2] == []
+    loads = [sum(p[2] - p[1] for p in pp) for pp in pieces]
+    assert max(loads) < 0.52 * sum(lens) and sorted(p[0] for pp in pieces for p in pp) == [0, 0, 1, 2]
+    exp = _whole(lens, seqs, depth, mq, ob.telowin_threshold(0.4, 99.9))
+    assert len(exp[0]) > 50 and len(exp[1]) > 20 and len(exp[2]) > 100 and len(exp[3]) > 100000
+    c = cuts[0][0]
+    assert any(r[0] == 0 and r[1] < c < r[2] for r in exp[2].tolist())        # an sdust interval of the one scan crosses the cut
+    for name, g, e in zip(("telofind", "telowin", "sdust", "coverage windows"), got, exp):
+        assert g == e.tolist(), name
+    assert tot == (sum(int(d.astype(np.int64).sum()) for d in depth), sum(int(x.astype(np.int64).sum()) for x in mq), sum(lens))
+
+
+def test_split_plan_leaves_an_assembly_without_large_contigs_alone_and_is_deterministic():
+    from cornetto_amd.dist import SplitPlan
+    from cornetto_amd.synth import contig_lengths
+    lens = contig_lengths(0)                                  # the HG002 assembly of the bench (100 contigs, the largest 242 Mb)
+    for world in (1, 2, 4, 8, 16):
+        plan = SplitPlan(lens, world, clean=lambda ci, lo, hi: True)
+        flat = sorted(p for pp in plan.pieces for p in pp)
+        if world <= 8:
+            assert not plan.any_split
+            assert [sorted(p[0] for p in pp) for pp in plan.pieces] == lpt_partition(lens, world)
+        else:                                                 # whole contigs: 22 % over the fair share
+            assert plan.any_split and max(plan.loads) < 1.001 * sum(lens) / world
+        # a partition of every contig into consecutive owned ranges
+        for ci, n in enumerate(lens):
+            own = [(p[1], p[2]) for p in flat if p[0] == ci]
+            assert own[0][0] == 0 and own[-1][1] == n and all(own[k][1] == own[k + 1][0] for k in range(len(own) - 1))
+    few = [250_000_000, 240_000_000, 100_000_000]
+    plan = SplitPlan(few, 8, clean=lambda ci, lo, hi: (lo // 1600) % 3 != 0)         # (two of three candidate positions are refused)
+    assert plan.any_split and max(plan.loads) < 1.15 * sum(few) / 8
+    assert plan.pieces == SplitPlan(few, 8, clean=lambda ci, lo, hi: (lo // 1600) % 3 != 0).pieces
+    for pp in plan.pieces:
+        for ci, s, e, lo, hi in pp:
+            assert s % plan.gran == 0 and (e % plan.gran == 0 or e == few[ci]) and lo == max(0, s - plan.halo) and hi == min(few[ci], e + plan.halo)

@@ -64,6 +64,19 @@ def test_two_ranks_strong_scaling_equals_one_rank():
     assert c["backend"] == ("nccl" if _n_gpus() >= 2 else "gloo") and c["distinct_devices"] == (_n_gpus() >= 2)
 
 
+@pytest.mark.timeout(1800)
+def test_two_ranks_over_pieces_of_cut_contigs_equal_one_rank():
+    """--split-tol -1: the ranks take [r, r + 1) x half of the bases, the contig the border falls into is cut on a clean position and both ranks
+    scan their piece of it with halos (cornetto_amd.dist.SplitPlan) — the records rank 0 puts together are those of the one-rank run"""
+    shared = [] if _n_gpus() >= 2 else ["--allow-shared-device"]
+    one = _run(1, ["--scaling", "strong"])
+    two = _run(2, ["--scaling", "strong", "--split-tol", "-1"] + shared)
+    assert two["config"].get("cut_contigs", 0) >= 1
+    assert one["determinism"]["identical"] and two["determinism"]["identical"]
+    assert two["gathered_digests"] == one["gathered_digests"]
+    assert two["config"]["bases_job"] == one["config"]["bases_job"]
+
+
 @pytest.mark.timeout(900)
 def test_ranks_sharing_a_device_are_refused():
     """a --gpus 2 run whose ranks land on ONE device must not print a multi-GPU line (exit 3) unless the test flag is given"""

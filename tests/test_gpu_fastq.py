@@ -158,17 +158,16 @@ def test_large_piece_many_reads(acc):
 
 
 # ---- through the CLI: `cornetto sdust reads.fastq` frames the records on the device ---------------------------------
-def test_config5_generator_100_mbases_vs_oracle(acc, monkeypatch):
-    """BASELINE config 5 at 100 Mbases: the SURVEY 8d generator (bench.make_fastq_piece: log-normal lengths 200 .. 200 000, every
+def test_config5_generator_100_mbases_vs_oracle(acc):
+    """BASELINE config 5 at 100 Mbases: the SURVEY 8d generator (synth.make_fastq_piece: log-normal lengths 200 .. 200 000, every
     fourth read with a homopolymer stretch) -> cornetto_fastq_split with the length test of `seq -m 10000` (src/seq.c:120) ->
     sdust per kept read; the oracle frames the same text (kseq restatement), filters by length and runs sdust read by read"""
     import sys
     import torch
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import bench
+    from cornetto_amd import synth
     from concurrent.futures import ThreadPoolExecutor
-    monkeypatch.delenv("CORNETTO_SDUST_SIFT", raising=False)
-    text_d, lens, off = bench.make_fastq_piece(torch, torch.device("cuda", 0), 100e6, 77)
+    text_d, lens, off = synth.make_fastq_piece(torch, torch.device("cuda", 0), 100e6, 77)
     text = text_d.cpu().numpy()
     del text_d
     assert lens.min() >= 200 and lens.max() <= 200_000 and 95e6 < lens.sum() < 105e6
@@ -178,7 +177,7 @@ def test_config5_generator_100_mbases_vs_oracle(acc, monkeypatch):
     iv = acc.sdust(reads, 20, 64)
     reads.close()
     kept = np.nonzero(lens >= 10000)[0]
-    hl = len(bench.FQ_HEAD % (0, 0))
+    hl = len(synth.FQ_HEAD % (0, 0))
     ob.lib()
 
     def one(i):

@@ -19,20 +19,20 @@ import oracle_bind as ob
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-THREADS = max(1, min(16, (os.cpu_count() or 2) - 1))
+THREADS = max(1, min(32, (os.cpu_count() or 2) - 1))
 
 
-def _make(lens, seed, profile="uniform", coverage=True):
+def _make(lens, seed, profile="uniform", coverage=True, dev=False):
     import torch
-    import bench
+    from cornetto_amd import synth
     import cornetto_amd
     dev = torch.device("cuda", 0)
-    bases, offs = bench.make_assembly(torch, dev, lens, seed, profile)
+    bases, offs = synth.make_assembly(torch, dev, lens, seed, profile)
     depth = mq = None
     if coverage:
-        depth, mq = bench.make_coverage(torch, dev, lens, offs, seed)
+        depth, mq = synth.make_coverage(torch, dev, lens, offs, seed)
     torch.cuda.synchronize()
-    acc = cornetto_amd.Accel(0)
+    acc = cornetto_amd.Accel(0, dev=dev)                  # dev: the development build of the library (the CORNETTO_SDUST_* switches exist there only)
     asm = acc.asm_wrap(bases.data_ptr(), offs, np.array(lens, dtype=np.int64))
     cov = acc.cov_wrap(depth.data_ptr(), mq.data_ptr(), offs, np.array(lens, dtype=np.int32)) if coverage else None
     return dict(torch=torch, acc=acc, asm=asm, cov=cov, lens=lens, offs=offs, bases=bases, depth=depth, mq=mq)
@@ -47,8 +47,8 @@ def _close(w):
 
 @pytest.fixture(scope="module")
 def world():
-    import bench
-    w = _make(bench.contig_lengths(1_000_000_000), 7)
+    from cornetto_amd import synth
+    w = _make(synth.contig_lengths(1_000_000_000), 7)
     yield w
     _close(w)
 
@@ -107,8 +107,8 @@ def test_the_bench_assembly_itself_every_contig_at_3gbp():
     """the exact workload `python bench.py` times — 3 160 108 082 bases in 100 contigs, seed 0xC0FFEE, with its coverage — EVERY contig against the
     oracle: telomere runs and windows, sdust intervals, every coverage window (63 M).  bench.py itself checks 5 contigs (453 Mbases) of it against the
     reference's own functions in the timed run; this is the other 86 %."""
-    import bench
-    lens = bench.contig_lengths(0)
+    from cornetto_amd import synth
+    lens = synth.contig_lengths(0)
     assert sum(lens) == 3_160_108_082 and len(lens) == 100
     w = _make(lens, 0xC0FFEE)
     try:
@@ -129,13 +129,13 @@ def test_the_bench_assembly_itself_every_contig_at_3gbp():
 @pytest.mark.parametrize("profile", ["humanlike", "satellite"])
 def test_the_repeat_rich_bench_assemblies_every_contig_at_3gbp(profile):
     """bench.py's other two workload profiles at their full 3.16 Gbp: sdust intervals and telomere runs / windows of EVERY contig against the oracle (the
-    stages the composition matters to: dp tiles, L2 skip, stepping, long chunks first).  2.4 minutes of 16 host cores for the two profiles (the oracle
-    walks find_perfect at every base of the arrays), so it runs on request only: CORNETTO_TEST_FULL=1 (green at the end of round 5:
-    profiles/r05_gpu_tests_full.log); the 1 Gbp tests of the same profiles below run always."""
-    if os.environ.get("CORNETTO_TEST_FULL", "0") in ("", "0"):
-        pytest.skip("set CORNETTO_TEST_FULL=1 (2.4 minutes)")
-    import bench
-    lens = bench.contig_lengths(0)
+    stages the composition matters to: dp tiles, L2 skip, stepping, long chunks first).  About 2.4 minutes of 16 host cores for the two profiles (the
+    oracle walks find_perfect at every base of the arrays); bench.py prints a number for each of these profiles, so the test runs always
+    (CORNETTO_TEST_FULL=0 skips it on a small host)."""
+    if os.environ.get("CORNETTO_TEST_FULL", "1") == "0":
+        pytest.skip("CORNETTO_TEST_FULL=0")
+    from cornetto_amd import synth
+    lens = synth.contig_lengths(0)
     w = _make(lens, 0xC0FFEE, profile, coverage=False)
     try:
         acc, asm = w["acc"], w["asm"]
@@ -150,14 +150,23 @@ def test_the_repeat_rich_bench_assemblies_every_contig_at_3gbp(profile):
 
 
 def test_sdust_decomposition_invariance_and_canonical_form(world, monkeypatch):
-    acc, asm = world["acc"], world["asm"]
-    a = acc.sdust(asm, 20, 64).copy()
-    monkeypatch.setenv("CORNETTO_SDUST_CHUNK", "4096")
-    b = acc.sdust(asm, 20, 64).copy()
-    monkeypatch.setenv("CORNETTO_SDUST_CHUNK", "777")
-    monkeypatch.setenv("CORNETTO_SDUST_ORDER", "0")
-    monkeypatch.setenv("CORNETTO_SDUST_WAVES", "1000")
-    c = acc.sdust(asm, 20, 64).copy()
+    """the product library's intervals (its one compiled-in decomposition) equal the development build's under other chunk sizes, orders and
+    wave counts over the same resident bases"""
+    import cornetto_amd
+    a = world["acc"].sdust(world["asm"], 20, 64).copy()
+    acc = cornetto_amd.Accel(0, dev=True)
+    asm = acc.asm_wrap(world["bases"].data_ptr(), world["offs"], np.array(world["lens"], dtype=np.int64))
+    try:
+        assert np.array_equal(a, acc.sdust(asm, 20, 64))
+        monkeypatch.setenv("CORNETTO_SDUST_CHUNK", "4096")
+        b = acc.sdust(asm, 20, 64).copy()
+        monkeypatch.setenv("CORNETTO_SDUST_CHUNK", "777")
+        monkeypatch.setenv("CORNETTO_SDUST_ORDER", "0")
+        monkeypatch.setenv("CORNETTO_SDUST_WAVES", "1000")
+        c = acc.sdust(asm, 20, 64).copy()
+    finally:
+        asm.close()
+        acc.close()
     assert len(a) > 10000
     assert np.array_equal(a, b) and np.array_equal(a, c)
     # canonical: by contig, start ascending, disjoint and non-adjacent (src/sdust/sdust.c:94-98)
@@ -269,11 +278,9 @@ def test_satellite_dense_1gbp_through_the_sift_stages(monkeypatch):
     """bench.py --profile satellite at 1 Gbp, the kernel family chosen from the sample of the bases (sift / resolve: 3 % of them
     lie in satellite arrays): canonical result, two calls equal, and the four smallest of the contigs that hold arrays — each
     of 12 Mb or more, arrays of 0.1-5 Mb — record for record against the oracle"""
-    import bench
-    monkeypatch.setenv("CORNETTO_SDUST_SIFT", "-1")          # (decided by the sample of the bases: sift, as by default)
-    monkeypatch.delenv("CORNETTO_SDUST_CHUNK", raising=False)
-    lens = bench.contig_lengths(1_000_000_000)
-    w = _make(lens, 0xC0FFEE, "satellite", coverage=False)
+    from cornetto_amd import synth
+    lens = synth.contig_lengths(1_000_000_000)
+    w = _make(lens, 0xC0FFEE, "satellite", coverage=False)             # (the product build: sift / resolve by default)
     try:
         acc, asm = w["acc"], w["asm"]
         acc.set_timing(2)
@@ -299,8 +306,8 @@ def test_humanlike_1gbp_against_the_oracle():
     L1-like diverged copies, microsatellites, 3 % satellite arrays: the composition the sieve of sd_sift is sensitive to.  Canonical
     result, two calls equal, several times the masked fraction of uniform sequence outside the arrays, and the eight smallest of
     the contigs of 12 Mb or more record for record against the oracle (sdust and telofind / telowin)"""
-    import bench
-    lens = bench.contig_lengths(1_000_000_000)
+    from cornetto_amd import synth
+    lens = synth.contig_lengths(1_000_000_000)
     w = _make(lens, 0xC0FFEE, "humanlike", coverage=False)
     try:
         acc, asm = w["acc"], w["asm"]
@@ -328,12 +335,12 @@ def test_satellite_dense_assembly_equals_the_oracle(monkeypatch, dense):
     """bench.py --profile satellite at 30 Mb: (CATTC)n / (GGAAT)n arrays over > 3 % of the bases, microsatellites,
     poly-A runs — thousands of consecutive low-complexity chunks: through sdust_dense beside the main kernel (2; the default
     takes that route from 1024 such chunks on) and through the main kernel's queue alone (0)"""
-    import bench
+    from cornetto_amd import synth
     monkeypatch.setenv("CORNETTO_SDUST_SIFT", "1" if dense == "sift" else "0")
     monkeypatch.setenv("CORNETTO_SDUST_DENSE", "1" if dense == "sift" else dense)
     monkeypatch.setenv("CORNETTO_SDUST_DENSE_SPLIT", "3")     # the flagged chunks cut in three on the first call (off by default)
-    lens = bench.contig_lengths(30_000_000)
-    w = _make(lens, 5, "satellite", coverage=False)
+    lens = synth.contig_lengths(30_000_000)
+    w = _make(lens, 5, "satellite", coverage=False, dev=True)
     try:
         acc, asm = w["acc"], w["asm"]
         thr = acc.telowin_threshold(0.4, 99.9)

@@ -121,17 +121,28 @@ SDUST_CASES = [
 @pytest.mark.parametrize("dense", ["2", "0", "sift"])
 @pytest.mark.parametrize("chunk", ["0", "16", "100", "256", "1000", "2048", "4096"])
 @pytest.mark.parametrize("fa,T,W,exp", SDUST_CASES)
-def test_sdust_golden(acc, golden_dir, monkeypatch, fa, T, W, exp, chunk, dense):
+def test_sdust_golden(dacc, golden_dir, monkeypatch, fa, T, W, exp, chunk, dense):
     """dense = "sift": the sift / resolve stages (chunk sizes they do not take fall back to the per-lane kernel by themselves);
     "2" / "0": the per-lane recurrence with / without its kernel for repeat arrays"""
+    acc = dacc                                   # the development build: the switches below exist there only
     monkeypatch.setenv("CORNETTO_SDUST_SIFT", "1" if dense == "sift" else "0")
     _sdust_golden(acc, golden_dir, monkeypatch, fa, T, W, exp, chunk, "1" if dense == "sift" else dense)
 
 
-def _sdust_golden(acc, golden_dir, monkeypatch, fa, T, W, exp, chunk, dense):
+@pytest.mark.parametrize("fa,T,W,exp", SDUST_CASES)
+def test_sdust_golden_product_build(acc, dacc, golden_dir, fa, T, W, exp):
+    """the product build (no switches: its one compiled-in configuration) against the reference's stdout, and the development build without
+    any switch set is the same configuration"""
+    recs = _records(golden_dir, fa)
+    assert gpu_sdust_text(acc, recs, T, W) == golden(golden_dir, exp)
+    assert gpu_sdust_text(dacc, recs, T, W) == golden(golden_dir, exp)
+
+
+def _sdust_golden(dacc, golden_dir, monkeypatch, fa, T, W, exp, chunk, dense):
     """chunk = bases per lane (0 = default heuristic); tiny chunks stress the speculative warm-up.  dense = 2: the chunks
     sampled as low-complexity always go to the per-lane kernel (sdust_dense) beside the main one (the default, 1, does that
     only when there are many of them), 0: everything to the main kernel"""
+    acc = dacc                                   # the development build: the switches below exist there only
     monkeypatch.setenv("CORNETTO_SDUST_CHUNK", chunk)
     monkeypatch.setenv("CORNETTO_SDUST_DENSE", dense)
     assert gpu_sdust_text(acc, _records(golden_dir, fa), T, W) == golden(golden_dir, exp)
@@ -265,7 +276,8 @@ def _rand_seqs(rng, n_seq, kind):
 @pytest.mark.parametrize("T,W,chunk", [(20, 64, "37"), (20, 64, "512"), (10, 32, "64"), (5, 64, "200"), (30, 16, "16"),
                                        (25, 100, "300"), (20, 8, "50"), (20, 257, "700"), (1, 3, "40"),
                                        (0, 64, "90"), (4, 64, "300"), (3, 20, "64"), (9, 64, "256"), (100, 64, "256")])
-def test_sdust_random_vs_oracle(acc, monkeypatch, T, W, chunk):
+def test_sdust_random_vs_oracle(dacc, monkeypatch, T, W, chunk):
+    acc = dacc                                   # the development build: the switches below exist there only
     monkeypatch.setenv("CORNETTO_SDUST_CHUNK", chunk)
     # a small grid: every lane takes many chunks from the queue, of unequal lengths, one after the other
     monkeypatch.setenv("CORNETTO_SDUST_WAVES", str(1 + (T + W) % 3))
@@ -284,9 +296,10 @@ def test_sdust_random_vs_oracle(acc, monkeypatch, T, W, chunk):
 
 
 @pytest.mark.parametrize("seed", list(range(48)))
-def test_sdust_random_thresholds_vs_oracle(acc, monkeypatch, seed):
+def test_sdust_random_thresholds_vs_oracle(dacc, monkeypatch, seed):
     """thresholds and windows drawn at random (T 5..120, W 3..66: m = T / 5 from 1 to 24, the bounds of the pass trigger change with
     every pair), chunk sizes down to a few windows, on random / tandem / two-letter sequences with non-bases"""
+    acc = dacc                                   # the development build: the switches below exist there only
     rng = np.random.default_rng(9000 + seed)
     T = int(rng.integers(5, 121))
     W = int(rng.integers(3, 67))
@@ -348,9 +361,10 @@ def _sift_stress_seq(rng, n, kind):
     (20, 64, "0", 0), (20, 64, "0", 1), (20, 64, "256", 0), (20, 64, "256", 1), (20, 64, "320", 1), (20, 64, "1024", 1),
     (20, 64, "3968", 1), (10, 32, "256", 1), (10, 32, "0", 0), (5, 64, "512", 1), (30, 16, "256", 1), (25, 66, "448", 1),
     (7, 20, "256", 0), (50, 50, "1792", 1), (100, 64, "0", 1), (12, 3, "256", 1), (20, 4, "256", 1), (20, 65, "640", 1)])
-def test_sdust_sift_vs_oracle(acc, monkeypatch, T, W, chunk, kind):
+def test_sdust_sift_vs_oracle(dacc, monkeypatch, T, W, chunk, kind):
     """the sift / resolve stages (sdust_sift.hpp) on sequences of many chunks: chunk borders inside repeat arrays, contigs that
     end inside an array, contigs shorter than a tile, chunks handed to the sequential kernel beside chunks that are not"""
+    acc = dacc                                   # the development build: the switches below exist there only
     monkeypatch.setenv("CORNETTO_SDUST_CHUNK", chunk)
     monkeypatch.setenv("CORNETTO_SDUST_SIFT", "1")
     rng = np.random.default_rng(4242 + T * 131 + W + int(chunk) + kind)
@@ -371,11 +385,12 @@ def test_sdust_sift_vs_oracle(acc, monkeypatch, T, W, chunk, kind):
 
 @pytest.mark.parametrize("dp,l2skip", [("1", "65"), ("1", "1"), ("24", "48"), ("65", "1"), ("65", "65"), ("8", "32")])
 @pytest.mark.parametrize("T,W,chunk", [(20, 64, "0"), (20, 66, "448"), (20, 65, "640"), (12, 40, "256"), (5, 7, "256"), (30, 16, "1024"), (2, 64, "0")])
-def test_sdust_dp_tiles_and_l2_skip_vs_oracle(acc, monkeypatch, T, W, chunk, dp, l2skip):
+def test_sdust_dp_tiles_and_l2_skip_vs_oracle(dacc, monkeypatch, T, W, chunk, dp, l2skip):
     """round 4: tiles resolved end-parallel (CORNETTO_SIFT_DP: from how many sifted positions per tile — 1: every tile that
     holds one, 65: none) and L1 batches that skip the second filter (CORNETTO_SIFT_L2SKIP) are scheduling choices: any
     superset of the inserting positions and either resolve stage give the reference's intervals.  Exact and diverged
     repeats of periods 1-7, chunk borders and contig ends inside them, hand-overs stepping -> dp -> dp -> stepping."""
+    acc = dacc                                   # the development build: the switches below exist there only
     monkeypatch.setenv("CORNETTO_SDUST_CHUNK", chunk)
     monkeypatch.setenv("CORNETTO_SDUST_SIFT", "1")
     monkeypatch.setenv("CORNETTO_SIFT_DP", dp)
@@ -407,8 +422,9 @@ def test_sdust_dp_tiles_and_l2_skip_vs_oracle(acc, monkeypatch, T, W, chunk, dp,
     assert got == exp, (T, W, chunk, dp, l2skip)
 
 
-def test_sdust_sift_off_equals_on(acc, monkeypatch):
+def test_sdust_sift_off_equals_on(dacc, monkeypatch):
     """CORNETTO_SDUST_SIFT=0 (the per-lane recurrence of sdust_w64 for every chunk) and the default give the same intervals"""
+    acc = dacc                                   # the development build: the switches below exist there only
     rng = np.random.default_rng(77)
     seqs = [_sift_stress_seq(rng, 400_000, 1), _sift_stress_seq(rng, 90_000, 0)]
     asm = acc.asm_upload(seqs)
@@ -420,10 +436,11 @@ def test_sdust_sift_off_equals_on(acc, monkeypatch):
     assert len(on) > 200 and np.array_equal(on, off)
 
 
-def test_sdust_fused_tail_with_an_estimate_that_does_not_hold(acc, monkeypatch):
+def test_sdust_fused_tail_with_an_estimate_that_does_not_hold(dacc, monkeypatch):
     """the one-launch tail of a repeated call (gather + st_fused + copy, sized by the last call's counts) when the counts of THIS call
     are larger than the estimate: no tile of st_fused may touch anything (rows beyond the estimate were never gathered, their heads
     would land behind the output block) and the call takes the long way — same intervals, on a fresh and on the grown workspace"""
+    acc = dacc                                   # the development build: the switches below exist there only
     rng = np.random.default_rng(515)
     seqs = [_sift_stress_seq(rng, 2_500_000, 1), _sift_stress_seq(rng, 90_000, 0)]
     asm = acc.asm_upload(seqs)
@@ -441,10 +458,11 @@ def test_sdust_fused_tail_with_an_estimate_that_does_not_hold(acc, monkeypatch):
     asm.close()
 
 
-def test_sdust_boost_from_another_thread_does_not_change_results(acc, monkeypatch):
+def test_sdust_boost_from_another_thread_does_not_change_results(dacc, monkeypatch):
     """cornetto_accel_set_share + cornetto_accel_boost: the resident sift waves take part of the chip; another host thread says "the rest is
     free now" while the call runs and the remaining waves are launched as a second kernel on the same chunk counters — same intervals,
     whenever the flag arrives (before the call, early, late, never)"""
+    acc = dacc                                   # the development build: the switches below exist there only
     import threading
     import time
     monkeypatch.setenv("CORNETTO_SDUST_SIFT", "1")
@@ -472,9 +490,10 @@ def test_sdust_boost_from_another_thread_does_not_change_results(acc, monkeypatc
     assert len(ref) > 5000
 
 
-def test_sdust_family_choice_by_sample_keeps_small_assemblies_on_the_sift_stages(acc, monkeypatch):
+def test_sdust_family_choice_by_sample_keeps_small_assemblies_on_the_sift_stages(dacc, monkeypatch):
     """CORNETTO_SDUST_SIFT=-1 (the choice by a sample of the bases): an assembly below 2 Gbases takes the sift stages whatever its
     composition (the per-lane kernel has a 4 ms floor); the intervals are the oracle's, plain or repeat-rich, call after call"""
+    acc = dacc                                   # the development build: the switches below exist there only
     monkeypatch.setenv("CORNETTO_SDUST_SIFT", "-1")
     monkeypatch.delenv("CORNETTO_SDUST_CHUNK", raising=False)
     rng = np.random.default_rng(5)
@@ -813,9 +832,10 @@ def test_cov_select_windows_whose_int_sums_wrap(w, inc):
     a.close()
 
 
-def test_sdust_repeatable_with_many_small_chunks(acc, golden_dir, monkeypatch):
+def test_sdust_repeatable_with_many_small_chunks(dacc, golden_dir, monkeypatch):
     """the chunk queue hands the chunks to different lanes / waves at different times on every run: 24 runs over
     ~100 k tiny chunks must all give the golden answer (a build of the kernel that spilled registers did not)"""
+    acc = dacc                                   # the development build: the switches below exist there only
     recs = _records(golden_dir, "mix.fa.gz")
     monkeypatch.setenv("CORNETTO_SDUST_CHUNK", "16")
     exp = golden(golden_dir, "mix.sdust.exp")
@@ -823,8 +843,9 @@ def test_sdust_repeatable_with_many_small_chunks(acc, golden_dir, monkeypatch):
         assert gpu_sdust_text(acc, recs, 20, 64) == exp, it
 
 
-def test_sdust_queue_and_order_do_not_change_results(acc, golden_dir, monkeypatch):
+def test_sdust_queue_and_order_do_not_change_results(dacc, golden_dir, monkeypatch):
     """the chunk queue (persistent waves), its low-complexity-first order and the grid size are scheduling only"""
+    acc = dacc                                   # the development build: the switches below exist there only
     recs = _records(golden_dir, "mix.fa.gz")
     monkeypatch.setenv("CORNETTO_SDUST_CHUNK", "100")
     exp = golden(golden_dir, "mix.sdust.exp")
@@ -845,10 +866,11 @@ def test_sdust_queue_and_order_do_not_change_results(acc, golden_dir, monkeypatc
 
 
 @pytest.mark.parametrize("chunk", ["64", "500", "1536", "1792"])
-def test_sdust_long_word_free_stretches_vs_oracle(acc, monkeypatch, chunk):
+def test_sdust_long_word_free_stretches_vs_oracle(dacc, monkeypatch, chunk):
     """more than 1024 bases without W-2 word emissions before a chunk: the lane's local backward scan gives
     up, the host builds the word-count table and reruns (sdust.hip, SD_SCAN_CAP) — still exact, including the
     stale-window quirk across the N-dense stretch"""
+    acc = dacc                                   # the development build: the switches below exist there only
     monkeypatch.setenv("CORNETTO_SDUST_CHUNK", chunk)
     rng = np.random.default_rng(int(chunk))
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -1037,9 +1059,10 @@ def test_lazy_result_copies_equal_the_synchronous_ones(acc):
 
 
 @pytest.mark.parametrize("sift", ["1", "0"])
-def test_launch_count_moves_with_every_resident_sdust_launch(acc, monkeypatch, sift):
+def test_launch_count_moves_with_every_resident_sdust_launch(dacc, monkeypatch, sift):
     """cornetto_accel_launch_count: readable from another thread while the call runs; bench.py waits for it to move before the other
     stream's first kernel (where the resident waves land decides how much room that stream finds on every CU)"""
+    acc = dacc                                   # the development build: the switches below exist there only
     import threading
     monkeypatch.setenv("CORNETTO_SDUST_SIFT", sift)
     rng = np.random.default_rng(11)

@@ -66,7 +66,8 @@ def test_first_call_queues_nothing_and_end_runs_it(acc):
         asm.close()
 
 
-def test_estimates_that_do_not_hold_take_the_long_way(acc):
+def test_estimates_that_do_not_hold_take_the_long_way(dacc):
+    acc = dacc                                   # the development build: the switches below exist there only
     asm, _ = _asm(acc, 13, n=4, lo=200000, hi=900000)
     try:
         ref = acc.sdust(asm, 20, 64).copy()

@@ -98,7 +98,7 @@ def test_panel_step_with_estimates_that_do_not_hold(monkeypatch, force):
     points answer; the step after it is queued again"""
     rng = np.random.default_rng(77)
     lens, seqs, depths, mqs = _workload(rng, n_ctg=8, scale=2)
-    a = cornetto_amd.Accel(0)
+    a = cornetto_amd.Accel(0, dev=True)               # the development build: CORNETTO_STEP_EST_FORCE exists there only
     asm = a.asm_upload(seqs)
     cov = a.cov_upload(depths, mqs)
     par = (b"TTAGGG", a.telowin_threshold(0.4, 99.9), 500, 50, 0.6, 1.4, 0.7, 1000, 5000, False)

@@ -933,7 +933,7 @@ def e2e_cli(R, cornetto_amd):
     return out
 
 
-def profile_parity(R, budget_bases=40_000_000):
+def profile_parity(R, budget_bases=45_000_000):
     """parity of the step's records on the workload currently loaded against the reference's own functions (oracle/_ref; the oracle port where
     that is absent) on the two smallest contigs that hold planted satellite arrays (make_assembly plants them in the contigs of at least 12 Mb),
     all four stages, record for record: the repeat-rich profiles print numbers of their own in the line, so they carry a check of their own"""

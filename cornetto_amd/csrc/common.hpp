@@ -277,6 +277,14 @@ struct DevBuf {
 };
 
 // ---- resident data sets -----------------------------------------------------------------------------
+// tiles.hpp: the prefix a table of pieces is filled from — first[c] = index of sequence c's first piece, n + 1 numbers — on the host and the device
+struct CnPrefix {
+    std::vector<int64_t> host;
+    int64_t *dev = nullptr;
+    size_t cap = 0;
+    void release() { if (dev) (void)hipFree(dev); dev = nullptr; cap = 0; }
+};
+
 struct cornetto_asm {
     const uint64_t uid = cn_uid_counter.fetch_add(1);
     const uint8_t *d_bases = nullptr;  // 1 B/base, every contig starts at a multiple of 64
@@ -300,10 +308,13 @@ struct cornetto_asm {
     int64_t tw_n_words = -1, tw_n_tiles = 0;   // telowin on the marks of a fused scan: words of the bitmap (-1: layout not built yet), window tiles
     int64_t *d_tw_boff = nullptr;
     int2 *d_tw_tiles = nullptr;
+    std::vector<int64_t> tw_boff;        //   first bit of every contig in the mark bitmap (host copy of d_tw_boff)
     int64_t sd_chunk = -1;               // sdust: chunk size the cached chunk table was built for
     std::vector<int32_t> sd_chunk_ctg;   // contig of every chunk
     void *d_sd_chunks = nullptr;
     int64_t sd_n_chunks = 0;
+    bool tf_warmed = false, sd_warmed = false;   // cn_result_prewarm has been called for the first scan of this object
+    CnPrefix sd_pref, tf_pref, tw_pref;  // tiles.hpp: first piece of every contig in the chunk / tile tables (host copy alive while its upload may be in flight)
     uint32_t *d_sd_plan = nullptr;       // sdust: {initial claim flags [n], queue order [n + 160], dense list [n]} of the cached plan
     int64_t sd_plan_key = -1, sd_plan_dense = 0;
     bool sd_refined = false;             // sdust: the flagged chunks of the table have been cut into shorter ones (or need not be)
@@ -344,13 +355,16 @@ struct cornetto_cov {
     std::vector<int32_t> n_reg;          // windows per contig for (w, inc)
     int32_t *d_n_reg = nullptr;
     int2 *d_cw_tiles = nullptr;          // window tiles of the last selection (mode, min_len)
-    std::vector<int2> cw_tiles;
+    int64_t n_cw_tiles = 0;
+    std::vector<int32_t> cw_first;       //   host copy of d_cw_first
     int32_t *d_cw_first = nullptr;       //   first of them of every contig (their number: the contig has none)
     int cw_mode = -1;
     int32_t cw_min_len = 0, cw_only = -2;
     // what the last packed selection gave, and for which parameters: the next one with the same parameters sizes its result copy by it
     // and checks afterwards (cornetto_panel_step: no round trip for the count); -1: none yet
     int64_t cw_est_key = -1, cw_est_cnt = -1;
+    bool cw_warmed = false;              // cn_result_prewarm has been called for the first selection over this object
+    CnPrefix cb_pref, cw_pref;           // tiles.hpp: as in cornetto_asm
 };
 
 // Development switches (chunk sizes, kernel-family selection, forced estimates, ablations): read from the environment ONLY in the development
@@ -358,6 +372,20 @@ struct cornetto_cov {
 // families load that one).  In the product build every switch is its default at compile time and the names do not exist in the binary
 // (tests/test_abi.py greps libcornetto_hip.so for them).
 #ifdef CN_DEV
+#include <time.h>
+// CORNETTO_TRACE=1 (development build): wall-clock stamps of the phases of a library call on stderr
+static inline void cn_trace(const char *what)
+{
+    static const int on = [] { const char *s = getenv("CORNETTO_TRACE"); return (s && *s) ? atoi(s) : 0; }();
+    if (!on) return;
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    static double t0 = 0.0;
+    const double now = t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+    if (t0 == 0.0) t0 = now;
+    fprintf(stderr, "[lib trace] %-32s %9.3f ms\n", what, now - t0);
+}
+#define CN_TRACE(what) cn_trace(what)
 static inline int cn_dev_int(const char *name, int dflt)
 {
     const char *s = getenv(name);
@@ -366,6 +394,7 @@ static inline int cn_dev_int(const char *name, int dflt)
 #define CN_DEV_INT(name, dflt) cn_dev_int(name, dflt)
 #else
 #define CN_DEV_INT(name, dflt) (dflt)
+#define CN_TRACE(what) ((void)0)
 #endif
 
 static inline int64_t cn_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -374,6 +403,7 @@ static inline int64_t cn_align_up(int64_t x, int64_t a) { return (x + a - 1) / a
 // pool of pinned host buffers, so the device-to-host copy runs at full PCIe rate and never page-faults on
 // fresh memory.  Either kind is released with cornetto_free() (runtime.hip).
 void *cn_result_alloc(size_t bytes);
+void cn_result_prewarm(size_t bytes);   // (runtime.hip)
 
 // An assembly object with room for n sequences of the given lengths in the resident layout (every sequence at a
 // multiple of 64, zero-filled, contig table on the device); the caller fills a->owned (runtime.hip).

@@ -22,6 +22,7 @@
 
 #include "common.hpp"
 #include "scan.hpp"
+#include "tiles.hpp"
 #include "ivlmerge.hpp"
 #include "internal.hpp"
 
@@ -502,6 +503,27 @@ int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int3
 
 }  // extern "C"
 
+// tiles.hpp: window tile j of contig i
+struct CwTileFill {
+    int2 *out;
+    __device__ void operator()(int64_t t, int ci, int64_t j) const { out[t] = make_int2(ci, (int)(j * 256)); }
+};
+// tiles.hpp: block tile j of contig i, and the same with the contig's length and offset in one 32-byte record (CbArgs::tmeta)
+struct CbTileFill {
+    int2 *tiles;
+    int4 *tmeta;
+    const int32_t *len;
+    const int64_t *off;
+    __device__ void operator()(int64_t t, int ci, int64_t j) const
+    {
+        const int b = (int)(j * CB_THREADS);
+        const unsigned long long o = (unsigned long long)off[ci];
+        tiles[t] = make_int2(ci, b);
+        tmeta[2 * t] = make_int4(ci, b, len[ci], 0);
+        tmeta[2 * t + 1] = make_int4((int)(uint32_t)o, (int)(uint32_t)(o >> 32), 0, 0);
+    }
+};
+
 int cn_cov_prepare_impl(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int32_t inc, uint64_t sums[3])
 {
     if (inc < 1) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "cov_prepare: needs window_inc >= 1 (got -i %d: the reference divides by it)", inc);
@@ -529,42 +551,34 @@ int cn_cov_prepare_impl(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int32
         c->cw_mode = -1;
         c->blk_off.assign(c->n + 1, 0);
         c->n_reg.assign(c->n, 0);
-        std::vector<int2> tiles;
         for (int32_t i = 0; i < c->n; ++i) {
             if (c->len[i] < 1) return cn_fail(h, CORNETTO_E_ARG, "cov_prepare: contig %d is empty (a bedgraph cannot produce that)", i);
             c->n_reg[i] = n_reg_host(c->len[i], w, inc);
-            const int64_t nb = cn_align_up((int64_t)c->n_reg[i] + q + 1, CB_THREADS);
-            c->blk_off[i + 1] = c->blk_off[i] + nb;
-            for (int64_t b = 0; b < nb; b += CB_THREADS) tiles.push_back(make_int2(i, (int)b));
+            c->blk_off[i + 1] = c->blk_off[i] + cn_align_up((int64_t)c->n_reg[i] + q + 1, CB_THREADS);
         }
         c->n_blk = c->blk_off[c->n];
-        c->n_cb_tiles = (int64_t)tiles.size();
+        // the block tiles on the device (tiles.hpp): tile j of contig i = its blocks j CB_THREADS ..., with what cov_blocks needs of the contig
+        const int64_t ntl = cntiles::prefix(h, c->cb_pref, c->n, [&](int32_t i) { return (c->blk_off[i + 1] - c->blk_off[i]) / CB_THREADS; });
+        if (ntl < 0) return cn_fail(h, CORNETTO_E_NOMEM, "cov_prepare: device allocation failed");
+        c->n_cb_tiles = ntl;
         if (c->d_blk) { (void)hipFree(c->d_blk); c->d_blk = nullptr; }
         if (c->d_blk_off) { (void)hipFree(c->d_blk_off); c->d_blk_off = nullptr; }
         if (c->d_cb_tiles) { (void)hipFree(c->d_cb_tiles); c->d_cb_tiles = nullptr; }
         if (c->d_cb_tmeta) { (void)hipFree(c->d_cb_tmeta); c->d_cb_tmeta = nullptr; }
         if (c->d_n_reg) { (void)hipFree(c->d_n_reg); c->d_n_reg = nullptr; }
-        const size_t nt = tiles.size();
+        const size_t nt = (size_t)ntl;
         if (nt == 0) { built.keep = true; return CORNETTO_OK; }
         // prefixes [n_blk] uint2, heads [n_blk] uint2, then two arrays of tile offsets [nt] u32 each
         if (hipMalloc((void **)&c->d_blk, (size_t)c->n_blk * sizeof(uint4) + 2 * nt * sizeof(uint32_t)) != hipSuccess ||
             hipMalloc((void **)&c->d_blk_off, (size_t)(c->n + 1) * 8) != hipSuccess ||
             hipMalloc((void **)&c->d_cb_tiles, nt * sizeof(int2)) != hipSuccess ||
+            hipMalloc((void **)&c->d_cb_tmeta, 2 * nt * sizeof(int4)) != hipSuccess ||
             hipMalloc((void **)&c->d_n_reg, (size_t)c->n * 4) != hipSuccess)
             return cn_fail(h, CORNETTO_E_NOMEM, "cov_prepare: device allocation failed");
-        CN_HIP(h, hipMemcpyAsync(c->d_cb_tiles, tiles.data(), nt * sizeof(int2), hipMemcpyHostToDevice, h->stream));
-        std::vector<int4> tmeta(2 * nt);
-        for (size_t k = 0; k < nt; ++k) {
-            const int32_t ci = tiles[k].x;
-            const unsigned long long o = (unsigned long long)c->off[ci];
-            tmeta[2 * k] = make_int4(ci, tiles[k].y, c->len[ci], 0);
-            tmeta[2 * k + 1] = make_int4((int)(uint32_t)o, (int)(uint32_t)(o >> 32), 0, 0);
-        }
-        if (hipMalloc((void **)&c->d_cb_tmeta, 2 * nt * sizeof(int4)) != hipSuccess) return cn_fail(h, CORNETTO_E_NOMEM, "cov_prepare: device allocation failed");
-        CN_HIP(h, hipMemcpyAsync(c->d_cb_tmeta, tmeta.data(), 2 * nt * sizeof(int4), hipMemcpyHostToDevice, h->stream));
-        CN_HIP(h, hipMemcpyAsync(c->d_blk_off, c->blk_off.data(), (size_t)(c->n + 1) * 8, hipMemcpyHostToDevice, h->stream));
-        CN_HIP(h, hipMemcpyAsync(c->d_n_reg, c->n_reg.data(), (size_t)c->n * 4, hipMemcpyHostToDevice, h->stream));
-        CN_HIP(h, hipStreamSynchronize(h->stream));   // `tiles` is a local
+        cntiles::fill<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->stream>>>(c->cb_pref.dev, c->n, ntl, CbTileFill{c->d_cb_tiles, c->d_cb_tmeta, c->d_len, c->d_off});
+        CN_HIP(h, hipGetLastError());
+        CN_HIP(h, hipMemcpyAsync(c->d_blk_off, c->blk_off.data(), (size_t)(c->n + 1) * 8, hipMemcpyHostToDevice, h->stream));   // (members of the object: alive
+        CN_HIP(h, hipMemcpyAsync(c->d_n_reg, c->n_reg.data(), (size_t)c->n * 4, hipMemcpyHostToDevice, h->stream));            //  while the copies run)
         built.keep = true;
     }
     const size_t nt = (size_t)c->n_cb_tiles;
@@ -606,6 +620,9 @@ int cn_cov_prepare_impl(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int32
     const unsigned nb64 = (unsigned)std::min<size_t>(1024, (nt + 255) / 256);
     CN_LAUNCH(h, "cov_total64", cov_total64<<<dim3(nb64), dim3(256), 0, h->stream>>>(d_t64, (int64_t)nt, d_grand));
     CN_HIP(h, hipMemcpyAsync(p_grand, d_grand, 16, hipMemcpyDeviceToHost, h->stream));
+    // (the selection that follows sizes its result behind its kernels the first time: a pinned block for a sixth of the windows in the packed
+    // form is made while the block sums run — cn_result_prewarm)
+    if (!c->cw_warmed && c->inc > 0 && (c->cw_warmed = true)) cn_result_prewarm((size_t)(c->total / c->inc / 6 + 1) * sizeof(cornetto_regpk_t));
     CN_HIP(h, hipStreamSynchronize(h->stream));
     sums[0] = p_grand[0];
     sums[1] = p_grand[1];
@@ -650,33 +667,32 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
     if (packed && !raw_packed) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "cov_select_packed: window size %d > 32768 (a wrapped sum's mean does not fit 16 bits)", w);
     const size_t raw_bytes = raw_packed ? sizeof(cornetto_regpk_t) : sizeof(cornetto_regrec_t);
     if (c->cw_mode != mode || c->cw_min_len != min_len || c->cw_only != only_ctg) {   // window tiles, cached
-        c->cw_tiles.clear();
-        for (int32_t i = 0; i < c->n; ++i) {
-            if (only_ctg >= 0 && i != only_ctg) continue;
-            if (mode == 1 && !(c->len[i] >= min_len)) continue;   // short contigs print one '.' line and no windows
-            if (mode == 2 && !(c->len[i] > min_len)) continue;
-            for (int32_t j = 0; j < c->n_reg[i]; j += 256) c->cw_tiles.push_back(make_int2(i, j));
-        }
+        // on the device (tiles.hpp): window tile j of contig i = its windows 256 j ...; the contigs the selection leaves out have none
+        const int64_t ntl = cntiles::prefix(h, c->cw_pref, c->n, [&](int32_t i) -> int64_t {
+            if (only_ctg >= 0 && i != only_ctg) return 0;
+            if (mode == 1 && !(c->len[i] >= min_len)) return 0;   // short contigs print one '.' line and no windows
+            if (mode == 2 && !(c->len[i] > min_len)) return 0;
+            return ((int64_t)c->n_reg[i] + 255) / 256;
+        });
+        if (ntl < 0) return cn_fail(h, CORNETTO_E_NOMEM, "cov: device allocation failed");
         if (c->d_cw_tiles) { (void)hipFree(c->d_cw_tiles); c->d_cw_tiles = nullptr; }
         if (c->d_cw_first) { (void)hipFree(c->d_cw_first); c->d_cw_first = nullptr; }
-        if (!c->cw_tiles.empty()) {
-            std::vector<int32_t> first((size_t)c->n + 1);
-            size_t ti = 0;
-            for (int32_t i = 0; i < c->n; ++i) {                 // tiles are in contig order
-                while (ti < c->cw_tiles.size() && c->cw_tiles[ti].x < i) ++ti;
-                first[i] = (int32_t)ti;                          // (a contig without tiles: the first tile of the next one that has — or their number)
-            }
-            if (hipMalloc((void **)&c->d_cw_tiles, c->cw_tiles.size() * sizeof(int2)) != hipSuccess || hipMalloc((void **)&c->d_cw_first, ((size_t)c->n + 1) * 4) != hipSuccess)
+        c->n_cw_tiles = ntl;
+        if (ntl > 0) {
+            // the first tile of every contig (a contig without tiles: the first tile of the next one that has — or their number)
+            c->cw_first.resize((size_t)c->n + 1);
+            for (int32_t i = 0; i <= c->n; ++i) c->cw_first[i] = (int32_t)c->cw_pref.host[i];
+            if (hipMalloc((void **)&c->d_cw_tiles, (size_t)ntl * sizeof(int2)) != hipSuccess || hipMalloc((void **)&c->d_cw_first, ((size_t)c->n + 1) * 4) != hipSuccess)
                 return cn_fail(h, CORNETTO_E_NOMEM, "cov: device allocation failed");
-            CN_HIP(h, hipMemcpyAsync(c->d_cw_tiles, c->cw_tiles.data(), c->cw_tiles.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
-            CN_HIP(h, hipMemcpyAsync(c->d_cw_first, first.data(), (size_t)c->n * 4, hipMemcpyHostToDevice, h->stream));
-            CN_HIP(h, hipStreamSynchronize(h->stream));   // `first` is a local
+            cntiles::fill<<<dim3((unsigned)((ntl + 255) / 256)), dim3(256), 0, h->stream>>>(c->cw_pref.dev, c->n, ntl, CwTileFill{c->d_cw_tiles});
+            CN_HIP(h, hipGetLastError());
+            CN_HIP(h, hipMemcpyAsync(c->d_cw_first, c->cw_first.data(), (size_t)c->n * 4, hipMemcpyHostToDevice, h->stream));   // (a member of the object)
         }
         c->cw_mode = mode;
         c->cw_min_len = min_len;
         c->cw_only = only_ctg;
     }
-    const size_t nt = c->cw_tiles.size();
+    const size_t nt = (size_t)c->n_cw_tiles;
     if (nt == 0) return CORNETTO_OK;                 // (spec: not queued — the exact call makes the empty result)
     const size_t nt_blk = (size_t)c->n_cb_tiles;
     const uint2 *d_pre = reinterpret_cast<const uint2 *>(c->d_blk), *d_head = d_pre + c->n_blk;

@@ -416,11 +416,13 @@ extern "C" int cornetto_fasta_split(cornetto_accel_t *h, const char *text, int64
     }
     CN_HIP(h, hipSetDevice(h->device));
     cn_timing_begin(h);
+    CN_TRACE("fasta_split: enter");
     const int64_t nt = (n + FQ_TILE - 1) / FQ_TILE;
     uint8_t *d_text = (uint8_t *)cn_ws(h, WS_FQ_TEXT, (size_t)n + 64);
     uint32_t *d_cnt = (uint32_t *)cn_ws(h, WS_FQ_CNT, ((size_t)2 * nt + (nt + 4095) / 4096 + 16) * 4 + 64);
     unsigned long long *p_small = (unsigned long long *)cn_pin(h, PIN_SMALL, 64);
     if (!d_text || !d_cnt || !p_small) return cn_fail(h, CORNETTO_E_NOMEM, "fasta_split: workspace allocation failed");
+    CN_TRACE("fasta_split: text workspace");
     uint32_t *d_off = d_cnt + nt, *d_part = d_off + nt;
     unsigned long long *d_tot = reinterpret_cast<unsigned long long *>(((uintptr_t)(d_part + (nt + 4095) / 4096 + 1) + 7) & ~(uintptr_t)7);
     uint32_t *d_bad = reinterpret_cast<uint32_t *>(d_tot + 3);
@@ -429,6 +431,7 @@ extern "C" int cornetto_fasta_split(cornetto_accel_t *h, const char *text, int64
     CN_TRY(cnscan::exclusive_u32(h, "fq_scan", d_cnt, nt, 1, d_off, d_part, d_tot));
     CN_HIP(h, hipMemcpyAsync(p_small, d_tot, 8, hipMemcpyDeviceToHost, h->stream));
     CN_HIP(h, hipStreamSynchronize(h->stream));
+    CN_TRACE("fasta_split: text up, newlines counted");
     const int64_t n_nl = (int64_t)p_small[0];
     const bool virt = text[n - 1] != '\n';     // the bytes behind the last newline are a line too (complete only if `final`)
     const int64_t n_lines = n_nl + (virt ? 1 : 0);
@@ -453,6 +456,7 @@ extern "C" int cornetto_fasta_split(cornetto_accel_t *h, const char *text, int64
     CN_HIP(h, hipMemcpyAsync(p_small, d_tot + 1, 16, hipMemcpyDeviceToHost, h->stream));
     CN_HIP(h, hipMemcpyAsync(p_u, d_bad, 4, hipMemcpyDeviceToHost, h->stream));
     CN_HIP(h, hipStreamSynchronize(h->stream));
+    CN_TRACE("fasta_split: lines, heads");
     const int64_t n_rec = (int64_t)p_small[0];
     if (p_small[1] > 0xFFFFFFFFull) return cn_fail(h, CORNETTO_E_ARG, "fasta_split: sequence bytes of one piece exceed 2^32");
     int64_t n_use = final ? n_rec : n_rec - 1;            // the last record of a piece that is not the last one may go on
@@ -495,11 +499,13 @@ extern "C" int cornetto_fasta_split(cornetto_accel_t *h, const char *text, int64
     *recs = out;
     *n_recs = n_use;
     *consumed = used;
+    CN_TRACE("fasta_split: record table");
     if (seqs) {
         std::vector<int32_t> lens((size_t)n_use);
         for (int64_t i = 0; i < n_use; ++i) lens[(size_t)i] = (int32_t)out[i].len;
         cornetto_asm_t *a = nullptr;
         int rc = cn_asm_alloc(h, lens.data(), (int32_t)n_use, &a);
+        CN_TRACE("fasta_split: assembly allocated");
         if (rc == CORNETTO_OK && n_use > 0) {
             cornetto_accel::Rec r1{"fa_linedst", cn_event(h), cn_event(h)}, r2{"fa_copy", cn_event(h), cn_event(h)};
             (void)hipEventRecord(r1.a, h->stream);
@@ -521,6 +527,7 @@ extern "C" int cornetto_fasta_split(cornetto_accel_t *h, const char *text, int64
             return rc;
         }
         *seqs = a;
+        CN_TRACE("fasta_split: sequences copied");
     }
     cn_timing_end(h);
     return CORNETTO_OK;

@@ -32,6 +32,7 @@
 
 #include "common.hpp"
 #include "scan.hpp"
+#include "tiles.hpp"
 #include "ivlmerge.hpp"
 
 namespace {
@@ -44,6 +45,17 @@ __device__ int sd_find_start(const SdArgs &A, const SdChunk ch, const uint8_t *s
 
 struct SdChunk {
     int32_t ctg, start, end;
+};
+// tiles.hpp: chunk j of contig c
+struct SdChunkFill {
+    SdChunk *out;
+    const int32_t *len;
+    int32_t chunk;
+    __device__ void operator()(int64_t t, int c, int64_t j) const
+    {
+        const int64_t s = j * chunk, e = s + chunk;
+        out[t] = SdChunk{c, (int32_t)s, (int32_t)(e < len[c] ? e : len[c])};
+    }
 };
 
 struct SdArgs {
@@ -1685,6 +1697,7 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
         h->sd_slots = per_cu * cus;
         h->sd_cus = cus;
     }
+    stamp("kernel attributes");
     const int64_t sd_waves = w64_path ? CN_DEV_INT("CORNETTO_SDUST_WAVES", std::max(1, h->sd_slots / h->sd_cus * h->share / 100) * h->sd_cus) : 0;
 
     // chunk = bases per lane.  Small enough that a long low-complexity array is shared by many waves, large
@@ -1751,6 +1764,26 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
     const int64_t small = std::max<int64_t>(64, (chunk / tail_div + 63) / 64 * 64);
     const int64_t tail_from = tail_pct > 0 && tail_div > 1 ? a->total - a->total * tail_pct / 100 : a->total + 1;   // in bases, assembly order
     const int64_t key = chunk + (int64_t)tail_pct * (1ll << 40) + (int64_t)tail_div * (1ll << 48) + (sift_on ? 1ll << 56 : 0);
+    if (a->sd_chunk != key && tail_pct == 0) {
+        // the table on the device (tiles.hpp): chunk j of contig c = [j chunk, min(len, (j + 1) chunk))
+        const int64_t nch = cntiles::prefix(h, a->sd_pref, a->n, [&](int32_t c) { return ((int64_t)a->len[c] + chunk - 1) / chunk; });
+        if (nch < 0) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: device allocation failed");
+        if (nch > 0x7fffffffll) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "sdust: too many chunks");
+        if (a->d_sd_chunks) { (void)hipFree(a->d_sd_chunks); a->d_sd_chunks = nullptr; }
+        if (nch > 0) {
+            if (hipMalloc(&a->d_sd_chunks, (size_t)nch * sizeof(SdChunk)) != hipSuccess)
+                return cn_fail(h, CORNETTO_E_NOMEM, "sdust: device allocation failed");
+            cntiles::fill<<<dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, h->stream>>>(a->sd_pref.dev, a->n, nch,
+                                                                                           SdChunkFill{reinterpret_cast<SdChunk *>(a->d_sd_chunks), a->d_len, (int32_t)chunk});
+            CN_HIP(h, hipGetLastError());
+        }
+        a->sd_tail0 = nch;
+        a->sd_chunk = key;
+        a->sd_n_chunks = nch;
+        a->sd_flagged = -1;
+        a->sd_refined = false;
+        a->sd_plan_key = -1;
+    }
     if (a->sd_chunk != key) {
         std::vector<SdChunk> chunks;
         int64_t seen = 0;
@@ -1828,6 +1861,7 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
     const size_t nc = (size_t)a->sd_n_chunks;
     cornetto_ivl_t *o = nullptr;
     int64_t n_out = 0;
+    stamp("chunk table");
     if (nc > 0) {
         const SdChunk *d_chunks = reinterpret_cast<const SdChunk *>(a->d_sd_chunks);
         // per chunk: count (4 B) + ordered offset (4 B) + scan partials; then {total u64, ovf u32}
@@ -1836,6 +1870,7 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
         unsigned long long *p_tot = (unsigned long long *)cn_pin(h, PIN_SMALL, 2048);
         if (!d_cnt || !d_tot || !p_tot) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
         uint32_t *d_off = d_cnt + nc, *d_part = d_off + nc;
+        stamp("small workspaces");
         const bool env_stats = CN_DEV_INT("CORNETTO_SDUST_STATS", 0) != 0;
         const bool want_stats = env_stats || h->sd_stats != 0;
         size_t cap = (size_t)std::max<int64_t>(16, chunk / 32);
@@ -1856,6 +1891,7 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
             // P slot rows: one per resident lane (sdust_w64) / unused by the older kernels
             uint32_t *d_slots = (uint32_t *)cn_ws(h, WS_SD_OFF, (size_t)(std::max<int64_t>(sd_waves, 1) + SD_WPB) * 64 * 64 * sizeof(uint32_t));
             if (!d_slots) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: workspace allocation failed");
+            stamp("row + slot workspaces");
             const bool use_w64 = w64_path;                              // CORNETTO_SDUST_VARIANT=1 forces the per-lane reference-shaped kernel
             SdArgs A{a->d_bases, a->d_off, a->d_len, d_chunks, (int32_t)nc, T, W, d_out, d_cnt, (uint32_t)cap,
                      want_stats ? d_tot + 2 : nullptr, reinterpret_cast<uint32_t *>(d_tot + 1), d_slots, nullptr,
@@ -2140,6 +2176,9 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
                 }
             }
             stamp("main kernel queued");
+            // (no counts of an earlier call: the result array is sized behind the kernel — pin a block of its likely size while the kernel runs: one
+            // interval per ~4 kb in assembly sequence, cn_result_prewarm)
+            if (!one_go && sift_on && !a->sd_warmed && (a->sd_warmed = true)) cn_result_prewarm((size_t)(a->total / 4096 + 1) * sizeof(cornetto_ivl_t));
             CN_HIP(h, hipMemcpyAsync(p_tot, d_tot, want_stats ? 2048 : 128, hipMemcpyDeviceToHost, h->stream));
             CN_HIP(h, hipStreamSynchronize(h->stream));
             stamp("main kernel done");
@@ -2197,6 +2236,7 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
         if (tot > 0x7fffffffull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "sdust: %llu intervals", tot);
         o = (cornetto_ivl_t *)cn_result_alloc((tot ? tot : 1) * sizeof(cornetto_ivl_t));
         if (!o) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: host allocation failed");
+        stamp("result buffer");
         if (tot > 0) {
             // dense list + stitched list + the merge's scratch.  The chunk lists are merged with the reference's own rule
             // (src/sdust/sdust.c:94-98) on the device: ivlmerge.hpp, distance 0.
@@ -2208,6 +2248,7 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
             CN_LAUNCH(h, "sdust_gather", sdust_gather<<<dim3(nbg), dim3(256), 0, h->stream>>>(d_out, d_cnt, d_off, (uint32_t)cap, d_chunks, (int32_t)nc, d_dst));
             CN_TRY(cnivl::merge(h, "sdust_stitch", d_dst, (int64_t)n, 0, ws, d_st, d_tot + 9));
             stamp("gather+stitch queued");
+            if (trace) { (void)hipStreamSynchronize(h->stream); stamp("gather+stitch done (trace only)"); }
             if (hipMemcpyAsync(o, d_st, n * sizeof(cornetto_ivl_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
                 hipMemcpyAsync(p_tot, d_tot + 9, 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
                 hipStreamSynchronize(h->stream) != hipSuccess) {

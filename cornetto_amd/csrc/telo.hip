@@ -26,6 +26,7 @@
 
 #include "common.hpp"
 #include "scan.hpp"
+#include "tiles.hpp"
 #include "internal.hpp"
 
 namespace {
@@ -565,6 +566,13 @@ struct WinLayout {
     int64_t n_words = 0;
 };
 
+// tiles.hpp: piece j of sequence c = (c, j step)
+struct TileFill {
+    int2 *out;
+    int32_t step;
+    __device__ void operator()(int64_t t, int c, int64_t j) const { out[t] = make_int2(c, (int)(j * step)); }
+};
+
 WinLayout win_layout_from_lengths(const int32_t *len, int32_t n, const int64_t *byte_off /* may be null */)
 {
     WinLayout L;
@@ -682,16 +690,30 @@ int telowin_from_hits(cornetto_accel_t *h, const cornetto_hit_t *hits, int64_t n
 int ensure_tw_layout(cornetto_accel_t *h, cornetto_asm_t *am)
 {
     if (am->tw_n_words >= 0) return CORNETTO_OK;
-    const WinLayout L = win_layout_from_lengths(am->len.data(), am->n, nullptr);
-    if (!L.bit_off.empty()) {
-        const bool ok = hipMalloc((void **)&am->d_tw_boff, L.bit_off.size() * 8) == hipSuccess && hipMalloc((void **)&am->d_tw_tiles, (L.tiles.size() + 1) * sizeof(int2)) == hipSuccess &&
-                        hipMemcpyAsync(am->d_tw_boff, L.bit_off.data(), L.bit_off.size() * 8, hipMemcpyHostToDevice, h->stream) == hipSuccess &&
-                        (L.tiles.empty() || hipMemcpyAsync(am->d_tw_tiles, L.tiles.data(), L.tiles.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream) == hipSuccess) &&
-                        hipStreamSynchronize(h->stream) == hipSuccess;
-        if (!ok) return cn_fail(h, CORNETTO_E_NOMEM, "telo_scan: device allocation failed");
+    // as win_layout_from_lengths(): the marks of the contigs back to back, every contig from a multiple of 64 bits; window tile j0 of contig c =
+    // windows j0 .. j0 + 255 of its J + 1 (J = the first j with 200 j + 1000 >= len).  The tiles are written on the device (tiles.hpp).
+    am->tw_boff.resize((size_t)am->n);
+    int64_t bits = 0;
+    for (int32_t c = 0; c < am->n; ++c) {
+        am->tw_boff[c] = bits;
+        bits = cn_align_up(bits + am->len[c], 64);
     }
-    am->tw_n_tiles = (int64_t)L.tiles.size();
-    am->tw_n_words = L.n_words;
+    const int64_t ntl = cntiles::prefix(h, am->tw_pref, am->n, [&](int32_t c) {
+        const int64_t J = am->len[c] > 1000 ? ((int64_t)am->len[c] - 1000 + 199) / 200 : 0;
+        return J / 256 + 1;
+    });
+    if (ntl < 0) return cn_fail(h, CORNETTO_E_NOMEM, "telo_scan: device allocation failed");
+    if (am->n > 0) {
+        const bool ok = hipMalloc((void **)&am->d_tw_boff, (size_t)am->n * 8) == hipSuccess && hipMalloc((void **)&am->d_tw_tiles, ((size_t)ntl + 1) * sizeof(int2)) == hipSuccess &&
+                        hipMemcpyAsync(am->d_tw_boff, am->tw_boff.data(), (size_t)am->n * 8, hipMemcpyHostToDevice, h->stream) == hipSuccess;
+        if (!ok) return cn_fail(h, CORNETTO_E_NOMEM, "telo_scan: device allocation failed");
+        if (ntl > 0) {
+            cntiles::fill<<<dim3((unsigned)((ntl + 255) / 256)), dim3(256), 0, h->stream>>>(am->tw_pref.dev, am->n, ntl, TileFill{am->d_tw_tiles, 256});
+            CN_HIP(h, hipGetLastError());
+        }
+    }
+    am->tw_n_tiles = ntl;
+    am->tw_n_words = bits / 64 + 4;
     return CORNETTO_OK;
 }
 
@@ -732,21 +754,21 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
     }
     // tiles in contig order (cached with the assembly)
     if (a->tf_n_tiles < 0) {
-        std::vector<int2> tiles;
-        a->tf_ctg_tile0.assign(a->n + 1, 0);
-        for (int32_t c = 0; c < a->n; ++c) {
-            a->tf_ctg_tile0[c] = (int32_t)tiles.size();
-            for (int64_t s = 0; s < a->len[c]; s += TF_TILE) tiles.push_back(make_int2(c, (int)s));
-        }
-        a->tf_ctg_tile0[a->n] = (int32_t)tiles.size();
-        if (!tiles.empty()) {
-            if (hipMalloc((void **)&a->d_tf_tiles, tiles.size() * sizeof(int2)) != hipSuccess || hipMalloc((void **)&a->d_tf_ct0, ((size_t)a->n + 1) * 4) != hipSuccess)
+        // on the device (tiles.hpp): tile j of contig c = (c, j TF_TILE); the first tile of every contig stays on the host as well (32-bit: the
+        // kernels' tile indices)
+        const int64_t ntl = cntiles::prefix(h, a->tf_pref, a->n, [&](int32_t c) { return ((int64_t)a->len[c] + TF_TILE - 1) / TF_TILE; });
+        if (ntl < 0) return cn_fail(h, CORNETTO_E_NOMEM, "telofind: device allocation failed");
+        if (ntl > 0x7fffffffll) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "telofind: too many tiles");
+        a->tf_ctg_tile0.resize((size_t)a->n + 1);
+        for (int32_t c = 0; c <= a->n; ++c) a->tf_ctg_tile0[c] = (int32_t)a->tf_pref.host[c];
+        if (ntl > 0) {
+            if (hipMalloc((void **)&a->d_tf_tiles, (size_t)ntl * sizeof(int2)) != hipSuccess || hipMalloc((void **)&a->d_tf_ct0, ((size_t)a->n + 1) * 4) != hipSuccess)
                 return cn_fail(h, CORNETTO_E_NOMEM, "telofind: device allocation failed");
-            CN_HIP(h, hipMemcpyAsync(a->d_tf_tiles, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
-            CN_HIP(h, hipMemcpyAsync(a->d_tf_ct0, a->tf_ctg_tile0.data(), ((size_t)a->n + 1) * 4, hipMemcpyHostToDevice, h->stream));
-            CN_HIP(h, hipStreamSynchronize(h->stream));
+            cntiles::fill<<<dim3((unsigned)((ntl + 255) / 256)), dim3(256), 0, h->stream>>>(a->tf_pref.dev, a->n, ntl, TileFill{a->d_tf_tiles, (int32_t)TF_TILE});
+            CN_HIP(h, hipGetLastError());
+            CN_HIP(h, hipMemcpyAsync(a->d_tf_ct0, a->tf_ctg_tile0.data(), ((size_t)a->n + 1) * 4, hipMemcpyHostToDevice, h->stream));   // (a member: alive)
         }
-        a->tf_n_tiles = (int64_t)tiles.size();
+        a->tf_n_tiles = ntl;
     }
     const std::vector<int32_t> &ctg_tile0 = a->tf_ctg_tile0;
     const size_t nt = (size_t)a->tf_n_tiles;
@@ -820,6 +842,9 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
         }
         CN_TRY(launch(A));
         if (bitmap_valid) *bitmap_valid = want_bitmap;
+        // (the first scan of an assembly sizes its result behind the kernel: a pinned block of the likely size is made while the kernel runs —
+        // one run per ~2 kb in assembly sequence with its planted arrays; cn_result_prewarm)
+        if (hits && !a->tf_warmed && (a->tf_warmed = true)) cn_result_prewarm((size_t)(a->total / 1536 + 1) * sizeof(cornetto_hit_t));
         if (hits) {
             // place of every tile in the dense, contig-ordered lists + list totals
             CN_TRY(cnscan::exclusive_u32_multi(h, "tf_order", reinterpret_cast<const uint32_t *>(d_tc), (int64_t)nt, 4, 4, d_offq, d_part, d_cnt));

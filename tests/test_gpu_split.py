@@ -67,8 +67,9 @@ def test_pieces_with_halos_equal_the_whole_contigs(world):
     got = [order_records(_cat(parts[0], HIT_DT), ("strand", "start")), order_records(_cat(parts[1], WIN_DT), ("start",)),
            stitch_intervals(_cat(parts[2], IVL_DT)), order_records(_cat(parts[3], REG_DT), ("st",))]
     exp = _whole(lens, seqs, depth, mq, ob.telowin_threshold(0.4, 99.9))
-    c = plan.cuts[0][0]
-    assert any(r[0] == 0 and r[1] < c < r[2] for r in exp[2].tolist())
+    if world == 2:                                    # (the cut of the two-rank plan lies inside the planted (AC)n array: an interval crosses it)
+        c = plan.cuts[0][0]
+        assert any(r[0] == 0 and r[1] < c < r[2] for r in exp[2].tolist())
     for name, g, w_, e in zip(("telofind", "telowin", "sdust", "coverage windows"), got, whole[:4], exp):
         assert np.array_equal(w_, e), name + ": whole contigs on the GPU against the oracle"
         assert np.array_equal(g, e), name + ": pieces against the oracle"

@@ -104,6 +104,11 @@ def lib(dev=False):
         "cornetto_khash_str_order": (C.c_int32, [C.POINTER(C.c_char_p), C.c_int32, vp, vp]),
         "cornetto_fastq_split": (C.c_int, [vp, vp, i64, C.c_int, i32, pp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), pp]),
         "cornetto_fasta_split": (C.c_int, [vp, vp, i64, C.c_int, pp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), pp]),
+        "cornetto_text_open": (C.c_int, [vp, i64, pp]),
+        "cornetto_text_free": (None, [vp, vp]),
+        "cornetto_text_put": (C.c_int, [vp, vp, vp, i64, i64, C.c_int]),
+        "cornetto_text_wait": (C.c_int, [vp, vp, C.c_int]),
+        "cornetto_fasta_split_text": (C.c_int, [vp, vp, i64, C.c_int, pp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), pp]),
         "cornetto_asm_upload": (C.c_int, [vp, vp, vp, i32, pp]),
         "cornetto_asm_wrap": (C.c_int, [vp, vp, vp, vp, i32, pp]),
         "cornetto_asm_free": (None, [vp, vp]),
@@ -298,6 +303,35 @@ class Accel:
         p, cnt, used, plain, seqs = C.c_void_p(), C.c_int64(), C.c_int64(), C.c_int32(), C.c_void_p()
         self._chk(self.L.cornetto_fasta_split(self.h, addr, n, 1 if final else 0, C.byref(p), C.byref(cnt), C.byref(used), C.byref(plain),
                                               C.byref(seqs) if want_seqs else None))
+        recs = _take(self.L, p, cnt.value, FAREC_DT)
+        res = _Resident(self, seqs, self.L.cornetto_asm_free, recs["len"]) if want_seqs else None
+        return recs, used.value, bool(plain.value), res
+
+    def fasta_split_slabs(self, text, slab_bytes, final=True, want_seqs=False):
+        """the same through cornetto_text_open / _put / cornetto_fasta_split_text: `text` reaches the device in slabs of slab_bytes from a ring of
+        four pinned slabs, out of order across the two copy queues"""
+        keep = np.frombuffer(bytes(text), dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text, dtype=np.uint8)
+        n = keep.size
+        t = C.c_void_p()
+        self._chk(self.L.cornetto_text_open(self.h, max(1, n), C.byref(t)))
+        ring = [self.L.cornetto_pinned_alloc(slab_bytes) for _ in range(4)]
+        try:
+            offs = list(range(0, n, slab_bytes))
+            order = offs[1::2] + offs[0::2]                  # (the device offsets are the caller's: any order)
+            for k, at in enumerate(order):
+                slot = k & 3
+                if k >= 4:
+                    self._chk(self.L.cornetto_text_wait(self.h, t, slot))
+                m = min(slab_bytes, n - at)
+                C.memmove(ring[slot], keep.ctypes.data + at, m)
+                self._chk(self.L.cornetto_text_put(self.h, t, ring[slot], m, at, slot))
+            p, cnt, used, plain, seqs = C.c_void_p(), C.c_int64(), C.c_int64(), C.c_int32(), C.c_void_p()
+            self._chk(self.L.cornetto_fasta_split_text(self.h, t, n, 1 if final else 0, C.byref(p), C.byref(cnt), C.byref(used), C.byref(plain),
+                                                       C.byref(seqs) if want_seqs else None))
+        finally:
+            self.L.cornetto_text_free(self.h, t)
+            for r in ring:
+                self.L.cornetto_pinned_free(r)
         recs = _take(self.L, p, cnt.value, FAREC_DT)
         res = _Resident(self, seqs, self.L.cornetto_asm_free, recs["len"]) if want_seqs else None
         return recs, used.value, bool(plain.value), res

@@ -387,6 +387,185 @@ static void *fa_ahead_thread(void *p)
     return NULL;
 }
 
+
+/* ---- an uncompressed FASTA FILE as ONE text on the device (round 6) ------------------------------------------------------------------
+ * The piece loop below pins buffers that must each hold whole records (256 MiB and more for an assembly), reads every contig that
+ * straddles a piece border twice, and frames, uploads and scans a dozen pieces one after the other, each a cold first pass over a new
+ * resident object: 0.45-0.63 s for the 3.16 GB assembly of which 0.15 s were the scans' pipeline.  Here the file goes through a small ring
+ * of pinned slabs (reader threads fill them from the page cache, two copy queues empty them: cornetto_text_put) into one device buffer, and
+ * the whole text is framed and scanned ONCE (cornetto_fasta_split_text).  Record names are read back from the file by offset.  Texts are
+ * limited to 2^32-256 bytes: a longer file takes several rounds, each ending at its last complete record.
+ * -> 1: the file (or all of it up to *resume_off, from where the sequential reader must go on: text that is not plain FASTA) was handled */
+#define WHOLE_SLOTS 16
+typedef struct {
+    int fd, n_slots, failed, pin_failed;
+    int64_t off0, total, slab, n_slab;
+    char *ring[WHOLE_SLOTS];
+    int64_t filled[WHOLE_SLOTS];  /* slab index + 1 the slot holds (0: none) */
+    int64_t allowed[WHOLE_SLOTS]; /* the slab index the slot may be filled with */
+    int64_t got[WHOLE_SLOTS];     /* bytes of it */
+    int64_t next;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+} whole_ring_t;
+
+static void *whole_reader(void *p)
+{
+    whole_ring_t *w = (whole_ring_t *)p;
+    for (;;) {
+        pthread_mutex_lock(&w->mu);
+        const int64_t i = w->next++;
+        if (i >= w->n_slab || w->failed) {
+            pthread_mutex_unlock(&w->mu);
+            return NULL;
+        }
+        const int s = (int)(i % w->n_slots);
+        while ((w->allowed[s] != i || !w->ring[s]) && !w->failed && !w->pin_failed) pthread_cond_wait(&w->cv, &w->mu);
+        const int stop = w->failed || w->pin_failed;
+        pthread_mutex_unlock(&w->mu);
+        if (stop) return NULL;
+        const int64_t at = i * w->slab, want = w->total - at < w->slab ? w->total - at : w->slab;
+        int64_t have = 0;
+        while (have < want) {
+            const ssize_t r = pread(w->fd, w->ring[s] + have, (size_t)(want - have), (off_t)(w->off0 + at + have));
+            if (r < 0 && errno == EINTR) continue;
+            if (r <= 0) break;
+            have += r;
+        }
+        pthread_mutex_lock(&w->mu);
+        if (have < want) w->failed = 1;          /* (a file that shrank under us, an I/O error) */
+        w->got[s] = have;
+        w->filled[s] = i + 1;
+        pthread_cond_broadcast(&w->cv);
+        pthread_mutex_unlock(&w->mu);
+    }
+}
+
+/* the slabs are page-locked one after the other (~5-20 GB/s: 128 MB take 10-25 ms) by a thread of their own, while the first ones are already
+ * being filled and copied */
+static void *whole_pinner(void *p)
+{
+    whole_ring_t *w = (whole_ring_t *)p;
+    for (int s = 0; s < w->n_slots; ++s) {
+        char *m = (char *)cornetto_pinned_alloc((size_t)w->slab);
+        pthread_mutex_lock(&w->mu);
+        if (!m) w->pin_failed = 1;
+        w->ring[s] = m;
+        pthread_cond_broadcast(&w->cv);
+        pthread_mutex_unlock(&w->mu);
+        if (!m) return NULL;
+    }
+    return NULL;
+}
+
+static int stream_whole_fasta(const char *path, int fd, int64_t size, scan_fn scan, void *arg, cornetto_accel_t **h_io, int64_t *resume_off, int trace,
+                              double t_begin)
+{
+    const int64_t LIMIT = 0xFFFFFF00LL - 4096;
+    cornetto_accel_t *h = *h_io;
+    if (!h) *h_io = h = cli_accel_open_end();
+    TRACE("device open");
+    cornetto_text_t *t = NULL;
+    const int64_t cap = size < LIMIT ? size : LIMIT;
+    cli_accel_check(h, cornetto_text_open(h, cap, &t), "allocating the text on the GPU");
+    TRACE("device text allocated");
+    whole_ring_t w;
+    memset(&w, 0, sizeof(w));
+    pthread_mutex_init(&w.mu, NULL);
+    pthread_cond_init(&w.cv, NULL);
+    w.fd = fd;
+    /* sixteen slabs of 8 MiB: a reader thread per slab in flight copies from the page cache at 4-6 GB/s, the two copy queues take ~45 GB/s */
+    w.slab = 8LL << 20;
+    if (cap < w.slab * WHOLE_SLOTS) w.slab = ((cap + WHOLE_SLOTS - 1) / WHOLE_SLOTS + 65535) & ~65535LL;   /* (a small file: a small ring) */
+    w.n_slots = (int)((cap + w.slab - 1) / w.slab);
+    if (w.n_slots > WHOLE_SLOTS) w.n_slots = WHOLE_SLOTS;
+    if (w.n_slots < 1) w.n_slots = 1;
+    pthread_t pin_th;
+    if (pthread_create(&pin_th, NULL, whole_pinner, &w) != 0) whole_pinner(&w);
+    else pthread_detach(pin_th);
+    int n_thr = getenv("CORNETTO_READ_THREADS") ? READ_THREADS : 16;
+    if (n_thr > w.n_slots) n_thr = w.n_slots;
+    int64_t off = 0;
+    int plain_all = 1;
+    while (off < size && plain_all) {
+        const int64_t n = size - off < cap ? size - off : cap;
+        const int final = off + n == size;
+        w.off0 = off;
+        w.total = n;
+        w.n_slab = (n + w.slab - 1) / w.slab;
+        w.next = 0;
+        w.failed = 0;
+        for (int s = 0; s < w.n_slots; ++s) { w.filled[s] = 0; w.allowed[s] = s; }
+        pthread_t th[64];
+        int n_started = 0;
+        for (int k = 0; k < n_thr && k < 64; ++k)
+            if (pthread_create(&th[n_started], NULL, whole_reader, &w) == 0) ++n_started;
+        if (n_started == 0) { CLI_ERROR("could not start a reader thread"); exit(EXIT_FAILURE); }
+        for (int64_t i = 0; i < w.n_slab; ++i) {
+            const int s = (int)(i % w.n_slots);
+            pthread_mutex_lock(&w.mu);
+            while (w.filled[s] != i + 1 && !w.failed && !w.pin_failed) pthread_cond_wait(&w.cv, &w.mu);
+            const int64_t got = w.got[s];
+            const int failed = w.pin_failed ? 2 : w.failed;
+            pthread_mutex_unlock(&w.mu);
+            if (failed == 2) { CLI_ERROR("could not allocate a %lld-byte pinned slab", (long long)w.slab); exit(EXIT_FAILURE); }
+            if (failed) { CLI_ERROR("reading %s failed", path); exit(EXIT_FAILURE); }
+            /* four copy queues: slab i goes out on queue i & 3 once the copy that used that queue last (slab i - 4) has left its slab, which then
+             * goes back to the readers: up to four copies in flight */
+            if (i >= 4) {
+                cli_accel_check(h, cornetto_text_wait(h, t, (int)(i & 3)), "copying the text to the GPU");
+                const int sp = (int)((i - 4) % w.n_slots);
+                pthread_mutex_lock(&w.mu);
+                w.allowed[sp] = i - 4 + w.n_slots;
+                pthread_cond_broadcast(&w.cv);
+                pthread_mutex_unlock(&w.mu);
+            }
+            cli_accel_check(h, cornetto_text_put(h, t, w.ring[s], got, i * w.slab, (int)(i & 3)), "copying the text to the GPU");
+        }
+        for (int k = 0; k < n_started; ++k) pthread_join(th[k], NULL);
+        TRACE("text on the device");
+        cornetto_farec_t *recs = NULL;
+        cornetto_asm_t *a = NULL;
+        int64_t nrec = 0, used = 0;
+        int32_t plain = 1;
+        cli_accel_check(h, cornetto_fasta_split_text(h, t, n, final, &recs, &nrec, &used, &plain, &a), "framing the FASTA records");
+        TRACE("records framed");
+        if (nrec) {
+            /* the names: from the file, by offset (the slabs are gone) */
+            cli_recname_t *r = (cli_recname_t *)cli_xmalloc(((size_t)nrec + 1) * sizeof(*r));
+            int64_t name_bytes = 0;
+            for (int64_t i = 0; i < nrec; ++i) name_bytes += recs[i].name_len + 1;
+            char *names = (char *)cli_xmalloc((size_t)name_bytes + 1), *q = names;
+            for (int64_t i = 0; i < nrec; ++i) {
+                int64_t have = 0;
+                while (have < recs[i].name_len) {
+                    const ssize_t g = pread(fd, q + have, (size_t)(recs[i].name_len - have), (off_t)(off + recs[i].head + 1 + have));
+                    if (g < 0 && errno == EINTR) continue;
+                    if (g <= 0) { CLI_ERROR("reading %s failed", path); exit(EXIT_FAILURE); }
+                    have += g;
+                }
+                r[i].name = q;
+                r[i].name_len = recs[i].name_len;
+                r[i].len = recs[i].len;
+                q += recs[i].name_len + 1;
+            }
+            scan(h, r, nrec, a, arg);
+            TRACE("scanned and printed");
+            free(names);
+            free(r);
+        }
+        cornetto_free(recs);
+        cornetto_asm_free(h, a);
+        off += used;
+        if (!plain) plain_all = 0;                 /* what follows at `off` is for the sequential reader */
+        else if (used == 0 && !final) plain_all = 0; /* one record longer than a text (2^32 bytes): the sequential reader reports it as the reference's reader would */
+        else if (final) off = size;
+    }
+    /* (the slabs, the text and the handle are left to the end of the process: main.c leaves with _exit) */
+    *resume_off = off;
+    return 1;
+}
+
 static void stream_records(const char *path, int must_open, scan_fn scan, void *arg)
 {
     const int trace = getenv("CORNETTO_CLI_TRACE") != NULL;
@@ -429,6 +608,26 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
         /* With read-ahead the FIRST piece is small (64 MiB; CORNETTO_CLI_FIRST_MB): pinning and reading it takes a quarter of the time of a
          * full piece, and that time stands in front of the first scan — beside the device's start-up, on this thread; the full-size buffers
          * are made by the read-ahead thread while the device works (round 5). */
+        /* the whole file as one text on the device (see stream_whole_fasta); CORNETTO_CLI_WHOLE=0 and an explicit piece size keep the piece loop */
+        {
+            const char *we = getenv("CORNETTO_CLI_WHOLE");
+            struct stat st;
+            if (use_ahead && !(we && !atoi(we)) && !getenv("CORNETTO_FASTQ_PIECE") && fstat(raw_fd, &st) == 0 && st.st_size > 0) {
+                int64_t resume = 0;
+                (void)stream_whole_fasta(path, raw_fd, (int64_t)st.st_size, scan, arg, &h, &resume, trace, t_begin);
+                close(raw_fd);
+                if (resume < (int64_t)st.st_size) {     /* not plain from there on: the sequential reader takes the rest */
+                    gzseek(fp, (z_off_t)resume, SEEK_SET);
+                    batch_scan_t bs = {scan, arg};
+                    cli_fastx_t *fx = cli_fastx_open_prefixed(fp, NULL, 0);
+                    batches_of(fx, h, scan_batch, &bs);
+                } else {
+                    gzclose(fp);
+                }
+                TRACE("done");
+                return;
+            }
+        }
         int64_t cap_buf = piece, cap_other = 0;
         if (use_ahead && !getenv("CORNETTO_FASTQ_PIECE")) {
             const char *fm = getenv("CORNETTO_CLI_FIRST_MB");

@@ -372,11 +372,17 @@ struct cornetto_cov {
 // families load that one).  In the product build every switch is its default at compile time and the names do not exist in the binary
 // (tests/test_abi.py greps libcornetto_hip.so for them).
 #ifdef CN_DEV
+static inline int cn_dev_int(const char *name, int dflt)
+{
+    const char *s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+#define CN_DEV_INT(name, dflt) cn_dev_int(name, dflt)
 #include <time.h>
 // CORNETTO_TRACE=1 (development build): wall-clock stamps of the phases of a library call on stderr
 static inline void cn_trace(const char *what)
 {
-    static const int on = [] { const char *s = getenv("CORNETTO_TRACE"); return (s && *s) ? atoi(s) : 0; }();
+    static const int on = cn_dev_int("CORNETTO_TRACE", 0);
     if (!on) return;
     struct timespec t;
     clock_gettime(CLOCK_MONOTONIC, &t);
@@ -386,12 +392,6 @@ static inline void cn_trace(const char *what)
     fprintf(stderr, "[lib trace] %-32s %9.3f ms\n", what, now - t0);
 }
 #define CN_TRACE(what) cn_trace(what)
-static inline int cn_dev_int(const char *name, int dflt)
-{
-    const char *s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
-}
-#define CN_DEV_INT(name, dflt) cn_dev_int(name, dflt)
 #else
 #define CN_DEV_INT(name, dflt) (dflt)
 #define CN_TRACE(what) ((void)0)

@@ -398,11 +398,10 @@ extern "C" int cornetto_fastq_split(cornetto_accel_t *h, const char *text, int64
 }
 
 
-extern "C" int cornetto_fasta_split(cornetto_accel_t *h, const char *text, int64_t n, int final, cornetto_farec_t **recs, int64_t *n_recs,
-                                    int64_t *consumed, int32_t *plain, cornetto_asm_t **seqs)
+// the framing of FASTA text that lies on the device (d_text: n bytes, readable up to n + 64; text_in != NULL: uploaded here first)
+static int fasta_split_core(cornetto_accel_t *h, const char *text_in, uint8_t *d_text_in, char first_ch, char last_ch, int64_t n, int final, cornetto_farec_t **recs,
+                            int64_t *n_recs, int64_t *consumed, int32_t *plain, cornetto_asm_t **seqs)
 {
-    if (!h || n < 0 || (n > 0 && !text) || !recs || !n_recs || !consumed || !plain)
-        return cn_fail(h, CORNETTO_E_ARG, "fasta_split: bad argument");
     if (n > 0xFFFFFF00LL) return cn_fail(h, CORNETTO_E_ARG, "fasta_split: pieces are limited to 2^32-256 bytes (got %lld)", (long long)n);
     *recs = nullptr;
     *n_recs = 0;
@@ -410,7 +409,7 @@ extern "C" int cornetto_fasta_split(cornetto_accel_t *h, const char *text, int64
     *plain = 1;
     if (seqs) *seqs = nullptr;
     if (n == 0) return CORNETTO_OK;
-    if (text[0] != '>') {      // kseq_read looks for the first '>' or '@' anywhere (:189-193): the caller's reader does that
+    if (first_ch != '>') {      // kseq_read looks for the first '>' or '@' anywhere (:189-193): the caller's reader does that
         *plain = 0;
         return CORNETTO_OK;
     }
@@ -418,7 +417,7 @@ extern "C" int cornetto_fasta_split(cornetto_accel_t *h, const char *text, int64
     cn_timing_begin(h);
     CN_TRACE("fasta_split: enter");
     const int64_t nt = (n + FQ_TILE - 1) / FQ_TILE;
-    uint8_t *d_text = (uint8_t *)cn_ws(h, WS_FQ_TEXT, (size_t)n + 64);
+    uint8_t *d_text = d_text_in ? d_text_in : (uint8_t *)cn_ws(h, WS_FQ_TEXT, (size_t)n + 64);
     uint32_t *d_cnt = (uint32_t *)cn_ws(h, WS_FQ_CNT, ((size_t)2 * nt + (nt + 4095) / 4096 + 16) * 4 + 64);
     unsigned long long *p_small = (unsigned long long *)cn_pin(h, PIN_SMALL, 64);
     if (!d_text || !d_cnt || !p_small) return cn_fail(h, CORNETTO_E_NOMEM, "fasta_split: workspace allocation failed");
@@ -426,14 +425,14 @@ extern "C" int cornetto_fasta_split(cornetto_accel_t *h, const char *text, int64
     uint32_t *d_off = d_cnt + nt, *d_part = d_off + nt;
     unsigned long long *d_tot = reinterpret_cast<unsigned long long *>(((uintptr_t)(d_part + (nt + 4095) / 4096 + 1) + 7) & ~(uintptr_t)7);
     uint32_t *d_bad = reinterpret_cast<uint32_t *>(d_tot + 3);
-    CN_HIP(h, hipMemcpyAsync(d_text, text, (size_t)n, hipMemcpyHostToDevice, h->stream));
+    if (text_in) CN_HIP(h, hipMemcpyAsync(d_text, text_in, (size_t)n, hipMemcpyHostToDevice, h->stream));
     CN_LAUNCH(h, "fq_nl_count", fq_nl_count<<<dim3((unsigned)nt), dim3(FQ_THREADS), 0, h->stream>>>(d_text, n, d_cnt));
     CN_TRY(cnscan::exclusive_u32(h, "fq_scan", d_cnt, nt, 1, d_off, d_part, d_tot));
     CN_HIP(h, hipMemcpyAsync(p_small, d_tot, 8, hipMemcpyDeviceToHost, h->stream));
     CN_HIP(h, hipStreamSynchronize(h->stream));
     CN_TRACE("fasta_split: text up, newlines counted");
     const int64_t n_nl = (int64_t)p_small[0];
-    const bool virt = text[n - 1] != '\n';     // the bytes behind the last newline are a line too (complete only if `final`)
+    const bool virt = last_ch != '\n';     // the bytes behind the last newline are a line too (complete only if `final`)
     const int64_t n_lines = n_nl + (virt ? 1 : 0);
     // per line: newline offset, header flag, payload, their exclusive scans (n_lines + 1 entries: the last holds the totals),
     // destination; per record: header line
@@ -531,4 +530,84 @@ extern "C" int cornetto_fasta_split(cornetto_accel_t *h, const char *text, int64
     }
     cn_timing_end(h);
     return CORNETTO_OK;
+}
+
+extern "C" int cornetto_fasta_split(cornetto_accel_t *h, const char *text, int64_t n, int final, cornetto_farec_t **recs, int64_t *n_recs,
+                                    int64_t *consumed, int32_t *plain, cornetto_asm_t **seqs)
+{
+    if (!h || n < 0 || (n > 0 && !text) || !recs || !n_recs || !consumed || !plain)
+        return cn_fail(h, CORNETTO_E_ARG, "fasta_split: bad argument");
+    return fasta_split_core(h, text, nullptr, n > 0 ? text[0] : 0, n > 0 ? text[n - 1] : 0, n, final, recs, n_recs, consumed, plain, seqs);
+}
+
+// ---- a text put on the device slab by slab (include/cornetto_accel.h: cornetto_text_*) ------------------------------------------------
+struct cornetto_text {
+    uint8_t *d = nullptr;
+    int64_t cap = 0;
+    hipStream_t q[4] = {nullptr, nullptr, nullptr, nullptr};     // copy queues: one copy in flight moves ~28 GB/s over PCIe, several ~45
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // the last copy of slot s (the caller's slab ring has up to four slabs)
+};
+
+extern "C" int cornetto_text_open(cornetto_accel_t *h, int64_t capacity, cornetto_text_t **out)
+{
+    if (!h || !out || capacity < 1 || capacity > 0xFFFFFF00LL) return cn_fail(h, CORNETTO_E_ARG, "text_open: bad argument");
+    *out = nullptr;
+    CN_HIP(h, hipSetDevice(h->device));
+    cornetto_text_t *t = new (std::nothrow) cornetto_text;
+    if (!t) return cn_fail(h, CORNETTO_E_NOMEM, "text_open: host allocation failed");
+    bool ok = hipMalloc((void **)&t->d, (size_t)capacity + 256) == hipSuccess;
+    for (int i = 0; ok && i < 4; ++i) ok = hipStreamCreateWithFlags(&t->q[i], hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < 4; ++i) ok = hipEventCreateWithFlags(&t->ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        cornetto_text_free(h, t);
+        return cn_fail(h, CORNETTO_E_NOMEM, "text_open: device allocation of %lld bytes failed", (long long)capacity);
+    }
+    t->cap = capacity;
+    *out = t;
+    return CORNETTO_OK;
+}
+
+extern "C" void cornetto_text_free(cornetto_accel_t *h, cornetto_text_t *t)
+{
+    if (!t) return;
+    if (h) (void)hipSetDevice(h->device);
+    for (int i = 0; i < 4; ++i)
+        if (t->q[i]) { (void)hipStreamSynchronize(t->q[i]); (void)hipStreamDestroy(t->q[i]); }
+    for (int i = 0; i < 4; ++i)
+        if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
+    if (t->d) (void)hipFree(t->d);
+    delete t;
+}
+
+extern "C" int cornetto_text_put(cornetto_accel_t *h, cornetto_text_t *t, const char *slab, int64_t n, int64_t at, int slot)
+{
+    if (!h || !t || !slab || n < 0 || at < 0 || at + n > t->cap || slot < 0 || slot > 3) return cn_fail(h, CORNETTO_E_ARG, "text_put: bad argument");
+    if (n == 0) return CORNETTO_OK;
+    CN_HIP(h, hipSetDevice(h->device));
+    hipStream_t q = t->q[slot];
+    CN_HIP(h, hipMemcpyAsync(t->d + at, slab, (size_t)n, hipMemcpyHostToDevice, q));
+    CN_HIP(h, hipEventRecord(t->ev[slot], q));
+    return CORNETTO_OK;
+}
+
+extern "C" int cornetto_text_wait(cornetto_accel_t *h, cornetto_text_t *t, int slot)
+{
+    if (!h || !t || slot < 0 || slot > 3) return cn_fail(h, CORNETTO_E_ARG, "text_wait: bad argument");
+    CN_HIP(h, hipSetDevice(h->device));
+    CN_HIP(h, hipEventSynchronize(t->ev[slot]));
+    return CORNETTO_OK;
+}
+
+extern "C" int cornetto_fasta_split_text(cornetto_accel_t *h, cornetto_text_t *t, int64_t n, int final, cornetto_farec_t **recs, int64_t *n_recs, int64_t *consumed,
+                                         int32_t *plain, cornetto_asm_t **seqs)
+{
+    if (!h || !t || n < 0 || n > t->cap || !recs || !n_recs || !consumed || !plain) return cn_fail(h, CORNETTO_E_ARG, "fasta_split_text: bad argument");
+    CN_HIP(h, hipSetDevice(h->device));
+    for (int i = 0; i < 4; ++i) CN_HIP(h, hipStreamSynchronize(t->q[i]));      // every slab is on the device
+    char ends[2] = {0, 0};
+    if (n > 0) {
+        CN_HIP(h, hipMemcpy(&ends[0], t->d, 1, hipMemcpyDeviceToHost));
+        CN_HIP(h, hipMemcpy(&ends[1], t->d + n - 1, 1, hipMemcpyDeviceToHost));
+    }
+    return fasta_split_core(h, nullptr, t->d, ends[0], ends[1], n, final, recs, n_recs, consumed, plain, seqs);
 }

@@ -425,6 +425,21 @@ typedef struct cornetto_farec {
 int cornetto_fasta_split(cornetto_accel_t *h, const char *text, int64_t n, int final, cornetto_farec_t **recs, int64_t *n_recs,
                          int64_t *consumed, int32_t *plain, cornetto_asm_t **seqs);
 
+/* The same over a text that is put on the device slab by slab — a whole uncompressed FASTA file read through a small ring of pinned
+ * slabs instead of pinned pieces that must each hold whole records (`cornetto telofind` / `sdust` on an assembly: one framing and one
+ * scan for the file; src/find_telomere.c:101, src/sdust/sdust.c:196 read it record by record).  cornetto_text_open(): a device buffer
+ * of `capacity` bytes (at most 2^32-256).  cornetto_text_put(): bytes [at, at + n) of the text from `slab` (pinned memory:
+ * cornetto_pinned_alloc), asynchronously, on copy queue `slot` (0..3: puts of different slots run side by side — one copy in
+ * flight moves ~28 GB/s over PCIe, several ~45); cornetto_text_wait() returns when the last put of that slot has left its slab.  cornetto_fasta_split_text(): waits for every
+ * put, then frames the first n bytes exactly as cornetto_fasta_split() frames `text` (head offsets are offsets into the text). */
+typedef struct cornetto_text cornetto_text_t;
+int cornetto_text_open(cornetto_accel_t *h, int64_t capacity, cornetto_text_t **out);
+void cornetto_text_free(cornetto_accel_t *h, cornetto_text_t *t);
+int cornetto_text_put(cornetto_accel_t *h, cornetto_text_t *t, const char *slab, int64_t n, int64_t at, int slot);
+int cornetto_text_wait(cornetto_accel_t *h, cornetto_text_t *t, int slot);
+int cornetto_fasta_split_text(cornetto_accel_t *h, cornetto_text_t *t, int64_t n, int final, cornetto_farec_t **recs, int64_t *n_recs,
+                              int64_t *consumed, int32_t *plain, cornetto_asm_t **seqs);
+
 /* ---------------------------------------------------------------------------------------------------
  * panel interval stage — scripts/create-cornetto.sh:41-66 without bedtools / sort / awk (parity with bedtools itself
  * is unpinned: see cornetto_amd/csrc/panel.hip)

@@ -348,6 +348,27 @@ def test_fasta_random_layouts(acc):
         assert plain and used == len(text) and len(recs) == len(exp), it
 
 
+def test_fasta_text_in_slabs_equals_the_text_in_one_piece(acc):
+    """cornetto_text_open / cornetto_text_put (a ring of four pinned slabs, two copy queues, slabs out of order) + cornetto_fasta_split_text
+    give the records, the consumed bytes, the plain flag and the resident sequences of cornetto_fasta_split over the same text"""
+    rng = np.random.default_rng(33)
+    for it in range(12):
+        text = fasta_text(rng, int(rng.integers(1, 40)), width=[None, 60, 7][it % 3], crlf=(it % 4 == 0))
+        if it == 5:
+            text += b"@r1\nACGT\n+\nIIII\n" + fasta_text(rng, 2)
+        if it % 5 == 0 and text.endswith(b"\n"):
+            text = text[:-1]
+        for final in (True, False):
+            a = acc.fasta_split(text, final=final, want_seqs=True)
+            b = acc.fasta_split_slabs(text, [64, 1000, 4096, 1 << 20][it % 4], final=final, want_seqs=True)
+            assert np.array_equal(a[0], b[0]) and a[1:3] == b[1:3], (it, final)
+            if len(a[0]):
+                assert np.array_equal(acc.sdust(a[3], 20, 64), acc.sdust(b[3], 20, 64))
+                assert np.array_equal(acc.telofind(a[3], b"TTAGGG"), acc.telofind(b[3], b"TTAGGG"))
+            a[3].close()
+            b[3].close()
+
+
 def test_fasta_not_plain_and_pieces(acc):
     rng = np.random.default_rng(32)
     text = fasta_text(rng, 10, width=60)

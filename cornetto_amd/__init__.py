@@ -390,7 +390,8 @@ class Accel:
         if n > 207 and s[206]:
             # the sift / resolve kernel (csrc/sdust_sift.hpp): positions after each filter, steps of the stepping stages
             return {"kernel": "sd_sift", "chunks": s[255], "tiles_of_64_bases": s[206], "positions_ct_above_T10": s[203], "after_L1": s[204], "after_L2": s[205],
-                    "resolve_steps": s[200], "resolve_window_reads": s[201], "dp_tiles": s[208], "passes_with_candidates": s[202], "base_by_base_steps_of_chunks_with_other_bytes": s[207]}
+                    "resolve_steps": s[200], "resolve_window_reads": s[201], "dp_tiles": s[208], "passes_with_candidates": s[202], "base_by_base_steps_of_chunks_with_other_bytes": s[207],
+                    "window_reads_behind_a_gap_of": {"2": s[209], "3-4": s[210], "5-8": s[211]} if n > 211 else None}
         if not waves or not s[2]:
             return None
         hist = []

@@ -475,6 +475,9 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(C
 
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     int ntl = 0, ntl2 = 0;                            // (uniform) entries in the two lists
+#ifdef SIFT_L2_ADAPT
+    int l2_hot = 0, l2_skipped = 0;                   // (uniform) consecutive full L2 batches that kept nearly everything; L1 batches sifted without L2 since
+#endif
     // L2: the 16-term sums (every candidate of more than 16 words needs them positive), the exact walk over the shorter suffixes.
     // Round 5: no counters.  The 16 (word, count) pairs that end at the lane's position are 32 consecutive bytes of the buffer: nine aligned
     // dword reads, realigned by the lane's 0 or 2 bytes and split into four registers of words and four of counts (oldest position in byte
@@ -563,6 +566,13 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(C
             keep = on && (seen != 0u || sc || (pos && long_ok));
         }
         if (STATS) st_l2 += (unsigned long long)__popcll(sd_ballot(keep));
+#ifdef SIFT_L2_ADAPT
+        if (nb == 64) {                               // inside a repeat the walk keeps what L1 kept: two such batches in a row switch it off for a while
+            const int kept = __popcll(sd_ballot(keep));
+            l2_hot = kept >= SIFT_L2_ADAPT ? (l2_hot < 2 ? l2_hot + 1 : 2) : 0;
+            l2_skipped = 0;
+        }
+#endif
         if (keep) (void)__hip_atomic_fetch_or(&sb[o >> 5], 1u << (o & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     // L1: the partial sums of 10 ct - T over the last k words must be positive for k = 1 .. lmin (every candidate has more words)
@@ -586,7 +596,13 @@ __global__ __launch_bounds__(64 * SIFT_WPB) __attribute__((amdgpu_waves_per_eu(C
         }
         const bool ok = on && dmin > 0;
         const unsigned long long m = sd_ballot(ok);
+#ifdef SIFT_L2_ADAPT
+        const bool hot = l2_hot >= 2 && __popcll(m) >= 16;
+        if (hot && ++l2_skipped >= 12) l2_hot = 1;    // (look again: the next full L2 batch decides)
+        if (__popcll(m) >= A.l2_skip || hot) {
+#else
         if (__popcll(m) >= A.l2_skip) {
+#endif
             // most of a full batch passed: a repeat, where L2 keeps nearly everything as well and the dp tiles take any superset
             // at the same price — the survivors are sifted positions at once (any superset of the inserting positions is exact)
             if (STATS) st_l1 += (unsigned long long)__popcll(m);

@@ -69,8 +69,9 @@ def test_two_ranks_over_pieces_of_cut_contigs_equal_one_rank():
     """--split-tol -1: the ranks take [r, r + 1) x half of the bases, the contig the border falls into is cut on a clean position and both ranks
     scan their piece of it with halos (cornetto_amd.dist.SplitPlan) — the records rank 0 puts together are those of the one-rank run"""
     shared = [] if _n_gpus() >= 2 else ["--allow-shared-device"]
-    one = _run(1, ["--scaling", "strong"])
-    two = _run(2, ["--scaling", "strong", "--split-tol", "-1"] + shared)
+    big = ["--gbases", "0.2"]                      # (200 Mb: half of the bases ends 7.6 Mb into a contig of 9.3 Mb; at 50 Mb no contig is long enough to be cut)
+    one = _run(1, ["--scaling", "strong"] + big)
+    two = _run(2, ["--scaling", "strong", "--split-tol", "-1"] + big + shared)
     assert two["config"].get("cut_contigs", 0) >= 1
     assert one["determinism"]["identical"] and two["determinism"]["identical"]
     assert two["gathered_digests"] == one["gathered_digests"]

@@ -94,6 +94,7 @@ def lib(dev=False):
         "cornetto_accel_set_lazy": (C.c_int, [vp, C.c_int]),
         "cornetto_accel_wait": (C.c_int, [vp]),
         "cornetto_accel_set_timing": (C.c_int, [vp, C.c_int]),
+        "cornetto_accel_warm": (C.c_int, [vp, C.c_int]),
         "cornetto_accel_sdust_stats": (C.c_int, [vp, C.c_int, vp, C.c_int]),
         "cornetto_cov_select_merged": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_int, C.c_int32, C.c_int32, C.POINTER(vp), C.POINTER(C.c_int64)]),
         "cornetto_ivl_merge": (C.c_int, [vp, vp, C.c_int64, C.c_int32, C.POINTER(vp), C.POINTER(C.c_int64)]),
@@ -290,6 +291,10 @@ class Accel:
         recs = _take(self.L, p, cnt.value, FQREC_DT)
         res = _Resident(self, reads, self.L.cornetto_asm_free, recs["len"][recs["keep"] == 1]) if want_reads else None
         return recs, used.value, bool(plain.value), res
+
+    def warm(self, what=7):
+        """cornetto_accel_warm(): every entry point of the groups (1 sdust, 2 telo, 4 coverage) once on a built-in 4 kb input"""
+        self._chk(self.L.cornetto_accel_warm(self.h, what))
 
     def fasta_split(self, text, final=True, want_seqs=False):
         """text: bytes-like FASTA piece beginning with '>' (or (address, size)) -> (records FAREC_DT, consumed bytes, plain

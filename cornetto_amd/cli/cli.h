@@ -55,6 +55,7 @@ cornetto_accel_t *cli_accel_open(void);
 /* `want` bytes at file offset `off` with up to n_threads pread() threads -> bytes read (short only at the end of the file), -1 on a read error */
 int64_t cli_pread_parallel(int fd, char *dst, int64_t want, int64_t off, int n_threads);
 void cli_accel_open_begin(void);
+void cli_accel_warm_hint(int what);   /* before cli_accel_open_begin(): CORNETTO_WARM_* to run behind the open, on a handle of its own */
 cornetto_accel_t *cli_accel_open_end(void);
 void cli_accel_open_cancel(void);
 /* print the handle's last error and exit(EXIT_FAILURE) if rc != 0 */

@@ -601,6 +601,11 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
             struct stat st;
             if (strcmp(path, "-") && gzdirect(fp) && stat(path, &st) == 0 && S_ISREG(st.st_mode)) raw_fd = open(path, O_RDONLY);
         }
+        {
+            struct stat st;
+            if (fasta && raw_fd >= 0 && fstat(raw_fd, &st) == 0 && (int64_t)st.st_size >= (256LL << 20))
+                cli_accel_warm_hint(scan == sdust_scan ? CORNETTO_WARM_SDUST : CORNETTO_WARM_TELO);      /* (an assembly: its one scan should not be the runtime's first) */
+        }
         cli_accel_open_begin();
         /* read-ahead (uncompressed FASTA file; CORNETTO_CLI_AHEAD=0 switches it off) */
         const char *ahead_env = getenv("CORNETTO_CLI_AHEAD");

@@ -85,16 +85,37 @@ cornetto_accel_t *cli_accel_open(void)
 #include <pthread.h>
 static struct {
     pthread_t th;
-    int started, rc, dev;
+    int started, rc, dev, ready, warm;
     cornetto_accel_t *h;
-} g_open;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+} g_open = {.mu = PTHREAD_MUTEX_INITIALIZER, .cv = PTHREAD_COND_INITIALIZER};
 
 static void *open_thread(void *arg)
 {
     (void)arg;
-    g_open.rc = cornetto_accel_open(&g_open.h, g_open.dev, NULL);
+    cornetto_accel_t *h = NULL;
+    const int rc = cornetto_accel_open(&h, g_open.dev, NULL);
+    pthread_mutex_lock(&g_open.mu);
+    g_open.rc = rc;
+    g_open.h = h;
+    g_open.ready = 1;
+    pthread_cond_broadcast(&g_open.cv);
+    pthread_mutex_unlock(&g_open.mu);
+    if (rc == CORNETTO_OK && g_open.warm) {
+        /* what the first use of the runtime costs in a process (code objects, copy engines, the first pinned pools), paid here — on a handle of its
+         * own, beside the caller's reading and copying — instead of in its first scan (cornetto_accel_warm) */
+        cornetto_accel_t *w = NULL;
+        if (cornetto_accel_open(&w, g_open.dev, NULL) == CORNETTO_OK) {
+            (void)cornetto_accel_warm(w, g_open.warm);
+            cornetto_accel_close(w);
+        }
+    }
     return NULL;
 }
+
+/* a large input is on its way: warm the named entry points up (CORNETTO_WARM_*) behind the open; before cli_accel_open_begin() */
+void cli_accel_warm_hint(int what) { g_open.warm = what; }
 
 void cli_accel_open_begin(void)
 {
@@ -102,13 +123,18 @@ void cli_accel_open_begin(void)
     const char *d = getenv("CORNETTO_DEVICE");
     g_open.dev = d ? atoi(d) : 0;
     g_open.h = NULL;
+    g_open.ready = 0;
     if (pthread_create(&g_open.th, NULL, open_thread, NULL) == 0) g_open.started = 1;
 }
 
 cornetto_accel_t *cli_accel_open_end(void)
 {
     if (!g_open.started) return cli_accel_open();
-    pthread_join(g_open.th, NULL);
+    pthread_mutex_lock(&g_open.mu);
+    while (!g_open.ready) pthread_cond_wait(&g_open.cv, &g_open.mu);
+    pthread_mutex_unlock(&g_open.mu);
+    if (!g_open.warm) pthread_join(g_open.th, NULL);
+    else pthread_detach(g_open.th);                 /* (the warm-up goes on beside the caller; the process leaves with _exit) */
     g_open.started = 0;
     if (g_open.rc != CORNETTO_OK) {
         CLI_ERROR("cannot open HIP device %d: %s. The scans run on an AMD GPU; the sequential host path is a choice (--accel=no / CORNETTO_ACCEL=no), never a fallback.",

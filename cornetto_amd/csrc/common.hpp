@@ -313,7 +313,6 @@ struct cornetto_asm {
     std::vector<int32_t> sd_chunk_ctg;   // contig of every chunk
     void *d_sd_chunks = nullptr;
     int64_t sd_n_chunks = 0;
-    bool tf_warmed = false, sd_warmed = false;   // cn_result_prewarm has been called for the first scan of this object
     CnPrefix sd_pref, tf_pref, tw_pref;  // tiles.hpp: first piece of every contig in the chunk / tile tables (host copy alive while its upload may be in flight)
     uint32_t *d_sd_plan = nullptr;       // sdust: {initial claim flags [n], queue order [n + 160], dense list [n]} of the cached plan
     int64_t sd_plan_key = -1, sd_plan_dense = 0;
@@ -363,7 +362,6 @@ struct cornetto_cov {
     // what the last packed selection gave, and for which parameters: the next one with the same parameters sizes its result copy by it
     // and checks afterwards (cornetto_panel_step: no round trip for the count); -1: none yet
     int64_t cw_est_key = -1, cw_est_cnt = -1;
-    bool cw_warmed = false;              // cn_result_prewarm has been called for the first selection over this object
     CnPrefix cb_pref, cw_pref;           // tiles.hpp: as in cornetto_asm
 };
 

@@ -538,6 +538,7 @@ int cn_cov_prepare_impl(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int32
     const int32_t q = w / inc, r = w % inc;
     sums[0] = sums[1] = 0;
     sums[2] = (uint64_t)c->total;
+    CN_TRACE("cov_prepare: enter");
     if (c->w != w || c->inc != inc || !c->d_blk) {
         // (re)build the decomposition for these window sizes; cached for later calls.  A failure anywhere inside (an allocation, a copy) leaves
         // the cache invalid — the next call with the same sizes rebuilds instead of indexing with offsets that were never uploaded.
@@ -581,6 +582,7 @@ int cn_cov_prepare_impl(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int32
         CN_HIP(h, hipMemcpyAsync(c->d_n_reg, c->n_reg.data(), (size_t)c->n * 4, hipMemcpyHostToDevice, h->stream));            //  while the copies run)
         built.keep = true;
     }
+    CN_TRACE("cov_prepare: tables");
     const size_t nt = (size_t)c->n_cb_tiles;
     if (nt == 0) return CORNETTO_OK;
     uint2 *d_t32 = (uint2 *)cn_ws(h, WS_CB_T32, nt * sizeof(uint2) + ((nt + 4095) / 4096 + 1) * 4 * 2);
@@ -591,6 +593,7 @@ int cn_cov_prepare_impl(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int32
     uint32_t *d_part = reinterpret_cast<uint32_t *>(d_t32 + nt);
     uint2 *d_pre = reinterpret_cast<uint2 *>(c->d_blk), *d_head = d_pre + c->n_blk;
     uint32_t *d_toff_d = reinterpret_cast<uint32_t *>(d_head + c->n_blk), *d_toff_q = d_toff_d + nt;
+    CN_TRACE("cov_prepare: workspaces");
     CN_HIP(h, hipMemsetAsync(d_grand, 0, 16, h->stream));
     static const int cb_tmeta = CN_DEV_INT("CORNETTO_COV_TMETA", 1);
     CbArgs A{c->d_depth, c->d_mq, c->d_off, c->d_len, c->d_cb_tiles, inc, r, d_pre, d_head, (int64_t)nt, cb_tmeta ? c->d_cb_tmeta : nullptr, d_t32, d_t64};
@@ -620,10 +623,9 @@ int cn_cov_prepare_impl(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int32
     const unsigned nb64 = (unsigned)std::min<size_t>(1024, (nt + 255) / 256);
     CN_LAUNCH(h, "cov_total64", cov_total64<<<dim3(nb64), dim3(256), 0, h->stream>>>(d_t64, (int64_t)nt, d_grand));
     CN_HIP(h, hipMemcpyAsync(p_grand, d_grand, 16, hipMemcpyDeviceToHost, h->stream));
-    // (the selection that follows sizes its result behind its kernels the first time: a pinned block for a sixth of the windows in the packed
-    // form is made while the block sums run — cn_result_prewarm)
-    if (!c->cw_warmed && c->inc > 0 && (c->cw_warmed = true)) cn_result_prewarm((size_t)(c->total / c->inc / 6 + 1) * sizeof(cornetto_regpk_t));
+    CN_TRACE("cov_prepare: queued");
     CN_HIP(h, hipStreamSynchronize(h->stream));
+    CN_TRACE("cov_prepare: done");
     sums[0] = p_grand[0];
     sums[1] = p_grand[1];
     c->sums[0] = sums[0]; c->sums[1] = sums[1]; c->sums[2] = (uint64_t)c->total;

@@ -1,6 +1,11 @@
 // runtime.hip — handle lifetime, resident data sets (bases / coverage in HBM) and small utilities of the
 // C ABI declared in include/cornetto_accel.h.
 #include "common.hpp"
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <set>
+#include <thread>
 
 #include <map>
 #include <mutex>
@@ -19,21 +24,69 @@ constexpr size_t POOL_KEEP_BYTES = 4ull << 30;       // ... and its byte budget 
 constexpr size_t POOL_KEEP = 12;                     // free buffers kept; beyond that the one that has waited longest goes back to the driver
 }  // namespace
 
+// Blocks that are being pinned ahead of their use (cn_result_prewarm): capacities requested and not yet in the free list.  One background thread
+// pins them one after the other, in the order of the requests (= the order in which a step needs them).
+namespace {
+std::condition_variable g_pre_cv;                    // (with g_pool_mu) a request arrived / a block landed
+std::deque<std::pair<size_t, int>> g_pre_queue;      // capacity, device
+std::multiset<size_t> g_pre_pending;                 // queued or being pinned
+bool g_pre_running = false;
+
+void pre_worker()
+{
+    std::unique_lock<std::mutex> lk(g_pool_mu);
+    for (;;) {
+        if (g_pre_queue.empty()) {
+            // (the thread ends when nothing has been asked for a while: a process that scans once does not keep it)
+            if (!g_pre_cv.wait_for(lk, std::chrono::milliseconds(200), [] { return !g_pre_queue.empty(); })) {
+                g_pre_running = false;
+                return;
+            }
+        }
+        // (the largest first: the step wants the selected coverage windows, its largest result, before the telomere runs and the sdust intervals)
+        auto big = g_pre_queue.begin();
+        for (auto q = g_pre_queue.begin(); q != g_pre_queue.end(); ++q)
+            if (q->first > big->first) big = q;
+        const std::pair<size_t, int> job = *big;
+        g_pre_queue.erase(big);
+        lk.unlock();
+        (void)hipSetDevice(job.second);
+        void *p = nullptr;
+        const bool ok = hipHostMalloc(&p, job.first, hipHostMallocDefault) == hipSuccess && p;
+        lk.lock();
+        auto it = g_pre_pending.find(job.first);
+        if (it != g_pre_pending.end()) g_pre_pending.erase(it);
+        if (ok) {
+            g_pool_free.emplace(job.first, p);
+            g_pool_age[p] = ++g_pool_clock;
+            g_pool_free_bytes += job.first;
+        }
+        g_pre_cv.notify_all();
+    }
+}
+}  // namespace
+
 void *cn_result_alloc(size_t bytes)
 {
     if (bytes < POOL_MIN) return malloc(bytes ? bytes : 1);
     size_t cap = POOL_MIN;
     while (cap < bytes) cap <<= 1;
     {
-        std::lock_guard<std::mutex> lk(g_pool_mu);
-        auto it = g_pool_free.lower_bound(cap);
-        if (it != g_pool_free.end() && it->first <= 2 * cap) {
-            void *p = it->second;
-            g_pool_live[p] = it->first;
-            g_pool_free_bytes -= it->first;
-            g_pool_free.erase(it);
-            g_pool_age.erase(p);
-            return p;
+        std::unique_lock<std::mutex> lk(g_pool_mu);
+        for (;;) {
+            auto it = g_pool_free.lower_bound(cap);
+            if (it != g_pool_free.end() && it->first <= 2 * cap) {
+                void *p = it->second;
+                g_pool_live[p] = it->first;
+                g_pool_free_bytes -= it->first;
+                g_pool_free.erase(it);
+                g_pool_age.erase(p);
+                return p;
+            }
+            // a block that would serve is being pinned ahead (cn_result_prewarm): it is ready sooner than one pinned from here
+            auto pe = g_pre_pending.lower_bound(cap);
+            if (pe == g_pre_pending.end() || *pe > 2 * cap) break;
+            g_pre_cv.wait(lk);
         }
     }
     void *p = nullptr;
@@ -43,27 +96,35 @@ void *cn_result_alloc(size_t bytes)
     return p;
 }
 
-// A pinned block for a result of about `bytes` put into the pool ahead of its use, unless one that would serve is waiting there: called by the
-// first scan of a resident object right after its main kernel is launched — page-locking runs at ~20 GB/s (3 ms for the 60 MB of selected
-// windows of a 3 Gbp assembly, 35 of the first pass's 40 ms were such first-time costs until round 5) and the kernel it hides behind takes
-// longer.  A guess that is too small or too large only means the exact allocation behind the kernel pins again, as it did before.
+// A pinned block for a result of about `bytes` on its way into the pool ahead of its use, unless one that would serve is there or on its way: called
+// when a resident object comes into being, for the results its scans will return — page-locking runs at ~20 GB/s (3 ms for the 60 MB of selected
+// windows of a 3 Gbp assembly), and until round 5 every first scan paid it behind its kernels: 35 of the first pass's 45 ms were such first-time costs.
+// A guess that is too small only means the exact allocation pins again, as it did before; one that is too large, a block that waits in the pool.
 void cn_result_prewarm(size_t bytes)
 {
     if (bytes < POOL_MIN) return;
     size_t cap = POOL_MIN;
     while (cap < bytes) cap <<= 1;
-    {
-        std::lock_guard<std::mutex> lk(g_pool_mu);
-        auto it = g_pool_free.lower_bound(cap / 2);
-        if (it != g_pool_free.end() && it->first <= 2 * cap) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_pool_free.lower_bound(cap);
+    if (it != g_pool_free.end() && it->first <= 2 * cap) return;
+    auto pe = g_pre_pending.lower_bound(cap);
+    if (pe != g_pre_pending.end() && *pe <= 2 * cap) return;
+    g_pre_pending.insert(cap);
+    g_pre_queue.emplace_back(cap, dev);
+    if (!g_pre_running) {
+        try {
+            std::thread(pre_worker).detach();
+            g_pre_running = true;
+        } catch (...) {
+            g_pre_queue.pop_back();
+            g_pre_pending.erase(g_pre_pending.find(cap));
+            return;
+        }
     }
-    void *p = nullptr;
-    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess || !p) return;
-    {
-        std::lock_guard<std::mutex> lk(g_pool_mu);
-        g_pool_live[p] = cap;
-    }
-    cornetto_free(p);                                  // (into the free list, under the pool's own rules)
+    g_pre_cv.notify_all();
 }
 
 extern "C" {
@@ -229,6 +290,66 @@ int cornetto_accel_boost(cornetto_accel_t *h, int on)
     return CORNETTO_OK;
 }
 
+int cornetto_accel_warm(cornetto_accel_t *h, int what)
+{
+    // Every entry point once on 4 kb: the first use of a code object loads it, the first copies set the copy engines up, the first results make the small
+    // pools — 13 of the 25 ms by which the first pass of a process over an assembly exceeded the second (tools/perf_cold.py --warm 1).  A caller that
+    // has something else to do first (read its input) runs this on the thread that opened the handle.
+    if (!h) return CORNETTO_E_ARG;
+    const int32_t n = 4096;
+    std::vector<uint8_t> seq((size_t)n);
+    std::vector<uint16_t> d((size_t)n), q((size_t)n);
+    uint32_t x = 12345u;
+    for (int32_t i = 0; i < n; ++i) {
+        x = x * 1664525u + 1013904223u;
+        seq[(size_t)i] = "ACGT"[(x >> 24) & 3];
+        d[(size_t)i] = (uint16_t)(20 + ((x >> 16) & 15));
+        q[(size_t)i] = (uint16_t)(d[(size_t)i] >> ((i / 700) & 1));
+    }
+    for (int32_t i = 100; i < 700; ++i) seq[(size_t)i] = "TTAGGG"[(i - 100) % 6];
+    for (int32_t i = 1000; i < 1100; ++i) seq[(size_t)i] = 'A';
+    int rc = CORNETTO_OK;
+    if (what & (CORNETTO_WARM_SDUST | CORNETTO_WARM_TELO)) {
+        const uint8_t *sp = seq.data();
+        const int64_t ln = n;
+        cornetto_asm_t *a = nullptr;
+        rc = cornetto_asm_upload(h, &sp, &ln, 1, &a);
+        if (rc == CORNETTO_OK && (what & CORNETTO_WARM_SDUST)) {
+            for (int rep = 0; rep < 2 && rc == CORNETTO_OK; ++rep) {      // (the second call takes the one-go path)
+                cornetto_ivl_t *iv = nullptr;
+                int64_t ni = 0;
+                rc = cornetto_sdust_asm(h, a, 20, 64, &iv, &ni);
+                cornetto_free(iv);
+            }
+        }
+        if (rc == CORNETTO_OK && (what & CORNETTO_WARM_TELO)) {
+            cornetto_hit_t *hits = nullptr;
+            cornetto_win_t *wins = nullptr;
+            int64_t nh = 0, nw = 0;
+            rc = cornetto_telo_scan(h, a, "TTAGGG", 0.39, &hits, &nh, &wins, &nw);
+            cornetto_free(hits);
+            free(wins);
+        }
+        cornetto_asm_free(h, a);
+    }
+    if (rc == CORNETTO_OK && (what & CORNETTO_WARM_COV)) {
+        const uint16_t *dp = d.data(), *qp = q.data();
+        cornetto_cov_t *c = nullptr;
+        rc = cornetto_cov_upload(h, &dp, &qp, &n, 1, &c);
+        uint64_t sums[3];
+        if (rc == CORNETTO_OK) rc = cornetto_cov_prepare(h, c, 500, 50, sums);
+        if (rc == CORNETTO_OK) {
+            cornetto_regpk_t *pk = nullptr;
+            int64_t np = 0, *cf = nullptr;
+            rc = cornetto_cov_select_packed(h, c, 10, 60, 0.4f, 100, 1000, 0, &pk, &np, &cf);
+            cornetto_free(pk);
+            free(cf);
+        }
+        if (c) cornetto_cov_free(h, c);
+    }
+    return rc;
+}
+
 int cornetto_accel_set_timing(cornetto_accel_t *h, int level)
 {
     if (!h || level < 0 || level > 2) return cn_fail(h, CORNETTO_E_ARG, "set_timing: level must be 0, 1 or 2");
@@ -262,6 +383,12 @@ static int asm_finish_table(cornetto_accel_t *h, cornetto_asm_t *a)
         CN_HIP(h, hipMemcpyAsync(a->d_len, a->len.data(), a->n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     }
     CN_HIP(h, hipStreamSynchronize(h->stream));
+    // the results the scans of an assembly will return, pinned while the caller gets to its first scan (cn_result_prewarm): a telomere run per ~1.5 kb
+    // with planted arrays, an sdust interval per ~4 kb — assemblies only: a batch of reads or a test's kilobases pin what they need when they need it
+    if (a->total >= (64ll << 20)) {
+        cn_result_prewarm((size_t)(a->total / 1536 + 1) * sizeof(cornetto_hit_t));
+        cn_result_prewarm((size_t)(a->total / 4096 + 1) * sizeof(cornetto_ivl_t));
+    }
     return CORNETTO_OK;
 }
 
@@ -398,6 +525,9 @@ static int cov_finish_table(cornetto_accel_t *h, cornetto_cov_t *c)
         CN_HIP(h, hipMemcpyAsync(c->d_len, c->len.data(), c->n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     }
     CN_HIP(h, hipStreamSynchronize(h->stream));
+    // the selected windows a scan of the coverage will return, pinned while the caller gets to it (cn_result_prewarm): an eighth of the windows at the
+    // default step of 50 positions, 8 bytes each in the packed form
+    if (c->total >= (64ll << 20)) cn_result_prewarm((size_t)(c->total / 50 / 8 + 1) * sizeof(cornetto_regpk_t));
     return CORNETTO_OK;
 }
 

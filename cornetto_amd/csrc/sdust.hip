@@ -2176,9 +2176,6 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
                 }
             }
             stamp("main kernel queued");
-            // (no counts of an earlier call: the result array is sized behind the kernel — pin a block of its likely size while the kernel runs: one
-            // interval per ~4 kb in assembly sequence, cn_result_prewarm)
-            if (!one_go && sift_on && !a->sd_warmed && (a->sd_warmed = true)) cn_result_prewarm((size_t)(a->total / 4096 + 1) * sizeof(cornetto_ivl_t));
             CN_HIP(h, hipMemcpyAsync(p_tot, d_tot, want_stats ? 2048 : 128, hipMemcpyDeviceToHost, h->stream));
             CN_HIP(h, hipStreamSynchronize(h->stream));
             stamp("main kernel done");

@@ -842,9 +842,6 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
         }
         CN_TRY(launch(A));
         if (bitmap_valid) *bitmap_valid = want_bitmap;
-        // (the first scan of an assembly sizes its result behind the kernel: a pinned block of the likely size is made while the kernel runs —
-        // one run per ~2 kb in assembly sequence with its planted arrays; cn_result_prewarm)
-        if (hits && !a->tf_warmed && (a->tf_warmed = true)) cn_result_prewarm((size_t)(a->total / 1536 + 1) * sizeof(cornetto_hit_t));
         if (hits) {
             // place of every tile in the dense, contig-ordered lists + list totals
             CN_TRY(cnscan::exclusive_u32_multi(h, "tf_order", reinterpret_cast<const uint32_t *>(d_tc), (int64_t)nt, 4, 4, d_offq, d_part, d_cnt));

@@ -113,6 +113,16 @@ int cornetto_accel_last_timing(const cornetto_accel_t *h, const char **names, fl
  * Scheduling only: results do not depend on it. */
 int cornetto_accel_set_share(cornetto_accel_t *h, int percent);
 
+/* Every entry point of the named groups once on a 4 kb built-in input: what the first use of the runtime costs in a process (loading the code objects,
+ * setting the copy engines up, the first pinned pools: 13 of the 25 ms by which the first pass over an assembly exceeded the second) is paid here instead
+ * of in the first scan.  Optional; a caller that reads its input first runs it beside that, on the thread that opened the handle.  Nothing the reference
+ * has a counterpart for: its per-contig functions start at once (src/sdust/sdust.c:196-203). */
+#define CORNETTO_WARM_SDUST 1
+#define CORNETTO_WARM_TELO 2
+#define CORNETTO_WARM_COV 4
+#define CORNETTO_WARM_ALL 7
+int cornetto_accel_warm(cornetto_accel_t *h, int what);
+
 /* "The rest of the device is free now" (on != 0) / "is in use again" (on == 0): may be called from ANOTHER host thread than the one that is
  * inside cornetto_sdust_asm() on this handle.  While it is on, a running sdust call whose share is below 100 launches the waves it had left
  * to the other stream as a second kernel that draws from the same chunk counters, and later calls start with the whole chip.  bench.py

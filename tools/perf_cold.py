@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--gbases", type=float, default=0.0)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--fresh", type=int, default=2, help="how many fresh handle + wrap cycles")
+    ap.add_argument("--warm", type=int, default=0, help="1: every entry point once on a 4 kb assembly before anything is timed (what a warm-up inside cornetto_accel_open would buy)")
     ap.add_argument("--dev", type=int, default=0, help="1: the development build of the library (CORNETTO_SDUST_TRACE=1 prints the phases of a call)")
     a = ap.parse_args()
     import torch
@@ -29,6 +30,17 @@ def main():
     depth, mq = synth.make_coverage(torch, dev, lens, offs, 0xC0FFEE)
     torch.cuda.synchronize()
     ln64, ln32 = np.array(lens, dtype=np.int64), np.array(lens, dtype=np.int32)
+    if a.warm:
+        t0 = time.perf_counter()
+        wa = cornetto_amd.Accel(0, dev=bool(a.dev))
+        rng = np.random.default_rng(1)
+        sq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 4096)].copy()
+        sq[100:400] = np.frombuffer(b"TTAGGG" * 50, dtype=np.uint8)
+        wasm = wa.asm_upload([sq])
+        wcov = wa.cov_upload([rng.integers(10, 50, 4096).astype(np.uint16)], [rng.integers(10, 50, 4096).astype(np.uint16)])
+        wa.sdust(wasm, 20, 64); wa.telo_scan(wasm, b"TTAGGG", 0.39); wa.cov_prepare(wcov, 2500, 50); wa.cov_select_packed(wcov, 10, 60, 0.4, 100, 1000, False)
+        wasm.close(); wcov.close(); wa.close()
+        print("warm-up on 4 kb: %.2f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
     for f in range(a.fresh):
         t0 = time.perf_counter()
         acc = cornetto_amd.Accel(0, dev=bool(a.dev))

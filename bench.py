@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_ROUNDS = ("r05", "r04")                                         # the newest committed counter passes first
+PMC_ROUNDS = ("r06", "r05", "r04")                                         # the newest committed counter passes first
 PMC_FILE = os.path.join("profiles", "%s_%s_pmc_traffic_%s.json")    # % (round, workload profile, kernel symbol)
 SQ_FILE = os.path.join("profiles", "%s_%s_sq_%s.json")
 

@@ -144,6 +144,7 @@ def lib(dev=False):
         "cornetto_bgin_open": (C.c_int, [vp, pp]),
         "cornetto_bgin_close": (None, [vp, vp]),
         "cornetto_bgin_feed": (C.c_int, [vp, vp, cp, i64, cp, i64, C.c_int]),
+        "cornetto_bgin_prefetch": (C.c_int, [vp, vp, cp, i64, cp, i64]),
         "cornetto_bgin_pending": (None, [vp, C.POINTER(i64), C.POINTER(i64)]),
         "cornetto_bgin_unmatched_mq": (i64, [vp]),
         "cornetto_bgin_error": (C.POINTER(BgErr), [vp]),

@@ -253,6 +253,19 @@ struct cornetto_bgin {
     cornetto_bgerr_t err{0, 0, 0, 0};
     bool finished = false;
     int64_t left_mq = 0;      // tokens of cov-mq behind the last record when cov-total ended (the reference never looks at them: :204-207)
+    // cornetto_bgin_prefetch(): the pieces of the feeds to come on their way to the device while this feed's kernels run — two staging sets: one
+    // is being filled while the feed in front of it still copies out of the other
+    hipStream_t pf_stream = nullptr;
+    struct Staged {
+        hipEvent_t ev = nullptr;
+        uint8_t *buf[2] = {nullptr, nullptr};    // on the device, per file
+        size_t cap[2] = {0, 0};
+        const char *src[2] = {nullptr, nullptr}; // what is staged: the caller's pointers and lengths (a feed with the same ones takes it from here)
+        int64_t n[2] = {0, 0};
+        bool valid = false;
+        uint64_t seq = 0;
+    } pf[2];
+    uint64_t pf_seq = 0;
 };
 
 namespace {
@@ -310,7 +323,48 @@ void cornetto_bgin_close(cornetto_accel_t *h, cornetto_bgin_t *b)
     if (h) (void)hipSetDevice(h->device);
     if (b->d_a) (void)hipFree(b->d_a);
     if (b->d_b) (void)hipFree(b->d_b);
+    if (b->pf_stream) { (void)hipStreamSynchronize(b->pf_stream); (void)hipStreamDestroy(b->pf_stream); }
+    for (auto &st : b->pf) {
+        if (st.ev) (void)hipEventDestroy(st.ev);
+        for (int f = 0; f < 2; ++f)
+            if (st.buf[f]) (void)hipFree(st.buf[f]);
+    }
     delete b;
+}
+
+int cornetto_bgin_prefetch(cornetto_accel_t *h, cornetto_bgin_t *b, const char *tot, int64_t n_tot, const char *mq, int64_t n_mq)
+{
+    if (!h || !b || n_tot < 0 || n_mq < 0 || (n_tot > 0 && !tot) || (n_mq > 0 && !mq)) return cn_fail(h, CORNETTO_E_ARG, "bgin_prefetch: bad argument");
+    if (b->finished || b->err.kind) return CORNETTO_OK;
+    CN_HIP(h, hipSetDevice(h->device));
+    if (!b->pf_stream) {
+        CN_HIP(h, hipStreamCreateWithFlags(&b->pf_stream, hipStreamNonBlocking));
+        for (auto &st : b->pf) CN_HIP(h, hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+    }
+    // the set that is free, else the older one (a prefetch nobody fed: it is written over once its own copy and whatever reads it are through)
+    cornetto_bgin::Staged *st = !b->pf[0].valid ? &b->pf[0] : !b->pf[1].valid ? &b->pf[1] : (b->pf[0].seq < b->pf[1].seq ? &b->pf[0] : &b->pf[1]);
+    if (st->valid) CN_HIP(h, hipStreamSynchronize(b->pf_stream));
+    st->valid = false;
+    // (the feed that took this set last copied out of it on the handle's stream and synchronised that stream before it returned: nothing reads it now)
+    const char *src[2] = {tot, mq};
+    const int64_t nn[2] = {n_tot, n_mq};
+    for (int f = 0; f < 2; ++f) {
+        if ((size_t)nn[f] > st->cap[f]) {
+            if (st->buf[f]) (void)hipFree(st->buf[f]);
+            st->buf[f] = nullptr;
+            st->cap[f] = 0;
+            const size_t cap = ((size_t)nn[f] + (1u << 20)) & ~(size_t)4095;
+            if (hipMalloc((void **)&st->buf[f], cap) != hipSuccess) return cn_fail(h, CORNETTO_E_NOMEM, "bgin_prefetch: device allocation of %zu bytes failed", cap);
+            st->cap[f] = cap;
+        }
+        if (nn[f]) CN_HIP(h, hipMemcpyAsync(st->buf[f], src[f], (size_t)nn[f], hipMemcpyHostToDevice, b->pf_stream));
+        st->src[f] = src[f];
+        st->n[f] = nn[f];
+    }
+    CN_HIP(h, hipEventRecord(st->ev, b->pf_stream));
+    st->valid = true;
+    st->seq = ++b->pf_seq;
+    return CORNETTO_OK;
 }
 
 void cornetto_bgin_pending(const cornetto_bgin_t *b, int64_t *pend_tot, int64_t *pend_mq)
@@ -342,7 +396,20 @@ int cornetto_bgin_feed(cornetto_accel_t *h, cornetto_bgin_t *b, const char *tot,
         d_text[f] = (uint8_t *)cn_ws(h, f ? WS_BG_TEXT_B : WS_BG_TEXT_A, (size_t)n[f] + 64);
         if (!d_text[f]) return cn_fail(h, CORNETTO_E_NOMEM, "bgin_feed: workspace allocation failed");
         if (!b->pend[f].empty()) CN_HIP(h, hipMemcpyAsync(d_text[f], b->pend[f].data(), b->pend[f].size(), hipMemcpyHostToDevice, h->stream));
-        if (nnew[f]) CN_HIP(h, hipMemcpyAsync(d_text[f] + b->pend[f].size(), src[f], (size_t)nnew[f], hipMemcpyHostToDevice, h->stream));
+    }
+    // the new bytes: staged on the device by cornetto_bgin_prefetch() (the same pointers and lengths) — a copy inside the device behind what is
+    // left over from the last feed — or from the host now
+    cornetto_bgin::Staged *st = nullptr;
+    for (auto &x : b->pf)
+        if (x.valid && x.src[0] == tot && x.src[1] == mq && x.n[0] == n_tot && x.n[1] == n_mq) st = &x;
+    if (st) {
+        CN_HIP(h, hipStreamWaitEvent(h->stream, st->ev, 0));
+        st->valid = false;
+    }
+    for (int f = 0; f < 2; ++f) {
+        if (!nnew[f]) continue;
+        if (st) CN_HIP(h, hipMemcpyAsync(d_text[f] + b->pend[f].size(), st->buf[f], (size_t)nnew[f], hipMemcpyDeviceToDevice, h->stream));
+        else CN_HIP(h, hipMemcpyAsync(d_text[f] + b->pend[f].size(), src[f], (size_t)nnew[f], hipMemcpyHostToDevice, h->stream));
     }
     // a token cut by the end of the buffer is not complete yet (unless this is the end of the file)
     auto last_byte = [&](int f) -> int {

@@ -11,7 +11,7 @@ R=$PWD
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 PROBE="python3 $R/tools/perf_probe.py sdust --mbases $MB --features 1 --reps 2 --profile $PROFILE"
-CORNETTO_SDUST_STATS=1 $PROBE 2> $R/gpurun_out/${TAG}_stats.txt > $R/gpurun_out/${TAG}_probe.txt
+CORNETTO_LIB=$R/cornetto_amd/libcornetto_hip_dev.so CORNETTO_SDUST_STATS=1 $PROBE 2> $R/gpurun_out/${TAG}_stats.txt > $R/gpurun_out/${TAG}_probe.txt      # (the statistics build: a switch of the development library)
 $PROBE 2> /dev/null > $R/gpurun_out/${TAG}_probe_prod.txt      # (the production build: the kernel the bench times)
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM" "SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_WAVES" "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do

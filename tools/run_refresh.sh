@@ -1,7 +1,7 @@
 #!/bin/bash
 # end-of-round evidence: GPU tests, smoke, bench line, rocprofv3 kernel stats of the bench (two streams and serial, both workload
 # profiles), SQ / traffic counters of the two sdust kernel families.   bash tools/run_refresh.sh [tag]
-TAG=${1:-r05}
+TAG=${1:-r06}
 set -x
 mkdir -p gpurun_out
 R=$PWD

@@ -1,4 +1,6 @@
 # development aid: the two-stream bench step against the sift chunk size (= LDS per wave = resident waves per CU)
+# (round 6: the CORNETTO_SDUST_* / CORNETTO_SIFT_* switches this script sets exist in the development build of the library only)
+export CORNETTO_LIB=${CORNETTO_LIB:-$PWD/cornetto_amd/libcornetto_hip_dev.so}
 Q="--steps 30 --warmup 3 --no-cpu --no-e2e --no-reads --no-profiles --check-steps 0 --emulate-ranks="
 for c in ${@:-0 1408 0 1408}; do
 echo -n "chunk $c: "; CORNETTO_SDUST_CHUNK=$c python bench.py $Q 2>/dev/null | python -c "

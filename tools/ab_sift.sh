@@ -1,4 +1,6 @@
 # development aid: sd_sift alone (uniform / humanlike), default chunk and 2048, with the kernel's own statistics once
+# (round 6: the CORNETTO_SDUST_* / CORNETTO_SIFT_* switches this script sets exist in the development build of the library only)
+export CORNETTO_LIB=${CORNETTO_LIB:-$PWD/cornetto_amd/libcornetto_hip_dev.so}
 for P in uniform humanlike; do
 for c in 0 2048; do
 echo -n "$P chunk $c: "

@@ -1,3 +1,5 @@
+# (round 6: the CORNETTO_SDUST_* / CORNETTO_SIFT_* switches this script sets exist in the development build of the library only)
+export CORNETTO_LIB=${CORNETTO_LIB:-$PWD/cornetto_amd/libcornetto_hip_dev.so}
 for P in uniform humanlike; do
 for cfg in "0 0" "1408 0" "1280 0" "0 6144" "0 5376"; do set -- $cfg
 echo -n "$P chunk $1 blocks $2: "

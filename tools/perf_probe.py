@@ -22,8 +22,9 @@ def main():
     ap.add_argument("--read-len", type=int, default=0, help="instead of the assembly: reads of about this length (+-30 %%), --mbases in total")
     ap.add_argument("--simple-cov", type=int, default=0, help="uniform random depth (rocprofv3 --pmc crashes inside torch.poisson)")
     a = ap.parse_args()
-    if a.chunk:
+    if a.chunk:                     # (a development switch: the development build of the library reads it)
         os.environ["CORNETTO_SDUST_CHUNK"] = a.chunk
+        os.environ.setdefault("CORNETTO_LIB", os.path.join(ROOT, "cornetto_amd", "libcornetto_hip_dev.so"))
     import torch
     import bench
     import cornetto_amd

@@ -1,5 +1,7 @@
 #!/bin/bash
 # instruction counts of sd_sift with stages switched off (CORNETTO_SIFT_ABL: 4 = no tiles, 2 = no L1 / L2, 1 = no resolve): where the instructions go
+# (round 6: the CORNETTO_SDUST_* / CORNETTO_SIFT_* switches this script sets exist in the development build of the library only)
+export CORNETTO_LIB=${CORNETTO_LIB:-$PWD/cornetto_amd/libcornetto_hip_dev.so}
 R=$PWD
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp

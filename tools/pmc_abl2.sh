@@ -1,5 +1,7 @@
 #!/bin/bash
 # per-stage instruction and LDS-cycle counts of sd_sift (CORNETTO_SIFT_ABL: 4 no tiles, 2 no L1 / L2, 1 no resolve): bash tools/pmc_abl2.sh [profile] [abl values]
+# (round 6: the CORNETTO_SDUST_* / CORNETTO_SIFT_* switches this script sets exist in the development build of the library only)
+export CORNETTO_LIB=${CORNETTO_LIB:-$PWD/cornetto_amd/libcornetto_hip_dev.so}
 R=$PWD
 P=${1:-uniform}; shift
 mkdir -p $R/gpurun_out

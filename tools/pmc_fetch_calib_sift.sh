@@ -1,6 +1,8 @@
 #!/bin/bash
 # FETCH_SIZE of sd_sift calibrated in the kernel's OWN access pattern: the stages behind the staging switched off (CORNETTO_SIFT_ABL=7: the kernel
 # still fetches every region — chunk + the 128 bases in front — exactly once, 1.0833 B/base for 1536-base chunks; 135: not even that), against the full kernel
+# (round 6: the CORNETTO_SDUST_* / CORNETTO_SIFT_* switches this script sets exist in the development build of the library only)
+export CORNETTO_LIB=${CORNETTO_LIB:-$PWD/cornetto_amd/libcornetto_hip_dev.so}
 R=$PWD
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp

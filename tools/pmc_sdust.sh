@@ -3,6 +3,8 @@
 # FETCH_SIZE calibration on known byte counts (tools/ubench/fetch_calib).  Writes tracked-size summaries:
 #   gpurun_out/<tag>_sq_sdust.json   gpurun_out/<tag>_pmc_traffic.json      (copy them to profiles/)
 #   bash tools/pmc_sdust.sh <tag> [mbases] [profile]
+# (round 6: the CORNETTO_SDUST_* / CORNETTO_SIFT_* switches this script sets exist in the development build of the library only)
+export CORNETTO_LIB=${CORNETTO_LIB:-$PWD/cornetto_amd/libcornetto_hip_dev.so}
 TAG=${1:-r02}
 MB=${2:-3160}
 PROFILE=${3:-uniform}

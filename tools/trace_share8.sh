@@ -1,6 +1,8 @@
 #!/bin/bash
 # timeline of a step: rocprofv3 kernel trace of the last two steps + the host-side stamps of the sdust call
 #   bash tools/trace_share8.sh <tag> [extra bench args, default "--rank-share 8,1"]
+# (round 6: the CORNETTO_SDUST_* / CORNETTO_SIFT_* switches this script sets exist in the development build of the library only)
+export CORNETTO_LIB=${CORNETTO_LIB:-$PWD/cornetto_amd/libcornetto_hip_dev.so}
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r05}; shift
 X=${*:---rank-share 8,1}
 Q="--steps 8 --warmup 2 --no-cpu --no-e2e --no-reads --no-profiles --check-steps 0 --emulate-ranks= $X"

@@ -157,7 +157,10 @@ typedef struct {
 static void *bg_round_thread(void *p)
 {
     bg_round_t *r = (bg_round_t *)p;
+    const double t0 = cli_realtime();
     for (int f = 0; f < 2; ++f) r->got[f] = r->want[f] > 0 ? cli_pread_parallel(r->fd[f], r->dst[f], r->want[f], r->off[f], r->n_threads) : 0;
+    if (getenv("CORNETTO_CLI_TRACE"))
+        fprintf(stderr, "[cli trace] round read: %lld + %lld bytes in %.2f ms\n", (long long)r->got[0], (long long)r->got[1], (cli_realtime() - t0) * 1e3);
     return NULL;
 }
 

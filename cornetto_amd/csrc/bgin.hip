@@ -416,6 +416,7 @@ int cornetto_bgin_feed(cornetto_accel_t *h, cornetto_bgin_t *b, const char *tot,
         if (n[f] == 0) return ' ';
         return nnew[f] ? (unsigned char)src[f][nnew[f] - 1] : (unsigned char)b->pend[f].back();
     };
+    CN_TRACE("bgin_feed: copies queued");
     uint32_t *d_tok[2];
     int64_t ntok[2], all_tok[2];
     const bool eof[2] = {(final & 1) != 0, (final & 2) != 0};
@@ -426,6 +427,7 @@ int cornetto_bgin_feed(cornetto_accel_t *h, cornetto_bgin_t *b, const char *tot,
         all_tok[f] = ntok[f];
         if (!eof[f] && open_token && ntok[f] > 0) --ntok[f];   // the last token may continue in the next piece
     }
+    CN_TRACE("bgin_feed: tokenised");
     int64_t nrec = std::min(ntok[0] / 4, ntok[1] / 4);
     const int64_t fresh = nrec - b->ctx;   // records consumed by this call
     // small device block: err key, n_break, n_clamp, details
@@ -483,6 +485,7 @@ int cornetto_bgin_feed(cornetto_accel_t *h, cornetto_bgin_t *b, const char *tot,
         }
         b->n_clamp += p_small[2];
     }
+    CN_TRACE("bgin_feed: records");
     // offsets needed for the carry: start of the first unconsumed token, start of the context (last two consumed records)
     int64_t cut[2], ctx_start[2];
     const int new_ctx = (int)std::min<int64_t>(2, nrec);
@@ -546,6 +549,7 @@ int cornetto_bgin_feed(cornetto_accel_t *h, cornetto_bgin_t *b, const char *tot,
         b->started = true;
         b->ctx = new_ctx;
     }
+    CN_TRACE("bgin_feed: carry");
     cn_timing_end(h);
     return CORNETTO_OK;
 }

@@ -1,9 +1,10 @@
 #!/bin/bash
 # the rocprofv3 --kernel-trace --stats part of tools/run_refresh.sh alone: bash tools/run_kernel_stats.sh [tag]
-TAG=${1:-r03}
+TAG=${1:-r06}
 R=$PWD
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
+export CORNETTO_BENCH_WARM=0     # (no 4 kb warm-up launches in the traced runs: every sd_sift / cov_blocks / tf_scan row of the statistics is a full-size launch)
 rm -rf $R/gpurun_out/prof_${TAG} $R/gpurun_out/prof_${TAG}_serial $R/gpurun_out/prof_${TAG}_sat
 Q="--steps 5 --warmup 1 --no-cpu --no-e2e --no-reads --no-profiles --check-steps 0 --emulate-ranks="
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG} -- python3 $R/bench.py $Q > $R/gpurun_out/${TAG}_bench_prof.log 2>&1

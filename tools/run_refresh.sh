@@ -16,6 +16,7 @@ timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 timeout 1200 python bench.py --steps 20 --warmup 2 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"; tail -1 gpurun_out/${TAG}_bench.json | cut -c1-300
 timeout 600 python bench.py --steps 10 --warmup 2 --serial --no-cpu --no-e2e --no-reads --no-profiles --emulate-ranks "" > gpurun_out/${TAG}_bench_serial.json 2>> gpurun_out/${TAG}_bench.err
 cd /tmp && export TMPDIR=/tmp
+export CORNETTO_BENCH_WARM=0     # (no 4 kb warm-up launches in the traced runs: every sd_sift / cov_blocks / tf_scan row of the statistics is a full-size launch)
 rm -rf $R/gpurun_out/prof_${TAG} $R/gpurun_out/prof_${TAG}_serial $R/gpurun_out/prof_${TAG}_sat $R/gpurun_out/prof_${TAG}_hum $R/gpurun_out/prof_${TAG}_share8
 Q="--steps 5 --warmup 1 --no-cpu --no-e2e --no-reads --no-profiles --check-steps 0 --emulate-ranks="
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG} -- python3 $R/bench.py $Q > $R/gpurun_out/${TAG}_bench_prof.log 2>&1

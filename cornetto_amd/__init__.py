@@ -534,19 +534,29 @@ class Accel:
         return out
 
     # ---- bedgraph ingest ---------------------------------------------------------------------------
-    def bedgraph_ingest(self, tot_pieces, mq_pieces):
+    def bedgraph_ingest(self, tot_pieces, mq_pieces, prefetch=0):
         """stream the two per-base bedgraphs (iterables of bytes pieces, any split points) through the device
-        parser; returns (resident coverage, [contig names], clamped count).  Raises BedgraphFormatError."""
+        parser; returns (resident coverage, [contig names], clamped count).  Raises BedgraphFormatError.
+        prefetch: 1 = cornetto_bgin_prefetch() of the next pieces in front of every feed (two pieces on their way, as the CLI does);
+        2 = the same, and every third prefetch is of pieces that are NOT fed next (the feed must ignore what is staged)"""
         L = self.L
         bg = C.c_void_p()
         self._chk(L.cornetto_bgin_open(self.h, C.byref(bg)))
         try:
             ta, qa = list(tot_pieces), list(mq_pieces)
-            n = max(len(ta), len(qa), 1)
+            n_t, n_q = len(ta), len(qa)
+            n = max(n_t, n_q, 1)
+            # (ctypes hands a bytes object's own buffer to a c_char_p parameter: the same address for the prefetch and the feed that follows)
+            ta += [b""] * (n - n_t)
+            qa += [b""] * (n - n_q)
+            if prefetch:
+                self._chk(L.cornetto_bgin_prefetch(self.h, bg, ta[0], len(ta[0]), qa[0], len(qa[0])))
             for i in range(n):
-                t = ta[i] if i < len(ta) else b""
-                q = qa[i] if i < len(qa) else b""
-                fin = (1 if i >= len(ta) - 1 else 0) | (2 if i >= len(qa) - 1 else 0)
+                t, q = ta[i], qa[i]
+                fin = (1 if i >= n_t - 1 else 0) | (2 if i >= n_q - 1 else 0)
+                if prefetch and i + 1 < n:
+                    j = i + 1 if not (prefetch == 2 and i % 3 == 2) else 0          # (mode 2: something else than the next pieces now and then)
+                    self._chk(L.cornetto_bgin_prefetch(self.h, bg, ta[j], len(ta[j]), qa[j], len(qa[j])))
                 rc = L.cornetto_bgin_feed(self.h, bg, t, len(t), q, len(q), fin)
                 if rc == -6:
                     e = L.cornetto_bgin_error(bg).contents

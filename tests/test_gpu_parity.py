@@ -952,6 +952,62 @@ def test_bedgraph_ingest_matches_host_parse(acc, golden_dir, bg_ctgs, mean):
     cov.close()
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mean", [200000, 3000])
+def test_bedgraph_ingest_with_the_next_pieces_on_their_way(acc, golden_dir, mean, mode):
+    """cornetto_bgin_prefetch(): pieces staged on the device ahead of their feed (mode 1, as the CLI does) and prefetches that no feed takes (mode 2)
+    give the coverage the feeds alone give"""
+    t, q = _bg_text(golden_dir)
+    rng = np.random.default_rng(mean)
+    tp, qp = _split(t, rng, mean), _split(q, rng, mean + 7)
+    a, na, ca = acc.bedgraph_ingest(tp, qp)
+    b, nb, cb = acc.bedgraph_ingest(tp, qp, prefetch=mode)
+    try:
+        assert na == nb and ca == cb and list(a.lens) == list(b.lens)
+        assert acc.cov_prepare(a, 300, 7) == acc.cov_prepare(b, 300, 7)
+        for ci in range(len(a.lens)):
+            assert np.array_equal(acc.cov_regs(a, ci), acc.cov_regs(b, ci)), ci
+    finally:
+        a.close()
+        b.close()
+
+
+def test_accel_warm_and_text_api_arguments(acc):
+    """cornetto_accel_warm() leaves the handle as it found it; cornetto_text_* refuses what it cannot take"""
+    import ctypes as C
+    import cornetto_amd
+    L = acc.L
+    rng = np.random.default_rng(9)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 50000)].copy()
+    seq[1000:1600] = np.frombuffer(b"TTAGGG" * 100, dtype=np.uint8)
+    asm = acc.asm_upload([seq])
+    try:
+        before = (acc.sdust(asm, 20, 64).copy(), acc.telofind(asm, b"TTAGGG").copy())
+        acc.warm(7)
+        acc.warm(1)
+        after = (acc.sdust(asm, 20, 64), acc.telofind(asm, b"TTAGGG"))
+        assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+    finally:
+        asm.close()
+    t = C.c_void_p()
+    assert L.cornetto_text_open(acc.h, 0, C.byref(t)) == -3 and L.cornetto_text_open(acc.h, 1 << 33, C.byref(t)) == -3        # CORNETTO_E_ARG
+    assert L.cornetto_text_open(acc.h, 1000, C.byref(t)) == 0
+    slab = L.cornetto_pinned_alloc(4096)
+    try:
+        assert L.cornetto_text_put(acc.h, t, slab, 600, 500, 0) == -3             # beyond the capacity
+        assert L.cornetto_text_put(acc.h, t, slab, 10, 0, 4) == -3                # no such queue
+        C.memmove(slab, b">a\nACGT\n>b\nGG\n", 14)
+        assert L.cornetto_text_put(acc.h, t, slab, 14, 0, 3) == 0 and L.cornetto_text_wait(acc.h, t, 3) == 0
+        p, cnt, used, plain = C.c_void_p(), C.c_int64(), C.c_int64(), C.c_int32()
+        assert L.cornetto_fasta_split_text(acc.h, t, 2000, 1, C.byref(p), C.byref(cnt), C.byref(used), C.byref(plain), None) == -3
+        assert L.cornetto_fasta_split_text(acc.h, t, 14, 1, C.byref(p), C.byref(cnt), C.byref(used), C.byref(plain), None) == 0
+        assert (cnt.value, used.value, plain.value) == (2, 14, 1)
+        L.cornetto_free(p)
+    finally:
+        L.cornetto_text_free(acc.h, t)
+        L.cornetto_pinned_free(slab)
+
+
 def _raw_depths(t, q):
     return ([int(l.split()[3]) for l in t.splitlines()], [int(l.split()[3]) for l in q.splitlines()])
 

@@ -431,6 +431,8 @@ class Rank:
         # every entry point once on a built-in 4 kb input (cornetto_accel_warm): the runtime's first-use costs — code objects, copy engines, the first
         # pinned pools — belong to opening the device, not to the first assembly (the CLI does the same behind its open, beside reading the file)
         t_w = time.perf_counter()
+        self.lazy = not args.serial and os.environ.get("CORNETTO_BENCH_LAZY", "1") != "0"
+        self.acc.set_lazy(self.lazy)                 # (in front of the warm-up: the copy stream exists when its copy queues are set up)
         if os.environ.get("CORNETTO_BENCH_WARM", "1") != "0":
             self.acc.warm(6)
             self.acc2.warm(1)

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <string>
 #include <utility>
@@ -91,6 +92,16 @@ static inline void *cn_ws(cornetto_accel_t *h, int slot, size_t bytes)
     cornetto_accel::Ws &w = h->dev[slot];
     if (bytes == 0) bytes = 16;
     if (w.bytes >= bytes) return w.p;
+#ifdef CN_WS_ASYNC
+    // (experiment, DESIGN 8 round 6: the stream-ordered allocator instead of hipMalloc, which waits for the kernels in flight on the device)
+    if (w.p) (void)hipFreeAsync(w.p, h->stream);
+    w.p = nullptr;
+    w.bytes = 0;
+    const size_t want = bytes + bytes / 8;
+    if (hipMallocAsync(&w.p, want, h->stream) == hipSuccess) w.bytes = want;
+    else w.p = nullptr;
+    return w.p;
+#else
     if (w.p) (void)hipFree(w.p);
     w.p = nullptr;
     w.bytes = 0;
@@ -99,6 +110,18 @@ static inline void *cn_ws(cornetto_accel_t *h, int slot, size_t bytes)
     else if (hipMalloc(&w.p, bytes) == hipSuccess) w.bytes = bytes;
     else w.p = nullptr;
     return w.p;
+#endif
+}
+
+// the tables of a resident object (freed with hipFree when the object goes)
+static inline hipError_t cn_obj_malloc(cornetto_accel_t *h, void **p, size_t bytes)
+{
+#ifdef CN_WS_ASYNC
+    return hipMallocAsync(p, bytes, h->stream);
+#else
+    (void)h;
+    return hipMalloc(p, bytes);
+#endif
 }
 
 // pinned host staging slot (for asynchronous device-to-host copies at full PCIe rate)
@@ -110,7 +133,9 @@ static inline void *cn_pin(cornetto_accel_t *h, int slot, size_t bytes)
     if (w.p) (void)hipHostFree(w.p);
     w.p = nullptr;
     w.bytes = 0;
-    const size_t want = bytes + bytes / 8;
+    // (at least 64 KB: hipHostMalloc / hipHostFree wait for the kernels in flight on the device — a slot that grows from the few bytes of a small
+    // first input to the few hundred of an assembly stalled the first scan of the assembly behind the other stream's kernel)
+    const size_t want = std::max<size_t>(bytes + bytes / 8, (size_t)64 << 10);
     if (hipHostMalloc(&w.p, want, hipHostMallocDefault) == hipSuccess) w.bytes = want;
     else w.p = nullptr;
     return w.p;

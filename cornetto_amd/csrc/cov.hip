@@ -570,11 +570,11 @@ int cn_cov_prepare_impl(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int32
         const size_t nt = (size_t)ntl;
         if (nt == 0) { built.keep = true; return CORNETTO_OK; }
         // prefixes [n_blk] uint2, heads [n_blk] uint2, then two arrays of tile offsets [nt] u32 each
-        if (hipMalloc((void **)&c->d_blk, (size_t)c->n_blk * sizeof(uint4) + 2 * nt * sizeof(uint32_t)) != hipSuccess ||
-            hipMalloc((void **)&c->d_blk_off, (size_t)(c->n + 1) * 8) != hipSuccess ||
-            hipMalloc((void **)&c->d_cb_tiles, nt * sizeof(int2)) != hipSuccess ||
-            hipMalloc((void **)&c->d_cb_tmeta, 2 * nt * sizeof(int4)) != hipSuccess ||
-            hipMalloc((void **)&c->d_n_reg, (size_t)c->n * 4) != hipSuccess)
+        if (cn_obj_malloc(h, (void **)&c->d_blk, (size_t)c->n_blk * sizeof(uint4) + 2 * nt * sizeof(uint32_t)) != hipSuccess ||
+            cn_obj_malloc(h, (void **)&c->d_blk_off, (size_t)(c->n + 1) * 8) != hipSuccess ||
+            cn_obj_malloc(h, (void **)&c->d_cb_tiles, nt * sizeof(int2)) != hipSuccess ||
+            cn_obj_malloc(h, (void **)&c->d_cb_tmeta, 2 * nt * sizeof(int4)) != hipSuccess ||
+            cn_obj_malloc(h, (void **)&c->d_n_reg, (size_t)c->n * 4) != hipSuccess)
             return cn_fail(h, CORNETTO_E_NOMEM, "cov_prepare: device allocation failed");
         cntiles::fill<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->stream>>>(c->cb_pref.dev, c->n, ntl, CbTileFill{c->d_cb_tiles, c->d_cb_tmeta, c->d_len, c->d_off});
         CN_HIP(h, hipGetLastError());
@@ -654,6 +654,7 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
                            CnCovSpec *spec = nullptr)
 {
     const bool packed = pk_out != nullptr || spec != nullptr;
+    CN_TRACE("cov_select: enter");
     const int64_t est_key = cov_est_key(c, mode, lo, hi, low_mq, edge, min_len);
     if (spec) {
         spec->queued = false;
@@ -684,7 +685,7 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
             // the first tile of every contig (a contig without tiles: the first tile of the next one that has — or their number)
             c->cw_first.resize((size_t)c->n + 1);
             for (int32_t i = 0; i <= c->n; ++i) c->cw_first[i] = (int32_t)c->cw_pref.host[i];
-            if (hipMalloc((void **)&c->d_cw_tiles, (size_t)ntl * sizeof(int2)) != hipSuccess || hipMalloc((void **)&c->d_cw_first, ((size_t)c->n + 1) * 4) != hipSuccess)
+            if (cn_obj_malloc(h, (void **)&c->d_cw_tiles, (size_t)ntl * sizeof(int2)) != hipSuccess || cn_obj_malloc(h, (void **)&c->d_cw_first, ((size_t)c->n + 1) * 4) != hipSuccess)
                 return cn_fail(h, CORNETTO_E_NOMEM, "cov: device allocation failed");
             cntiles::fill<<<dim3((unsigned)((ntl + 255) / 256)), dim3(256), 0, h->stream>>>(c->cw_pref.dev, c->n, ntl, CwTileFill{c->d_cw_tiles});
             CN_HIP(h, hipGetLastError());
@@ -739,6 +740,7 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
         d_cf = (uint32_t *)cn_ws(h, WS_CW_CF, ((size_t)c->n + 1) * 4);
         if (!p_cf || !d_cf) return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: allocation failed");
     }
+    CN_TRACE("cov_select: tables + small workspaces");
     // selection, ordering and (packed) the first record of every contig are queued in one go: the ordering kernels read the count on the
     // device, so the host meets it once — together with the per-contig offsets — and only then sizes the result
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -787,7 +789,9 @@ static int cov_run_windows(cornetto_accel_t *h, cornetto_cov_t *c, int32_t only_
         if (attempt == 1 || cnt > 0x7fffffffull) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "cov: %llu selected windows", cnt);
         cap = (size_t)cnt;   // exact rerun, never a truncated answer
     }
+    CN_TRACE("cov_select: kernels done, count known");
     cornetto_regrec_t *o = keep_on_device ? d_dst : (cornetto_regrec_t *)cn_result_alloc((cnt ? cnt : 1) * rec_bytes);
+    CN_TRACE("cov_select: result block");
     if (!o) return cn_fail(h, CORNETTO_E_NOMEM, "cov_select: host allocation failed");
     if (cnt) {
         if (!keep_on_device && (cn_result_d2h(h, o, d_dst, (size_t)cnt * rec_bytes) != hipSuccess || (!h->lazy && hipStreamSynchronize(h->stream) != hipSuccess))) {

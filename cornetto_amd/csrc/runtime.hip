@@ -143,6 +143,15 @@ int cornetto_accel_open(cornetto_accel_t **out, int device, void *stream)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return CORNETTO_E_NODEVICE;
     if (hipSetDevice(device) != hipSuccess) return CORNETTO_E_NODEVICE;
+#ifdef CN_WS_ASYNC
+    {
+        hipMemPool_t pool = nullptr;
+        if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool) {
+            uint64_t thr = ~0ull;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+        }
+    }
+#endif
     cornetto_accel_t *h = new (std::nothrow) cornetto_accel;
     if (!h) return CORNETTO_E_NOMEM;
     h->device = device;
@@ -269,6 +278,13 @@ int cornetto_accel_set_lazy(cornetto_accel_t *h, int on)
         h->copies_pending = false;
     }
     h->lazy = on ? 1 : 0;
+    if (on && !h->copy_stream) {
+        // (now, not at the first lazy copy: creating a queue takes milliseconds while another stream's kernel is running — the first selection of a
+        // two-stream step spent 5 of its 6 ms here)
+        CN_HIP(h, hipSetDevice(h->device));
+        CN_HIP(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        CN_HIP(h, hipEventCreateWithFlags(&h->ev_cp, hipEventDisableTiming));
+    }
     return CORNETTO_OK;
 }
 
@@ -309,6 +325,25 @@ int cornetto_accel_warm(cornetto_accel_t *h, int what)
     for (int32_t i = 100; i < 700; ++i) seq[(size_t)i] = "TTAGGG"[(i - 100) % 6];
     for (int32_t i = 1000; i < 1100; ++i) seq[(size_t)i] = 'A';
     int rc = CORNETTO_OK;
+    {
+        // the copy engines: the first few device-to-host copies of a quarter megabyte and more on a stream block their caller for ~7 ms each (the runtime
+        // sets a copy queue up; traced in the telomere window scan's 256 KB read-back: three slow calls, then none) — on this handle's streams, now
+        CN_HIP(h, hipSetDevice(h->device));
+        const size_t nb = (size_t)1 << 20;
+        void *dv = cn_ws(h, WS_FQ_CNT, nb);
+        void *pv = cn_result_alloc(nb);
+        if (dv && pv) {
+            for (int i = 0; i < 4; ++i) {
+                (void)hipMemcpyAsync(pv, dv, nb, hipMemcpyDeviceToHost, h->stream);
+                (void)hipStreamSynchronize(h->stream);
+                if (h->copy_stream) {
+                    (void)hipMemcpyAsync(pv, dv, nb, hipMemcpyDeviceToHost, h->copy_stream);
+                    (void)hipStreamSynchronize(h->copy_stream);
+                }
+            }
+        }
+        if (pv) cornetto_free(pv);
+    }
     if (what & (CORNETTO_WARM_SDUST | CORNETTO_WARM_TELO)) {
         const uint8_t *sp = seq.data();
         const int64_t ln = n;

@@ -1771,7 +1771,7 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
         if (nch > 0x7fffffffll) return cn_fail(h, CORNETTO_E_UNSUPPORTED, "sdust: too many chunks");
         if (a->d_sd_chunks) { (void)hipFree(a->d_sd_chunks); a->d_sd_chunks = nullptr; }
         if (nch > 0) {
-            if (hipMalloc(&a->d_sd_chunks, (size_t)nch * sizeof(SdChunk)) != hipSuccess)
+            if (cn_obj_malloc(h, &a->d_sd_chunks, (size_t)nch * sizeof(SdChunk)) != hipSuccess)
                 return cn_fail(h, CORNETTO_E_NOMEM, "sdust: device allocation failed");
             cntiles::fill<<<dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, h->stream>>>(a->sd_pref.dev, a->n, nch,
                                                                                            SdChunkFill{reinterpret_cast<SdChunk *>(a->d_sd_chunks), a->d_len, (int32_t)chunk});
@@ -1920,7 +1920,7 @@ int sdust_asm_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, int32_t T, i
                 if (!walk_known) {
                     if (a->d_sd_walk) { (void)hipFree(a->d_sd_walk); a->d_sd_walk = nullptr; }
                     a->sd_walk_key = -1;
-                    if (hipMalloc((void **)&a->d_sd_walk, walk_words * 4) != hipSuccess) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: device allocation failed");
+                    if (cn_obj_malloc(h, (void **)&a->d_sd_walk, walk_words * 4) != hipSuccess) return cn_fail(h, CORNETTO_E_NOMEM, "sdust: device allocation failed");
                     CN_HIP(h, hipMemsetAsync(a->d_sd_walk, 0, (2 + 2 * nc) * 4, h->stream));
                 }
                 uint32_t *d_wflag = a->d_sd_walk + 2 + nc, *d_wrank = d_wflag + nc, *d_worder = d_wrank + nc, *d_wpart = d_worder + nc;

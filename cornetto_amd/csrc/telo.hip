@@ -601,19 +601,26 @@ int run_tw_scan_dev(cornetto_accel_t *h, const unsigned long long *d_bitmap, con
         unsigned long long *p_cnt = (unsigned long long *)cn_pin(h, PIN_SMALL, 64);
         if (!d_cnt || !p_cnt) return cn_fail(h, CORNETTO_E_NOMEM, "telowin: workspace allocation failed");
         size_t cap = std::max<size_t>(1u << 16, h->dev[WS_TW_OUT].bytes / sizeof(int4));
+        CN_TRACE("tw_scan: small workspaces");
         for (int attempt = 0; attempt < 2; ++attempt) {
             int4 *d_out = (int4 *)cn_ws(h, WS_TW_OUT, cap * sizeof(int4));
             if (!d_out) return cn_fail(h, CORNETTO_E_NOMEM, "telowin: workspace allocation failed");
+            CN_TRACE("tw_scan: out workspace");
             CN_HIP(h, hipMemsetAsync(d_cnt, 0, 8, h->stream));
+            CN_TRACE("tw_scan: memset queued");
             TwArgs A{d_bitmap, d_boff, d_len, d_tiles, thr, d_out, d_cnt, (uint32_t)std::min<size_t>(cap, 0x7fffffff)};
             CN_LAUNCH(h, "tw_scan", tw_scan<<<dim3((unsigned)n_tiles), dim3(256), 0, h->stream>>>(A));
+            CN_TRACE("tw_scan: kernel queued");
             // the count and, with it, the first 16 K windows (an assembly has ~10 K): one round trip instead of two
             const size_t spec = std::min<size_t>(cap, 16384);
             int4 *p_spec = (int4 *)cn_pin(h, PIN_TW, spec * sizeof(int4));
             if (!p_spec) return cn_fail(h, CORNETTO_E_NOMEM, "telowin: pinned allocation failed");
+            CN_TRACE("tw_scan: pinned block");
             CN_HIP(h, hipMemcpyAsync(p_cnt, d_cnt, 8, hipMemcpyDeviceToHost, h->stream));
             CN_HIP(h, hipMemcpyAsync(p_spec, d_out, spec * sizeof(int4), hipMemcpyDeviceToHost, h->stream));
+            CN_TRACE("tw_scan: queued");
             CN_HIP(h, hipStreamSynchronize(h->stream));
+            CN_TRACE("tw_scan: synchronised");
             const unsigned long long cnt = p_cnt[0];
             if (cnt > cap) {   // exact retry with the true size; never a truncated answer
                 if (attempt == 1) return cn_fail(h, CORNETTO_E_HIP, "telowin: %llu windows after resizing", cnt);
@@ -704,7 +711,7 @@ int ensure_tw_layout(cornetto_accel_t *h, cornetto_asm_t *am)
     });
     if (ntl < 0) return cn_fail(h, CORNETTO_E_NOMEM, "telo_scan: device allocation failed");
     if (am->n > 0) {
-        const bool ok = hipMalloc((void **)&am->d_tw_boff, (size_t)am->n * 8) == hipSuccess && hipMalloc((void **)&am->d_tw_tiles, ((size_t)ntl + 1) * sizeof(int2)) == hipSuccess &&
+        const bool ok = cn_obj_malloc(h, (void **)&am->d_tw_boff, (size_t)am->n * 8) == hipSuccess && cn_obj_malloc(h, (void **)&am->d_tw_tiles, ((size_t)ntl + 1) * sizeof(int2)) == hipSuccess &&
                         hipMemcpyAsync(am->d_tw_boff, am->tw_boff.data(), (size_t)am->n * 8, hipMemcpyHostToDevice, h->stream) == hipSuccess;
         if (!ok) return cn_fail(h, CORNETTO_E_NOMEM, "telo_scan: device allocation failed");
         if (ntl > 0) {
@@ -762,7 +769,7 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
         a->tf_ctg_tile0.resize((size_t)a->n + 1);
         for (int32_t c = 0; c <= a->n; ++c) a->tf_ctg_tile0[c] = (int32_t)a->tf_pref.host[c];
         if (ntl > 0) {
-            if (hipMalloc((void **)&a->d_tf_tiles, (size_t)ntl * sizeof(int2)) != hipSuccess || hipMalloc((void **)&a->d_tf_ct0, ((size_t)a->n + 1) * 4) != hipSuccess)
+            if (cn_obj_malloc(h, (void **)&a->d_tf_tiles, (size_t)ntl * sizeof(int2)) != hipSuccess || cn_obj_malloc(h, (void **)&a->d_tf_ct0, ((size_t)a->n + 1) * 4) != hipSuccess)
                 return cn_fail(h, CORNETTO_E_NOMEM, "telofind: device allocation failed");
             cntiles::fill<<<dim3((unsigned)((ntl + 255) / 256)), dim3(256), 0, h->stream>>>(a->tf_pref.dev, a->n, ntl, TileFill{a->d_tf_tiles, (int32_t)TF_TILE});
             CN_HIP(h, hipGetLastError());
@@ -772,6 +779,7 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
     }
     const std::vector<int32_t> &ctg_tile0 = a->tf_ctg_tile0;
     const size_t nt = (size_t)a->tf_n_tiles;
+    CN_TRACE("telofind: tile table");
 
     cornetto_hit_t *out = nullptr;
     int64_t n_out = 0;
@@ -840,13 +848,16 @@ int telofind_impl(cornetto_accel_t *h, const cornetto_asm_t *a_in, const char *m
         } else {
             A.mode = 0;
         }
+        CN_TRACE("telofind: workspaces, tables uploaded");
         CN_TRY(launch(A));
+        CN_TRACE("telofind: tf_scan queued");
         if (bitmap_valid) *bitmap_valid = want_bitmap;
         if (hits) {
             // place of every tile in the dense, contig-ordered lists + list totals
             CN_TRY(cnscan::exclusive_u32_multi(h, "tf_order", reinterpret_cast<const uint32_t *>(d_tc), (int64_t)nt, 4, 4, d_offq, d_part, d_cnt));
             CN_HIP(h, hipMemcpyAsync(p_cnt, d_cnt, 64, hipMemcpyDeviceToHost, h->stream));
             CN_HIP(h, hipStreamSynchronize(h->stream));   // also covers the `lut` upload
+            CN_TRACE("telofind: counts on the host");
             unsigned long long cnt[4] = {p_cnt[0], p_cnt[1], p_cnt[2], p_cnt[3]};
             const uint32_t ovf = (uint32_t)(p_cnt[4] & 0xFFFFFFFFull);
             for (int q = 0; q < 4; ++q)
@@ -1025,7 +1036,10 @@ int cn_telo_scan_impl(cornetto_accel_t *h, const cornetto_asm_t *a, const char *
     // a bordered motif needs the runs themselves to build the marks, so the hits are always fetched then
     const std::string m(motif ? motif : "");
     const bool need_hits = hits || has_border(m) || has_border(revcomp(m));
+    CN_TRACE("telo_scan: enter");
     int rc = telofind_impl(h, a, motif, need_hits ? &hh : nullptr, need_hits ? &nh : nullptr, true, &d_bitmap, &valid);
+    CN_TRACE("telo_scan: telofind done");
+    if (CN_DEV_INT("CORNETTO_TRACE_SYNC", 0)) { (void)hipStreamSynchronize(h->stream); CN_TRACE("telo_scan: (trace) stream drained"); }
     if (rc == CORNETTO_OK) {
         if (valid) {
             cornetto_asm_t *am = const_cast<cornetto_asm_t *>(a);   // (its window layout was built with the bitmap: ensure_tw_layout)
@@ -1034,6 +1048,7 @@ int cn_telo_scan_impl(cornetto_accel_t *h, const cornetto_asm_t *a, const char *
             rc = telowin_from_hits(h, hh, nh, a->len.data(), a->n, thr_adj, wins, n_wins);
         }
     }
+    CN_TRACE("telo_scan: windows done");
     {   // what the next scan of this assembly with this motif and threshold may size itself by (cn_telo_spec_queue); the list totals were
         // noted by telofind_impl
         cornetto_asm_t *am = const_cast<cornetto_asm_t *>(a);

@@ -45,7 +45,7 @@ static inline int64_t prefix(cornetto_accel_t *h, CnPrefix &P, int32_t n, Count 
     P.host[n] = tot;
     if (P.cap < (size_t)n + 1) {
         P.release();
-        if (hipMalloc((void **)&P.dev, ((size_t)n + 1) * 8) != hipSuccess) return -1;
+        if (cn_obj_malloc(h, (void **)&P.dev, ((size_t)n + 1) * 8) != hipSuccess) return -1;
         P.cap = (size_t)n + 1;
     }
     if (hipMemcpyAsync(P.dev, P.host.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess) return -1;

@@ -266,6 +266,7 @@ void cli_order_by_length_desc(const int64_t *lens64, const int32_t *lens32, int3
  * an uncompressed regular file is read straight into a pinned piece: one thread copies from the page cache at 5-8 GB/s, which is
  * the largest share of the wall time of a 3 GB assembly or of a pair of per-base bedgraphs */
 #include <errno.h>
+#include <sched.h>
 #include <unistd.h>
 #define CLI_PREAD_MAX 64
 typedef struct {
@@ -280,12 +281,20 @@ static void *pread_thread(void *p)
     pread_job_t *j = (pread_job_t *)p;
     j->got = 0;
     j->failed = 0;
+    const double t0 = getenv("CORNETTO_CLI_TRACE_READS") ? cli_realtime() : 0.0;
     while (j->got < j->want) {
         const ssize_t r = pread(j->fd, j->dst + j->got, (size_t)(j->want - j->got), (off_t)(j->off + j->got));
         if (r < 0 && errno == EINTR) continue;
         if (r < 0) j->failed = 1;
         if (r <= 0) break; /* r == 0: end of the file */
         j->got += r;
+    }
+    if (t0 > 0.0) {
+        cpu_set_t cs;
+        CPU_ZERO(&cs);
+        (void)sched_getaffinity(0, sizeof(cs), &cs);
+        fprintf(stderr, "[cli trace] pread job: %lld bytes at %lld in %.2f ms (from %.3f) on cpu %d of %d allowed\n", (long long)j->got, (long long)j->off,
+                (cli_realtime() - t0) * 1e3, t0, sched_getcpu(), CPU_COUNT(&cs));
     }
     return NULL;
 }

@@ -10,6 +10,6 @@ for name, mq in (("t", False), ("q", True)):
     t = synth.make_bedgraph_text(torch, dev, 50_000_000, 11, mq)
     t.cpu().numpy().tofile("/dev/shm/bgtrace_%s.bg" % name)
 PY
-CORNETTO_CLI_TRACE=1 CORNETTO_TRACE=1 cornetto_amd/cornetto_dev noboringbits /dev/shm/bgtrace_t.bg -q /dev/shm/bgtrace_q.bg > /dev/null 2> /dev/shm/bgtrace.err
-grep "trace" /dev/shm/bgtrace.err | sed -n "1,30p"
+CORNETTO_CLI_TRACE_READS=1 CORNETTO_CLI_TRACE=1 CORNETTO_TRACE=1 cornetto_amd/cornetto_dev noboringbits /dev/shm/bgtrace_t.bg -q /dev/shm/bgtrace_q.bg > /dev/null 2> /dev/shm/bgtrace.err
+grep "trace" /dev/shm/bgtrace.err | sed -n "60,110p"
 rm -f /dev/shm/bgtrace_*.bg /dev/shm/bgtrace.err

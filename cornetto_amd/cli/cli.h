@@ -53,6 +53,7 @@ cornetto_accel_t *cli_accel_open(void);
 /* the same, with the HIP initialisation running on a helper thread between _begin() and _end() (while the input is read);
  * _cancel() drops it when no device work turned up */
 /* `want` bytes at file offset `off` with up to n_threads pread() threads -> bytes read (short only at the end of the file), -1 on a read error */
+int64_t cli_read_at(int fd, char *dst, int64_t want, int64_t off, int *failed);   /* pread(), or a copy out of a kept mapping for a file on tmpfs */
 int64_t cli_pread_parallel(int fd, char *dst, int64_t want, int64_t off, int n_threads);
 void cli_accel_open_begin(void);
 void cli_accel_warm_hint(int what);   /* before cli_accel_open_begin(): CORNETTO_WARM_* to run behind the open, on a handle of its own */

@@ -425,13 +425,7 @@ static void *whole_reader(void *p)
         pthread_mutex_unlock(&w->mu);
         if (stop) return NULL;
         const int64_t at = i * w->slab, want = w->total - at < w->slab ? w->total - at : w->slab;
-        int64_t have = 0;
-        while (have < want) {
-            const ssize_t r = pread(w->fd, w->ring[s] + have, (size_t)(want - have), (off_t)(w->off0 + at + have));
-            if (r < 0 && errno == EINTR) continue;
-            if (r <= 0) break;
-            have += r;
-        }
+        const int64_t have = cli_read_at(w->fd, w->ring[s], want, w->off0 + at, NULL);
         pthread_mutex_lock(&w->mu);
         if (have < want) w->failed = 1;          /* (a file that shrank under us, an I/O error) */
         w->got[s] = have;

@@ -276,19 +276,79 @@ typedef struct {
     int failed; /* a pread() returned < 0 (EIO, ESTALE ...): not an end of file */
 } pread_job_t;
 
+/* Bytes [off, off + want) of a regular file into dst: -> bytes read (short at the end of the file), -1 on a read error.
+ * A file on tmpfs (/dev/shm: where a pipeline leaves what its next step reads) is copied out of a shared mapping instead of with pread(): the first
+ * read() of a page that was just written marks it accessed, one page at a time under the LRU lock, and eight or thirty-two reader threads share 12-14 GB/s
+ * of such first reads — a memcpy out of the mapping does 75 GB/s on the same first pass (tools/ubench/pread_rate, profiles/r06_pread_rate.txt).  The mapping
+ * of a file is made once and kept.  Files elsewhere keep pread(): an I/O error there is a return value, not a SIGBUS. */
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/vfs.h>
+static struct {
+    pthread_mutex_t mu;
+    int n;
+    struct { dev_t dev; ino_t ino; const char *map; int64_t size; } e[8];
+} g_maps = {.mu = PTHREAD_MUTEX_INITIALIZER};
+
+static const char *tmpfs_mapping(int fd, int64_t *size)
+{
+    struct stat st;
+    struct statfs fs;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) return NULL;
+    pthread_mutex_lock(&g_maps.mu);
+    for (int i = 0; i < g_maps.n; ++i)
+        if (g_maps.e[i].dev == st.st_dev && g_maps.e[i].ino == st.st_ino && g_maps.e[i].size == (int64_t)st.st_size) {
+            const char *m = g_maps.e[i].map;
+            *size = g_maps.e[i].size;
+            pthread_mutex_unlock(&g_maps.mu);
+            return m;
+        }
+    const char *m = NULL;
+    const char *off_env = getenv("CORNETTO_CLI_MMAP");
+    if (g_maps.n < 8 && !(off_env && !atoi(off_env)) && fstatfs(fd, &fs) == 0 && (unsigned long)fs.f_type == 0x01021994UL /* TMPFS_MAGIC */) {
+        void *p = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
+        if (p != MAP_FAILED) {
+            m = (const char *)p;
+            g_maps.e[g_maps.n].dev = st.st_dev;
+            g_maps.e[g_maps.n].ino = st.st_ino;
+            g_maps.e[g_maps.n].map = m;
+            g_maps.e[g_maps.n].size = (int64_t)st.st_size;
+            ++g_maps.n;
+            *size = (int64_t)st.st_size;
+        }
+    }
+    pthread_mutex_unlock(&g_maps.mu);
+    return m;
+}
+
+int64_t cli_read_at(int fd, char *dst, int64_t want, int64_t off, int *failed)
+{
+    if (failed) *failed = 0;
+    if (want <= 0) return 0;
+    int64_t size = 0;
+    const char *map = tmpfs_mapping(fd, &size);
+    if (map) {
+        if (off >= size) return 0;
+        const int64_t n = want < size - off ? want : size - off;
+        memcpy(dst, map + off, (size_t)n);
+        return n;
+    }
+    int64_t got = 0;
+    while (got < want) {
+        const ssize_t r = pread(fd, dst + got, (size_t)(want - got), (off_t)(off + got));
+        if (r < 0 && errno == EINTR) continue;
+        if (r < 0 && failed) *failed = 1;
+        if (r <= 0) break; /* r == 0: end of the file */
+        got += r;
+    }
+    return got;
+}
+
 static void *pread_thread(void *p)
 {
     pread_job_t *j = (pread_job_t *)p;
-    j->got = 0;
-    j->failed = 0;
     const double t0 = getenv("CORNETTO_CLI_TRACE_READS") ? cli_realtime() : 0.0;
-    while (j->got < j->want) {
-        const ssize_t r = pread(j->fd, j->dst + j->got, (size_t)(j->want - j->got), (off_t)(j->off + j->got));
-        if (r < 0 && errno == EINTR) continue;
-        if (r < 0) j->failed = 1;
-        if (r <= 0) break; /* r == 0: end of the file */
-        j->got += r;
-    }
+    j->got = cli_read_at(j->fd, j->dst, j->want, j->off, &j->failed);
     if (t0 > 0.0) {
         cpu_set_t cs;
         CPU_ZERO(&cs);

@@ -174,6 +174,18 @@ __global__ __launch_bounds__(64) void k(unsigned long long *t0, unsigned long lo
             R8(X)
 #undef X
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (KIND == 34) {  // v_dot4_u32_u8 (round 6: the bit planes of tf_scan)
+#define X(i) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(v[i]) : "v"(v[(i + 1) & 7]), "s"(s1));
+            R16(X)
+#undef X
+        } else if (KIND == 35) {  // v_bitop3_b32, two vector registers and a scalar one
+#define X(i) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x90" : "+v"(v[i]) : "v"(v[(i + 1) & 7]), "s"(s1));
+            R16(X)
+#undef X
+        } else if (KIND == 36) {  // v_dot4_u32_u8 with the accumulator chained (dependent pairs, as the planes make them)
+#define X(i) asm volatile("v_dot4_u32_u8 %0, %1, %2, 0\n\tv_dot4_u32_u8 %0, %3, %4, %0" : "+v"(v[i]) : "v"(v[(i + 1) & 7]), "s"(s1), "v"(v[(i + 2) & 7]), "s"(s2));
+            R8(X)
+#undef X
         }
     }
     const unsigned long long b = __builtin_amdgcn_s_memtime();
@@ -200,6 +212,7 @@ int main(int argc, char **argv)
         {"v_alignbit_b32", 16, k<26>}, {"ds_read_b32 random of 64 entries (8 in flight)", 8, k<27>}, {"ds_read_b32 lane-indexed (8 in flight)", 8, k<28>},
         {"ds_or_b32 random of 64 entries (8 in flight)", 8, k<29>}, {"ds_bpermute_b32 random lanes (8 in flight)", 8, k<30>},
         {"ds_bpermute_b32 neighbour lane (8 in flight)", 8, k<31>}, {"ds_read_b64 random of 64 entries", 8, k<32>}, {"ds_read_b128 random of 64 entries", 8, k<33>},
+        {"v_dot4_u32_u8", 16, k<34>}, {"v_bitop3_b32 (v, v, s)", 16, k<35>}, {"v_dot4_u32_u8 chained pairs", 16, k<36>},
     };
     unsigned long long *t0, *t1; unsigned *sink;
     const int maxb = cus * 32;

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(TF_THREADS) void tf_scan(TfArgs A)
             q2 = Mr & ~((Mr << k) | (pR >> (64 - k)));
             q3 = Mr & ~((Mr >> k) | (nR << (64 - k)));
             if (A.bitmap && s0 >= 0 && s0 < len)
-                A.bitmap[(m_bm[it] + s0) >> 6] = smear(Mf, pF, k) | smear(Mr, pR, k);
+                A.bitmap[(m_bm[it] + s0) >> 6] = smear(Mf | Mr, pF | pR, k);      // (the union of [p, p + k) over the matches of either strand: one smear, not two)
         }
     }
     // packed 4 x 16-bit exclusive scan over the workgroup (a tile holds < 2^15 heads per list)

@@ -13,10 +13,12 @@
 
 // ---- pinned result pool ------------------------------------------------------------------------------
 namespace {
-std::mutex g_pool_mu;
-std::unordered_map<void *, size_t> g_pool_live;      // pinned buffers currently owned by callers
-std::multimap<size_t, void *> g_pool_free;           // pinned buffers ready for reuse, by capacity
-std::unordered_map<void *, uint64_t> g_pool_age;     // when a free buffer was handed back (the oldest one makes room)
+// (These objects are never destroyed: the background thread below may still wait on the condition variable when the process leaves main(), and the
+// destructor of a condition variable with a waiter blocks until the waiter's 200 ms are over — or the waiter wakes to a dead mutex.)
+std::mutex &g_pool_mu = *new std::mutex;
+std::unordered_map<void *, size_t> &g_pool_live = *new std::unordered_map<void *, size_t>;      // pinned buffers currently owned by callers
+std::multimap<size_t, void *> &g_pool_free = *new std::multimap<size_t, void *>;                // pinned buffers ready for reuse, by capacity
+std::unordered_map<void *, uint64_t> &g_pool_age = *new std::unordered_map<void *, uint64_t>;   // when a free buffer was handed back (the oldest one makes room)
 uint64_t g_pool_clock = 0;
 constexpr size_t POOL_MIN = 1u << 20;                // below this, plain malloc
 size_t g_pool_free_bytes = 0;                        // capacity of the free list
@@ -27,9 +29,9 @@ constexpr size_t POOL_KEEP = 12;                     // free buffers kept; beyon
 // Blocks that are being pinned ahead of their use (cn_result_prewarm): capacities requested and not yet in the free list.  One background thread
 // pins them one after the other, in the order of the requests (= the order in which a step needs them).
 namespace {
-std::condition_variable g_pre_cv;                    // (with g_pool_mu) a request arrived / a block landed
-std::deque<std::pair<size_t, int>> g_pre_queue;      // capacity, device
-std::multiset<size_t> g_pre_pending;                 // queued or being pinned
+std::condition_variable &g_pre_cv = *new std::condition_variable;                    // (with g_pool_mu) a request arrived / a block landed
+std::deque<std::pair<size_t, int>> &g_pre_queue = *new std::deque<std::pair<size_t, int>>;      // capacity, device
+std::multiset<size_t> &g_pre_pending = *new std::multiset<size_t>;                   // queued or being pinned
 bool g_pre_running = false;
 
 void pre_worker()

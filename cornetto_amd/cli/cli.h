@@ -110,7 +110,8 @@ typedef struct {
 } cli_str_t;
 
 typedef struct cli_fastx cli_fastx_t;
-cli_fastx_t *cli_fastx_open(const char *path); /* "-" = stdin; NULL on failure */
+extern int cli_dash_is_stdin;                  /* set by sdust_main: "-" = stdin (the other FASTA sub-commands open a file of that name, as the reference does) */
+cli_fastx_t *cli_fastx_open(const char *path); /* NULL on failure */
 /* a reader over `n` bytes at `prefix` (borrowed: must outlive the reads of them) followed by the rest of the open
  * gzFile `gz` (owned: closed by cli_fastx_close) */
 cli_fastx_t *cli_fastx_open_prefixed(void *gz, const void *prefix, size_t n);

@@ -232,7 +232,7 @@ static void multi_stream(const char *path, int must_open, const multi_what_t *wh
     cli_fastx_t *fx = cli_fastx_open(path);
     if (!fx) {
         if (must_open) {
-            CLI_ERROR("Failed to open %s : No such file or directory.", path); /* F_CHK, src/error.h:114-119 */
+            CLI_ERROR("Could not to open file %s: %s", path, strerror(errno)); /* F_CHK, src/error.h:114-119: its words */
             exit(EXIT_FAILURE);
         }
         return;
@@ -564,10 +564,10 @@ static void stream_records(const char *path, int must_open, scan_fn scan, void *
 {
     const int trace = getenv("CORNETTO_CLI_TRACE") != NULL;
     const double t_begin = cli_realtime();
-    gzFile fp = strcmp(path, "-") ? gzopen(path, "r") : gzdopen(fileno(stdin), "r");
+    gzFile fp = (cli_dash_is_stdin && !strcmp(path, "-")) ? gzdopen(fileno(stdin), "r") : gzopen(path, "r");
     if (!fp) {
         if (must_open) {
-            CLI_ERROR("Failed to open %s : No such file or directory.", path); /* F_CHK, src/error.h:114-119 */
+            CLI_ERROR("Could not to open file %s: %s", path, strerror(errno)); /* F_CHK, src/error.h:114-119: its words */
             exit(EXIT_FAILURE);
         }
         return; /* sdust: the reference has no NULL check (src/sdust/sdust.c:194) and crashes; we just stop */
@@ -793,7 +793,7 @@ static void host_stream(const char *path, int must_open, const multi_what_t *wha
     cli_fastx_t *fx = cli_fastx_open(path);
     if (!fx) {
         if (must_open) {
-            CLI_ERROR("Failed to open %s : No such file or directory.", path); /* F_CHK, src/error.h:114-119 */
+            CLI_ERROR("Could not to open file %s: %s", path, strerror(errno)); /* F_CHK, src/error.h:114-119: its words */
             exit(EXIT_FAILURE);
         }
         return;
@@ -884,6 +884,7 @@ int sdust_main(int argc, char *argv[])
 {
     sdust_opt_t o = {64, 20}; /* src/sdust/sdust.c:183 */
     int c;
+    cli_dash_is_stdin = 1;    /* src/sdust/sdust.c:194 */
     /* ketopt(..., permute=1, "w:t:") of the reference == POSIX getopt with GNU permutation */
     optind = 1;
     while ((c = getopt(argc, argv, "w:t:")) >= 0) {
@@ -932,7 +933,7 @@ int assbed_main(int argc, char *argv[])
     }
     cli_fastx_t *fx = cli_fastx_open(argv[optind]);
     if (!fx) {
-        CLI_ERROR("Failed to open %s : No such file or directory.", argv[optind]);
+        CLI_ERROR("Could not to open file %s: %s", argv[optind], strerror(errno)); /* F_CHK, src/error.h:114-119: its words */
         exit(EXIT_FAILURE);
     }
     cli_str_t name = {0, 0, 0}, comment = {0, 0, 0}, seq = {0, 0, 0}, qual = {0, 0, 0};
@@ -972,7 +973,7 @@ int seq_main(int argc, char *argv[])
     }
     cli_fastx_t *fx = cli_fastx_open(argv[optind]);
     if (!fx) {
-        CLI_ERROR("Failed to open %s : No such file or directory.", argv[optind]);
+        CLI_ERROR("Could not to open file %s: %s", argv[optind], strerror(errno)); /* F_CHK, src/error.h:114-119: its words */
         exit(EXIT_FAILURE);
     }
     cli_str_t name = {0, 0, 0}, comment = {0, 0, 0}, seq = {0, 0, 0}, qual = {0, 0, 0};

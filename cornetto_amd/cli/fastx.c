@@ -26,9 +26,13 @@ struct cli_fastx {
     size_t pre_left;
 };
 
+/* "-" is the standard input for `sdust` alone (src/sdust/sdust.c:194); telofind, fa2bed and seq hand their argument to gzopen() as it is
+ * (src/find_telomere.c:96, src/assbed.c:92, src/seq.c:106): a file of that name, or their "Could not to open file" and exit status 1 */
+int cli_dash_is_stdin = 0;
+
 cli_fastx_t *cli_fastx_open(const char *path)
 {
-    gzFile fp = strcmp(path, "-") ? gzopen(path, "r") : gzdopen(fileno(stdin), "r");
+    gzFile fp = (cli_dash_is_stdin && !strcmp(path, "-")) ? gzdopen(fileno(stdin), "r") : gzopen(path, "r");
     if (!fp) return NULL;
     gzbuffer(fp, 1 << 18);
     cli_fastx_t *f = (cli_fastx_t *)cli_xmalloc(sizeof(*f));

@@ -152,10 +152,19 @@ def test_text_parsers_in_front_of_the_device_calls(cli, golden_dir, tmp_path):
     for sub in ("sdust", "telofind"):
         assert run(cli, [sub, os.path.join(golden_dir, "mix.fa.gz")])[0] == 1
         assert run(cli, [sub, "-"], stdin=b">a\nACGT\n")[0] == 1
-    rc, out, err = run(cli, ["seq", "-m", "3", "-"], stdin=b"@r c\nACGT\n+\nIIII\n@t\nAC\n+\nII\n@cut\nACGT\n+\nII")
+    fq = tmp_path / "r.fq"
+    fq.write_bytes(b"@r c\nACGT\n+\nIIII\n@t\nAC\n+\nII\n@cut\nACGT\n+\nII")
+    rc, out, err = run(cli, ["seq", "-m", "3", str(fq)])
     assert out == b"@r\tc\nACGT\n+\nIIII\n"
-    rc, out, err = run(cli, ["fa2bed", "-"], stdin=b">a b c\r\nAC\r\nGT\r\n>e\n\n>f\nA")
+    fa = tmp_path / "r.fa"
+    fa.write_bytes(b">a b c\r\nAC\r\nGT\r\n>e\n\n>f\nA")
+    rc, out, err = run(cli, ["fa2bed", str(fa)])
     assert rc == 0 and out == b"a\t0\t4\ne\t0\t0\nf\t0\t1\n"
+    # "-" is the standard input for sdust alone (src/sdust/sdust.c:194); seq, fa2bed and telofind hand it to gzopen() as a file name
+    # (src/seq.c:106, src/assbed.c:92, src/find_telomere.c:96): F_CHK's message and exit status 1, nothing on stdout
+    for sub in (["seq", "-m", "3"], ["fa2bed"]):
+        rc, out, err = run(cli, sub + ["-"], stdin=fq.read_bytes())
+        assert rc == 1 and out == b"" and b"Could not to open file -: No such file or directory" in err
 
 
 def _bedgraph_pair(tmp_path, lens, seed, digits_t=(10_000, 60_000), digits_q=(0, 10)):

@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""development aid: randomised differential run of the CLI on the DEVICE path against the unmodified reference binary (oracle/_ref/cornetto, which
+travels with the snapshot): stdout and exit status, byte for byte, with seeds the test suite does not use.
+  fasta   telofind / sdust (-w / -t varied) / fa2bed / seq on random FASTA and FASTQ text: wrapped and unwrapped records, CRLF, lower case, N runs and
+          IUPAC letters, empty records, a missing last newline, planted telomere arrays and low-complexity runs, gzip input, stdin
+  panel   (no)boringbits on random per-base bedgraph pairs: -w / -i smaller, equal, larger than each other, -m, -e, -L, -H, -Q; contig lengths at and around
+          multiples of -i; the command lines on which the reference dies of its assert (SIGABRT); malformed lines (the reference's five checks: exit 1);
+          one device, contigs dealt to several handles, the text itself cut into shares
+   python tools/fuzz_cli.py [fasta|panel|all] [first_seed] [n_seeds]"""
+import gzip
+import os
+import random
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "cornetto_amd", "cornetto")
+REF = os.path.join(ROOT, "oracle", "_ref", "cornetto")
+
+
+def run(binary, args, env=None, data=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([binary] + args, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+    return p.returncode, p.stdout, p.stderr
+
+
+def rand_seq(rnd, n):
+    kind = rnd.random()
+    alpha = "ACGT" if kind < 0.6 else "ACGTacgt" if kind < 0.8 else "ACGTNacgtnRYKM"
+    s = [rnd.choice(alpha) for _ in range(n)]
+    for _ in range(rnd.randint(0, max(1, n // 300))):
+        if n < 20:
+            break
+        p = rnd.randrange(n)
+        unit = rnd.choice(["TTAGGG", "CCCTAA", "A", "AT", "CAG", "N", "ttaggg", "GGAAT", "TTAGGGTTAGGC", "n"])
+        rep = (unit * rnd.randint(1, 120))[: n - p]
+        s[p:p + len(rep)] = list(rep)
+    return "".join(s)
+
+
+def fasta_text(rnd):
+    fastq = rnd.random() < 0.25
+    eol = "\r\n" if rnd.random() < 0.15 else "\n"
+    out = []
+    for r in range(rnd.randint(1, 7)):
+        n = rnd.choice([0, 1, 2, 5, 63, 64, 65, 200, 1000, 5000, 20000, 70000]) if rnd.random() < 0.5 else rnd.randint(0, 40000)
+        seq = rand_seq(rnd, n)
+        name = "ctg%d" % r + (" some comment" if rnd.random() < 0.3 else "")
+        if fastq:
+            out.append("@" + name + eol + seq + eol + "+" + eol + "".join(rnd.choice("!#5I~") for _ in range(n)) + eol)
+        else:
+            wrap = rnd.choice([0, 0, 60, 70, 7])
+            body = seq if not wrap else eol.join(seq[i:i + wrap] for i in range(0, len(seq), wrap))
+            out.append(">" + name + eol + body + (eol if body or rnd.random() < 0.7 else ""))
+    text = "".join(out)
+    if rnd.random() < 0.2 and text.endswith(eol):
+        text = text[: -len(eol)]
+    return text.encode()
+
+
+def fuzz_fasta(seed, tmp):
+    rnd = random.Random(seed)
+    text = fasta_text(rnd)
+    path = os.path.join(tmp, "f.fa")
+    gz = rnd.random() < 0.2
+    if gz:
+        path += ".gz"
+        with gzip.open(path, "wb") as f:
+            f.write(text)
+    else:
+        with open(path, "wb") as f:
+            f.write(text)
+    sub = rnd.choice(["telofind", "sdust", "sdust", "fa2bed", "seq"])
+    args, data = [sub], None
+    if sub == "sdust":
+        if rnd.random() < 0.6:
+            args += ["-w", str(rnd.choice([64, 40, 30, 16, 8, 66, 100, 200])), "-t", str(rnd.choice([20, 25, 10, 5, 30, 2]))]
+    elif sub == "seq":
+        if rnd.random() < 0.7:
+            args += ["-m", str(rnd.choice([0, 1, 100, 1000, 10000]))]
+    if rnd.random() < 0.15 and not gz:
+        args.append("-")
+        data = text
+    else:
+        args.append(path)
+    rr = run(REF, args, data=data)
+    env = {"CORNETTO_DEVICES": "0,0"} if rnd.random() < 0.2 else {}
+    gg = run(CLI, args, env, data=data)
+    # (seq on FASTA prints "(null)" for the absent quality in the reference: undefined behaviour, SURVEY appendix A-5 — not compared)
+    if sub == "seq" and b"(null)" in rr[1]:
+        return True, None
+    ok = (gg[0], gg[1]) == (rr[0], rr[1])
+    return ok, None if ok else (args, env, gz, len(text), gg[0], rr[0], len(gg[1]), len(rr[1]), gg[2][-300:])
+
+
+def fuzz_panel(seed, tmp):
+    rnd = random.Random(seed)
+    w = rnd.choice([1, 2, 7, 50, 64, 100, 300, 777, 2500])
+    inc = rnd.choice([1, 2, 7, 49, 50, 51, 64, 65, 100, 299, 301, 350, 1000, 2600])
+    lens = []
+    for c in range(rnd.randint(1, 5)):
+        r = rnd.random()
+        L = rnd.randint(1, 200) if r < 0.3 else rnd.choice([inc, inc + 1, inc * 3, inc * 3 + 1, inc * 2 + w, w, w + 1, w + 51, inc * 5 + rnd.randint(0, w), 256 * inc + rnd.randint(-1, 1)]) if r < 0.6 else rnd.randint(200, 9000)
+        lens.append(max(1, min(L, 30000)))
+    t, q = [], []
+    hi = rnd.choice([60, 60, 3, 1000, 65535])
+    for ci, L in enumerate(lens):
+        for p in range(L):
+            d = rnd.randint(0, hi)
+            t.append("c%d\t%d\t%d\t%d\n" % (ci, p, p + 1, d))
+            q.append("c%d\t%d\t%d\t%d\n" % (ci, p, p + 1, rnd.randint(0, d)))
+    bad = rnd.random() < 0.15
+    if bad and len(t) > 3:
+        # one of the reference's five checks (src/boringbits_main.c:204-287): contig names differ, starts differ, a line that is not one position
+        k = rnd.randrange(len(t))
+        f = t[k].rstrip("\n").split("\t")
+        kind = rnd.randrange(4)
+        if kind == 0:
+            q[k] = "x" + q[k]
+        elif kind == 1:
+            f[2] = str(int(f[2]) + 1)
+            t[k] = "\t".join(f) + "\n"
+        elif kind == 2:
+            f[1] = str(int(f[1]) + 1)
+            f[2] = str(int(f[2]) + 1)
+            t[k] = "\t".join(f) + "\n"
+        else:
+            q = q[:-1]
+    a, b = os.path.join(tmp, "t.bg"), os.path.join(tmp, "q.bg")
+    open(a, "w").write("".join(t))
+    open(b, "w").write("".join(q))
+    args = [rnd.choice(["noboringbits", "boringbits"]), a, "-q", b, "-w", str(w), "-i", str(inc), "-m", str(rnd.choice([1, 100, 1000, 100000])),
+            "-e", str(rnd.choice([0, 5, 100, 5000])), "-L", rnd.choice(["0.4", "0.2", "0.9"]), "-H", rnd.choice(["2.5", "1.2", "3"]), "-Q", rnd.choice(["0.4", "0.9", "0.1"])]
+    rr = run(REF, args)
+    env = rnd.choice([{}, {}, {"CORNETTO_DEVICES": "0,0,0"}, {"CORNETTO_DEVICES": "0,0", "CORNETTO_BG_SHARD_MIN": "1"}, {"CORNETTO_BG_PIECE": "4096"}])
+    gg = run(CLI, args, env)
+    ok = (gg[0], gg[1]) == (rr[0], rr[1])
+    return ok, None if ok else (args[0], args[4:], lens, env, bad, gg[0], rr[0], len(gg[1]), len(rr[1]), gg[2][-300:])
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    n = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+    if not os.path.exists(REF):
+        print("oracle/_ref/cornetto is not built (python -c 'import __graft_entry__ as g; g.build()' where /root/reference is)")
+        return 2
+    bad = 0
+    stats = {}
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
+        for kind, fn in (("fasta", fuzz_fasta), ("panel", fuzz_panel)):
+            if what not in (kind, "all"):
+                continue
+            nb = 0
+            for seed in range(s0, s0 + n):
+                ok, info = fn(seed, tmp)
+                if not ok:
+                    nb += 1
+                    print("%s seed %d: MISMATCH %r" % (kind, seed, info), flush=True)
+            stats[kind] = (n, nb)
+            bad += nb
+    print("fuzz_cli: " + ", ".join("%s %d seeds from %d, %d mismatches" % (k, v[0], s0, v[1]) for k, v in stats.items()))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

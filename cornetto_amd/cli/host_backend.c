@@ -582,8 +582,10 @@ int cli_host_telobreaks(const int32_t *ctg_len, int32_t n_ctg, const cornetto_iv
     int rc = 0;
     for (int64_t i = 0; i < n_sd && !rc; ++i) {                                       /* :79-90 */
         if (sd[i].ctg < 0 || sd[i].ctg >= n_ctg) continue;
-        if (sd[i].start < 0 || sd[i].finish > ctg_len[sd[i].ctg]) rc = -1;
-        else bits_set(low[sd[i].ctg], sd[i].start, sd[i].finish);
+        /* (beyond the contig's end: sdust's own intervals at a contig's end reach there; the reference sets those bits and never reads them) */
+        const int64_t fin_i = sd[i].finish > ctg_len[sd[i].ctg] ? ctg_len[sd[i].ctg] : sd[i].finish;
+        if (sd[i].start < 0) rc = -1;
+        else if (sd[i].start < fin_i) bits_set(low[sd[i].ctg], sd[i].start, fin_i);
     }
     for (int64_t i = 0; i < n_tel && !rc; ++i) {                                      /* :95-128 */
         if (tel[i].matched < 24 || tel[i].ctg < 0 || tel[i].ctg >= n_ctg) continue;   /* MIN_TEL, :10,:98 */

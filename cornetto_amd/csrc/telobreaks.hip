@@ -55,9 +55,14 @@ __global__ void tb_fill(TbArgs A, const cornetto_ivl_t *sd, int64_t n)
     if (i >= n) return;
     const cornetto_ivl_t v = sd[i];
     if (v.ctg < 0 || v.ctg >= A.n_ctg) return;                                   // name not in the lens file (:83)
-    if (v.start < 0 || v.finish > A.ctg_len[v.ctg]) { atomicOr(A.err, 1u); return; }
-    if (v.start >= v.finish) return;
-    tb_or_range(A.bits + A.woff[v.ctg], v.start, v.finish);
+    // An interval that reaches beyond its contig's end is what sdust itself prints for a low-complexity run at the end of a contig — a telomere —
+    // (the finish of such an interval is up to W beyond the last base: src/sdust/sdust.c:88-102 does not cut it), and the reference sets those bits
+    // beyond its bitset (:85) and never reads them (:103,:118,:136 stop at the length): they are cut here.  A negative start has no such reading.
+    if (v.start < 0) { atomicOr(A.err, 1u); return; }
+    const int len = A.ctg_len[v.ctg];
+    const int fin = v.finish > len ? len : v.finish;
+    if (v.start >= fin) return;
+    tb_or_range(A.bits + A.woff[v.ctg], v.start, fin);
 }
 
 // are the bits [a, b) all set?

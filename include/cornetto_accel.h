@@ -504,8 +504,11 @@ typedef struct {
  * matched < 24 are ignored (MIN_TEL, :10,:98).  out[] = the numbers the reference prints (:140-142): for every maximal
  * run of the low-complexity bitset that contains a telomere row together with its 100-base flanks (clipped to the
  * contig): {ctg, first position - 1 clamped at 0, last position}, by contig index, then by position.
- * The reference prints contigs in khash bucket order: cornetto_khash_str_order().  Coordinates outside the contig are
- * unchecked heap indices in the reference; here they are CORNETTO_E_FORMAT.  Release out with cornetto_free(). */
+ * The reference prints contigs in khash bucket order: cornetto_khash_str_order().  An sd interval that ends beyond its contig
+ * is cut at the contig's end: sdust itself prints such intervals for a low-complexity run at the end of a contig (up to W
+ * beyond the last base), the reference sets those bits beyond its bitset (:85) and never reads them (:103,:118,:136).  Other
+ * coordinates outside the contig (a negative start, a telomere row beyond the end) are unchecked heap indices in the reference;
+ * here they are CORNETTO_E_FORMAT.  Release out with cornetto_free(). */
 int cornetto_telobreaks(cornetto_accel_t *h, const int32_t *ctg_len, int32_t n_ctg, const cornetto_ivl_t *sd, int64_t n_sd,
                         const cornetto_telrow_t *tel, int64_t n_tel, cornetto_ivl_t **out, int64_t *n_out);
 

@@ -99,7 +99,16 @@ def test_telobreaks_rejects_coordinates_outside_the_contig(acc):
     ok_sd = np.array([(0, 0, 500)], cornetto_amd.IVL_DT)
     ok_tel = np.array([(0, 100, 200, 100)], cornetto_amd.TELROW_DT)
     assert len(acc.telobreaks(lens, ok_sd, ok_tel)) == 1
-    for sd, tel in ((np.array([(0, 0, 1001)], cornetto_amd.IVL_DT), ok_tel), (ok_sd, np.array([(0, 900, 1001, 101)], cornetto_amd.TELROW_DT)),
+    # an sdust interval that ends beyond the contig (sdust prints them at a contig's end: up to W beyond the last base) is cut at the end, which is
+    # what the reference's unchecked writes amount to (:85 sets bits that :103,:118,:136 never read)
+    for fin in (1001, 1063, 5000):
+        sd_over = np.array([(0, 700, fin)], cornetto_amd.IVL_DT)
+        tel_end = np.array([(0, 900, 1000, 100)], cornetto_amd.TELROW_DT)
+        got = acc.telobreaks(lens, sd_over, tel_end)
+        assert [tuple(int(x) for x in r) for r in got] == [(0, 699, 999)]
+        exp = ob.telobreaks(lens, np.array([(0, 700, fin)], ob.SPAN_DT), tel_end.astype(ob.TELROW_DT))
+        assert [tuple(int(x) for x in r) for r in exp] == [(0, 699, 999)]
+    for sd, tel in ((ok_sd, np.array([(0, 900, 1001, 101)], cornetto_amd.TELROW_DT)),
                     (np.array([(0, -1, 5)], cornetto_amd.IVL_DT), ok_tel)):
         with pytest.raises(cornetto_amd.AccelError):
             acc.telobreaks(lens, sd, tel)

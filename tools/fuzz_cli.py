@@ -6,7 +6,8 @@ travels with the snapshot): stdout and exit status, byte for byte, with seeds th
   panel   (no)boringbits on random per-base bedgraph pairs: -w / -i smaller, equal, larger than each other, -m, -e, -L, -H, -Q; contig lengths at and around
           multiples of -i; the command lines on which the reference dies of its assert (SIGABRT); malformed lines (the reference's five checks: exit 1);
           one device, contigs dealt to several handles, the text itself cut into shares
-   python tools/fuzz_cli.py [fasta|panel|all] [first_seed] [n_seeds]"""
+  telo    telowin (identity and threshold varied) and telobreaks on the reference's own telofind / sdust / fa2bed outputs for such a FASTA (scripts/telostats.sh)
+   python tools/fuzz_cli.py [fasta|telo|panel|all] [first_seed] [n_seeds]"""
 import gzip
 import os
 import random
@@ -95,6 +96,40 @@ def fuzz_fasta(seed, tmp):
     return ok, None if ok else (args, env, gz, len(text), gg[0], rr[0], len(gg[1]), len(rr[1]), gg[2][-300:])
 
 
+def fuzz_telo(seed, tmp):
+    """the pipeline of scripts/telostats.sh on a random FASTA: the reference's own telofind / sdust / fa2bed outputs are the inputs of telowin and telobreaks"""
+    rnd = random.Random(seed)
+    text = fasta_text(rnd)
+    path = os.path.join(tmp, "p.fa")
+    open(path, "wb").write(text)
+    tel = run(REF, ["telofind", path])[1]
+    sd = run(REF, ["sdust", path])[1]
+    bed = run(REF, ["fa2bed", path])[1]
+    lens = b"".join(f.split(b"\t")[0] + b"\t" + f.split(b"\t")[2] + b"\n" for f in bed.splitlines() if f.count(b"\t") >= 2)
+    if rnd.random() < 0.3:                               # (any order of the lines: the reference's hash tables do not care)
+        ls = sd.splitlines(True)
+        rnd.shuffle(ls)
+        sd = b"".join(ls)
+    pt, ps, pl = os.path.join(tmp, "p.telomere"), os.path.join(tmp, "p.sdust"), os.path.join(tmp, "p.lens")
+    open(pt, "wb").write(tel)
+    open(ps, "wb").write(sd)
+    open(pl, "wb").write(lens)
+    if rnd.random() < 0.5:
+        args = ["telowin", pt, rnd.choice(["99.9", "90", "100", "50"]), rnd.choice(["0.4", "0.1", "0.8", "0.01"])]
+        if rnd.random() < 0.3:
+            args = args[:3]                              # (the threshold is optional: src/telomere_windows.c:54-56)
+    else:
+        args = ["telobreaks", pl, ps, pt]
+    rr = run(REF, args)
+    gg = run(CLI, args)
+    # (an sdust interval that ends beyond its contig — sdust prints them at a contig's end — is an unchecked write beyond the reference's bitset,
+    # src/telomere_breaks.c:85: most of the time nothing reads it, sometimes the allocator notices (SIGABRT) or the page ends (SIGSEGV): not compared)
+    if args[0] == "telobreaks" and rr[0] in (-6, -11):
+        return True, None
+    ok = (gg[0], gg[1]) == (rr[0], rr[1])
+    return ok, None if ok else (args[0], args[2:] if args[0] == "telowin" else "", len(text), gg[0], rr[0], len(gg[1]), len(rr[1]), gg[2][-300:])
+
+
 def fuzz_panel(seed, tmp):
     rnd = random.Random(seed)
     w = rnd.choice([1, 2, 7, 50, 64, 100, 300, 777, 2500])
@@ -150,7 +185,7 @@ def main():
     bad = 0
     stats = {}
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
-        for kind, fn in (("fasta", fuzz_fasta), ("panel", fuzz_panel)):
+        for kind, fn in (("fasta", fuzz_fasta), ("telo", fuzz_telo), ("panel", fuzz_panel)):
             if what not in (kind, "all"):
                 continue
             nb = 0

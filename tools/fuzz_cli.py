@@ -88,6 +88,14 @@ def fuzz_fasta(seed, tmp):
         args.append(path)
     rr = run(REF, args, data=data)
     env = {"CORNETTO_DEVICES": "0,0"} if rnd.random() < 0.2 else {}
+    # the streaming paths of the CLI, with sizes that make a small text many pieces: the piece loop (a record cut by a piece's end, a piece without a
+    # record start), the read-ahead and the whole-text path on and off, the sequential reader instead of the device's framing, batches of a few records
+    if rnd.random() < 0.6:
+        for key, vals in (("CORNETTO_FASTQ_PIECE", ["64", "100", "517", "3000", "65536"]), ("CORNETTO_BATCH_BASES", ["1", "700", "50000"]), ("CORNETTO_CLI_WHOLE", ["0", "1"]),
+                          ("CORNETTO_CLI_AHEAD", ["0", "1"]), ("CORNETTO_READ_THREADS", ["1", "3"]), ("CORNETTO_CLI_MMAP", ["0", "1"]), ("CORNETTO_FASTQ_SPLIT", ["host", "device"]),
+                          ("CORNETTO_FASTQ_GROW", ["0", "1"])):
+            if rnd.random() < 0.35:
+                env[key] = rnd.choice(vals)
     gg = run(CLI, args, env, data=data)
     # (seq on FASTA prints "(null)" for the absent quality in the reference: undefined behaviour, SURVEY appendix A-5 — not compared)
     if sub == "seq" and b"(null)" in rr[1]:
@@ -163,16 +171,62 @@ def fuzz_panel(seed, tmp):
             t[k] = "\t".join(f) + "\n"
         else:
             q = q[:-1]
+    # token layouts that fscanf("%s\t%d\t%d\t%d\n") reads the same way or refuses in its own way (src/boringbits_main.c:205-262): any white space between the
+    # tokens, a record over two lines, blank lines, signs and leading zeros, depths beyond 65535 (cut, with a warning), a contig whose first line does not
+    # start at 0 (not checked), a name that comes back later (a new contig), five columns, a missing column, a token that is no number, no last newline
+    odd = rnd.random() < 0.35
+    if odd and len(t) > 6:
+        for _ in range(rnd.randint(1, 4)):
+            k = rnd.randrange(len(t))
+            kind = rnd.randrange(12)
+            ft, fq = t[k].rstrip("\n").split("\t"), q[k].rstrip("\n").split("\t")
+            if kind == 0:
+                t[k] = " ".join(ft) + "\n"
+            elif kind == 1:
+                t[k] = ft[0] + "\n" + ft[1] + "\t\t" + ft[2] + " \n\n" + ft[3] + "\n"
+            elif kind == 2:
+                q[k] = "\n\n" + q[k] + "\n"
+            elif kind == 3:
+                t[k] = "\t".join([ft[0], "+" + ft[1], "0" + ft[2], "00" + ft[3]]) + "\n"
+            elif kind == 4:
+                t[k] = "\t".join(ft[:3] + [str(rnd.choice([65535, 65536, 70000, 1000000]))]) + "\n"
+            elif kind == 5:
+                q[k] = "\t".join(fq[:3] + [str(rnd.choice([65536, 99999]))]) + "\n"
+            elif kind == 6:
+                t[k] = t[k].rstrip("\n") + "\textra\n"
+            elif kind == 7:
+                t[k] = "\t".join(ft[:3]) + "\n"
+            elif kind == 8:
+                q[k] = "\t".join([fq[0], fq[1], fq[2], "x" + fq[3]]) + "\n"
+            elif kind == 9:
+                t[k] = "\t".join(ft[:3] + ["-" + ft[3]]) + "\n"
+            elif kind == 10 and k + 1 < len(t):
+                # the rest of this contig under another name, and the old name again later
+                name = ft[0]
+                j = k
+                while j < len(t) and t[j].startswith(name + "\t"):
+                    t[j] = "z" + t[j]
+                    q[j] = "z" + q[j]
+                    j += 1
+            else:
+                t[-1] = t[-1].rstrip("\n")
+                q[-1] = q[-1].rstrip("\n")
     a, b = os.path.join(tmp, "t.bg"), os.path.join(tmp, "q.bg")
     open(a, "w").write("".join(t))
     open(b, "w").write("".join(q))
+    if rnd.random() < 0.15:
+        for pth in (a, b):
+            data_ = open(pth, "rb").read()
+            with gzip.open(pth + ".gz", "wb") as f:
+                f.write(data_)
+        a, b = a + ".gz", b + ".gz"
     args = [rnd.choice(["noboringbits", "boringbits"]), a, "-q", b, "-w", str(w), "-i", str(inc), "-m", str(rnd.choice([1, 100, 1000, 100000])),
             "-e", str(rnd.choice([0, 5, 100, 5000])), "-L", rnd.choice(["0.4", "0.2", "0.9"]), "-H", rnd.choice(["2.5", "1.2", "3"]), "-Q", rnd.choice(["0.4", "0.9", "0.1"])]
     rr = run(REF, args)
     env = rnd.choice([{}, {}, {"CORNETTO_DEVICES": "0,0,0"}, {"CORNETTO_DEVICES": "0,0", "CORNETTO_BG_SHARD_MIN": "1"}, {"CORNETTO_BG_PIECE": "4096"}])
     gg = run(CLI, args, env)
     ok = (gg[0], gg[1]) == (rr[0], rr[1])
-    return ok, None if ok else (args[0], args[4:], lens, env, bad, gg[0], rr[0], len(gg[1]), len(rr[1]), gg[2][-300:])
+    return ok, None if ok else (args[0], args[4:], lens, env, bad, odd, gg[0], rr[0], len(gg[1]), len(rr[1]), gg[2][-300:], rr[2][-200:])
 
 
 def main():

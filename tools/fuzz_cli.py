@@ -118,12 +118,51 @@ def fuzz_telo(seed, tmp):
         ls = sd.splitlines(True)
         rnd.shuffle(ls)
         sd = b"".join(ls)
+    if rnd.random() < 0.4 and tel:
+        # the telofind rows as telowin reads them (src/telomere_windows.c:65-80: six %s per line, atoi on three of them, a new scaffold whenever the
+        # name changes): rows in any order inside a contig, twice, with blanks for tabs, a seventh column, empty and reversed spans, signs and zeros
+        # in the numbers, a contig's rows in two places (the name comes back: a second scaffold of that name).  Every row keeps six columns and
+        # stays inside its contig: fewer columns and spans beyond the length are stale stack and heap writes in the reference.
+        rows = [r.split(b"\t") for r in tel.splitlines() if r.count(b"\t") >= 5]
+        blocks, cur = [], None
+        for r in rows:
+            if cur is None or cur[0][0] != r[0]:
+                cur = []
+                blocks.append(cur)
+            cur.append(r)
+        for b_ in blocks:
+            if rnd.random() < 0.5:
+                rnd.shuffle(b_)
+            for r in list(b_):
+                k = rnd.random()
+                if k < 0.05:
+                    b_.append(list(r))
+                elif k < 0.10:
+                    r[3], r[4] = r[4], r[3]
+                elif k < 0.15:
+                    r[4] = r[3]
+                elif k < 0.20:
+                    r[3] = b"+" + r[3]
+                    r[4] = b"00" + r[4]
+                elif k < 0.25:
+                    r.append(b"extra")
+        if len(blocks) > 1 and rnd.random() < 0.3:
+            k = rnd.randrange(len(blocks))
+            if len(blocks[k]) > 1:
+                h = len(blocks[k]) // 2
+                blocks.append(blocks[k][h:])
+                blocks[k] = blocks[k][:h]
+        sep = rnd.choice([b"\t", b" ", b"  \t "])
+        tel_w = b"".join(sep.join(r) + b"\n" for b_ in blocks for r in b_)
+    else:
+        tel_w = tel
     pt, ps, pl = os.path.join(tmp, "p.telomere"), os.path.join(tmp, "p.sdust"), os.path.join(tmp, "p.lens")
-    open(pt, "wb").write(tel)
+    is_win = rnd.random() < 0.5
+    open(pt, "wb").write(tel_w if is_win else tel)
     open(ps, "wb").write(sd)
     open(pl, "wb").write(lens)
-    if rnd.random() < 0.5:
-        args = ["telowin", pt, rnd.choice(["99.9", "90", "100", "50"]), rnd.choice(["0.4", "0.1", "0.8", "0.01"])]
+    if is_win:
+        args = ["telowin", pt, rnd.choice(["99.9", "90", "100", "50", "1e2", "99.99999"]), rnd.choice(["0.4", "0.1", "0.8", "0.01", "1", "0"])]
         if rnd.random() < 0.3:
             args = args[:3]                              # (the threshold is optional: src/telomere_windows.c:54-56)
     else:

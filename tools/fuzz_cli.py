@@ -41,14 +41,16 @@ def rand_seq(rnd, n):
     return "".join(s)
 
 
-def fasta_text(rnd):
+def fasta_text(rnd, max_rec=7, max_len=40000):
     fastq = rnd.random() < 0.25
     eol = "\r\n" if rnd.random() < 0.15 else "\n"
     out = []
-    for r in range(rnd.randint(1, 7)):
-        n = rnd.choice([0, 1, 2, 5, 63, 64, 65, 200, 1000, 5000, 20000, 70000]) if rnd.random() < 0.5 else rnd.randint(0, 40000)
+    style = rnd.randrange(4)
+    for r in range(rnd.randint(1, max_rec)):
+        n = rnd.choice([0, 1, 2, 5, 63, 64, 65, 200, 1000, 5000, 20000, 70000]) if rnd.random() < 0.5 else rnd.randint(0, max_len)
+        n = min(n, max(max_len, 70000) if max_rec <= 7 else max_len)
         seq = rand_seq(rnd, n)
-        name = "ctg%d" % r + (" some comment" if rnd.random() < 0.3 else "")
+        name = ("ctg%d" % r, "ptg%06dl" % r, "h%dtg%06dl" % (1 + r % 2, r), "chr%d_MATERNAL|arrow" % r)[style] + (" some comment" if rnd.random() < 0.3 else "")
         if fastq:
             out.append("@" + name + eol + seq + eol + "+" + eol + "".join(rnd.choice("!#5I~") for _ in range(n)) + eol)
         else:
@@ -107,7 +109,8 @@ def fuzz_fasta(seed, tmp):
 def fuzz_telo(seed, tmp):
     """the pipeline of scripts/telostats.sh on a random FASTA: the reference's own telofind / sdust / fa2bed outputs are the inputs of telowin and telobreaks"""
     rnd = random.Random(seed)
-    text = fasta_text(rnd)
+    many = rnd.random() < 0.4
+    text = fasta_text(rnd, 60, 6000) if many else fasta_text(rnd)      # (many short contigs: the reference's hash tables grow, its print order is their bucket order)
     path = os.path.join(tmp, "p.fa")
     open(path, "wb").write(text)
     tel = run(REF, ["telofind", path])[1]
@@ -158,6 +161,21 @@ def fuzz_telo(seed, tmp):
         tel_w = tel
     pt, ps, pl = os.path.join(tmp, "p.telomere"), os.path.join(tmp, "p.sdust"), os.path.join(tmp, "p.lens")
     is_win = rnd.random() < 0.5
+    if not is_win and rnd.random() < 0.5:
+        # telobreaks (src/telomere_breaks.c:60-128): the lens file in another order, a name twice, names that are missing (their rows are dropped), the
+        # telomere rows in any order
+        ll = lens.splitlines(True)
+        if rnd.random() < 0.5:
+            rnd.shuffle(ll)
+        if ll and rnd.random() < 0.3:
+            ll.insert(rnd.randrange(len(ll) + 1), rnd.choice(ll))
+        if len(ll) > 1 and rnd.random() < 0.4:
+            del ll[rnd.randrange(len(ll))]
+        lens = b"".join(ll)
+        tl = tel.splitlines(True)
+        if rnd.random() < 0.5:
+            rnd.shuffle(tl)
+        tel = b"".join(tl)
     open(pt, "wb").write(tel_w if is_win else tel)
     open(ps, "wb").write(sd)
     open(pl, "wb").write(lens)

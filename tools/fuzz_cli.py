@@ -7,7 +7,8 @@ travels with the snapshot): stdout and exit status, byte for byte, with seeds th
           multiples of -i; the command lines on which the reference dies of its assert (SIGABRT); malformed lines (the reference's five checks: exit 1);
           one device, contigs dealt to several handles, the text itself cut into shares
   telo    telowin (identity and threshold varied) and telobreaks on the reference's own telofind / sdust / fa2bed outputs for such a FASTA (scripts/telostats.sh)
-   python tools/fuzz_cli.py [fasta|telo|panel|all] [first_seed] [n_seeds]"""
+  bigenough  (host only) random assembly bed / boring-bits bed / -T / -r, lengths up to and beyond 2^31, malformed entries
+   python tools/fuzz_cli.py [fasta|telo|panel|bigenough|all] [first_seed] [n_seeds]"""
 import gzip
 import os
 import random
@@ -195,6 +196,59 @@ def fuzz_telo(seed, tmp):
     return ok, None if ok else (args[0], args[2:] if args[0] == "telowin" else "", len(text), gg[0], rr[0], len(gg[1]), len(rr[1]), gg[2][-300:])
 
 
+def fuzz_bigenough(seed, tmp):
+    """bigenough (host only on both sides: src/bigenough_main.c:92-296): random assembly bed and boring-bits bed, -T 0 .. 100, the readfish csv (-r), malformed entries"""
+    rnd = random.Random(seed)
+    n = rnd.randint(1, 40)
+    style = rnd.randrange(3)
+    names = [("ctg%d" % i, "h%dtg%06dl" % (1 + i % 2, i), "chr%d_%s" % (i // 2 + 1, "MATERNAL" if i % 2 else "PATERNAL"))[style] for i in range(n)]
+    lens = [rnd.choice([1, 10, 1000, 50000, 3_000_000, 250_000_000, 2_147_483_647, 3_000_000_000]) if rnd.random() < 0.3 else rnd.randint(1, 5_000_000) for _ in range(n)]
+    chroms = "".join("%s\t0\t%d\n" % (nm, L) for nm, L in zip(names, lens))
+    rows = []
+    for nm, L in zip(names, lens):
+        if rnd.random() < 0.25:
+            continue
+        p = 0
+        for _ in range(rnd.randint(1, 6)):
+            if p >= L:
+                break
+            a = rnd.randint(p, min(L - 1, p + max(1, L // 3)))
+            b = rnd.randint(a + 1, min(L, a + 1 + max(1, L // 2)))
+            rows.append("%s\t%d\t%d\n" % (nm, a, b))
+            p = b
+    if rnd.random() < 0.3:
+        rnd.shuffle(rows)
+    kind = rnd.random()
+    if kind < 0.05 and rows:
+        rows[rnd.randrange(len(rows))] = "nosuchctg\t0\t10\n"
+    elif kind < 0.10 and rows:
+        rows[rnd.randrange(len(rows))] = "\n"
+    elif kind < 0.15 and rows:
+        f = rows[0].split("\t")
+        rows[0] = "%s\t%s\t%s" % (f[0], f[2].strip(), f[1]) + "\n"          # end < start
+    elif kind < 0.20:
+        chroms += chroms.splitlines(True)[0]                                  # a contig twice in the assembly bed
+    elif kind < 0.25 and rows:
+        rows[-1] = rows[-1].rstrip("\n")                                      # no last newline
+    elif kind < 0.30 and rows:
+        rows[0] = rows[0].replace("\t", " ")
+    pc, pb, pr_, pr2 = (os.path.join(tmp, x) for x in ("chroms.bed", "in.bed", "ref.csv", "got.csv"))
+    open(pc, "w").write(chroms)
+    open(pb, "w").write("".join(rows))
+    T = rnd.choice([None, "0", "1", "33", "50", "99", "100", "101", "-1"])
+    base = ["bigenough"] + (["-T", T] if T is not None else []) + [pc, pb]
+    for f in (pr_, pr2):
+        if os.path.exists(f):
+            os.remove(f)
+    with_csv = rnd.random() < 0.7
+    rr = run(REF, base + (["-r", pr_] if with_csv else []))
+    gg = run(CLI, base + (["-r", pr2] if with_csv else []))
+    csv_r = open(pr_, "rb").read() if os.path.exists(pr_) else None
+    csv_g = open(pr2, "rb").read() if os.path.exists(pr2) else None
+    ok = (gg[0], gg[1], csv_g) == (rr[0], rr[1], csv_r)
+    return ok, None if ok else (base[1:3], n, kind, gg[0], rr[0], len(gg[1]), len(rr[1]), csv_g == csv_r, gg[2][-200:], rr[2][-200:])
+
+
 def fuzz_panel(seed, tmp):
     rnd = random.Random(seed)
     w = rnd.choice([1, 2, 7, 50, 64, 100, 300, 777, 2500])
@@ -296,7 +350,7 @@ def main():
     bad = 0
     stats = {}
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
-        for kind, fn in (("fasta", fuzz_fasta), ("telo", fuzz_telo), ("panel", fuzz_panel)):
+        for kind, fn in (("fasta", fuzz_fasta), ("telo", fuzz_telo), ("panel", fuzz_panel), ("bigenough", fuzz_bigenough)):
             if what not in (kind, "all"):
                 continue
             nb = 0

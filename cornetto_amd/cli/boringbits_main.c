@@ -625,8 +625,8 @@ static void bb_multi(cornetto_accel_t *h0, const cornetto_cov_t *cov, int32_t n_
     sums[0] = sums[1] = sums[2] = 0;
     for (int d = 0; d < n_dev; ++d)
         for (int k = 0; k < 3; ++k) sums[k] += dv[d].sums[k];            /* the one exchange: 3 x u64 per device */
-    *mean_depth = (int32_t)round((double)sums[0] / (double)sums[2]);     /* :293 */
-    *mean_mq = (int32_t)round((double)sums[1] / (double)sums[2]);        /* :294 */
+    *mean_depth = (int32_t)round((double)(int64_t)sums[0] / (double)sums[2]);     /* :293 (the totals are signed: negative depth values in the text count as they are) */
+    *mean_mq = (int32_t)round((double)(int64_t)sums[1] / (double)sums[2]);        /* :294 */
     for (int d = 0; d < n_dev; ++d) {
         dv[d].lo = cornetto_cov_threshold(opt->low_cov_thresh, *mean_depth);   /* :518 */
         dv[d].hi = cornetto_cov_threshold(opt->high_cov_thresh, *mean_depth);  /* :519 */
@@ -689,8 +689,8 @@ static void bb_sharded(cornetto_accel_t *h0, bg_job_t *jobs, const int *devs, in
     sums[0] = sums[1] = sums[2] = 0;
     for (int d = 0; d < n_sh; ++d)
         for (int k = 0; k < 3; ++k) sums[k] += dv[d].sums[k];            /* the one exchange: 3 x u64 per device */
-    *mean_depth = (int32_t)round((double)sums[0] / (double)sums[2]);     /* :293 */
-    *mean_mq = (int32_t)round((double)sums[1] / (double)sums[2]);        /* :294 */
+    *mean_depth = (int32_t)round((double)(int64_t)sums[0] / (double)sums[2]);     /* :293 (the totals are signed: negative depth values in the text count as they are) */
+    *mean_mq = (int32_t)round((double)(int64_t)sums[1] / (double)sums[2]);        /* :294 */
     for (int d = 0; d < n_sh; ++d) {
         dv[d].lo = cornetto_cov_threshold(opt->low_cov_thresh, *mean_depth);   /* :518 */
         dv[d].hi = cornetto_cov_threshold(opt->high_cov_thresh, *mean_depth);  /* :519 */
@@ -1059,8 +1059,8 @@ int boringbits_main(int argc, char *argv[], int8_t boring)
         uint64_t sums[3];
         cli_accel_check(h, cornetto_cov_prepare(h, cov, opt.window_size, opt.window_inc, sums), "window block sums");
         /* double accumulators of the reference hold these integers exactly (:283-285) */
-        mean_depth = (int32_t)round((double)sums[0] / (double)sums[2]);   /* :293 */
-        mean_mq = (int32_t)round((double)sums[1] / (double)sums[2]);      /* :294 */
+        mean_depth = (int32_t)round((double)(int64_t)sums[0] / (double)sums[2]);   /* :293 (the totals are signed: negative depth values in the text count as they are) */
+        mean_mq = (int32_t)round((double)(int64_t)sums[1] / (double)sums[2]);      /* :294 */
         const int32_t lo_t = cornetto_cov_threshold(opt.low_cov_thresh, mean_depth);   /* :518 */
         const int32_t hi_t = cornetto_cov_threshold(opt.high_cov_thresh, mean_depth);  /* :519 */
         if (panel_bed)

@@ -162,6 +162,7 @@ struct BgArgs {
     uint4 *breaks;           // {global index lo, hi, name offset in ta, name length}
     uint32_t break_cap;
     unsigned long long *n_clamp;
+    unsigned long long *neg_corr;   // [2]: what the stored uint16 of a NEGATIVE depth / mq depth is above the value itself (a multiple of 65536), summed
 };
 
 __global__ __launch_bounds__(256) void bg_records(BgArgs A)
@@ -219,6 +220,10 @@ __global__ __launch_bounds__(256) void bg_records(BgArgs A)
     if (clamp) atomicAdd(A.n_clamp, (unsigned long long)clamp);
     A.da[gi] = (uint16_t)da;                                                     // negative values wrap as in the reference
     A.db[gi] = (uint16_t)db;
+    // ... in the ARRAYS (:282-283); the reference's totals take the int itself (:285-286: tot_depth += depth1): the difference goes with the
+    // coverage object, and cornetto_cov_prepare() takes it off the sums of the arrays
+    if (da < 0) atomicAdd(A.neg_corr, (unsigned long long)((long long)(uint16_t)da - (long long)da));
+    if (db < 0) atomicAdd(A.neg_corr + 1, (unsigned long long)((long long)(uint16_t)db - (long long)db));
     if (first) {
         const uint32_t k = atomicAdd(A.n_break, 1u);
         if (k < A.break_cap) A.breaks[k] = make_uint4((uint32_t)(gi & 0xFFFFFFFFll), (uint32_t)(gi >> 32), a.name_off, a.name_len);
@@ -250,6 +255,7 @@ struct cornetto_bgin {
     struct Brk { int64_t index; std::string name; };
     std::vector<Brk> breaks;
     unsigned long long n_clamp = 0;
+    unsigned long long neg_corr[2] = {0, 0};   // (see BgArgs::neg_corr)
     cornetto_bgerr_t err{0, 0, 0, 0};
     bool finished = false;
     int64_t left_mq = 0;      // tokens of cov-mq behind the last record when cov-total ended (the reference never looks at them: :204-207)
@@ -459,7 +465,7 @@ int cornetto_bgin_feed(cornetto_accel_t *h, cornetto_bgin_t *b, const char *tot,
             CN_HIP(h, hipMemsetAsync(d_small, 0, 256, h->stream));
             CN_HIP(h, hipMemsetAsync(d_small, 0xFF, 8, h->stream));
             BgArgs A{d_text[0], d_text[1], n[0], n[1], d_tok[0], d_tok[1], nrec, b->ctx, (b->n_rec - b->ctx == 0) ? 1 : 0, b->n_rec, b->d_a, b->d_b,
-                     d_small, reinterpret_cast<int32_t *>(d_small + 4), reinterpret_cast<uint32_t *>(d_small + 1), d_brk, break_cap, d_small + 2};
+                     d_small, reinterpret_cast<int32_t *>(d_small + 4), reinterpret_cast<uint32_t *>(d_small + 1), d_brk, break_cap, d_small + 2, d_small + 14};
             CN_LAUNCH(h, "bg_records", bg_records<<<dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, h->stream>>>(A));
             CN_HIP(h, hipMemcpyAsync(p_small, d_small, 256, hipMemcpyDeviceToHost, h->stream));
             CN_HIP(h, hipStreamSynchronize(h->stream));
@@ -484,6 +490,8 @@ int cornetto_bgin_feed(cornetto_accel_t *h, cornetto_bgin_t *b, const char *tot,
             return CORNETTO_E_FORMAT;
         }
         b->n_clamp += p_small[2];
+        b->neg_corr[0] += p_small[14];
+        b->neg_corr[1] += p_small[15];
     }
     CN_TRACE("bgin_feed: records");
     // offsets needed for the carry: start of the first unconsumed token, start of the context (last two consumed records)
@@ -568,6 +576,8 @@ int cornetto_bgin_finish(cornetto_accel_t *h, cornetto_bgin_t *b, cornetto_cov_t
     cornetto_cov_t *c = new (std::nothrow) cornetto_cov;
     if (!c) return cn_fail(h, CORNETTO_E_NOMEM, "bgin_finish: host allocation failed");
     c->n = nc;
+    c->sum_corr[0] = b->neg_corr[0];
+    c->sum_corr[1] = b->neg_corr[1];
     std::vector<int64_t> src_off(nc);
     int64_t pos = 0;
     for (int32_t i = 0; i < nc; ++i) {

@@ -626,8 +626,10 @@ int cn_cov_prepare_impl(cornetto_accel_t *h, cornetto_cov_t *c, int32_t w, int32
     CN_TRACE("cov_prepare: queued");
     CN_HIP(h, hipStreamSynchronize(h->stream));
     CN_TRACE("cov_prepare: done");
-    sums[0] = p_grand[0];
-    sums[1] = p_grand[1];
+    // (a coverage read from bedgraph text with negative depth values: the totals take the values, the arrays their uint16 — common.hpp sum_corr; the
+    // sums are then two's complement numbers, negative where the negative values outweigh the others)
+    sums[0] = p_grand[0] - c->sum_corr[0];
+    sums[1] = p_grand[1] - c->sum_corr[1];
     c->sums[0] = sums[0]; c->sums[1] = sums[1]; c->sums[2] = (uint64_t)c->total;
     return CORNETTO_OK;
 }

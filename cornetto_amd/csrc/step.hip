@@ -33,7 +33,7 @@ int cornetto_panel_step(cornetto_accel_t *h, const cornetto_asm_t *asm_in, const
         if (xr != 0) return cn_fail(h, CORNETTO_E_ARG, "panel_step: the exchange of the sums failed (%d)", xr);
     }
     if (sums[2] == 0) return cn_fail(h, CORNETTO_E_ARG, "panel_step: no positions");
-    const int32_t mean = (int32_t)round((double)sums[0] / (double)sums[2]);          // src/boringbits_main.c:293
+    const int32_t mean = (int32_t)round((double)(int64_t)sums[0] / (double)sums[2]);          // src/boringbits_main.c:293 (signed: cornetto_cov_prepare)
     thr[0] = cornetto_cov_threshold(o->low_cov, mean);                               // :518
     thr[1] = cornetto_cov_threshold(o->high_cov, mean);                              // :519
     // ---- everything else, queued in one go where the last step left its counts

@@ -280,7 +280,9 @@ int32_t cornetto_regs_assert(int32_t length, int32_t window_size, int32_t window
 /* Stage 1: per-`window_inc` block sums on the device plus the exact totals the mean needs.
  * sums[0] = sum of depth, sums[1] = sum of mq_depth, sums[2] = number of positions; the caller forms
  * mean = (int)round(sums[0]/sums[2]) (src/boringbits_main.c:283-285,293-294) — across ranks after an
- * all-reduce of sums[].  Needs window_inc >= 1; window_inc > window_size is computed as the reference computes it (:346-366).
+ * all-reduce of sums[].  For a coverage read from bedgraph text that holds NEGATIVE depth values (the reference takes them: %d) the
+ * arrays hold their uint16 (:282-283) and the totals the values themselves (:285-286): sums[0] and sums[1] are then two's complement
+ * numbers — form the mean from (int64_t)sums[.].  Needs window_inc >= 1; window_inc > window_size is computed as the reference computes it (:346-366).
  * CORNETTO_E_ASSERT when cornetto_regs_assert() is non-zero for any contig: get_regs() runs over EVERY contig before the
  * reference prints anything, so the process ends there with nothing on stdout. */
 int cornetto_cov_prepare(cornetto_accel_t *h, cornetto_cov_t *c, int32_t window_size, int32_t window_inc,

@@ -109,9 +109,15 @@ def fuzz_fasta(seed, tmp):
             f.write(text)
     sub = rnd.choice(["telofind", "sdust", "sdust", "fa2bed", "seq"])
     args, data = [sub], None
+    motif = None
+    if sub == "telofind" and rnd.random() < 0.6:
+        # the optional second argument (src/find_telomere.c:89-91): any string — with and without a border, longer than the automaton's 32 bytes, lower
+        # case (never found: the sequence is upper-cased, the motif is not), letters that are no bases
+        motif = rnd.choice(["TTAGGG", "CCCTAA", "TTTAGGG", "TTAGGGTTAGGG", "AAAA", "ACACA", "A", "AC", "GATC", "ttaggg", "TTANGG", "N", "NN", "GGAAT", "CATTC",
+                            "ACGT" * 9, "TTAGGG" * 7, "TA" * 20, "R", "TTAGGGT", "AT", "CAG"])
     if sub == "sdust":
         if rnd.random() < 0.6:
-            args += ["-w", str(rnd.choice([64, 40, 30, 16, 8, 66, 100, 200])), "-t", str(rnd.choice([20, 25, 10, 5, 30, 2]))]
+            args += ["-w", str(rnd.choice([64, 40, 30, 16, 8, 66, 100, 200, 5, 4, 3])), "-t", str(rnd.choice([20, 25, 10, 5, 30, 2, 1, 0, 1000]))]
     elif sub == "seq":
         if rnd.random() < 0.7:
             args += ["-m", str(rnd.choice([0, 1, 100, 1000, 10000]))]
@@ -120,6 +126,8 @@ def fuzz_fasta(seed, tmp):
         data = text
     else:
         args.append(path)
+    if motif is not None:
+        args.append(motif)
     rr = run(REF, args, data=data)
     env = {"CORNETTO_DEVICES": "0,0"} if rnd.random() < 0.2 else {}
     # the streaming paths of the CLI, with sizes that make a small text many pieces: the piece loop (a record cut by a piece's end, a piece without a

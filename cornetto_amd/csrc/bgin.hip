@@ -163,6 +163,11 @@ struct BgArgs {
     uint32_t break_cap;
     unsigned long long *n_clamp;
     unsigned long long *neg_corr;   // [2]: what the stored uint16 of a NEGATIVE depth / mq depth is above the value itself (a multiple of 65536), summed
+    // ... and one by one, for the contig each belongs to (cornetto_cov_shard() deals contigs to devices): {global index << 1 | file, the difference}; neg_n counts
+    // every one, the list holds the first neg_cap (more than that in ONE call: the feed is refused — such a file is not coverage)
+    unsigned long long *neg_list;
+    uint32_t *neg_n;
+    uint32_t neg_cap;
 };
 
 __global__ __launch_bounds__(256) void bg_records(BgArgs A)
@@ -222,8 +227,18 @@ __global__ __launch_bounds__(256) void bg_records(BgArgs A)
     A.db[gi] = (uint16_t)db;
     // ... in the ARRAYS (:282-283); the reference's totals take the int itself (:285-286: tot_depth += depth1): the difference goes with the
     // coverage object, and cornetto_cov_prepare() takes it off the sums of the arrays
-    if (da < 0) atomicAdd(A.neg_corr, (unsigned long long)((long long)(uint16_t)da - (long long)da));
-    if (db < 0) atomicAdd(A.neg_corr + 1, (unsigned long long)((long long)(uint16_t)db - (long long)db));
+    if (da < 0) {
+        const unsigned long long d = (unsigned long long)((long long)(uint16_t)da - (long long)da);
+        atomicAdd(A.neg_corr, d);
+        const uint32_t k = atomicAdd(A.neg_n, 1u);
+        if (k < A.neg_cap) { A.neg_list[2 * k] = (unsigned long long)gi << 1; A.neg_list[2 * k + 1] = d; }
+    }
+    if (db < 0) {
+        const unsigned long long d = (unsigned long long)((long long)(uint16_t)db - (long long)db);
+        atomicAdd(A.neg_corr + 1, d);
+        const uint32_t k = atomicAdd(A.neg_n, 1u);
+        if (k < A.neg_cap) { A.neg_list[2 * k] = ((unsigned long long)gi << 1) | 1ull; A.neg_list[2 * k + 1] = d; }
+    }
     if (first) {
         const uint32_t k = atomicAdd(A.n_break, 1u);
         if (k < A.break_cap) A.breaks[k] = make_uint4((uint32_t)(gi & 0xFFFFFFFFll), (uint32_t)(gi >> 32), a.name_off, a.name_len);
@@ -256,6 +271,7 @@ struct cornetto_bgin {
     std::vector<Brk> breaks;
     unsigned long long n_clamp = 0;
     unsigned long long neg_corr[2] = {0, 0};   // (see BgArgs::neg_corr)
+    std::vector<unsigned long long> neg;       // {record index << 1 | file, difference} of every negative value (BgArgs::neg_list)
     cornetto_bgerr_t err{0, 0, 0, 0};
     bool finished = false;
     int64_t left_mq = 0;      // tokens of cov-mq behind the last record when cov-total ended (the reference never looks at them: :204-207)
@@ -460,12 +476,16 @@ int cornetto_bgin_feed(cornetto_accel_t *h, cornetto_bgin_t *b, const char *tot,
             b->cap = ncap;
         }
         for (int attempt = 0; attempt < 2; ++attempt) {
-            uint4 *d_brk = (uint4 *)cn_ws(h, WS_BG_BRK, (size_t)break_cap * sizeof(uint4));
+            // (the contig-start list, and behind it the list of negative values: 16 bytes each)
+            constexpr uint32_t NEG_CAP = 1u << 16;
+            uint4 *d_brk = (uint4 *)cn_ws(h, WS_BG_BRK, ((size_t)break_cap + NEG_CAP) * sizeof(uint4));
             if (!d_brk) return cn_fail(h, CORNETTO_E_NOMEM, "bgin_feed: workspace allocation failed");
+            unsigned long long *d_neg = reinterpret_cast<unsigned long long *>(d_brk + break_cap);
             CN_HIP(h, hipMemsetAsync(d_small, 0, 256, h->stream));
             CN_HIP(h, hipMemsetAsync(d_small, 0xFF, 8, h->stream));
             BgArgs A{d_text[0], d_text[1], n[0], n[1], d_tok[0], d_tok[1], nrec, b->ctx, (b->n_rec - b->ctx == 0) ? 1 : 0, b->n_rec, b->d_a, b->d_b,
-                     d_small, reinterpret_cast<int32_t *>(d_small + 4), reinterpret_cast<uint32_t *>(d_small + 1), d_brk, break_cap, d_small + 2, d_small + 14};
+                     d_small, reinterpret_cast<int32_t *>(d_small + 4), reinterpret_cast<uint32_t *>(d_small + 1), d_brk, break_cap, d_small + 2, d_small + 14,
+                     d_neg, reinterpret_cast<uint32_t *>(d_small + 16), NEG_CAP};
             CN_LAUNCH(h, "bg_records", bg_records<<<dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, h->stream>>>(A));
             CN_HIP(h, hipMemcpyAsync(p_small, d_small, 256, hipMemcpyDeviceToHost, h->stream));
             CN_HIP(h, hipStreamSynchronize(h->stream));
@@ -477,6 +497,14 @@ int cornetto_bgin_feed(cornetto_accel_t *h, cornetto_bgin_t *b, const char *tot,
             }
             brk.resize(nb);
             if (nb) CN_HIP(h, hipMemcpy(brk.data(), d_brk, (size_t)nb * sizeof(uint4), hipMemcpyDeviceToHost));
+            const uint32_t nneg = (uint32_t)(p_small[16] & 0xFFFFFFFFull);
+            if (nneg > NEG_CAP && p_small[0] == ~0ull)
+                return cn_fail(h, CORNETTO_E_UNSUPPORTED, "bgin_feed: %u negative depth values in one piece of text (at most %u are kept apart for the totals)", nneg, NEG_CAP);
+            if (nneg && p_small[0] == ~0ull) {
+                const size_t at = b->neg.size();
+                b->neg.resize(at + 2 * (size_t)nneg);
+                CN_HIP(h, hipMemcpy(b->neg.data() + at, d_neg, (size_t)nneg * 16, hipMemcpyDeviceToHost));
+            }
             break;
         }
         if (p_small[0] != ~0ull) {   // the record with the smallest index that fails a check decides (the reference stops there)
@@ -578,6 +606,18 @@ int cornetto_bgin_finish(cornetto_accel_t *h, cornetto_bgin_t *b, cornetto_cov_t
     c->n = nc;
     c->sum_corr[0] = b->neg_corr[0];
     c->sum_corr[1] = b->neg_corr[1];
+    if (!b->neg.empty()) {                         // ... and per contig (the breaks are sorted by record index): cornetto_cov_shard()
+        c->ctg_corr.assign(2 * (size_t)nc, 0ull);
+        for (size_t i = 0; i + 1 < b->neg.size(); i += 2) {
+            const int64_t gi = (int64_t)(b->neg[i] >> 1);
+            size_t lo = 0, hi = (size_t)nc;           // the last contig whose first record is <= gi
+            while (lo + 1 < hi) {
+                const size_t mid = (lo + hi) / 2;
+                if (b->breaks[mid].index <= gi) lo = mid; else hi = mid;
+            }
+            if (nc) c->ctg_corr[2 * lo + (b->neg[i] & 1ull)] += b->neg[i + 1];
+        }
+    }
     std::vector<int64_t> src_off(nc);
     int64_t pos = 0;
     for (int32_t i = 0; i < nc; ++i) {

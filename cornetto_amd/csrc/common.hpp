@@ -362,6 +362,7 @@ struct cornetto_cov {
     // a coverage that came from bedgraph text (cornetto_bgin_finish) with NEGATIVE depth values: what their stored uint16 values are above the
     // values themselves, summed — the reference's totals take the int (src/boringbits_main.c:285-286), its arrays the uint16 (:282-283)
     unsigned long long sum_corr[2] = {0, 0};
+    std::vector<unsigned long long> ctg_corr;   // the same per contig ([2 c], [2 c + 1]); empty: none
     int32_t n = 0;
     std::vector<int64_t> off;          // element offset of contig i (multiple of 64)
     std::vector<int32_t> len;

@@ -631,6 +631,14 @@ int cornetto_cov_shard(cornetto_accel_t *h_src, const cornetto_cov_t *src, corne
         c->total += src->len[ctgs[i]];
         pos = cn_align_up(pos + src->len[ctgs[i]], 64);
     }
+    if (!src->ctg_corr.empty()) {                      // (negative depth values of a coverage read from text go with their contigs: common.hpp sum_corr)
+        c->ctg_corr.assign(2 * (size_t)n, 0ull);
+        for (int32_t i = 0; i < n; ++i)
+            for (int f = 0; f < 2; ++f) {
+                c->ctg_corr[2 * (size_t)i + f] = src->ctg_corr[2 * (size_t)ctgs[i] + f];
+                c->sum_corr[f] += src->ctg_corr[2 * (size_t)ctgs[i] + f];
+            }
+    }
     const size_t bytes = (size_t)(pos + SLACK) * sizeof(uint16_t);
     if (hipMalloc(&c->owned_d, bytes) != hipSuccess || hipMalloc(&c->owned_q, bytes) != hipSuccess) {
         cornetto_cov_free(h_dst, c);

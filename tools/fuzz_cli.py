@@ -380,6 +380,30 @@ def fuzz_panel(seed, tmp):
         a, b = a + ".gz", b + ".gz"
     args = [rnd.choice(["noboringbits", "boringbits"]), a, "-q", b, "-w", str(w), "-i", str(inc), "-m", str(rnd.choice([1, 100, 1000, 100000])),
             "-e", str(rnd.choice([0, 5, 100, 5000])), "-L", rnd.choice(["0.4", "0.2", "0.9"]), "-H", rnd.choice(["2.5", "1.2", "3"]), "-Q", rnd.choice(["0.4", "0.9", "0.1"])]
+    if rnd.random() < 0.4:
+        # the option table as getopt_long reads it (src/boringbits_main.c:45-64, :576-640): long spellings with and without '=', options behind the
+        # file, the options the reference takes and ignores (-t -K -B -v -o, --debug-break, --profile-cpu, --accel=yes), values its checks refuse
+        longs = {"-w": "--window-size", "-i": "--window-inc", "-m": "--min-ctg-len", "-e": "--edge-len", "-L": "--low-thresh", "-H": "--high-thresh", "-Q": "--low-mq-thresh", "-q": "--qual"}
+        cmd, rest = args[0], args[1:]
+        pos, opts = rest[0], []
+        it = iter(rest[1:])
+        for o in it:
+            v = next(it)
+            k = rnd.random()
+            if k < 0.3:
+                opts.append([longs[o] + "=" + v])
+            elif k < 0.5:
+                opts.append([longs[o], v])
+            elif k < 0.6:
+                opts.append([o + v])
+            else:
+                opts.append([o, v])
+        for extra in rnd.sample([["-t", "4"], ["-K", "100"], ["-B", "1M"], ["-v", "3"], ["--threads", "2"], ["--debug-break=1"], ["--profile-cpu=yes"], ["--accel=yes"], ["-o", os.path.join(tmp, "ignored.out")],
+                                 ["-t", "0"], ["-K", "0"], ["-K", "-3"]], rnd.randint(0, 3)):
+            opts.append(extra)
+        rnd.shuffle(opts)
+        cut = rnd.randint(0, len(opts))
+        args = [cmd] + [x for o in opts[:cut] for x in o] + [pos] + [x for o in opts[cut:] for x in o]
     rr = run(REF, args)
     env = rnd.choice([{}, {}, {"CORNETTO_DEVICES": "0,0,0"}, {"CORNETTO_DEVICES": "0,0", "CORNETTO_BG_SHARD_MIN": "1"}, {"CORNETTO_BG_PIECE": "4096"}])
     gg = run(CLI, args, env)

@@ -8,7 +8,8 @@ travels with the snapshot): stdout and exit status, byte for byte, with seeds th
           one device, contigs dealt to several handles, the text itself cut into shares
   telo    telowin (identity and threshold varied) and telobreaks on the reference's own telofind / sdust / fa2bed outputs for such a FASTA (scripts/telostats.sh)
   bigenough  (host only) random assembly bed / boring-bits bed / -T / -r, lengths up to and beyond 2^31, malformed entries
-   python tools/fuzz_cli.py [fasta|telo|panel|bigenough|all] [first_seed] [n_seeds]"""
+  khash   telobreaks on synthetic tables of up to 30 000 contigs that all print: the reference's hash-table order
+   python tools/fuzz_cli.py [fasta|telo|panel|bigenough|khash|all] [first_seed] [n_seeds]"""
 import gzip
 import os
 import random
@@ -243,6 +244,54 @@ def fuzz_telo(seed, tmp):
     return ok, None if ok else (args[0], args[2:] if args[0] == "telowin" else "", len(text), gg[0], rr[0], len(gg[1]), len(rr[1]), gg[2][-300:])
 
 
+def fuzz_khash(seed, tmp):
+    """telobreaks on synthetic tables with MANY contigs whose every telomere row lies inside a low-complexity run: every contig prints, in the bucket
+    order of the reference's hash table (khash 0.2.8: src/khash.h) after its resizes — names of several shapes and lengths, 1 .. 30 000 of them"""
+    rnd = random.Random(seed)
+    n = rnd.choice([1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 100, 1000, 3000, rnd.randint(1, 30000)])
+    shape = rnd.randrange(5)
+    names = set()
+    while len(names) < n:
+        i = len(names)
+        if shape == 0:
+            nm = "ptg%06dl" % i
+        elif shape == 1:
+            nm = "h%dtg%06dl" % (1 + i % 2, i)
+        elif shape == 2:
+            nm = "".join(rnd.choice("abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789_|.-") for _ in range(rnd.randint(1, 24)))
+        elif shape == 3:
+            nm = "chr%d_%s" % (i, rnd.choice(["MATERNAL", "PATERNAL"]))
+        else:
+            nm = str(rnd.randrange(1 << 30))
+        names.add(nm)
+    names = list(names)
+    rnd.shuffle(names)
+    lens, sd, te = [], [], []
+    for nm in names:
+        L = rnd.randint(400, 3000)
+        lens.append("%s\t%d\n" % (nm, L))
+        if rnd.random() < 0.9:
+            a = rnd.randint(0, 50)
+            b = rnd.randint(L - 50, L)
+            sd.append("%s\t%d\t%d\n" % (nm, a, b))
+            s0 = rnd.randint(a + 100, max(a + 100, b - 160)) if b - a > 300 else a
+            e0 = min(b, s0 + rnd.choice([24, 30, 48, 60]))
+            te.append("%s\t%d\t%d\t%d\t%d\t%d\n" % (nm, L, rnd.randint(0, 1), s0, e0, e0 - s0))
+    rnd.shuffle(sd)
+    rnd.shuffle(te)
+    pl, ps, pt = (os.path.join(tmp, x) for x in ("k.lens", "k.sdust", "k.telomere"))
+    open(pl, "w").write("".join(lens))
+    open(ps, "w").write("".join(sd))
+    open(pt, "w").write("".join(te))
+    args = ["telobreaks", pl, ps, pt]
+    rr = run(REF, args)
+    gg = run(CLI, args)
+    if rr[0] in ("timeout", -6, -11):
+        return True, None
+    ok = (gg[0], gg[1]) == (rr[0], rr[1])
+    return ok, None if ok else (n, shape, gg[0], rr[0], len(gg[1]), len(rr[1]), gg[2][-200:])
+
+
 def fuzz_bigenough(seed, tmp):
     """bigenough (host only on both sides: src/bigenough_main.c:92-296): random assembly bed and boring-bits bed, -T 0 .. 100, the readfish csv (-r), malformed entries"""
     rnd = random.Random(seed)
@@ -421,7 +470,7 @@ def main():
     bad = 0
     stats = {}
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
-        for kind, fn in (("fasta", fuzz_fasta), ("telo", fuzz_telo), ("panel", fuzz_panel), ("bigenough", fuzz_bigenough)):
+        for kind, fn in (("fasta", fuzz_fasta), ("telo", fuzz_telo), ("panel", fuzz_panel), ("bigenough", fuzz_bigenough), ("khash", fuzz_khash)):
             if what not in (kind, "all"):
                 continue
             nb = 0

@@ -161,6 +161,12 @@ class SplitPlan:
                 ci = min(max(ci, 0), len(self.lengths) - 1)
                 n, off = self.lengths[ci], x - int(starts[ci])
                 prev = borders[-1] if borders else (0, 0)
+                if prev[0] > ci:
+                    # the border before this one found no clean cut and moved to the END of this contig: this one cannot lie in front of it (found by
+                    # tests/test_dist_gloo.py::test_split_plan_properties_on_random_assemblies: the piece behind the earlier border owned the contig's
+                    # tail, and so did the piece behind this cut)
+                    borders.append(prev)
+                    continue
                 lo_ok = (prev[1] if prev[0] == ci else 0) + max(min_piece, 2 * self.halo)
                 c = None
                 if off >= lo_ok and n - off >= max(min_piece, 2 * self.halo):

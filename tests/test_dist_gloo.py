@@ -314,3 +314,58 @@ def test_split_plan_leaves_an_assembly_without_large_contigs_alone_and_is_determ
     for pp in plan.pieces:
         for ci, s, e, lo, hi in pp:
             assert s % plan.gran == 0 and (e % plan.gran == 0 or e == few[ci]) and lo == max(0, s - plan.halo) and hi == min(few[ci], e + plan.halo)
+
+
+def test_split_plan_properties_on_random_assemblies():
+    """randomised: whatever the contig lengths and the number of ranks, the pieces of a SplitPlan own every base of every contig exactly once, in contig
+    order over the ranks; a piece's scan range reaches one halo beyond a cut and stops at a contig's end; cuts lie on the granule (64-base tiles, 200-base
+    telomere windows, the window step), no piece is shorter than -m, only clean positions are cut, and the plan is a function of its arguments"""
+    import numpy as np
+    from cornetto_amd.dist import SplitPlan
+    rng = np.random.default_rng(20261004)
+    n_cut = 0
+    for it in range(400):
+        nctg = int(rng.integers(1, 30))
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            lens = rng.integers(1, 5_000_000, size=nctg)
+        elif kind == 1:
+            lens = np.concatenate([[int(rng.integers(50_000_000, 250_000_000))], rng.integers(1000, 20_000_000, size=nctg)])
+        elif kind == 2:
+            lens = np.array([int(rng.integers(100_000_000, 300_000_000))] * int(rng.integers(1, 4)) + [int(x) for x in rng.integers(0, 3_000_000, size=nctg)])
+        else:
+            lens = (10 ** rng.uniform(3, 8.3, size=nctg)).astype(np.int64)
+        lens = [int(x) for x in lens]
+        world = int(rng.choice([1, 2, 3, 4, 7, 8, 16]))
+        inc = int(rng.choice([50, 1, 49, 130, 1000]))
+        window = int(rng.choice([2500, 300, 5000]))
+        dirty = {(int(c), int(p)) for c, p in zip(rng.integers(0, len(lens), size=40), rng.integers(0, 300_000_000, size=40))}
+
+        def clean(ci, lo, hi, dirty=dirty):
+            return not any(c == ci and lo <= p < hi for c, p in dirty)
+        plan = SplitPlan(lens, world, clean=clean, window=window, inc=inc, W=64, min_ctg_len=1000000)
+        again = SplitPlan(lens, world, clean=clean, window=window, inc=inc, W=64, min_ctg_len=1000000)
+        assert plan.pieces == again.pieces
+        assert len(plan.pieces) == world
+        owned = {ci: [] for ci in range(len(lens))}
+        last = (-1, -1)
+        for r in range(world):
+            for ci, s, e, lo, hi in plan.pieces[r]:
+                n = lens[ci]
+                assert 0 <= lo <= s <= e <= hi <= n, (lens, world, plan.pieces[r])
+                if plan.any_split:                                                  # (cut: the contigs in input order over the ranks; not cut: dealt by length)
+                    assert (ci, s) > last or (e == s and n == 0)
+                last = (ci, s)
+                owned[ci].append((s, e))
+                assert lo == (s - plan.halo if s > 0 else 0) and hi == (e + plan.halo if e < n else n)
+                if s > 0:
+                    assert s % plan.gran == 0 and clean(ci, s - plan.halo, s + plan.halo)
+                if (s, e) != (0, n):
+                    assert e - s > 1000000 and e - s >= 2 * plan.halo                # a piece of a cut contig is longer than -m
+                    n_cut += 1
+        for ci, n in enumerate(lens):
+            spans = sorted(owned[ci])
+            assert spans and spans[0][0] == 0 and spans[-1][1] == n, (ci, n, spans)
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:])), (ci, spans)   # no gap, no overlap
+        assert sum(plan.loads) == sum(lens)
+    assert n_cut > 50

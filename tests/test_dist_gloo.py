@@ -369,3 +369,69 @@ def test_split_plan_properties_on_random_assemblies():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:])), (ci, spans)   # no gap, no overlap
         assert sum(plan.loads) == sum(lens)
     assert n_cut > 50
+
+
+def test_pieces_give_back_the_whole_contigs_records_on_random_plans():
+    """randomised: the records of a whole contig — intervals (sdust: some cross a cut, touch it, reach beyond the contig's end) and records owned by where
+    they start (telomere runs, windows) — seen through the pieces of a SplitPlan (every piece "scans" its [lo, hi) and reports what it finds there, in
+    its own coordinates), cut down by own_intervals / own_points, gathered in rank order and stitched, are the whole contig's records again"""
+    import numpy as np
+    from cornetto_amd.dist import SplitPlan, stitch_intervals, order_records
+    IVL = np.dtype([("ctg", "<i4"), ("start", "<i4"), ("finish", "<i4")])
+    HIT = np.dtype([("ctg", "<i4"), ("strand", "<i4"), ("start", "<i4"), ("end", "<i4")])
+    rng = np.random.default_rng(777)
+    n_cross = 0
+    for it in range(200):
+        lens = [int(x) for x in rng.integers(2_000_000, 40_000_000, size=int(rng.integers(1, 6)))]
+        lens.insert(int(rng.integers(0, len(lens) + 1)), int(rng.integers(80_000_000, 200_000_000)))
+        world = int(rng.choice([2, 3, 4, 8]))
+        plan = SplitPlan(lens, world, clean=lambda ci, lo, hi: True)
+        cuts = {ci: sorted(c) for ci, c in plan.cuts.items()}
+        # the whole contigs' records: disjoint, non-touching intervals (as sdust's union gives them), some placed across and at the cuts
+        ivls, hits = [], []
+        for ci, n in enumerate(lens):
+            pts = sorted(set(int(x) for x in rng.integers(0, n - 200, size=60)) | {c - int(rng.integers(1, 60)) for c in cuts[ci]} | {c for c in cuts[ci][:1]})
+            last = -10
+            for p in pts:
+                if p <= last + 1 or p < 0:
+                    continue
+                f = min(n + 30, p + int(rng.integers(7, 150)))
+                if cuts[ci] and rng.random() < 0.1:
+                    f = max(f, cuts[ci][0] + (0 if rng.random() < 0.5 else 40))       # ends exactly at a cut, or crosses it
+                ivls.append((ci, p, f))
+                last = f
+            ivls.append((ci, max(last + 5, n - 40), n + 25))                            # reaches beyond the contig's end (src/sdust/sdust.c:88-102)
+            for p in sorted(set(int(x) for x in rng.integers(0, n - 10, size=80)) | set(cuts[ci]) | {c - 1 for c in cuts[ci]}):
+                hits.append((ci, int(rng.integers(0, 2)), p, p + 6))
+        whole_i = np.array(sorted(ivls), dtype=IVL)
+        # (intervals made above may overlap where a forced end passed the next start: the union, as the reference gives it)
+        whole_i = stitch_intervals(whole_i)
+        whole_h = order_records(np.array(hits, dtype=HIT), ["strand", "start"])
+        got_i, got_h = [], []
+        for r in range(world):
+            loc_i, loc_h = [], []
+            for li, (ci, s, e, lo, hi) in enumerate(plan.pieces[r]):
+                n = lens[ci]
+                for c, a, b in whole_i[whole_i["ctg"] == ci].tolist():
+                    # what a scan of [lo, hi) reports: the part of the interval inside it (beyond the contig's end only for a piece that ends there)
+                    a2, b2 = max(a, lo), (b if hi == n else min(b, hi))
+                    if b2 > a2:
+                        loc_i.append((li, a2 - lo, b2 - lo))
+                for c, st, a, b in whole_h[whole_h["ctg"] == ci].tolist():
+                    if lo <= a and b <= hi:
+                        loc_h.append((li, st, a - lo, b - lo))
+            oi = plan.own_intervals(r, np.array(loc_i, dtype=IVL))
+            oh = plan.own_points(r, np.array(loc_h, dtype=HIT), "start")
+            g = np.array(plan.global_ctg(r), dtype=np.int32)
+            if len(oi):
+                oi["ctg"] = g[oi["ctg"]]
+            if len(oh):
+                oh["ctg"] = g[oh["ctg"]]
+            got_i.append(oi)
+            got_h.append(oh)
+        gi = stitch_intervals(np.concatenate(got_i))
+        gh = order_records(np.concatenate(got_h), ["strand", "start"])
+        assert gi.tolist() == whole_i.tolist(), (lens, world, cuts)
+        assert gh.tolist() == whole_h.tolist(), (lens, world, cuts)
+        n_cross += sum(1 for c, a, b in whole_i.tolist() if any(a < x < b for x in cuts[c]))
+    assert n_cross > 20

@@ -411,7 +411,7 @@ def fuzz_panel(seed, tmp):
                 # the rest of this contig under another name, and the old name again later
                 name = ft[0]
                 j = k
-                while j < len(t) and t[j].startswith(name + "\t"):
+                while j < len(t) and j < len(q) and t[j].startswith(name + "\t"):
                     t[j] = "z" + t[j]
                     q[j] = "z" + q[j]
                     j += 1
@@ -447,7 +447,7 @@ def fuzz_panel(seed, tmp):
                 opts.append([o + v])
             else:
                 opts.append([o, v])
-        for extra in rnd.sample([["-t", "4"], ["-K", "100"], ["-B", "1M"], ["-v", "3"], ["--threads", "2"], ["--debug-break=1"], ["--profile-cpu=yes"], ["--accel=yes"], ["-o", os.path.join(tmp, "ignored.out")],
+        for extra in rnd.sample([["-t", "4"], ["-K", "100"], ["-B", "1M"], ["-v", "3"], ["--threads", "2"], ["--debug-break=1"], ["--profile-cpu=yes"]] + ([] if os.environ.get("CORNETTO_ACCEL") == "no" else [["--accel=yes"]]) + [["-o", os.path.join(tmp, "ignored.out")],
                                  ["-t", "0"], ["-K", "0"], ["-K", "-3"]], rnd.randint(0, 3)):
             opts.append(extra)
         rnd.shuffle(opts)
@@ -457,7 +457,7 @@ def fuzz_panel(seed, tmp):
     env = rnd.choice([{}, {}, {"CORNETTO_DEVICES": "0,0,0"}, {"CORNETTO_DEVICES": "0,0", "CORNETTO_BG_SHARD_MIN": "1"}, {"CORNETTO_BG_PIECE": "4096"}])
     gg = run(CLI, args, env)
     ok = (gg[0], gg[1]) == (rr[0], rr[1])
-    return ok, None if ok else (args[0], args[4:], lens, env, bad, odd, gg[0], rr[0], len(gg[1]), len(rr[1]), gg[2][-300:], rr[2][-200:])
+    return ok, None if ok else (args, lens, env, bad, odd, gg[0], rr[0], len(gg[1]), len(rr[1]), gg[2][-300:], rr[2][-200:])
 
 
 def main():

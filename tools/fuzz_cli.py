@@ -386,7 +386,11 @@ def fuzz_panel(seed, tmp):
         for _ in range(rnd.randint(1, 4)):
             k = rnd.randrange(len(t))
             kind = rnd.randrange(12)
+            if k >= len(q):
+                continue
             ft, fq = t[k].rstrip("\n").split("\t"), q[k].rstrip("\n").split("\t")
+            if len(ft) != 4 or len(fq) != 4:             # (a line an earlier turn of this loop has changed)
+                continue
             if kind == 0:
                 t[k] = " ".join(ft) + "\n"
             elif kind == 1:

@@ -18,7 +18,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLI = os.path.join(ROOT, "cornetto_amd", "cornetto")
+CLI = os.environ.get("CORNETTO_FUZZ_CLI") or os.path.join(ROOT, "cornetto_amd", "cornetto")      # (e.g. cornetto_amd/cornetto_asan: make -C cornetto_amd asan=1)
 REF = os.path.join(ROOT, "oracle", "_ref", "cornetto")
 
 

@@ -376,3 +376,36 @@ def test_device_list_errors(cli, golden_dir):
     assert rc == 1 and out == b"" and b"cannot open HIP device 63" in err
     rc, out, err = run(cli, ["sdust", os.path.join(golden_dir, "probe.fa")], {"CORNETTO_DEVICES": "0"})       # one device: the usual path
     assert rc == 0 and out == golden(golden_dir, "probe.sdust.exp")
+
+
+@pytest.mark.parametrize("env", [{}, {"CORNETTO_DEVICES": "0,0,0"}, {"CORNETTO_DEVICES": "0,0", "CORNETTO_BG_SHARD_MIN": "1"}, {"CORNETTO_BG_PIECE": "4096"}])
+def test_panel_negative_depth_values_count_as_themselves_in_the_mean(cli, tmp_path, env):
+    """`%d` reads a negative depth: the reference stores its uint16 in the arrays (src/boringbits_main.c:282-283) and adds the value itself to the totals
+    behind the mean (:285-286) — on one device, with the contigs dealt to several handles, with the text cut into shares and fed in pieces: stdout of the
+    device path against the unmodified reference (found by tools/fuzz_cli.py, seeds 920000 and 80066 of the panel cases)"""
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "cornetto")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/cornetto not built")
+    rng = np.random.default_rng(5)
+    t, q = [], []
+    for ci, n in enumerate((7000, 900, 4000)):
+        d = rng.integers(20, 40, size=n)
+        m = np.minimum(d, rng.integers(0, 40, size=n))
+        for p in range(n):
+            dv, mv = int(d[p]), int(m[p])
+            if (ci, p) in ((0, 2767), (0, 5197), (2, 100)):
+                dv = -37 if p != 5197 else -70000                    # (-70000: one more than a whole turn of the uint16 below zero)
+            if (ci, p) == (1, 10):
+                mv = -3
+            t.append("c%d\t%d\t%d\t%d\n" % (ci, p, p + 1, dv))
+            q.append("c%d\t%d\t%d\t%d\n" % (ci, p, p + 1, mv))
+    a, b = tmp_path / "t.bg", tmp_path / "q.bg"
+    a.write_text("".join(t))
+    b.write_text("".join(q))
+    for sub, opts in (("noboringbits", ["-w", "50", "-i", "1", "-m", "100", "-e", "100"]), ("boringbits", ["-w", "300", "-i", "7", "-m", "1000", "-e", "50", "-H", "1.2"]),
+                      ("noboringbits", ["-w", "2500", "-i", "50", "-m", "100", "-e", "5", "-L", "0.9"])):
+        args = [sub, str(a), "-q", str(b)] + opts
+        pr = subprocess.run([ref] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        rc, out, err = run(cli, args, env)
+        assert (rc, out) == (pr.returncode, pr.stdout), (args, env, rc, pr.returncode, len(out), len(pr.stdout), err.decode()[-300:])
+        assert pr.returncode == 0 and len(pr.stdout) > 100
